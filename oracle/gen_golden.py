@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""Generates tests/golden/*.npz by IMPORTING THE REFERENCE (read-only) in this
+container and checks the oracle restatement against it on the way.
+
+Run:  python oracle/gen_golden.py            (needs /root/reference; CPU only)
+
+Nothing of the reference is copied: the outputs are input/expected-output
+vectors only.  Weights come from oracle.corenet_oracle.make_state(seed), so the
+GPU box can regenerate identical weights without the reference.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch as t
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("CORENET_REFERENCE", "/root/reference/src")
+sys.path.insert(0, REF)
+# dataclasses_jsonschema is not installed; forward/backward never call to_dict
+_m = types.ModuleType("dataclasses_jsonschema")
+_m.JsonSchemaMixin = type("JsonSchemaMixin", (), {})
+sys.modules["dataclasses_jsonschema"] = _m
+
+from corenet import configuration as C                      # noqa: E402  (reference)
+from corenet.model import core_net, batch_renorm, losses    # noqa: E402
+from corenet.model import ray_traced_skip_connection as rts  # noqa: E402
+from corenet import voxel_metrics                            # noqa: E402
+from oracle import corenet_oracle as O                       # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+t.manual_seed(0)
+t.set_num_threads(8)
+
+
+def maxrel(a, b):
+  a, b = a.double(), b.double()
+  return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def ref_model(num_classes, sd):
+  cfg = C.CoreNetConfig(decoder=C.DecoderConfig(
+      resolution=(128, 128, 128), num_output_channels=num_classes,
+      last_upscale_factor=2, latent_channels=64, skip_fraction=0.75))
+  net = core_net.CoreNet(cfg)
+  net.load_state_dict({k: v.clone() for k, v in sd.items()})
+  return net
+
+
+def gen_model(tag, num_classes, nbt, batch, loss_name, training=True):
+  sd = O.make_state(seed=0, num_classes=num_classes, nbt=nbt)
+  image, v2s, off, grid = O.synthetic_batch(batch, seed=0, num_classes=num_classes)
+  net = ref_model(num_classes, sd)
+  net.train(training)
+  logits = net(image, v2s, off)
+  loss_fn = getattr(losses, loss_name)
+  loss = loss_fn(grid, logits)
+  out = dict(logits_sub=logits.detach()[:, :, ::16, ::16, ::16].numpy(),
+             logits_sum=np.float64(logits.double().sum().item()),
+             logits_abs_sum=np.float64(logits.double().abs().sum().item()),
+             loss=np.float32(loss.item()))
+  # the oracle restatement on the same inputs
+  sd_o = {k: v.clone() for k, v in sd.items()}
+  if training:
+    for k in sd_o:
+      if sd_o[k].dtype == t.float32 and ("running" not in k):
+        sd_o[k].requires_grad_(True)
+  lo = O.corenet_forward(sd_o, image, v2s, off, training=training)
+  print(f"[{tag}] oracle vs reference logits max-rel = {maxrel(lo.detach(), logits.detach()):.3e}")
+  assert maxrel(lo.detach(), logits.detach()) < 1e-4
+  if training:
+    loss.backward()
+    lo_loss = getattr(O, loss_name)(grid, lo)
+    lo_loss.backward()
+    gn, worst = {}, 0.0
+    for name, p in net.named_parameters():
+      gn[name] = np.float64(p.grad.double().norm().item())
+      worst = max(worst, maxrel(sd_o[name].grad, p.grad))
+    print(f"[{tag}] oracle vs reference worst param-grad max-rel = {worst:.3e}")
+    assert worst < 2e-3
+    out["grad_names"] = np.array(list(gn.keys()))
+    out["grad_norms"] = np.array(list(gn.values()))
+    # a few full gradients (small tensors) for direct comparison
+    for name in ["decoder.stage_6.t1.weight", "decoder.stage_6.b2.weight",
+                 "decoder.rt_skip_5.compress_channels.weight",
+                 "decoder.stage_0.bias", "encoder.stage1.conv.bias"]:
+      out["grad::" + name] = dict(net.named_parameters())[name].grad.numpy()
+    # running stats after the step
+    sdn = net.state_dict()
+    for name in ["decoder.stage_6.b1.running_mean", "decoder.stage_6.b1.running_var",
+                 "encoder.stage1_part2.bn.running_mean", "encoder.stage5.c.op_c.bn.running_var"]:
+      out["buf::" + name] = sdn[name].numpy()
+      assert maxrel(sd_o[name], sdn[name]) < 1e-4
+  np.savez_compressed(os.path.join(OUT, f"model_{tag}.npz"), **out)
+
+
+def gen_batch_renorm():
+  out = {}
+  g = t.Generator().manual_seed(7)
+  x = t.randn(3, 5, 4, 6, generator=g) * 2 + 0.7
+  out["x"] = x.numpy()
+  for tag, nbt, training in (("train0", 0, True), ("train30k", 30000, True), ("eval", 123, False)):
+    bn = batch_renorm.BatchRenorm(5, eps=1e-3)
+    with t.no_grad():
+      bn.weight.copy_(t.tensor([1.0, 0.5, 2.0, 1.5, 0.8]))
+      bn.bias.copy_(t.tensor([0.0, 0.1, -0.2, 0.3, 1.0]))
+      bn.running_mean.copy_(t.tensor([0.5, 0.9, -0.3, 2.5, 0.7]))
+      bn.running_var.copy_(t.tensor([4.0, 0.2, 9.0, 1.0, 30.0]))
+      bn.num_batches_tracked.fill_(nbt)
+    bn.train(training)
+    xi = x.clone().requires_grad_(True)
+    y = bn(xi)
+    gy = t.randn(y.shape, generator=t.Generator().manual_seed(8))
+    y.backward(gy)
+    out[f"{tag}_y"] = y.detach().numpy()
+    out[f"{tag}_gx"] = xi.grad.numpy()
+    out[f"{tag}_gw"] = bn.weight.grad.numpy()
+    out[f"{tag}_gb"] = bn.bias.grad.numpy()
+    out[f"{tag}_rm"] = bn.running_mean.numpy()
+    out[f"{tag}_rv"] = bn.running_var.numpy()
+    out["gy"] = gy.numpy()
+    # oracle check
+    sd = {"weight": bn.weight.detach().clone(), "bias": bn.bias.detach().clone(),
+          "running_mean": t.tensor([0.5, 0.9, -0.3, 2.5, 0.7]),
+          "running_var": t.tensor([4.0, 0.2, 9.0, 1.0, 30.0]),
+          "num_batches_tracked": t.tensor(nbt)}
+    yo = O.batch_renorm(x, sd, "", training)
+    assert maxrel(yo, y.detach()) < 1e-6, tag
+    assert maxrel(sd["running_var"], bn.running_var) < 1e-6
+  np.savez_compressed(os.path.join(OUT, "batch_renorm.npz"), **out)
+  print("[batch_renorm] ok")
+
+
+def gen_sample_grid2d():
+  """SampleGrid2d fwd/bwd incl. an edge-case camera (outside image + behind camera)."""
+  out = {}
+  g = t.Generator().manual_seed(11)
+  B, Cin, Cs, h, w, R = 2, 7, 5, 16, 16, 16
+  mod = rts.SampleGrid2d(Cin, Cs, (R, R, R))
+  with t.no_grad():
+    mod.compress_channels.weight.copy_(t.randn(Cs, Cin, 1, 1, generator=g))
+    mod.compress_channels.bias.copy_(t.randn(Cs, generator=g))
+  src = t.randn(B, Cin, h, w, generator=g)
+  cam = O.canonical_camera()
+  m0 = cam @ O.scale([1.0 / R] * 3)
+  # edge case: shift the grid so ~30% projects outside and a slab is behind the camera
+  m1 = cam @ O.translate(t.tensor([0.35, -0.2, -0.55])) @ O.scale([1.6 / R] * 3)
+  mats = t.stack([m0, m1])
+  off = t.tensor([[0.5, 0.5, 0.5], [0.25, 0.75, 0.5]])
+  srcg = src.clone().requires_grad_(True)
+  y = mod(srcg, mats, off)
+  gy = t.randn(y.shape, generator=g)
+  y.backward(gy)
+  out.update(src=src.numpy(), weight=mod.compress_channels.weight.detach().numpy(),
+             bias=mod.compress_channels.bias.detach().numpy(), mats=mats.numpy(),
+             off=off.numpy(), y=y.detach().numpy(), gy=gy.numpy(),
+             gsrc=srcg.grad.numpy(),
+             gweight=mod.compress_channels.weight.grad.numpy(),
+             gbias=mod.compress_channels.bias.grad.numpy())
+  yo = O.sample_grid2d(src, mod.compress_channels.weight.detach(),
+                       mod.compress_channels.bias.detach(), mats, off, (R, R, R))
+  mism = int((yo != y.detach()).sum())
+  frac_zero = float((y.detach()[:, 0] == 0).float().mean())
+  print(f"[sample_grid2d] oracle vs reference mismatching elements: {mism}; zero fraction {frac_zero:.2f}")
+  assert mism == 0
+  # index parity at the real decoder scales with the canonical camera
+  for res, hw in ((8, 8), (16, 16), (32, 32), (64, 64)):
+    mod = rts.SampleGrid2d(1, 1, (res,) * 3)
+    with t.no_grad():
+      mod.compress_channels.weight.fill_(1.0); mod.compress_channels.bias.fill_(0.0)
+    idmap = t.arange(hw * hw, dtype=t.float32).reshape(1, 1, hw, hw) + 1
+    m = (cam @ O.scale([1.0 / 128] * 3) @ O.scale([128.0 / res] * 3))[None]
+    o = t.full((1, 3), 0.5)
+    yr = mod(idmap, m, o)
+    yo = O.ray_sample(idmap, m, o, (res,) * 3)
+    n = int((yr.detach() != yo).sum())
+    print(f"[ray index parity] res {res}: mismatches {n}")
+    assert n == 0
+    out[f"idx_{res}"] = yr.detach().numpy().astype(np.int32)[0, 0]
+  np.savez_compressed(os.path.join(OUT, "sample_grid2d.npz"), **out)
+
+
+def gen_losses():
+  out = {}
+  g = t.Generator().manual_seed(5)
+  logits = t.randn(2, 5, 6, 7, 8, generator=g)
+  gt = t.randint(0, 5, (2, 6, 7, 8), generator=g)
+  out["logits"], out["gt"] = logits.numpy(), gt.numpy()
+  for name in ("iou_agnostic", "iou_fgbg", "xent", "xent_times_iou_agnostic", "xent_times_iou_fgbg"):
+    l = logits.clone().requires_grad_(True)
+    v = getattr(losses, name)(gt, l)
+    v.backward()
+    out[name] = np.float32(v.item())
+    out[name + "_grad"] = l.grad.numpy()
+    vo = getattr(O, name)(gt, logits)
+    assert abs(float(vo) - float(v)) < 1e-6
+  np.savez_compressed(os.path.join(OUT, "losses.npz"), **out)
+  print("[losses] ok")
+
+
+if __name__ == "__main__":
+  gen_batch_renorm()
+  gen_sample_grid2d()
+  gen_losses()
+  gen_model("h7_train_b1", 2, 0, 1, "iou_fgbg")
+  gen_model("h7_train_b2_nbt30k", 2, 30000, 2, "iou_fgbg")
+  gen_model("h7_eval_b1", 2, 100, 1, "iou_fgbg", training=False)
+  gen_model("m9_train_b1", 14, 0, 1, "xent_times_iou_agnostic")
+  print("golden fixtures written to", OUT)
