@@ -1,0 +1,384 @@
+// BatchRenorm statistics / backward and the fused per-channel elementwise
+// kernels of the encoder/decoder blocks.  All HBM-bound: one coalesced float4
+// pass per tensor, fp64 accumulation of the per-channel sums.
+// Reference: model/batch_renorm.py:33-62, model/resnet50.py:72-82,109-115.
+#include "crn_common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct Slice { int64_t s0, s1; };
+__device__ __forceinline__ Slice block_slice(int64_t S) {
+  int64_t chunk = (S + gridDim.x - 1) / gridDim.x;
+  chunk = (chunk + 3) & ~(int64_t)3;
+  Slice r;
+  r.s0 = (int64_t)blockIdx.x * chunk;
+  r.s1 = min(S, r.s0 + chunk);
+  return r;
+}
+
+// Applies f(s, vec4) over a contiguous slice; VEC needs 16-B aligned rows.
+template <bool VEC, typename F4, typename F1>
+__device__ __forceinline__ void for_slice(Slice sl, F4 f4, F1 f1) {
+  if (VEC) {
+    for (int64_t s = sl.s0 + (int64_t)threadIdx.x * 4; s + 3 < sl.s1; s += (int64_t)kThreads * 4) f4(s);
+    const int64_t nfull = (sl.s1 > sl.s0) ? ((sl.s1 - sl.s0) & ~(int64_t)3) : 0;
+    for (int64_t s = sl.s0 + nfull + threadIdx.x; s < sl.s1; s += kThreads) f1(s);
+  } else {
+    for (int64_t s = sl.s0 + threadIdx.x; s < sl.s1; s += kThreads) f1(s);
+  }
+}
+
+// ---- statistics -------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void bn_partial_kernel(const float* x, int64_t S, int64_t sB,
+                                                               int pre_relu, double* ws) {
+  __shared__ double red[kThreads / 64];
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float* p = x + (int64_t)b * sB + (int64_t)c * S;
+  double s1 = 0.0, s2 = 0.0;
+  auto one = [&](float v) {
+    if (pre_relu) v = fmaxf(v, 0.f);
+    s1 += (double)v;
+    s2 += (double)v * (double)v;
+  };
+  for_slice<VEC>(block_slice(S),
+                 [&](int64_t s) { const f32x4 v = *reinterpret_cast<const f32x4*>(p + s);
+                                  one(v.x); one(v.y); one(v.z); one(v.w); },
+                 [&](int64_t s) { one(p[s]); });
+  const double t1 = crn_block_sum(s1, red);
+  const double t2 = crn_block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    const int nparts = gridDim.x * gridDim.z;
+    double* o = ws + ((int64_t)c * nparts + (int64_t)b * gridDim.x + blockIdx.x) * 2;
+    o[0] = t1; o[1] = t2;
+  }
+}
+
+__global__ void bn_finalize_kernel(const double* ws, int nparts, int C, double count,
+                                   const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, const int64_t* nbt, float eps, float momentum,
+                                   int training, float* scale, float* shift, float* saved) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float g = gamma[c], bt = beta[c];
+  if (!training) {          // batch_renorm.py:59: (x - running_mean) / running_std
+    const float rstd = 1.0f / sqrtf(running_var[c] + eps);
+    scale[c] = g * rstd;
+    shift[c] = bt - g * running_mean[c] * rstd;
+    return;
+  }
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < nparts; ++i) { s1 += ws[((int64_t)c * nparts + i) * 2]; s2 += ws[((int64_t)c * nparts + i) * 2 + 1]; }
+  const double mean_d = s1 / count;
+  double var_d = s2 / count - mean_d * mean_d;
+  if (var_d < 0.0) var_d = 0.0;
+  const float b_mean = (float)mean_d, b_var = (float)var_d;
+  const float b_std = sqrtf(b_var + eps);
+  const float run_std = sqrtf(running_var[c] + eps);
+  // batch_renorm.py:41-42: schedules from num_batches_tracked (before the increment)
+  const float nt = (float)nbt[0];
+  const float d_max = fminf(fmaxf(5.0f * (nt - 5000.f) / (25000.f - 5000.f), 0.f), 5.f);
+  const float r_max = 1.0f + fminf(fmaxf(2.0f * (nt - 5000.f) / (40000.f - 5000.f), 0.f), 2.f);
+  float r = b_std / run_std;
+  r = fminf(fmaxf(r, 1.0f / r_max), r_max);
+  float d = (b_mean - running_mean[c]) / run_std;
+  d = fminf(fmaxf(d, -d_max), d_max);
+  const float rstd = 1.0f / b_std;
+  scale[c] = g * r * rstd;
+  shift[c] = bt + g * (d - b_mean * r * rstd);
+  saved[c] = b_mean; saved[C + c] = rstd; saved[2 * C + c] = r; saved[3 * C + c] = d;
+  // batch_renorm.py:54-56 (the "unbiased" factor uses C = channel count)
+  const float unbiased = b_var * (float)C / (float)(C - 1);
+  running_var[c] += momentum * (unbiased - running_var[c]);
+  running_mean[c] += momentum * (b_mean - running_mean[c]);
+}
+
+// ---- backward ----------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void bn_bwd_partial_kernel(
+    const float* x, int64_t sBx, const float* dy, int64_t sBdy, int64_t S, int C, int pre_relu,
+    int post_relu, const float* scale, const float* shift, const float* saved, double* ws) {
+  __shared__ double red[kThreads / 64];
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float* px = x + (int64_t)b * sBx + (int64_t)c * S;
+  const float* pg = dy + (int64_t)b * sBdy + (int64_t)c * S;
+  const float sc = scale[c], sh = shift[c], mu = saved[c], rstd = saved[C + c];
+  double s1 = 0.0, s2 = 0.0;
+  auto one = [&](float xv, float gv) {
+    if (pre_relu) xv = fmaxf(xv, 0.f);
+    if (post_relu && !(xv * sc + sh > 0.f)) gv = 0.f;
+    s1 += (double)gv;
+    s2 += (double)gv * (double)((xv - mu) * rstd);
+  };
+  for_slice<VEC>(block_slice(S),
+                 [&](int64_t s) { const f32x4 a = *reinterpret_cast<const f32x4*>(px + s);
+                                  const f32x4 g = *reinterpret_cast<const f32x4*>(pg + s);
+                                  one(a.x, g.x); one(a.y, g.y); one(a.z, g.z); one(a.w, g.w); },
+                 [&](int64_t s) { one(px[s], pg[s]); });
+  const double t1 = crn_block_sum(s1, red);
+  const double t2 = crn_block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    const int nparts = gridDim.x * gridDim.z;
+    double* o = ws + ((int64_t)c * nparts + (int64_t)b * gridDim.x + blockIdx.x) * 2;
+    o[0] = t1; o[1] = t2;
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
+    const float* x, int64_t sBx, const float* dy, int64_t sBdy, int64_t S, int C, int pre_relu,
+    int post_relu, const float* gamma, const float* scale, const float* shift, const float* saved,
+    const double* ws, int nparts, double count, float* dx, int64_t sBdx, float* dgamma,
+    float* dbeta, int accumulate) {
+  __shared__ float sm[2];
+  const int c = blockIdx.y, b = blockIdx.z;
+  if (threadIdx.x == 0) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < nparts; ++i) { s1 += ws[((int64_t)c * nparts + i) * 2]; s2 += ws[((int64_t)c * nparts + i) * 2 + 1]; }
+    sm[0] = (float)(s1 / count); sm[1] = (float)(s2 / count);
+    if (blockIdx.x == 0 && b == 0) {
+      const float r = saved[2 * C + c], d = saved[3 * C + c];
+      const float dg = (float)(r * s2 + d * s1), db = (float)s1;
+      if (accumulate) { dgamma[c] += dg; dbeta[c] += db; } else { dgamma[c] = dg; dbeta[c] = db; }
+    }
+  }
+  __syncthreads();
+  const float mg = sm[0], mgx = sm[1];
+  const float sc = scale[c], sh = shift[c], mu = saved[c], rstd = saved[C + c];
+  const float k = gamma[c] * saved[2 * C + c] * rstd;
+  const float* px = x + (int64_t)b * sBx + (int64_t)c * S;
+  const float* pg = dy + (int64_t)b * sBdy + (int64_t)c * S;
+  float* po = dx + (int64_t)b * sBdx + (int64_t)c * S;
+  auto one = [&](float xr, float gv) -> float {
+    const float xv = pre_relu ? fmaxf(xr, 0.f) : xr;
+    if (post_relu && !(xv * sc + sh > 0.f)) gv = 0.f;
+    float o = k * (gv - mg - (xv - mu) * rstd * mgx);
+    if (pre_relu && !(xr > 0.f)) o = 0.f;
+    return o;
+  };
+  for_slice<VEC>(block_slice(S),
+                 [&](int64_t s) { const f32x4 a = *reinterpret_cast<const f32x4*>(px + s);
+                                  const f32x4 g = *reinterpret_cast<const f32x4*>(pg + s);
+                                  f32x4 o; o.x = one(a.x, g.x); o.y = one(a.y, g.y);
+                                  o.z = one(a.z, g.z); o.w = one(a.w, g.w);
+                                  *reinterpret_cast<f32x4*>(po + s) = o; },
+                 [&](int64_t s) { po[s] = one(px[s], pg[s]); });
+}
+
+// ---- block tails ---------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void affine_add_relu_kernel(
+    const float* x, const float* scale, const float* shift, const float* r, const float* rscale,
+    const float* rshift, int64_t S, int64_t sBx, int64_t sBr, float* y_pre, int64_t sBpre,
+    float* y, int64_t sBy, int relu) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
+  const float rsc = rscale ? rscale[c] : 1.f, rsh = rshift ? rshift[c] : 0.f;
+  const float* px = x + (int64_t)b * sBx + (int64_t)c * S;
+  const float* pr = r ? r + (int64_t)b * sBr + (int64_t)c * S : nullptr;
+  float* pp = y_pre ? y_pre + (int64_t)b * sBpre + (int64_t)c * S : nullptr;
+  float* py = y ? y + (int64_t)b * sBy + (int64_t)c * S : nullptr;
+  auto one = [&](float xv, float rv) -> float { return xv * sc + sh + (pr ? rv * rsc + rsh : 0.f); };
+  for_slice<VEC>(block_slice(S),
+                 [&](int64_t s) {
+                   const f32x4 a = *reinterpret_cast<const f32x4*>(px + s);
+                   f32x4 q = (f32x4){0.f, 0.f, 0.f, 0.f};
+                   if (pr) q = *reinterpret_cast<const f32x4*>(pr + s);
+                   f32x4 o; o.x = one(a.x, q.x); o.y = one(a.y, q.y); o.z = one(a.z, q.z); o.w = one(a.w, q.w);
+                   if (pp) *reinterpret_cast<f32x4*>(pp + s) = o;
+                   if (py) {
+                     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                     *reinterpret_cast<f32x4*>(py + s) = o;
+                   }
+                 },
+                 [&](int64_t s) {
+                   const float o = one(px[s], pr ? pr[s] : 0.f);
+                   if (pp) pp[s] = o;
+                   if (py) py[s] = relu ? fmaxf(o, 0.f) : o;
+                 });
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void relu_bwd_add_kernel(
+    const float* dy, const float* y_pre, const float* dy2, int64_t S, int64_t sBdy, int64_t sBpre,
+    int64_t sBdy2, float* dx, int64_t sBdx) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float* pg = dy ? dy + (int64_t)b * sBdy + (int64_t)c * S : nullptr;
+  const float* pp = y_pre + (int64_t)b * sBpre + (int64_t)c * S;
+  const float* p2 = dy2 ? dy2 + (int64_t)b * sBdy2 + (int64_t)c * S : nullptr;
+  float* po = dx + (int64_t)b * sBdx + (int64_t)c * S;
+  auto one = [&](float g, float p, float g2) -> float { return (p > 0.f ? g : 0.f) + g2; };
+  for_slice<VEC>(block_slice(S),
+                 [&](int64_t s) {
+                   f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f}, g2 = g;
+                   if (pg) g = *reinterpret_cast<const f32x4*>(pg + s);
+                   const f32x4 p = *reinterpret_cast<const f32x4*>(pp + s);
+                   if (p2) g2 = *reinterpret_cast<const f32x4*>(p2 + s);
+                   f32x4 o; o.x = one(g.x, p.x, g2.x); o.y = one(g.y, p.y, g2.y);
+                   o.z = one(g.z, p.z, g2.z); o.w = one(g.w, p.w, g2.w);
+                   *reinterpret_cast<f32x4*>(po + s) = o;
+                 },
+                 [&](int64_t s) { po[s] = one(pg ? pg[s] : 0.f, pp[s], p2 ? p2[s] : 0.f); });
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void bias_grad_partial_kernel(const float* dy, int64_t S,
+                                                                      int64_t sB, double* ws) {
+  __shared__ double red[kThreads / 64];
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float* p = dy + (int64_t)b * sB + (int64_t)c * S;
+  double s1 = 0.0;
+  for_slice<VEC>(block_slice(S),
+                 [&](int64_t s) { const f32x4 v = *reinterpret_cast<const f32x4*>(p + s);
+                                  s1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w; },
+                 [&](int64_t s) { s1 += (double)p[s]; });
+  const double t1 = crn_block_sum(s1, red);
+  if (threadIdx.x == 0) {
+    const int nparts = gridDim.x * gridDim.z;
+    ws[(int64_t)c * nparts + (int64_t)b * gridDim.x + blockIdx.x] = t1;
+  }
+}
+
+__global__ void bias_grad_final_kernel(const double* ws, int nparts, int C, float* db, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int i = 0; i < nparts; ++i) s += ws[(int64_t)c * nparts + i];
+  if (accumulate) db[c] += (float)s; else db[c] = (float)s;
+}
+
+inline bool vec_ok(int64_t S, std::initializer_list<int64_t> strides, std::initializer_list<const void*> ptrs) {
+  if (S & 3) return false;
+  for (int64_t s : strides) if (s & 3) return false;
+  for (const void* p : ptrs) if (p && ((uintptr_t)p & 15)) return false;
+  return true;
+}
+
+inline int nsplit_for(int64_t S, int C, int B) {
+  // enough blocks to fill 256 CUs x 8, >= 4096 elements per block
+  int64_t want = std::max<int64_t>(1, 2048 / std::max(1, C * B));
+  int64_t maxs = std::max<int64_t>(1, S / 4096);
+  return (int)std::min<int64_t>(std::min(want, maxs), 64);
+}
+
+constexpr int kMaxParts = 64 * 64;   // nsplit(<=64) * B(<=64)
+
+}  // namespace
+
+extern "C" size_t crn_batch_renorm_workspace_bytes(int C) {
+  return (size_t)C * kMaxParts * 2 * sizeof(double);
+}
+
+extern "C" int crn_batch_renorm_stats(const float* x, int B, int C, int64_t S, int64_t sB, int pre_relu,
+                                      const float* gamma, const float* beta, float* running_mean,
+                                      float* running_var, const int64_t* nbt, float eps, float momentum,
+                                      int training, float* scale, float* shift, float* saved,
+                                      double* ws, size_t ws_bytes, crnStream stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (B < 1 || C < 1 || S < 1 || B > 64) return CRN_EINVAL;
+  int nparts = 1;
+  if (training) {
+    const int ns = nsplit_for(S, C, B);
+    nparts = ns * B;
+    if (ws_bytes < (size_t)C * nparts * 2 * sizeof(double)) return CRN_ENOMEM;
+    dim3 grid(ns, C, B);
+    if (vec_ok(S, {sB}, {x}))
+      hipLaunchKernelGGL(bn_partial_kernel<true>, grid, dim3(kThreads), 0, st, x, S, sB, pre_relu, ws);
+    else
+      hipLaunchKernelGGL(bn_partial_kernel<false>, grid, dim3(kThreads), 0, st, x, S, sB, pre_relu, ws);
+    CRN_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(crn_cdiv(C, 128)), dim3(128), 0, st, ws, nparts, C,
+                     (double)B * (double)S, gamma, beta, running_mean, running_var, nbt, eps, momentum,
+                     training, scale, shift, saved);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_batch_renorm_bwd(const float* x, int64_t sB_x, const float* dy, int64_t sB_dy,
+                                    int B, int C, int64_t S, int pre_relu, int post_relu,
+                                    const float* gamma, const float* scale, const float* shift,
+                                    const float* saved, float* dx, int64_t sB_dx, float* dgamma,
+                                    float* dbeta, int accumulate, double* ws, size_t ws_bytes,
+                                    crnStream stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (B < 1 || C < 1 || S < 1 || B > 64) return CRN_EINVAL;
+  const int ns = nsplit_for(S, C, B);
+  const int nparts = ns * B;
+  if (ws_bytes < (size_t)C * nparts * 2 * sizeof(double)) return CRN_ENOMEM;
+  dim3 grid(ns, C, B);
+  const bool v = vec_ok(S, {sB_x, sB_dy, sB_dx}, {x, dy, dx});
+  if (v)
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, grid, dim3(kThreads), 0, st, x, sB_x, dy, sB_dy, S, C,
+                       pre_relu, post_relu, scale, shift, saved, ws);
+  else
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, grid, dim3(kThreads), 0, st, x, sB_x, dy, sB_dy, S, C,
+                       pre_relu, post_relu, scale, shift, saved, ws);
+  CRN_CHECK_LAUNCH();
+  if (v)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(kThreads), 0, st, x, sB_x, dy, sB_dy, S, C,
+                       pre_relu, post_relu, gamma, scale, shift, saved, ws, nparts,
+                       (double)B * (double)S, dx, sB_dx, dgamma, dbeta, accumulate);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(kThreads), 0, st, x, sB_x, dy, sB_dy, S, C,
+                       pre_relu, post_relu, gamma, scale, shift, saved, ws, nparts,
+                       (double)B * (double)S, dx, sB_dx, dgamma, dbeta, accumulate);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_affine_add_relu(const float* x, const float* scale, const float* shift,
+                                   const float* r, const float* rscale, const float* rshift,
+                                   int B, int C, int64_t S, int64_t sB_x, int64_t sB_r,
+                                   float* y_pre, int64_t sB_pre, float* y, int64_t sB_y, int relu,
+                                   crnStream stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (B < 1 || C < 1 || S < 1 || (!y && !y_pre)) return CRN_EINVAL;
+  dim3 grid(nsplit_for(S, C, B), C, B);
+  if (vec_ok(S, {sB_x, r ? sB_r : 0, y_pre ? sB_pre : 0, y ? sB_y : 0}, {x, r, y_pre, y}))
+    hipLaunchKernelGGL(affine_add_relu_kernel<true>, grid, dim3(kThreads), 0, st, x, scale, shift, r, rscale,
+                       rshift, S, sB_x, sB_r, y_pre, sB_pre, y, sB_y, relu);
+  else
+    hipLaunchKernelGGL(affine_add_relu_kernel<false>, grid, dim3(kThreads), 0, st, x, scale, shift, r, rscale,
+                       rshift, S, sB_x, sB_r, y_pre, sB_pre, y, sB_y, relu);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_relu_bwd_add(const float* dy, const float* y_pre, const float* dy2, int B, int C,
+                                int64_t S, int64_t sB_dy, int64_t sB_pre, int64_t sB_dy2, float* dx,
+                                int64_t sB_dx, crnStream stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (B < 1 || C < 1 || S < 1 || !y_pre || !dx) return CRN_EINVAL;
+  dim3 grid(nsplit_for(S, C, B), C, B);
+  if (vec_ok(S, {dy ? sB_dy : 0, sB_pre, dy2 ? sB_dy2 : 0, sB_dx}, {dy, y_pre, dy2, dx}))
+    hipLaunchKernelGGL(relu_bwd_add_kernel<true>, grid, dim3(kThreads), 0, st, dy, y_pre, dy2, S, sB_dy,
+                       sB_pre, sB_dy2, dx, sB_dx);
+  else
+    hipLaunchKernelGGL(relu_bwd_add_kernel<false>, grid, dim3(kThreads), 0, st, dy, y_pre, dy2, S, sB_dy,
+                       sB_pre, sB_dy2, dx, sB_dx);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_bias_grad(const float* dy, int B, int C, int64_t S, int64_t sB, float* db,
+                             int accumulate, double* ws, size_t ws_bytes, crnStream stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (B < 1 || C < 1 || S < 1 || B > 64) return CRN_EINVAL;
+  const int ns = nsplit_for(S, C, B);
+  const int nparts = ns * B;
+  if (ws_bytes < (size_t)C * nparts * sizeof(double)) return CRN_ENOMEM;
+  dim3 grid(ns, C, B);
+  if (vec_ok(S, {sB}, {dy}))
+    hipLaunchKernelGGL(bias_grad_partial_kernel<true>, grid, dim3(kThreads), 0, st, dy, S, sB, ws);
+  else
+    hipLaunchKernelGGL(bias_grad_partial_kernel<false>, grid, dim3(kThreads), 0, st, dy, S, sB, ws);
+  CRN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(bias_grad_final_kernel, dim3(crn_cdiv(C, 128)), dim3(128), 0, st, ws, nparts, C, db,
+                     accumulate);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}

@@ -1,0 +1,301 @@
+// Small HBM-bound kernels around the conv engine: image preprocessing, the
+// stem's BN+ReLU+maxpool, global average, the latent Linear layer, weight
+// (un)packing gathers, Adam.  References cited per kernel.
+#include "crn_common.h"
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+// resnet50.py:189-204: u8 RGB -> f32, flip to BGR, ADD the ImageNet means
+__global__ void preprocess_kernel(const uint8_t* img, int64_t HW, float* out, int64_t total) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int64_t s = e % HW;
+  const int c = (int)((e / HW) % 3);
+  const int64_t b = e / (3 * HW);
+  const float mean = c == 0 ? 103.939f : (c == 1 ? 116.779f : 123.68f);
+  out[e] = (float)img[(b * 3 + (2 - c)) * HW + s] + mean;
+}
+
+// resnet50.py:126-131: BatchRenorm -> ReLU -> ZeroPad2d(1) -> MaxPool2d(3, stride 2)
+__global__ void bn_relu_maxpool_fwd_kernel(const float* x, const float* scale, const float* shift,
+                                           int C, int H, int W, int Ho, int Wo, float* y,
+                                           int32_t* argmax, int64_t total) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int ow = (int)(e % Wo);
+  const int oh = (int)((e / Wo) % Ho);
+  const int64_t bc = e / ((int64_t)Wo * Ho);
+  const int c = (int)(bc % C);
+  const float sc = scale[c], sh = shift[c];
+  const float* p = x + bc * (int64_t)H * W;
+  float best = -INFINITY;
+  int bi = -1;
+  for (int dh = 0; dh < 3; ++dh)
+    for (int dw = 0; dw < 3; ++dw) {
+      const int ih = 2 * oh - 1 + dh, iw = 2 * ow - 1 + dw;
+      float v = 0.f;           // the zero pad
+      int idx = -1;
+      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+        idx = ih * W + iw;
+        v = fmaxf(p[idx] * sc + sh, 0.f);
+      }
+      if (v > best) { best = v; bi = idx; }
+    }
+  y[e] = best;
+  argmax[e] = (best > 0.f) ? bi : -1;   // zero-valued maxima carry no gradient through the ReLU
+}
+
+// gather form of the max-pool backward: deterministic, no atomics, no zero-fill
+__global__ void bn_relu_maxpool_bwd_kernel(const float* dy, const int32_t* argmax, int H, int W,
+                                           int Ho, int Wo, float* dx, int64_t total) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int iw = (int)(e % W);
+  const int ih = (int)((e / W) % H);
+  const int64_t bc = e / ((int64_t)W * H);
+  const int idx = ih * W + iw;
+  const float* g = dy + bc * (int64_t)Ho * Wo;
+  const int32_t* am = argmax + bc * (int64_t)Ho * Wo;
+  float s = 0.f;
+  // windows covering row ih: 2*oh-1 <= ih <= 2*oh+1
+  for (int oh = ih / 2; oh <= (ih + 1) / 2; ++oh)
+    for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow)
+      if (oh < Ho && ow < Wo && am[oh * Wo + ow] == idx) s += g[oh * Wo + ow];
+  dx[e] = s;
+}
+
+// resnet50.py:183: avg = relu(x_pre).mean over H*W ; one wave per (b,c)
+__global__ void relu_mean_fwd_kernel(const float* x, int C, int64_t S, int64_t sB, float* avg, int BC) {
+  const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wid >= BC) return;
+  const int b = wid / C, c = wid % C;
+  const float* p = x + (int64_t)b * sB + (int64_t)c * S;
+  double s = 0.0;
+  for (int64_t i = lane; i < S; i += 64) s += (double)fmaxf(p[i], 0.f);
+  s = crn_wave_sum(s);
+  if (lane == 0) avg[wid] = (float)(s / (double)S);
+}
+
+__global__ void relu_mean_bwd_kernel(const float* x, const float* davg, int C, int64_t S, int64_t sB,
+                                     float* dx, int64_t sBdx, int accumulate, int64_t total) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int64_t s = e % S;
+  const int c = (int)((e / S) % C);
+  const int64_t b = e / (S * C);
+  const float g = x[b * sB + c * S + s] > 0.f ? davg[b * C + c] / (float)S : 0.f;
+  float* o = dx + b * sBdx + c * S + s;
+  *o = accumulate ? *o + g : g;
+}
+
+// nn.Linear (reconstruction_decoder.py:49): one wave per (b,n)
+__global__ void linear_fwd_kernel(const float* x, const float* w, const float* bias, int B, int K,
+                                  int N, float* y, int ldy) {
+  const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wid >= B * N) return;
+  const int b = wid / N, n = wid % N;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += x[(int64_t)b * K + k] * w[(int64_t)n * K + k];
+  s = crn_wave_sum(s);
+  if (lane == 0) y[(int64_t)b * ldy + n] = s + (bias ? bias[n] : 0.f);
+}
+__global__ void linear_bwd_dx_kernel(const float* w, const float* dy, int lddy, int B, int K, int N, float* dx) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= B * K) return;
+  const int b = e / K, k = e % K;
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) s += dy[(int64_t)b * lddy + n] * w[(int64_t)n * K + k];
+  dx[e] = s;
+}
+__global__ void linear_bwd_dw_kernel(const float* x, const float* dy, int lddy, int B, int K, int N,
+                                     float* dw, float* db) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N * K) return;
+  const int n = e / K, k = e % K;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += dy[(int64_t)b * lddy + n] * x[(int64_t)b * K + k];
+  dw[e] = s;
+  if (k == 0 && db) {
+    float t = 0.f;
+    for (int b = 0; b < B; ++b) t += dy[(int64_t)b * lddy + n];
+    db[n] = t;
+  }
+}
+
+__global__ void fill_offset_kernel(float* x, int64_t sB, int64_t S, int c0, const float* offset, int64_t total) {
+  const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int64_t s = e % S;
+  const int j = (int)((e / S) % 3);
+  const int64_t b = e / (3 * S);
+  x[b * sB + (int64_t)(c0 + j) * S + s] = offset[b * 3 + j];
+}
+
+__global__ void gather_kernel(const float* src, const int32_t* idx, float* dst, int64_t n) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t i = idx[e];
+    dst[e] = i >= 0 ? src[i] : 0.f;
+  }
+}
+__global__ void scatter_kernel(const float* src, const int32_t* idx, float* dst, int64_t n, int accumulate) {
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t i = idx[e];
+    if (i >= 0) { if (accumulate) dst[i] += src[e]; else dst[i] = src[e]; }
+  }
+}
+__global__ void add_i64_kernel(int64_t* p, int n, int64_t v) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) p[e] += v;
+}
+
+// torch.optim.Adam (amsgrad=False, weight_decay=0), fp32, float4 per lane
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n4,
+                                                   int64_t n, float lr, float b1, float b2, float eps,
+                                                   float gs, float bc1, float bc2_sqrt) {
+  const float step = lr / bc1;
+  auto one = [&](float& pp, float gg, float& mm, float& vv) {
+    gg *= gs;
+    mm = mm + (1.f - b1) * (gg - mm);
+    vv = b2 * vv + (1.f - b2) * gg * gg;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pp -= step * (mm / denom);
+  };
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float P[4], M[4], V[4], G[4];
+    *reinterpret_cast<f32x4*>(P) = reinterpret_cast<f32x4*>(p)[i];
+    *reinterpret_cast<f32x4*>(M) = reinterpret_cast<f32x4*>(m)[i];
+    *reinterpret_cast<f32x4*>(V) = reinterpret_cast<f32x4*>(v)[i];
+    *reinterpret_cast<f32x4*>(G) = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) one(P[k], G[k], M[k], V[k]);
+    reinterpret_cast<f32x4*>(p)[i] = *reinterpret_cast<f32x4*>(P);
+    reinterpret_cast<f32x4*>(m)[i] = *reinterpret_cast<f32x4*>(M);
+    reinterpret_cast<f32x4*>(v)[i] = *reinterpret_cast<f32x4*>(V);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    if (i < n) one(p[i], g[i], m[i], v[i]);
+  }
+}
+
+inline unsigned nblk(int64_t n, int per = 256) { return (unsigned)std::max<int64_t>(1, (n + per - 1) / per); }
+
+}  // namespace
+
+extern "C" int crn_preprocess_caffe(const uint8_t* img, int B, int H, int W, float* out, crnStream s) {
+  const int64_t total = (int64_t)B * 3 * H * W;
+  hipLaunchKernelGGL(preprocess_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)s, img, (int64_t)H * W, out, total);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_bn_relu_maxpool_fwd(const float* x, const float* scale, const float* shift, int B, int C,
+                                       int H, int W, float* y, int32_t* argmax, crnStream s) {
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)B * C * Ho * Wo;
+  hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)s, x, scale, shift,
+                     C, H, W, Ho, Wo, y, argmax, total);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_bn_relu_maxpool_bwd(const float* dy, const int32_t* argmax, int B, int C, int H, int W,
+                                       float* dx_bn, crnStream s) {
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)B * C * H * W;
+  hipLaunchKernelGGL(bn_relu_maxpool_bwd_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)s, dy, argmax, H, W,
+                     Ho, Wo, dx_bn, total);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_relu_mean_fwd(const float* x_pre, int B, int C, int64_t S, int64_t sB, float* avg, crnStream s) {
+  const int BC = B * C;
+  hipLaunchKernelGGL(relu_mean_fwd_kernel, dim3(nblk((int64_t)BC * 64)), dim3(256), 0, (hipStream_t)s, x_pre, C, S,
+                     sB, avg, BC);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_relu_mean_bwd(const float* x_pre, const float* davg, int B, int C, int64_t S, int64_t sB,
+                                 float* dx, int64_t sB_dx, int accumulate, crnStream s) {
+  const int64_t total = (int64_t)B * C * S;
+  hipLaunchKernelGGL(relu_mean_bwd_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)s, x_pre, davg, C, S, sB,
+                     dx, sB_dx, accumulate, total);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_linear_fwd(const float* x, const float* w, const float* bias, int B, int K, int N, float* y,
+                              int ldy, crnStream s) {
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3(nblk((int64_t)B * N * 64)), dim3(256), 0, (hipStream_t)s, x, w, bias, B,
+                     K, N, y, ldy);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_linear_bwd(const float* x, const float* w, const float* dy, int lddy, int B, int K, int N,
+                              float* dx, float* dw, float* db, crnStream s) {
+  if (dx) {
+    hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(nblk((int64_t)B * K)), dim3(256), 0, (hipStream_t)s, w, dy, lddy, B,
+                       K, N, dx);
+    CRN_CHECK_LAUNCH();
+  }
+  if (dw) {
+    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(nblk((int64_t)N * K)), dim3(256), 0, (hipStream_t)s, x, dy, lddy, B,
+                       K, N, dw, db);
+    CRN_CHECK_LAUNCH();
+  }
+  return CRN_OK;
+}
+
+extern "C" int crn_fill_offset_channels(float* x, int B, int64_t sB, int64_t S, int c0, const float* offset,
+                                        crnStream s) {
+  const int64_t total = (int64_t)B * 3 * S;
+  hipLaunchKernelGGL(fill_offset_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)s, x, sB, S, c0, offset, total);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, crnStream s) {
+  hipLaunchKernelGGL(gather_kernel, dim3(std::min(nblk(n), 4096u)), dim3(256), 0, (hipStream_t)s, src, idx, dst, n);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_scatter_f32(const float* src, const int32_t* idx, float* dst, int64_t n, int accumulate,
+                               crnStream s) {
+  hipLaunchKernelGGL(scatter_kernel, dim3(std::min(nblk(n), 4096u)), dim3(256), 0, (hipStream_t)s, src, idx, dst, n,
+                     accumulate);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_zero_f32(float* p, int64_t n, crnStream s) {
+  CRN_HIP(hipMemsetAsync(p, 0, (size_t)n * 4, (hipStream_t)s));
+  return CRN_OK;
+}
+
+extern "C" int crn_add_i64(int64_t* p, int n, int64_t v, crnStream s) {
+  hipLaunchKernelGGL(add_i64_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)s, p, n, v);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                             float lr, float beta1, float beta2, float eps, float grad_scale, int step,
+                             crnStream s) {
+  if (step < 1 || n < 1) return CRN_EINVAL;
+  if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return CRN_EINVAL;
+  const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
+  const int64_t n4 = n / 4;
+  hipLaunchKernelGGL(adam_kernel, dim3(std::min(nblk(n4), 8192u)), dim3(256), 0, (hipStream_t)s, param, grad, exp_avg,
+                     exp_avg_sq, n4, n, lr, beta1, beta2, eps, grad_scale, (float)bc1, (float)std::sqrt(bc2));
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" const char* crn_version(void) { return "corenet_hip 0.1 (gfx950)"; }

@@ -1,0 +1,229 @@
+/*
+ * corenet_hip.h -- C ABI of libcorenet_hip.so, the MI355X (gfx950) native
+ * implementation of the CoReNet forward/backward hot path.
+ *
+ * Plain C: raw device pointers, explicit sizes/strides, a hipStream_t passed as
+ * void*.  No torch types.  Every entry point returns 0 on success, a negative
+ * CRN_E* code on bad arguments, or a positive hipError_t.
+ *
+ * Each entry point names the reference (google-research/corenet, paths relative
+ * to src/corenet/) interface it replaces.  The Python host in corenet_amd/
+ * mirrors the reference's module API on top of these.
+ */
+#ifndef CORENET_HIP_H_
+#define CORENET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRN_OK 0
+#define CRN_EINVAL (-1)   /* bad argument (shape / alignment / unsupported mode) */
+#define CRN_ENOMEM (-2)   /* workspace too small */
+#define CRN_ENOCONV (-3)  /* iterative kernel did not converge within max rounds */
+
+typedef void* crnStream;  /* hipStream_t */
+
+/* Logical NCDHW view of an fp32 tensor.  element(b,c,d,h,w) lives at
+ *   base + b*sB + (chan_off ? chan_off[c] : c*sC) + d*sD + h*sH + w*sW
+ * chan_off (device int32 table) expresses space-to-depth / depth-to-space
+ * (pixel-shuffle) channel layouts without materialising them.              */
+typedef struct {
+  float* base;
+  int32_t B, C, D, H, W;
+  int64_t sB, sC;
+  const int32_t* chan_off;
+  int32_t sD, sH, sW;
+} crnView;
+
+/* Per-channel affine(+ReLU) applied to the INPUT of a conv while it is staged
+ * into LDS: v = x; if(pre_relu) v=max(v,0); v = v*scale[c]+shift[c];
+ * if(post_relu) v=max(v,0).  Zero padding is applied AFTER the transform
+ * (reference: BatchRenorm/ReLU modules precede the padded conv,
+ * reconstruction_decoder.py:56-60, resnet50.py:62-69).  scale==NULL => identity. */
+typedef struct {
+  const float* scale;
+  const float* shift;
+  int32_t pre_relu, post_relu;
+} crnInTransform;
+
+/* ---------------- convolutions (MFMA fp32 implicit GEMM) -------------------
+ * One stride-1 window correlation covers Conv2d / Conv3d / ConvTranspose3d
+ * forward and data-gradient of the reference (resnet50.py:62-69,95-107,124;
+ * reconstruction_decoder.py:49-95; ray_traced_skip_connection.py:38) through
+ * views + packed weights (corenet_amd/model/conv_geometry.py):
+ *   y[b,n,o] = bias[b*bias_sB+n] + sum_{c,t} T(x)[b,c,o - pad_lo + t] * w[(c*T+t)*Npad + n]
+ * w: packed [Cin][kd*kh*kw][Npad] fp32, Npad multiple of 16.
+ * splits>1 splits the Cin reduction over blocks (atomic accumulate; y is
+ * zeroed first by the call).                                                 */
+int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const float* w, int Npad,
+                 const float* bias, int bias_sB, const crnView* y,
+                 int kd, int kh, int kw, int pd, int ph, int pw,
+                 int splits, int accumulate /* y += result instead of y = result */,
+                 crnStream stream);
+
+/* Weight gradient in the same packed layout:
+ *   dw[(c*T+t)*Npad+n] = sum_{b,o} T(x)[b,c,o-pad_lo+t] * dy[b,n,o]
+ * dw must be zeroed by the caller or zero_first!=0.  Replaces autograd of the
+ * modules above.                                                             */
+int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const crnView* dy,
+                   float* dw, int Npad, int kd, int kh, int kw, int pd, int ph, int pw,
+                   int zero_first, crnStream stream);
+
+/* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0        (weight packing)            */
+int crn_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, crnStream s);
+/* dst[idx[i]] (+)= src[i] for idx[i] >= 0      (gradient un-packing)        */
+int crn_scatter_f32(const float* src, const int32_t* idx, float* dst, int64_t n,
+                    int accumulate, crnStream s);
+/* bias gradient: db[c] = sum_{b,s} dy[b,c,s]  (dy: [B][C][S], batch stride sB) */
+int crn_bias_grad(const float* dy, int B, int C, int64_t S, int64_t sB, float* db,
+                  int accumulate, double* workspace /* crn_batch_renorm_workspace_bytes(C) */,
+                  size_t workspace_bytes, crnStream s);
+
+/* ---------------- BatchRenorm (batch_renorm.py:33-62) ----------------------
+ * x: [B][C][S] with batch stride sB (spatial contiguous).  pre_relu: statistics
+ * of max(x,0) (decoder blocks are ReLU->BN->conv).
+ * train: batch mean / biased var -> r,d clamps from num_batches_tracked,
+ * running-stat update (Q3,Q4); writes per-channel
+ *   scale = gamma*r/sigma_b, shift = beta + gamma*(d - mu*r/sigma_b)
+ * and saves mu, 1/sigma_b, r, d for the backward.  eval: running stats.          */
+int crn_batch_renorm_stats(const float* x, int B, int C, int64_t S, int64_t sB, int pre_relu,
+                           const float* gamma, const float* beta,
+                           float* running_mean, float* running_var,
+                           const int64_t* num_batches_tracked /* read only; see crn_add_i64 */,
+                           float eps, float momentum, int training,
+                           float* scale, float* shift, float* saved /* [4][C] */,
+                           double* workspace, size_t workspace_bytes, crnStream s);
+size_t crn_batch_renorm_workspace_bytes(int C);
+
+/* Backward.  With x' = pre_relu ? max(x,0) : x, xn = (x'-mu)*rstd,
+ * out = x'*scale+shift, g = dy * (post_relu ? out>0 : 1):
+ *   dbeta = sum g ; dgamma = sum g*(r*xn+d)
+ *   dx = gamma*r*rstd*(g - mean(g) - xn*mean(g*xn)) * (pre_relu ? x>0 : 1)
+ * saved = [4][C]: mu, rstd, r, d written by crn_batch_renorm_stats(training).
+ * dgamma/dbeta are accumulated when accumulate != 0.                           */
+int crn_batch_renorm_bwd(const float* x, int64_t sB_x, const float* dy, int64_t sB_dy,
+                         int B, int C, int64_t S, int pre_relu, int post_relu,
+                         const float* gamma, const float* scale, const float* shift,
+                         const float* saved, float* dx, int64_t sB_dx,
+                         float* dgamma, float* dbeta, int accumulate,
+                         double* workspace, size_t workspace_bytes, crnStream s);
+
+/* y = act( x*scale[c]+shift[c] [+ r*rscale[c]+rshift[c]] ) ; optional second
+ * output y_pre (before the final ReLU).  Encoder block tails
+ * (resnet50.py:72-82,109-115).                                               */
+int crn_affine_add_relu(const float* x, const float* scale, const float* shift,
+                        const float* r, const float* rscale, const float* rshift,
+                        int B, int C, int64_t S, int64_t sB_x, int64_t sB_r,
+                        float* y_pre, int64_t sB_pre, float* y, int64_t sB_y,
+                        int relu, crnStream s);
+
+/* dx = dy * (y_pre > 0) [+ dy2]  : backward of the block-tail ReLU, merging the
+ * gradient arriving through the skip connection (dy2 may be NULL).           */
+int crn_relu_bwd_add(const float* dy, const float* y_pre, const float* dy2,
+                     int B, int C, int64_t S, int64_t sB_dy, int64_t sB_pre, int64_t sB_dy2,
+                     float* dx, int64_t sB_dx, crnStream s);
+
+/* ---------------- encoder odds and ends -------------------------------------
+ * preprocess_image_caffe (resnet50.py:189-204): u8 RGB -> f32 BGR + means.    */
+int crn_preprocess_caffe(const uint8_t* img, int B, int H, int W, float* out, crnStream s);
+/* ZeroPad2d(1)+MaxPool2d(3,2) on relu(x*scale+shift)  (resnet50.py:126-131).
+ * argmax (int32 flat input index, -1 when the max is the zero pad) is saved. */
+int crn_bn_relu_maxpool_fwd(const float* x, const float* scale, const float* shift,
+                            int B, int C, int H, int W, float* y, int32_t* argmax, crnStream s);
+int crn_bn_relu_maxpool_bwd(const float* dy, const int32_t* argmax, int B, int C, int H, int W,
+                            float* dx_bn /* grad wrt bn output, relu applied */, crnStream s);
+/* avg[b,c] = mean_s relu(x_pre[b,c,s]) (resnet50.py:183) and its backward,
+ * added into dx.                                                              */
+int crn_relu_mean_fwd(const float* x_pre, int B, int C, int64_t S, int64_t sB, float* avg, crnStream s);
+/* y[b,n] = bias[n] + sum_k x[b,k] w[n,k]  (nn.Linear, reconstruction_decoder.py:49) */
+int crn_linear_fwd(const float* x, const float* w, const float* bias, int B, int K, int N,
+                   float* y, int ldy, crnStream s);
+int crn_linear_bwd(const float* x, const float* w, const float* dy, int lddy, int B, int K, int N,
+                   float* dx, float* dw, float* db, crnStream s);
+/* dx[b,c,s] (+)= (x_pre>0) * davg[b,c] / S                                    */
+int crn_relu_mean_bwd(const float* x_pre, const float* davg, int B, int C, int64_t S, int64_t sB,
+                      float* dx, int64_t sB_dx, int accumulate, crnStream s);
+/* fill channels [c0,c0+3) of a [B][Ctot][S] tensor with offset[b][j]
+ * (reconstruction_decoder.py:108-110)                              */
+int crn_fill_offset_channels(float* x, int B, int64_t sB, int64_t S, int c0,
+                             const float* offset, crnStream s);
+
+/* ---------------- ray-traced skip connection --------------------------------
+ * Gather part of SampleGrid2d.forward (ray_traced_skip_connection.py:91-144):
+ * per voxel centre (x,y,z)+off: p = M*(.,1); u=(px/pw)/2+.5; ix=(int)(u*W);
+ * iy likewise (C truncation); +1 and clamp into the 1-px zero pad;
+ * zero when p.z < 0 (Q7).  map: [B][C][h][w] (batch stride map_sB);
+ * out: channels [0,C) of a view with batch stride out_sB, spatial D*H*W.
+ * matrix: [B][16] row-major layer matrix, offset: [B][3].                     */
+int crn_ray_sample_fwd(const float* map, int64_t map_sB, int B, int C, int h, int w,
+                       const float* matrix, const float* offset,
+                       float* out, int64_t out_sB, int D, int H, int W, crnStream s);
+/* Backward (reference: autograd index_put_(accumulate=True)): dmap must be
+ * zeroed by the caller unless zero_first.                                     */
+int crn_ray_sample_bwd(const float* dout, int64_t dout_sB, int B, int C, int D, int H, int W,
+                       const float* matrix, const float* offset,
+                       float* dmap, int64_t dmap_sB, int h, int w, int zero_first, crnStream s);
+
+/* ---------------- losses (losses.py) ---------------------------------------
+ * kind: 0 iou_fgbg (:64-114), 1 xent_times_iou_agnostic (:144-160),
+ *       2 iou_agnostic (:19-61), 3 xent (:117-141), 4 xent_times_iou_fgbg.
+ * logits [B][C][S] fp32, gt [B][S] int32 labels.  Writes loss[0] and, when
+ * dlogits != NULL, d loss / d logits * grad_scale.
+ * workspace: crn_loss_workspace_bytes(B,C).                                   */
+int crn_loss_fwd_bwd(int kind, const float* logits, const int32_t* gt, int B, int C, int64_t S,
+                     float* loss, float* dlogits, float grad_scale,
+                     void* workspace, size_t workspace_bytes, crnStream s);
+size_t crn_loss_workspace_bytes(int B, int C);
+
+/* ---------------- eval epilogue ---------------------------------------------
+ * argmax over classes + confusion matrix (evaluation_results.py:40-51,
+ * voxel_metrics.py:33-58): cm[gt*K+pred] += 1 (int64).  labels may be NULL.   */
+int crn_argmax_confusion(const float* logits, const int32_t* gt, int B, int C, int64_t S,
+                         int32_t* labels, int64_t* cm, crnStream s);
+
+/* ---------------- optimizer --------------------------------------------------
+ * torch.optim.Adam step (state.py:65; train hot loop pipeline.py:230) on a flat
+ * fp32 parameter slab.  grad_scale multiplies the gradient first (1/world).   */
+int crn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  int64_t n, float lr, float beta1, float beta2, float eps,
+                  float grad_scale, int step, crnStream s);
+
+/* ---------------- ground-truth side -------------------------------------------
+ * fill_inside_voxels_gpu (cc/fill_voxels_gpu.cu:136-171, module.cc:18-29):
+ * grid [N][D][H][W] of dtype (0 f32, 1 u8, 2 i32, 3 f64, 4 i64, 5 i16, 6 i8),
+ * contiguous.  out may alias grid (inplace=True).  Output strictly {0,1}
+ * (SURVEY Q10).  Bit-exact with the reference semantics for every input.     */
+int crn_fill_voxels(const void* grid, void* out, int dtype, int N, int D, int H, int W,
+                    void* workspace, size_t workspace_bytes, crnStream s);
+size_t crn_fill_voxels_workspace_bytes(int N, int D, int H, int W);
+
+/* voxelize_mesh (geometry/voxelization.py:32-164 + shaders/voxelize.{geom,frag}):
+ * triangles [T][3][3] (view space), tri_mesh [T] mesh index per triangle
+ * (misc_util.dynamic_tile), view2voxel [M][16]; grid [M][D][H][W] (or the
+ * (2D+1)(2H+1)(2W+1) sub-grid when sub_grid_side>0) is zeroed then marked.    */
+int crn_voxelize_mesh(const float* triangles, const int32_t* tri_mesh, int T,
+                      const float* view2voxel, int M, int D, int H, int W,
+                      int sub_grid_side, float image_resolution_multiplier,
+                      int conservative, int depth_multiplier, float* grid, crnStream s);
+/* per-scene label merge (batched_example.py:186-196): out[b] = max_m label_m*grid_m
+ * over the meshes [scene_mesh_start[b], scene_mesh_start[b+1]) of scene b, int32.
+ * sub_grid!=0: meshes_grid is the (2D+1)(2H+1)(2W+1) grid and the sub-grid
+ * centres are taken (voxelization.get_sub_grid_centers :167-182).            */
+int crn_merge_labels(const float* meshes_grid, const int32_t* scene_mesh_start,
+                     const int32_t* mesh_label, int B, int D, int H, int W, int sub_grid,
+                     int32_t* out, crnStream s);
+
+/* misc */
+int crn_zero_f32(float* p, int64_t n, crnStream s);
+/* p[i] += v, i < n : steps every BatchRenorm's num_batches_tracked (batch_renorm.py:57) */
+int crn_add_i64(int64_t* p, int n, int64_t v, crnStream s);
+const char* crn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* CORENET_HIP_H_ */
