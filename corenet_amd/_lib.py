@@ -1,0 +1,144 @@
+"""ctypes binding of libcorenet_hip.so (the C ABI declared in include/corenet_hip.h).
+
+There is NO fallback: if the shared library is missing, or a call fails, this
+raises.  PyTorch is used only for device memory (tensor.data_ptr()) and for the
+current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch as t
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("CORENET_HIP_LIB", os.path.join(_HERE, "lib", "libcorenet_hip.so"))
+
+c_i32p = C.POINTER(C.c_int32)
+c_f32p = C.c_void_p     # raw device pointers are passed as integers
+vp = C.c_void_p
+i64 = C.c_int64
+i32 = C.c_int
+f32 = C.c_float
+sz = C.c_size_t
+
+
+class CrnView(C.Structure):
+  """Mirror of crnView (include/corenet_hip.h)."""
+  _fields_ = [("base", vp), ("B", C.c_int32), ("C", C.c_int32), ("D", C.c_int32),
+              ("H", C.c_int32), ("W", C.c_int32), ("sB", i64), ("sC", i64),
+              ("chan_off", vp), ("sD", C.c_int32), ("sH", C.c_int32), ("sW", C.c_int32)]
+
+
+class CrnInTransform(C.Structure):
+  _fields_ = [("scale", vp), ("shift", vp), ("pre_relu", C.c_int32), ("post_relu", C.c_int32)]
+
+
+class HipError(RuntimeError):
+  pass
+
+
+_SIGS = {
+    "crn_conv_fwd": [C.POINTER(CrnView), C.POINTER(CrnInTransform), vp, i32, vp, i32,
+                     C.POINTER(CrnView), i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "crn_conv_wgrad": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32,
+                       i32, i32, i32, i32, i32, i32, i32, vp],
+    "crn_gather_f32": [vp, vp, vp, i64, vp],
+    "crn_scatter_f32": [vp, vp, vp, i64, i32, vp],
+    "crn_bias_grad": [vp, i32, i32, i64, i64, vp, i32, vp, sz, vp],
+    "crn_batch_renorm_stats": [vp, i32, i32, i64, i64, i32, vp, vp, vp, vp, vp, f32, f32, i32,
+                               vp, vp, vp, vp, sz, vp],
+    "crn_batch_renorm_bwd": [vp, i64, vp, i64, i32, i32, i64, i32, i32, vp, vp, vp, vp, vp, i64,
+                             vp, vp, i32, vp, sz, vp],
+    "crn_affine_add_relu": [vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i64, vp, i64, vp, i64, i32, vp],
+    "crn_relu_bwd_add": [vp, vp, vp, i32, i32, i64, i64, i64, i64, vp, i64, vp],
+    "crn_preprocess_caffe": [vp, i32, i32, i32, vp, vp],
+    "crn_bn_relu_maxpool_fwd": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],
+    "crn_bn_relu_maxpool_bwd": [vp, vp, i32, i32, i32, i32, vp, vp],
+    "crn_relu_mean_fwd": [vp, i32, i32, i64, i64, vp, vp],
+    "crn_relu_mean_bwd": [vp, vp, i32, i32, i64, i64, vp, i64, i32, vp],
+    "crn_linear_fwd": [vp, vp, vp, i32, i32, i32, vp, i32, vp],
+    "crn_linear_bwd": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp],
+    "crn_fill_offset_channels": [vp, i32, i64, i64, i32, vp, vp],
+    "crn_ray_sample_fwd": [vp, i64, i32, i32, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp],
+    "crn_ray_sample_bwd": [vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp],
+    "crn_loss_fwd_bwd": [i32, vp, vp, i32, i32, i64, vp, vp, f32, vp, sz, vp],
+    "crn_argmax_confusion": [vp, vp, i32, i32, i64, vp, vp, vp],
+    "crn_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp],
+    "crn_fill_voxels": [vp, vp, i32, i32, i32, i32, i32, vp, sz, vp],
+    "crn_voxelize_mesh": [vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp],
+    "crn_merge_labels": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp],
+    "crn_zero_f32": [vp, i64, vp],
+    "crn_add_i64": [vp, i32, i64, vp],
+}
+_SIZE_FNS = {
+    "crn_batch_renorm_workspace_bytes": [i32],
+    "crn_loss_workspace_bytes": [i32, i32],
+    "crn_fill_voxels_workspace_bytes": [i32, i32, i32, i32],
+}
+ALL_SYMBOLS = list(_SIGS) + list(_SIZE_FNS) + ["crn_version"]
+
+
+class _Lib:
+  def __init__(self, path: str):
+    if not os.path.exists(path):
+      raise ImportError(
+          f"{path} not found: build it with `python -m corenet_amd.build` "
+          "(corenet_amd has no CPU or eager-PyTorch fallback).")
+    self.path = path
+    self.cdll = C.CDLL(path)
+    for name, sig in _SIGS.items():
+      fn = getattr(self.cdll, name)
+      fn.argtypes = sig
+      fn.restype = C.c_int
+      setattr(self, "_" + name, fn)
+    for name, sig in _SIZE_FNS.items():
+      fn = getattr(self.cdll, name)
+      fn.argtypes = sig
+      fn.restype = C.c_size_t
+      setattr(self, name, fn)
+    self.cdll.crn_version.restype = C.c_char_p
+
+  def version(self) -> str:
+    return self.cdll.crn_version().decode()
+
+  def __getattr__(self, name):
+    # crn_xxx(...) with status checking
+    if name.startswith("crn_"):
+      fn = object.__getattribute__(self, "_" + name)
+
+      def call(*args):
+        rc = fn(*args)
+        if rc != 0:
+          raise HipError(f"{name} failed with status {rc}")
+      setattr(self, name, call)
+      return call
+    raise AttributeError(name)
+
+
+_lib: Optional[_Lib] = None
+
+
+def lib() -> _Lib:
+  global _lib
+  if _lib is None:
+    _lib = _Lib(LIB_PATH)
+  return _lib
+
+
+def ptr(x: Optional[t.Tensor]) -> Optional[int]:
+  """Device pointer of a tensor (None -> NULL)."""
+  if x is None:
+    return None
+  return x.data_ptr()
+
+
+def stream() -> int:
+  """The current torch HIP stream as a hipStream_t value."""
+  return t.cuda.current_stream().cuda_stream
+
+
+def require_gpu(x: t.Tensor, what: str = "tensor"):
+  if not x.is_cuda:
+    raise ValueError(f"{what}: Only CUDA(HIP) tensors are supported by the corenet_amd kernels")

@@ -1,0 +1,197 @@
+"""HipBackend: typed Python front of the C ABI (one method per entry point).
+
+All tensors are torch CUDA(HIP) tensors used as device memory; every call goes to
+libcorenet_hip.so on the current torch stream.  No torch compute ops here.
+tests/kernel_contract_emu.py implements the same interface with torch-CPU ops as
+an executable specification of each kernel's contract (test-only).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch as t
+
+from corenet_amd import _lib
+from corenet_amd._lib import CrnInTransform, CrnView, ptr
+from corenet_amd.views import View
+
+_DTYPE_CODE = {t.float32: 0, t.uint8: 1, t.int32: 2, t.float64: 3, t.int64: 4, t.int16: 5, t.int8: 6}
+
+
+def _cview(v: View) -> CrnView:
+  base = v.storage.data_ptr() + 4 * (v.offset - v.storage.storage_offset())
+  return CrnView(base, v.B, v.C, v.D, v.H, v.W, v.sB, v.sC,
+                 ptr(v.chan_off), v.sD, v.sH, v.sW)
+
+
+class Transform:
+  """Host mirror of crnInTransform."""
+  __slots__ = ("scale", "shift", "pre_relu", "post_relu")
+
+  def __init__(self, scale: t.Tensor, shift: t.Tensor, pre_relu=False, post_relu=False):
+    self.scale, self.shift = scale, shift
+    self.pre_relu, self.post_relu = bool(pre_relu), bool(post_relu)
+
+
+def _ctr(tr: Optional[Transform]):
+  if tr is None:
+    return None
+  return C.byref(CrnInTransform(ptr(tr.scale), ptr(tr.shift), int(tr.pre_relu), int(tr.post_relu)))
+
+
+class HipBackend:
+  name = "hip"
+
+  def __init__(self):
+    self.lib = _lib.lib()
+    self._ws = {}
+
+  # -- workspaces -----------------------------------------------------------
+  def workspace(self, key: str, nbytes: int, device) -> t.Tensor:
+    w = self._ws.get((key, str(device)))
+    if w is None or w.numel() < nbytes:
+      w = t.empty(max(nbytes, 1), dtype=t.uint8, device=device)
+      self._ws[(key, str(device))] = w
+    return w
+
+  def _bn_ws(self, Cn: int, device):
+    n = self.lib.crn_batch_renorm_workspace_bytes(Cn)
+    return self.workspace("bn", n, device), n
+
+  # -- convolution engine -----------------------------------------------------
+  def conv_fwd(self, x: View, tr: Optional[Transform], w: t.Tensor, npad: int,
+               bias: Optional[t.Tensor], bias_sB: int, y: View, window, pad_lo,
+               splits: int = 1, accumulate: bool = False):
+    self.lib.crn_conv_fwd(C.byref(_cview(x)), _ctr(tr), ptr(w), npad, ptr(bias), bias_sB,
+                          C.byref(_cview(y)), window[0], window[1], window[2],
+                          pad_lo[0], pad_lo[1], pad_lo[2], splits, int(accumulate), _lib.stream())
+
+  def conv_wgrad(self, x: View, tr: Optional[Transform], dy: View, dw: t.Tensor, npad: int,
+                 window, pad_lo, zero_first: bool = True):
+    self.lib.crn_conv_wgrad(C.byref(_cview(x)), _ctr(tr), C.byref(_cview(dy)), ptr(dw), npad,
+                            window[0], window[1], window[2], pad_lo[0], pad_lo[1], pad_lo[2],
+                            int(zero_first), _lib.stream())
+
+  def gather(self, src: t.Tensor, idx: t.Tensor, dst: t.Tensor):
+    self.lib.crn_gather_f32(ptr(src), ptr(idx), ptr(dst), idx.numel(), _lib.stream())
+
+  def scatter(self, src: t.Tensor, idx: t.Tensor, dst: t.Tensor, accumulate=False):
+    self.lib.crn_scatter_f32(ptr(src), ptr(idx), ptr(dst), idx.numel(), int(accumulate), _lib.stream())
+
+  def bias_grad(self, dy: t.Tensor, B, Cn, S, sB, db: t.Tensor, accumulate=False):
+    ws, n = self._bn_ws(Cn, dy.device)
+    self.lib.crn_bias_grad(ptr(dy), B, Cn, S, sB, ptr(db), int(accumulate), ptr(ws), n, _lib.stream())
+
+  # -- BatchRenorm --------------------------------------------------------------
+  def bn_stats(self, x: t.Tensor, B, Cn, S, sB, pre_relu, gamma, beta, rmean, rvar, nbt, eps,
+               momentum, training, scale, shift, saved):
+    ws, n = self._bn_ws(Cn, x.device)
+    self.lib.crn_batch_renorm_stats(ptr(x), B, Cn, S, sB, int(pre_relu), ptr(gamma), ptr(beta),
+                                    ptr(rmean), ptr(rvar), ptr(nbt), eps, momentum, int(training),
+                                    ptr(scale), ptr(shift), ptr(saved), ptr(ws), n, _lib.stream())
+
+  def bn_bwd(self, x, sB_x, dy, sB_dy, B, Cn, S, pre_relu, post_relu, gamma, scale, shift, saved,
+             dx, sB_dx, dgamma, dbeta, accumulate=False):
+    ws, n = self._bn_ws(Cn, x.device)
+    self.lib.crn_batch_renorm_bwd(ptr(x), sB_x, ptr(dy), sB_dy, B, Cn, S, int(pre_relu),
+                                  int(post_relu), ptr(gamma), ptr(scale), ptr(shift), ptr(saved),
+                                  ptr(dx), sB_dx, ptr(dgamma), ptr(dbeta), int(accumulate),
+                                  ptr(ws), n, _lib.stream())
+
+  def affine_add_relu(self, x, scale, shift, r, rscale, rshift, B, Cn, S, sB_x, sB_r,
+                      y_pre, sB_pre, y, sB_y, relu):
+    self.lib.crn_affine_add_relu(ptr(x), ptr(scale), ptr(shift), ptr(r), ptr(rscale), ptr(rshift),
+                                 B, Cn, S, sB_x, sB_r, ptr(y_pre), sB_pre, ptr(y), sB_y, int(relu),
+                                 _lib.stream())
+
+  def relu_bwd_add(self, dy, y_pre, dy2, B, Cn, S, sB_dy, sB_pre, sB_dy2, dx, sB_dx):
+    self.lib.crn_relu_bwd_add(ptr(dy), ptr(y_pre), ptr(dy2), B, Cn, S, sB_dy, sB_pre, sB_dy2,
+                              ptr(dx), sB_dx, _lib.stream())
+
+  # -- encoder odds and ends -------------------------------------------------------
+  def preprocess(self, img_u8, out):
+    B, _, H, W = img_u8.shape
+    self.lib.crn_preprocess_caffe(ptr(img_u8), B, H, W, ptr(out), _lib.stream())
+
+  def maxpool_fwd(self, x, scale, shift, B, Cn, H, W, y, argmax):
+    self.lib.crn_bn_relu_maxpool_fwd(ptr(x), ptr(scale), ptr(shift), B, Cn, H, W, ptr(y), ptr(argmax),
+                                     _lib.stream())
+
+  def maxpool_bwd(self, dy, argmax, B, Cn, H, W, dx):
+    self.lib.crn_bn_relu_maxpool_bwd(ptr(dy), ptr(argmax), B, Cn, H, W, ptr(dx), _lib.stream())
+
+  def relu_mean_fwd(self, x_pre, B, Cn, S, sB, avg):
+    self.lib.crn_relu_mean_fwd(ptr(x_pre), B, Cn, S, sB, ptr(avg), _lib.stream())
+
+  def relu_mean_bwd(self, x_pre, davg, B, Cn, S, sB, dx, sB_dx, accumulate=False):
+    self.lib.crn_relu_mean_bwd(ptr(x_pre), ptr(davg), B, Cn, S, sB, ptr(dx), sB_dx, int(accumulate),
+                               _lib.stream())
+
+  def linear_fwd(self, x, w, bias, B, K, N, y, ldy):
+    self.lib.crn_linear_fwd(ptr(x), ptr(w), ptr(bias), B, K, N, ptr(y), ldy, _lib.stream())
+
+  def linear_bwd(self, x, w, dy, lddy, B, K, N, dx, dw, db):
+    self.lib.crn_linear_bwd(ptr(x), ptr(w), ptr(dy), lddy, B, K, N, ptr(dx), ptr(dw), ptr(db),
+                            _lib.stream())
+
+  def fill_offset_channels(self, x, B, sB, S, c0, offset):
+    self.lib.crn_fill_offset_channels(ptr(x), B, sB, S, c0, ptr(offset), _lib.stream())
+
+  # -- ray-traced skip ------------------------------------------------------------------
+  def ray_sample_fwd(self, fmap, map_sB, B, Cn, h, w, matrix, offset, out, out_sB, D, H, W):
+    self.lib.crn_ray_sample_fwd(ptr(fmap), map_sB, B, Cn, h, w, ptr(matrix), ptr(offset),
+                                ptr(out), out_sB, D, H, W, _lib.stream())
+
+  def ray_sample_bwd(self, dout, dout_sB, B, Cn, D, H, W, matrix, offset, dmap, dmap_sB, h, w,
+                     zero_first=True):
+    self.lib.crn_ray_sample_bwd(ptr(dout), dout_sB, B, Cn, D, H, W, ptr(matrix), ptr(offset),
+                                ptr(dmap), dmap_sB, h, w, int(zero_first), _lib.stream())
+
+  # -- losses / metrics / optimizer ---------------------------------------------------------
+  def loss_fwd_bwd(self, kind, logits, gt_i32, B, Cn, S, loss, dlogits, grad_scale=1.0):
+    n = self.lib.crn_loss_workspace_bytes(B, Cn)
+    ws = self.workspace("loss", n, logits.device)
+    self.lib.crn_loss_fwd_bwd(kind, ptr(logits), ptr(gt_i32), B, Cn, S, ptr(loss), ptr(dlogits),
+                              grad_scale, ptr(ws), n, _lib.stream())
+
+  def argmax_confusion(self, logits, gt_i32, B, Cn, S, labels, cm):
+    self.lib.crn_argmax_confusion(ptr(logits), ptr(gt_i32), B, Cn, S, ptr(labels), ptr(cm), _lib.stream())
+
+  def adam_step(self, p, g, m, v, n, lr, b1, b2, eps, grad_scale, step):
+    self.lib.crn_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, b1, b2, eps, grad_scale, step,
+                           _lib.stream())
+
+  def add_i64(self, p, n, v):
+    self.lib.crn_add_i64(ptr(p), n, v, _lib.stream())
+
+  def zero(self, x: t.Tensor):
+    self.lib.crn_zero_f32(ptr(x), x.numel(), _lib.stream())
+
+  # -- ground-truth side ------------------------------------------------------------------------
+  def fill_voxels(self, grid: t.Tensor, out: t.Tensor):
+    N, D, H, W = grid.shape
+    n = self.lib.crn_fill_voxels_workspace_bytes(N, D, H, W)
+    ws = self.workspace("fill", n, grid.device)
+    self.lib.crn_fill_voxels(ptr(grid), ptr(out), _DTYPE_CODE[grid.dtype], N, D, H, W, ptr(ws), n,
+                             _lib.stream())
+
+  def voxelize_mesh(self, tri, tri_mesh, view2voxel, M, D, H, W, sub_side, mult, conservative,
+                    depth_mult, grid):
+    self.lib.crn_voxelize_mesh(ptr(tri), ptr(tri_mesh), tri.shape[0], ptr(view2voxel), M, D, H, W,
+                               sub_side, float(mult), int(conservative), depth_mult, ptr(grid),
+                               _lib.stream())
+
+  def merge_labels(self, meshes_grid, scene_start, labels, B, D, H, W, sub_grid, out):
+    self.lib.crn_merge_labels(ptr(meshes_grid), ptr(scene_start), ptr(labels), B, D, H, W,
+                              int(sub_grid), ptr(out), _lib.stream())
+
+
+_default: Optional[HipBackend] = None
+
+
+def default_backend() -> HipBackend:
+  global _default
+  if _default is None:
+    _default = HipBackend()
+  return _default

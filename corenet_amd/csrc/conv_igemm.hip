@@ -416,7 +416,10 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   if (lds_need(NSUB, CC) > 160 * 1024) return CRN_EINVAL;
   g.CC = CC; g.WSP = pad16mod32(g.T * NSUB * 16);
   g.nchunks = crn_cdiv(x->C, CC);
-  if (splits < 1) splits = 1;
+  if (splits < 1) {   // auto: fill the 256 CUs (x2 workgroups) when the output grid alone cannot
+    const int64_t blocks = (int64_t)g.tilesD * g.tilesH * g.tilesW * y->B * crn_cdiv(Npad, NSUB * 16);
+    splits = blocks >= 384 ? 1 : (int)std::min<int64_t>(g.nchunks, crn_cdiv(512, blocks));
+  }
   if (splits > g.nchunks) splits = g.nchunks;
   g.chunks_per_split = crn_cdiv(g.nchunks, splits);
   splits = crn_cdiv(g.nchunks, g.chunks_per_split);

@@ -1,0 +1,188 @@
+"""Maps the reference's Conv2d / Conv3d / ConvTranspose3d layers onto the
+stride-1 window correlation implemented by crn_conv_fwd / crn_conv_wgrad.
+
+Every layer gets two geometries:
+  fwd   : y = corr(T(x), Wf)         (wgrad uses the same geometry)
+  dgrad : dx = corr(dy, Wd)
+each with a window (kd,kh,kw), a low-side padding and an int32 *pack index*
+that gathers the packed weight [Cin_logical][taps][Npad] out of the flat
+parameter buffer (index -1 = structural zero).  The forward pack index doubles
+as the scatter map that un-packs weight gradients (it is injective).
+
+Reference layers: resnet50.py:62-69,95-107,122-124 (Conv2d incl. the stride-2
+1x1 and the 7x7/2 stem), reconstruction_decoder.py:52-95 (Conv3d,
+ConvTranspose3d k=3/7 stride 2, and the 1^3->4^3 stage_1), and
+ray_traced_skip_connection.py:38 (1x1 compress).
+
+Transposed convolution, stride 2 (per dimension, o = 2 i - p + k):
+  write o = 2 q + r.  Forward: i = q + d with k = -2 d + r + p, so the layer is a
+  stride-1 correlation over d in [dmin, dmax] producing 8*Cout "parity" channels
+  (n, rd, rh, rw) that the kernel's output view scatters as a pixel shuffle.
+  Data gradient: q = i + e with k = 2 e + r + p: a stride-1 correlation of the
+  space-to-depth view of dy.  No zero-insertion, no col2im, every MFMA row dense.
+"""
+from __future__ import annotations
+
+import dataclasses
+from typing import Tuple
+
+import numpy as np
+
+
+def pad16(n: int) -> int:
+  return (n + 15) // 16 * 16
+
+
+@dataclasses.dataclass
+class Geom:
+  window: Tuple[int, int, int]
+  pad_lo: Tuple[int, int, int]
+  index: np.ndarray      # int32 [Cin_logical * taps * Npad], -1 = 0
+  cin: int               # logical input channels
+  nout: int              # logical output channels
+  npad: int
+
+  @property
+  def taps(self) -> int:
+    return self.window[0] * self.window[1] * self.window[2]
+
+
+def _k3(shape_tail):
+  k = tuple(shape_tail)
+  return (1,) * (3 - len(k)) + k
+
+
+def conv_fwd(wshape, padding) -> Geom:
+  """nn.Conv{2,3}d(stride 1): W[n, c, t]."""
+  N, Cc = wshape[:2]
+  k = _k3(wshape[2:])
+  T = k[0] * k[1] * k[2]
+  npad = pad16(N)
+  idx = np.full((Cc, T, npad), -1, np.int64)
+  n = np.arange(N)[None, None, :]
+  c = np.arange(Cc)[:, None, None]
+  tt = np.arange(T)[None, :, None]
+  idx[:, :, :N] = (n * Cc + c) * T + tt
+  p = _k3((padding,) * (len(wshape) - 2)) if np.isscalar(padding) else _k3(padding)
+  if len(wshape) == 4:
+    p = (0,) + tuple(p[1:])
+  return Geom(k, tuple(p), idx.reshape(-1).astype(np.int32), Cc, N, npad)
+
+
+def conv_dgrad(wshape, padding) -> Geom:
+  """dx = corr(dy, flip(W)^T) with pad k-1-p."""
+  N, Cc = wshape[:2]
+  k = _k3(wshape[2:])
+  T = k[0] * k[1] * k[2]
+  npad = pad16(Cc)
+  idx = np.full((N, T, npad), -1, np.int64)
+  n = np.arange(N)[:, None, None]
+  c = np.arange(Cc)[None, None, :]
+  tt = np.arange(T)[None, :, None]
+  idx[:, :, :Cc] = (n * Cc + c) * T + (T - 1 - tt)
+  p = _k3((padding,) * (len(wshape) - 2)) if np.isscalar(padding) else _k3(padding)
+  if len(wshape) == 4:
+    p = (0,) + tuple(p[1:])
+  pad = tuple(kk - 1 - pp for kk, pp in zip(k, p))
+  return Geom(k, pad, idx.reshape(-1).astype(np.int32), N, Cc, npad)
+
+
+def _convt_ranges(ks: int, p: int):
+  dmin = -((ks - 1 - p) // 2)          # ceil((p - ks + 1) / 2)
+  dmax = (1 + p) // 2
+  emin = (0 - p) // 2                  # floor
+  emax = (ks - 1 - p) // 2
+  return dmin, dmax, emin, emax
+
+
+def convt_fwd(wshape, padding: int) -> Geom:
+  """nn.ConvTranspose3d(stride 2, output_padding 1): Wt[c, n, kd, kh, kw]."""
+  Cc, N, ks = wshape[0], wshape[1], wshape[2]
+  dmin, dmax, _, _ = _convt_ranges(ks, padding)
+  nw = dmax - dmin + 1
+  npad = pad16(N * 8)
+  wq = np.arange(nw)
+  r = np.arange(2)
+  kk = -2 * (wq[:, None] + dmin) + r[None, :] + padding       # [nw, 2] kernel index per dim
+  valid1 = (kk >= 0) & (kk < ks)
+  c = np.arange(Cc).reshape(Cc, 1, 1, 1, 1, 1, 1, 1)
+  n = np.arange(N).reshape(1, 1, 1, 1, N, 1, 1, 1)
+  kd = kk.reshape(1, nw, 1, 1, 1, 2, 1, 1); vd = valid1.reshape(1, nw, 1, 1, 1, 2, 1, 1)
+  kh = kk.reshape(1, 1, nw, 1, 1, 1, 2, 1); vh = valid1.reshape(1, 1, nw, 1, 1, 1, 2, 1)
+  kw = kk.reshape(1, 1, 1, nw, 1, 1, 1, 2); vw = valid1.reshape(1, 1, 1, nw, 1, 1, 1, 2)
+  flat = (((c * N + n) * ks + kd) * ks + kh) * ks + kw
+  flat = np.where(vd & vh & vw, flat, -1)                      # [C, nw,nw,nw, N, 2,2,2]
+  idx = np.full((Cc, nw ** 3, npad), -1, np.int64)
+  idx[:, :, :N * 8] = flat.reshape(Cc, nw ** 3, N * 8)
+  return Geom((nw,) * 3, (-dmin,) * 3, idx.reshape(-1).astype(np.int32), Cc, N * 8, npad)
+
+
+def convt_dgrad(wshape, padding: int) -> Geom:
+  Cc, N, ks = wshape[0], wshape[1], wshape[2]
+  _, _, emin, emax = _convt_ranges(ks, padding)
+  nw = emax - emin + 1
+  npad = pad16(Cc)
+  wq = np.arange(nw)
+  r = np.arange(2)
+  kk = 2 * (wq[None, :] + emin) + r[:, None] + padding         # [2, nw]
+  valid1 = (kk >= 0) & (kk < ks)
+  n = np.arange(N).reshape(N, 1, 1, 1, 1, 1, 1, 1)
+  c = np.arange(Cc).reshape(1, 1, 1, 1, 1, 1, 1, Cc)
+  kd = kk.reshape(1, 2, 1, 1, nw, 1, 1, 1); vd = valid1.reshape(1, 2, 1, 1, nw, 1, 1, 1)
+  kh = kk.reshape(1, 1, 2, 1, 1, nw, 1, 1); vh = valid1.reshape(1, 1, 2, 1, 1, nw, 1, 1)
+  kw = kk.reshape(1, 1, 1, 2, 1, 1, nw, 1); vw = valid1.reshape(1, 1, 1, 2, 1, 1, nw, 1)
+  flat = (((c * N + n) * ks + kd) * ks + kh) * ks + kw
+  flat = np.where(vd & vh & vw, flat, -1)                      # [N,2,2,2, nw,nw,nw, C]
+  idx = np.full((N * 8, nw ** 3, npad), -1, np.int64)
+  idx[:, :, :Cc] = flat.reshape(N * 8, nw ** 3, Cc)
+  return Geom((nw,) * 3, (-emin,) * 3, idx.reshape(-1).astype(np.int32), N * 8, Cc, npad)
+
+
+def stem_fwd(wshape=(64, 3, 7, 7), padding: int = 3) -> Geom:
+  """ZeroPad2d(3) + Conv2d(7, stride 2) on the 2x2 space-to-depth view of the
+  image: i = 2 o - p + k = 2 q + r  ->  q = o + d, k = 2 d + r + p."""
+  N, Cc, ks, _ = wshape
+  emin, emax = (0 - padding) // 2, (ks - 1 - padding) // 2
+  nw = emax - emin + 1
+  npad = pad16(N)
+  wq = np.arange(nw); r = np.arange(2)
+  kk = 2 * (wq[None, :] + emin) + r[:, None] + padding         # [2, nw]
+  valid1 = (kk >= 0) & (kk < ks)
+  c = np.arange(Cc).reshape(Cc, 1, 1, 1, 1, 1)
+  n = np.arange(N).reshape(1, 1, 1, 1, 1, N)
+  kh = kk.reshape(1, 2, 1, nw, 1, 1); vh = valid1.reshape(1, 2, 1, nw, 1, 1)
+  kw = kk.reshape(1, 1, 2, 1, nw, 1); vw = valid1.reshape(1, 1, 2, 1, nw, 1)
+  flat = ((n * Cc + c) * ks + kh) * ks + kw
+  flat = np.where(vh & vw, flat, -1)                           # [C,2,2, nw,nw, N]
+  idx = np.full((Cc * 4, nw * nw, npad), -1, np.int64)
+  idx[:, :, :N] = flat.reshape(Cc * 4, nw * nw, N)
+  return Geom((1, nw, nw), (0, -emin, -emin), idx.reshape(-1).astype(np.int32), Cc * 4, N, npad)
+
+
+def convt_1to4_fwd(wshape) -> Geom:
+  """stage_1: ConvTranspose3d(k=4) from a 1^3 grid == a dense layer onto the
+  (n, kd, kh, kw) logical channels of the 4^3 output (reconstruction_decoder.py:52-54)."""
+  Cc, N = wshape[0], wshape[1]
+  kv = int(np.prod(wshape[2:]))
+  nn = N * kv
+  npad = pad16(nn)
+  idx = np.full((Cc, 1, npad), -1, np.int64)
+  idx[:, 0, :nn] = np.arange(Cc)[:, None] * nn + np.arange(nn)[None, :]
+  return Geom((1, 1, 1), (0, 0, 0), idx.reshape(-1).astype(np.int32), Cc, nn, npad)
+
+
+def convt_1to4_dgrad(wshape) -> Geom:
+  Cc, N = wshape[0], wshape[1]
+  kv = int(np.prod(wshape[2:]))
+  nn = N * kv
+  npad = pad16(Cc)
+  idx = np.full((nn, 1, npad), -1, np.int64)
+  idx[:, 0, :Cc] = np.arange(Cc)[None, :] * nn + np.arange(nn)[:, None]
+  return Geom((1, 1, 1), (0, 0, 0), idx.reshape(-1).astype(np.int32), nn, Cc, npad)
+
+
+def bias_index(n_ref: int, repeat: int, npad: int) -> np.ndarray:
+  """Packed bias: logical channel j takes bias[j // repeat]."""
+  idx = np.full((npad,), -1, np.int64)
+  idx[:n_ref * repeat] = np.arange(n_ref * repeat) // repeat
+  return idx.astype(np.int32)

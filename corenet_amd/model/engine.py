@@ -1,0 +1,601 @@
+"""CoReNet forward/backward engine: the host-side plan that strings the HIP
+kernels together for core_net.CoreNet (core_net.py:36-43), i.e.
+preprocess -> ResNet-50 encoder (resnet50.py:176-186) -> decoder with
+ray-traced skips (reconstruction_decoder.py:119-152), and the matching
+backward pass.
+
+Python here only allocates buffers (torch), builds views / packed-weight index
+tables, and issues C-ABI calls through a backend object; every arithmetic
+operation on tensors happens inside libcorenet_hip.so.
+
+Dataflow choices (MI355X-first):
+  * all parameters live in ONE flat fp32 slab (one Adam launch, one RCCL
+    all-reduce over one contiguous gradient slab), exposed to PyTorch under the
+    reference's state_dict names/shapes;
+  * conv outputs are stored pre-normalisation; BatchRenorm-apply + ReLU are fused
+    into the consumer conv's LDS staging, so normalised activations never touch HBM;
+  * decoder stages write straight into the concat buffer of the next stage and
+    the ray-sample kernel fills the skip channels in place (no torch.cat copies);
+  * strided / transposed convolutions are views (views.py), never materialised.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch as t
+
+from corenet_amd import views as V
+from corenet_amd.backend import Transform
+from corenet_amd.model import conv_geometry as G
+
+BN_EPS = 1e-3        # resnet50.py:63, reconstruction_decoder.py:44
+BN_MOMENTUM = 0.01   # batch_renorm.py:19
+
+ENC_STAGES = (("stage2", "abc", (64, 64, 256), 1), ("stage3", "abcd", (128, 128, 512), 2),
+              ("stage4", "abcdef", (256, 256, 1024), 2), ("stage5", "abc", (512, 512, 2048), 2))
+LOSS_KINDS = {"iou_fgbg": 0, "xent_times_iou_agnostic": 1, "iou_agnostic": 2, "xent": 3,
+              "xent_times_iou_fgbg": 4}
+
+
+def param_specs(num_classes: int, latent: int = 64, skip_fraction: float = 0.75):
+  """(key, shape, kind) in the reference's state_dict order (core_net.CoreNet)."""
+  specs = []
+  def conv(p, co, ci, *k):
+    specs.append((p + "weight", (co, ci) + tuple(k), "param"))
+    specs.append((p + "bias", (co,), "param"))
+  def bn(p, c):
+    specs.append((p + "weight", (c,), "param"))
+    specs.append((p + "bias", (c,), "param"))
+    specs.append((p + "running_mean", (c,), "buffer"))
+    specs.append((p + "running_var", (c,), "buffer"))
+    specs.append((p + "num_batches_tracked", (), "nbt"))
+  e = "encoder."
+  conv(e + "stage1.conv.", 64, 3, 7, 7)
+  bn(e + "stage1_part2.bn.", 64)
+  cin = 64
+  for name, blocks, f, _ in ENC_STAGES:
+    for bl in blocks:
+      p = f"{e}{name}.{bl}."
+      conv(p + "op_a.conv.", f[0], cin, 1, 1); bn(p + "op_a.bn.", f[0])
+      conv(p + "op_b.conv.", f[1], f[0], 3, 3); bn(p + "op_b.bn.", f[1])
+      conv(p + "op_c.conv.", f[2], f[1], 1, 1); bn(p + "op_c.bn.", f[2])
+      if bl == "a":
+        conv(p + "shortcut.conv.", f[2], cin, 1, 1); bn(p + "shortcut.bn.", f[2])
+      cin = f[2]
+  d = "decoder."
+  specs.append((d + "stage_0.weight", (latent, 2048), "param"))
+  specs.append((d + "stage_0.bias", (latent,), "param"))
+  bn(d + "stage_1.b1.", latent + 3)
+  specs.append((d + "stage_1.t1.weight", (latent + 3, 256, 4, 4, 4), "param"))
+  specs.append((d + "stage_1.t1.bias", (256,), "param"))
+  chans = {2: (256, 128, 3, 3), 3: (128, 64, 5, 7), 4: (64, 32, 5, 7), 5: (32, 16, 5, 7),
+           6: (16, num_classes, 5, 7)}
+  src_c = {2: 2048, 3: 1024, 4: 512, 5: 256}
+  cin = 256
+  for st in range(2, 7):
+    cmid, cout, k1, k2 = chans[st]
+    p = f"{d}stage_{st}."
+    bn(p + "b1.", cin)
+    conv(p + "c1.", cmid, cin, k1, k1, k1)
+    bn(p + "b2.", cmid)
+    specs.append((p + "t1.weight", (cmid, cout, k2, k2, k2), "param"))
+    specs.append((p + "t1.bias", (cout,), "param"))
+    if st in src_c:
+      sk = round(cout * skip_fraction)
+      conv(f"{d}rt_skip_{st}.compress_channels.", sk, src_c[st] + 3, 1, 1)
+      cin = cout + sk
+  return specs
+
+
+class ParamStore:
+  """Flat fp32 parameter / gradient / buffer slabs with reference-named views."""
+
+  def __init__(self, specs, device, dtype=t.float32):
+    self.specs = specs
+    self.device = device
+    self.off: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+    np_, nb, nn = 0, 0, 0
+    for key, shape, kind in specs:
+      n = int(np.prod(shape)) if len(shape) else 1
+      n4 = (n + 3) // 4 * 4        # keep every tensor 16-B aligned inside the slab
+      if kind == "param":
+        self.off[key] = (np_, shape); np_ += n4
+      elif kind == "buffer":
+        self.off[key] = (nb, shape); nb += n4
+      else:
+        self.off[key] = (nn, shape); nn += 1
+    self.kind = {k: kd for k, _, kd in specs}
+    self.params = t.zeros(np_, dtype=dtype, device=device)
+    self.grads = t.zeros(np_, dtype=dtype, device=device)
+    self.buffers = t.zeros(nb, dtype=dtype, device=device)
+    self.nbt = t.zeros(nn, dtype=t.int64, device=device)
+
+  def slab(self, key):
+    return {"param": self.params, "buffer": self.buffers, "nbt": self.nbt}[self.kind[key]]
+
+  def view(self, key, grad=False) -> t.Tensor:
+    o, shape = self.off[key]
+    n = int(np.prod(shape)) if len(shape) else 1
+    slab = self.grads if grad else self.slab(key)
+    return slab[o:o + n].view(shape)
+
+  def offset(self, key) -> int:
+    return self.off[key][0]
+
+
+@dataclasses.dataclass
+class BN:
+  """One BatchRenorm instance bound to the slabs + its per-step work buffers."""
+  C: int
+  gamma: t.Tensor
+  beta: t.Tensor
+  rmean: t.Tensor
+  rvar: t.Tensor
+  nbt: t.Tensor
+  dgamma: t.Tensor
+  dbeta: t.Tensor
+  scale: t.Tensor
+  shift: t.Tensor
+  saved: t.Tensor
+
+
+@dataclasses.dataclass
+class Conv:
+  """One reference conv layer bound to its packed weights."""
+  name: str
+  fwd: G.Geom
+  dgrad: Optional[G.Geom]
+  wf: t.Tensor              # packed forward weight      (slice of eng.packed)
+  wd: Optional[t.Tensor]    # packed data-gradient weight
+  bias: t.Tensor            # packed bias [npad]
+  gwf: t.Tensor             # packed weight gradient     (slice of eng.gpacked)
+  dbias: t.Tensor           # reference-layout bias grad (slice of the grad slab)
+  n_ref: int                # reference output channels (bias length)
+
+
+class Engine:
+  """Builds and runs the forward/backward plan for a fixed per-GPU batch size."""
+
+  def __init__(self, num_classes: int, resolution=(128, 128, 128), latent_channels: int = 64,
+               skip_fraction: float = 0.75, last_upscale_factor: int = 2, device="cuda",
+               backend=None, dtype=t.float32):
+    if tuple(resolution) != (128, 128, 128) or last_upscale_factor != 2:
+      # the reference decoder only runs at 128^3 with factor 2
+      raise ValueError("the CoReNet decoder is only defined for resolution 128^3, "
+                       "last_upscale_factor 2 (reconstruction_decoder.py:38-54,93-95)")
+    if backend is None:
+      from corenet_amd.backend import default_backend
+      backend = default_backend()
+    self.be = backend
+    # fp32 is the only dtype of the HIP kernels; float64 exists so that the CPU
+    # contract emulator (tests/) can check the host wiring far below fp32 noise.
+    assert dtype == t.float32 or getattr(backend, "name", "") == "emu"
+    self.dtype = dtype
+    self.device = t.device(device)
+    self.num_classes = num_classes
+    self.latent = latent_channels
+    self.resolution = tuple(resolution)
+    self.specs = param_specs(num_classes, latent_channels, skip_fraction)
+    self.store = ParamStore(self.specs, self.device, dtype)
+    self.skip_ch = {2: round(128 * skip_fraction), 3: round(64 * skip_fraction),
+                    4: round(32 * skip_fraction), 5: round(16 * skip_fraction)}
+    self._build_layers()
+    self.plans: Dict[int, "Plan"] = {}
+    self.adam_m: Optional[t.Tensor] = None
+    self.adam_v: Optional[t.Tensor] = None
+    self.adam_t = 0
+    self.weights_dirty = True
+
+  # ------------------------------------------------------------------ layers
+  def _bn(self, prefix: str) -> BN:
+    s = self.store
+    c = s.off[prefix + "weight"][1][0]
+    dev = self.device
+    return BN(c, s.view(prefix + "weight"), s.view(prefix + "bias"), s.view(prefix + "running_mean"),
+              s.view(prefix + "running_var"), s.view(prefix + "num_batches_tracked"),
+              s.view(prefix + "weight", grad=True), s.view(prefix + "bias", grad=True),
+              t.zeros(c, device=dev, dtype=self.dtype), t.zeros(c, device=dev, dtype=self.dtype),
+              t.zeros(4 * c, device=dev, dtype=self.dtype))
+
+  def _build_layers(self):
+    s = self.store
+    self.convs: Dict[str, Conv] = {}
+    self.bns: Dict[str, BN] = {}
+    reg: List[Tuple[str, G.Geom, Optional[G.Geom], int, int]] = []   # name, fwd, dgrad, repeat, nref
+
+    def add(name, fwd, dgrad, repeat=1):
+      nref = s.off[name + "bias"][1][0]
+      reg.append((name, fwd, dgrad, repeat, nref))
+
+    for key, shape, kind in self.specs:
+      if kind != "param" or not key.endswith("weight") or len(shape) < 4:
+        if key.endswith("running_mean"):
+          p = key[:-len("running_mean")]
+          self.bns[p] = self._bn(p)
+        continue
+      name = key[:-len("weight")]
+      if name == "encoder.stage1.conv.":
+        add(name, G.stem_fwd(shape, 3), None)
+      elif name == "decoder.stage_1.t1.":
+        add(name, G.convt_1to4_fwd(shape), G.convt_1to4_dgrad(shape), repeat=64)
+      elif ".t1." in name:
+        p = 1 if shape[2] == 3 else 3
+        add(name, G.convt_fwd(shape, p), G.convt_dgrad(shape, p), repeat=8)
+      else:
+        p = shape[-1] // 2
+        add(name, G.conv_fwd(shape, p), G.conv_dgrad(shape, p))
+    # one gather builds every packed weight / bias from the flat parameter slab
+    idx_parts, sizes = [], []
+    for name, fwd, dgrad, repeat, nref in reg:
+      wo, bo = s.offset(name + "weight"), s.offset(name + "bias")
+      def shift(ix, o):
+        return np.where(ix >= 0, ix.astype(np.int64) + o, -1)
+      parts = [shift(fwd.index, wo), shift(G.bias_index(nref, repeat, fwd.npad), bo)]
+      if dgrad is not None:
+        parts.append(shift(dgrad.index, wo))
+      idx_parts.append(parts)
+    flat = np.concatenate([p for parts in idx_parts for p in parts])
+    assert flat.max() < 2 ** 31
+    self.pack_index = t.as_tensor(flat.astype(np.int32), device=self.device)
+    self.packed = t.zeros(flat.shape[0], dtype=self.dtype, device=self.device)
+    gsize = sum(len(parts[0]) for parts in idx_parts)
+    self.gpacked = t.zeros(gsize, dtype=self.dtype, device=self.device)
+    self.gscatter_index = t.as_tensor(
+        np.concatenate([parts[0] for parts in idx_parts]).astype(np.int32), device=self.device)
+    po, go = 0, 0
+    for (name, fwd, dgrad, repeat, nref), parts in zip(reg, idx_parts):
+      nwf, nb = len(parts[0]), len(parts[1])
+      wf = self.packed[po:po + nwf]; po += nwf
+      bias = self.packed[po:po + nb]; po += nb
+      wd = None
+      if dgrad is not None:
+        wd = self.packed[po:po + len(parts[2])]; po += len(parts[2])
+      gwf = self.gpacked[go:go + nwf]; go += nwf
+      self.convs[name] = Conv(name, fwd, dgrad, wf, wd, bias, gwf,
+                              s.view(name + "bias", grad=True), nref)
+
+  def pack_weights(self):
+    """flat parameter slab -> packed kernel layouts (1 launch)."""
+    self.be.gather(self.store.params, self.pack_index, self.packed)
+    self.weights_dirty = False
+
+  # -------------------------------------------------------------------- plans
+  def plan(self, batch: int) -> "Plan":
+    p = self.plans.get(batch)
+    if p is None:
+      p = Plan(self, batch)
+      self.plans[batch] = p
+    return p
+
+  # ----------------------------------------------------------------- optimizer
+  def adam_step(self, lr: float, eps: float, betas=(0.9, 0.999), grad_scale: float = 1.0):
+    """torch.optim.Adam step on the whole parameter slab (state.py:65, pipeline.py:230)."""
+    if self.adam_m is None:
+      self.adam_m = t.zeros_like(self.store.params)
+      self.adam_v = t.zeros_like(self.store.params)
+    self.adam_t += 1
+    self.be.adam_step(self.store.params, self.store.grads, self.adam_m, self.adam_v,
+                      self.store.params.numel(), lr, betas[0], betas[1], eps, grad_scale, self.adam_t)
+    self.weights_dirty = True
+
+
+class Plan:
+  """Buffers + the explicit forward / backward sequences for one batch size."""
+
+  def __init__(self, eng: Engine, B: int):
+    self.eng, self.B = eng, B
+    self.be = eng.be
+    dev = eng.device
+    self.dev = dev
+    f = lambda *shape: t.zeros(*shape, dtype=eng.dtype, device=dev)
+    self.img = f(B, 3, 256, 256)
+    self.y1 = f(B, 64, 128, 128)
+    self.gy1 = f(B, 64, 128, 128); self.gy1b = f(B, 64, 128, 128)
+    self.p1 = f(B, 64, 64, 64)
+    self.p1_arg = t.zeros(B, 64, 64, 64, dtype=t.int32, device=dev)
+    # encoder block buffers
+    self.blocks = []
+    cin, hw = 64, 64
+    for name, blocks, filt, stride in ENC_STAGES:
+      for bl in blocks:
+        st = stride if bl == "a" else 1
+        ho = hw // st
+        blk = dict(prefix=f"encoder.{name}.{bl}.", cin=cin, f=filt, stride=st, hin=hw, h=ho,
+                   down=(bl == "a"), final=(bl == blocks[-1]), stage=name)
+        blk["ya"] = f(B, filt[0], ho, ho); blk["yb"] = f(B, filt[1], ho, ho); blk["yc"] = f(B, filt[2], ho, ho)
+        if blk["down"]:
+          blk["ys"] = f(B, filt[2], ho, ho)
+        blk["out"] = f(B, filt[2], ho, ho)
+        # gradients
+        blk["gpre"] = f(B, filt[2], ho, ho); blk["gyc"] = f(B, filt[2], ho, ho)
+        blk["gab"] = f(B, filt[1], ho, ho); blk["gyb"] = f(B, filt[1], ho, ho)
+        blk["gaa"] = f(B, filt[0], ho, ho); blk["gya"] = f(B, filt[0], ho, ho)
+        if blk["down"]:
+          blk["gys"] = f(B, filt[2], ho, ho)
+          blk["gin"] = f(B, cin, hw, hw)
+        self.blocks.append(blk)
+        cin, hw = filt[2], ho
+    # stage-final pre-ReLU features + the 3 offset channels (Q6), and their grads
+    self.feat = {"stage2": f(B, 256 + 3, 64, 64), "stage3": f(B, 512 + 3, 32, 32),
+                 "stage4": f(B, 1024 + 3, 16, 16), "stage5": f(B, 2048 + 3, 8, 8)}
+    self.gfeat = {k: t.zeros_like(v) for k, v in self.feat.items()}
+    self.avg = f(B, 2048); self.gavg = f(B, 2048)
+    L = eng.latent
+    self.z0 = f(B, L + 3); self.gz0 = f(B, L + 3); self.gv0 = f(B, L + 3)
+    # decoder: concat buffers U_k (input of stage k), mid tensors W_k
+    C = eng.num_classes
+    sk = eng.skip_ch
+    self.dec = {2: dict(cin=256, cmid=256, cout=128, r=4), 3: dict(cin=128 + sk[2], cmid=128, cout=64, r=8),
+                4: dict(cin=64 + sk[3], cmid=64, cout=32, r=16), 5: dict(cin=32 + sk[4], cmid=32, cout=16, r=32),
+                6: dict(cin=16 + sk[5], cmid=16, cout=C, r=64)}
+    for k, d in self.dec.items():
+      r = d["r"]
+      d["u"] = f(B, d["cin"], r, r, r); d["gu"] = f(B, d["cin"], r, r, r)
+      d["w"] = f(B, d["cmid"], r, r, r); d["gw"] = f(B, d["cmid"], r, r, r)
+      d["gv1"] = f(B, d["cin"], r, r, r); d["gv2"] = f(B, d["cmid"], r, r, r)
+    self.logits = f(B, C, 128, 128, 128)
+    self.glogits = f(B, C, 128, 128, 128)
+    self.skip_src = {2: "stage5", 3: "stage4", 4: "stage3", 5: "stage2"}
+    self.skip_hw = {2: 8, 3: 16, 4: 32, 5: 64}
+    self.smap = {k: f(B, sk[k], self.skip_hw[k], self.skip_hw[k]) for k in sk}
+    self.gsmap = {k: t.zeros_like(v) for k, v in self.smap.items()}
+    self.layer_mats = f(4, B, 16)
+    self.layer_scales = t.tensor([[128.0 / (2 * self.dec[k]["r"])] * 3 + [1.0] for k in (2, 3, 4, 5)],
+                                 dtype=eng.dtype, device=dev).reshape(4, 1, 1, 4)
+    self.offset = f(B, 3)
+    self.loss = f(1)
+    self.gt = t.zeros(B, 128, 128, 128, dtype=t.int32, device=dev)
+
+  # ------------------------------------------------------------------ helpers
+  def _stats(self, bn: BN, x: t.Tensor, S: int, sB: int, pre_relu: bool, training: bool):
+    self.be.bn_stats(x, self.B, bn.C, S, sB, pre_relu, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.nbt,
+                     BN_EPS, BN_MOMENTUM, training, bn.scale, bn.shift, bn.saved)
+
+  def _conv(self, cv: Conv, x: V.View, tr, y: V.View, accumulate=False):
+    g = cv.fwd
+    self.be.conv_fwd(x, tr, cv.wf, g.npad, cv.bias, 0, y, g.window, g.pad_lo, 0, accumulate)
+
+  def _dgrad(self, cv: Conv, dy: V.View, dx: V.View, accumulate=False):
+    g = cv.dgrad
+    self.be.conv_fwd(dy, None, cv.wd, g.npad, None, 0, dx, g.window, g.pad_lo, 0, accumulate)
+
+  def _wgrad(self, cv: Conv, x: V.View, tr, dy: V.View):
+    g = cv.fwd
+    self.be.conv_wgrad(x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False)
+
+  def _bias_grad(self, cv: Conv, dy: t.Tensor, S: int, sB: int):
+    self.be.bias_grad(dy, self.B, cv.n_ref, S, sB, cv.dbias)
+
+  # ------------------------------------------------------------------ forward
+  def forward(self, image_u8: t.Tensor, v2s: t.Tensor, offset: t.Tensor, training: bool) -> t.Tensor:
+    eng, be, B = self.eng, self.be, self.B
+    if eng.weights_dirty:
+      eng.pack_weights()
+    cv, bn = eng.convs, eng.bns
+    self.training = training
+    self.offset.copy_(offset)
+    # layer matrices v2s @ scale(128 / r) for the four skip grids (reconstruction_decoder.py:111-116)
+    v = v2s.to(self.layer_mats.dtype).reshape(1, B, 4, 4)
+    self.layer_mats.copy_((v * self.layer_scales).reshape(4, B, 16))    # exact: column scaling
+    be.preprocess(image_u8, self.img)
+    # stem (resnet50.py:122-131)
+    c1 = cv["encoder.stage1.conv."]
+    self._conv(c1, V.space_to_depth_view(V.view_of(self.img), (1, 2, 2)), None, V.view_of(self.y1))
+    b1 = bn["encoder.stage1_part2.bn."]
+    self._stats(b1, self.y1, 128 * 128, 64 * 128 * 128, False, training)
+    be.maxpool_fwd(self.y1, b1.scale, b1.shift, B, 64, 128, 128, self.p1, self.p1_arg)
+    cur = self.p1
+    for blk in self.blocks:
+      cur = self._block_fwd(blk, cur, training)
+    f5 = self.feat["stage5"]
+    be.relu_mean_fwd(f5, B, 2048, 64, f5.stride(0), self.avg)
+    for k in ("stage2", "stage3", "stage4", "stage5"):
+      ft = self.feat[k]
+      be.fill_offset_channels(ft, B, ft.stride(0), ft.shape[2] * ft.shape[3], ft.shape[1] - 3, self.offset)
+    # decoder (reconstruction_decoder.py:136-151)
+    L = eng.latent
+    s = eng.store
+    be.linear_fwd(self.avg, s.view("decoder.stage_0.weight"), s.view("decoder.stage_0.bias"),
+                  B, 2048, L, self.z0, L + 3)
+    be.fill_offset_channels(self.z0, B, L + 3, 1, L, self.offset)
+    b = bn["decoder.stage_1.b1."]
+    self._stats(b, self.z0, 1, L + 3, True, training)
+    zv = V.view_of(self.z0.view(B, L + 3, 1, 1, 1))
+    u2 = self.dec[2]["u"]
+    self._conv(cv["decoder.stage_1.t1."], zv, Transform(b.scale, b.shift, pre_relu=True),
+               V.flat_channel_view(V.view_of(u2)))
+    for k in range(2, 7):
+      d = self.dec[k]
+      r, S = d["r"], d["r"] ** 3
+      p = f"decoder.stage_{k}."
+      b1_, b2_ = bn[p + "b1."], bn[p + "b2."]
+      self._stats(b1_, d["u"], S, d["cin"] * S, True, training)
+      self._conv(cv[p + "c1."], V.view_of(d["u"]), Transform(b1_.scale, b1_.shift, pre_relu=True),
+                 V.view_of(d["w"]))
+      self._stats(b2_, d["w"], S, d["cmid"] * S, True, training)
+      out = self.dec[k + 1]["u"] if k < 6 else self.logits
+      ov = V.space_to_depth_view(V.view_of(out).channels(0, d["cout"]), (2, 2, 2))
+      self._conv(cv[p + "t1."], V.view_of(d["w"]), Transform(b2_.scale, b2_.shift, pre_relu=True), ov)
+      if k < 6:
+        ft = self.feat[self.skip_src[k]]
+        hw = self.skip_hw[k]
+        self._conv(cv[f"decoder.rt_skip_{k}.compress_channels."], V.view_of(ft), None,
+                   V.view_of(self.smap[k]))
+        ro = 2 * r
+        be.ray_sample_fwd(self.smap[k], self.smap[k].stride(0), B, eng.skip_ch[k], hw, hw,
+                          self.layer_mats[k - 2], self.offset,
+                          out[:, d["cout"]:], out.stride(0), ro, ro, ro)
+    if training:
+      be.add_i64(eng.store.nbt, eng.store.nbt.numel(), 1)     # batch_renorm.py:57
+    return self.logits
+
+  def _block_fwd(self, blk, cur: t.Tensor, training: bool) -> t.Tensor:
+    eng, be, B = self.eng, self.be, self.B
+    cv, bn = eng.convs, eng.bns
+    p = blk["prefix"]
+    h = blk["h"]; S = h * h
+    f1, f2, f3 = blk["f"]
+    xin = V.view_of(cur)
+    if blk["stride"] == 2:
+      xin = V.strided_view(xin, (1, 2, 2))
+    ba, bb, bc = bn[p + "op_a.bn."], bn[p + "op_b.bn."], bn[p + "op_c.bn."]
+    self._conv(cv[p + "op_a.conv."], xin, None, V.view_of(blk["ya"]))
+    self._stats(ba, blk["ya"], S, f1 * S, False, training)
+    self._conv(cv[p + "op_b.conv."], V.view_of(blk["ya"]), Transform(ba.scale, ba.shift, post_relu=True),
+               V.view_of(blk["yb"]))
+    self._stats(bb, blk["yb"], S, f2 * S, False, training)
+    self._conv(cv[p + "op_c.conv."], V.view_of(blk["yb"]), Transform(bb.scale, bb.shift, post_relu=True),
+               V.view_of(blk["yc"]))
+    self._stats(bc, blk["yc"], S, f3 * S, False, training)
+    if blk["final"]:
+      pre, sB_pre = self.feat[blk["stage"]], self.feat[blk["stage"]].stride(0)
+    else:
+      pre, sB_pre = None, 0
+    if blk["down"]:
+      bs = bn[p + "shortcut.bn."]
+      self._conv(cv[p + "shortcut.conv."], xin, None, V.view_of(blk["ys"]))
+      self._stats(bs, blk["ys"], S, f3 * S, False, training)
+      be.affine_add_relu(blk["yc"], bc.scale, bc.shift, blk["ys"], bs.scale, bs.shift, B, f3, S,
+                         f3 * S, f3 * S, pre, sB_pre, blk["out"], f3 * S, True)
+    else:
+      be.affine_add_relu(blk["yc"], bc.scale, bc.shift, cur, None, None, B, f3, S,
+                         f3 * S, f3 * S, pre, sB_pre, blk["out"], f3 * S, True)
+    blk["in"] = cur
+    return blk["out"]
+
+  # ------------------------------------------------------------------ backward
+  def backward(self, glogits: t.Tensor):
+    """Fills eng.store.grads with d loss / d params given d loss / d logits."""
+    eng, be, B = self.eng, self.be, self.B
+    cv, bn = eng.convs, eng.bns
+    assert self.training, "backward needs a training-mode forward"
+    be.zero(eng.gpacked)
+    L = eng.latent
+    g_out = glogits
+    for k in range(6, 1, -1):
+      d = self.dec[k]
+      r, S = d["r"], d["r"] ** 3
+      ro, So = 2 * r, (2 * r) ** 3
+      p = f"decoder.stage_{k}."
+      b1_, b2_ = bn[p + "b1."], bn[p + "b2."]
+      ctot = g_out.shape[1]
+      if k < 6:    # ray-traced skip: scatter-add, compress conv grads
+        hw = self.skip_hw[k]
+        ns = eng.skip_ch[k]
+        be.ray_sample_bwd(g_out[:, d["cout"]:], g_out.stride(0), B, ns, ro, ro, ro,
+                          self.layer_mats[k - 2], self.offset, self.gsmap[k], self.gsmap[k].stride(0),
+                          hw, hw, True)
+        cs = cv[f"decoder.rt_skip_{k}.compress_channels."]
+        ft = self.feat[self.skip_src[k]]
+        self._wgrad(cs, V.view_of(ft), None, V.view_of(self.gsmap[k]))
+        self._bias_grad(cs, self.gsmap[k], hw * hw, ns * hw * hw)
+        self._dgrad(cs, V.view_of(self.gsmap[k]), V.view_of(self.gfeat[self.skip_src[k]]))
+      ct = cv[p + "t1."]
+      gv = V.space_to_depth_view(V.view_of(g_out).channels(0, d["cout"]), (2, 2, 2))
+      tr2 = Transform(b2_.scale, b2_.shift, pre_relu=True)
+      self._wgrad(ct, V.view_of(d["w"]), tr2, gv)
+      self._bias_grad(ct, g_out, So, ctot * So)
+      self._dgrad(ct, gv, V.view_of(d["gv2"]))
+      be.bn_bwd(d["w"], d["cmid"] * S, d["gv2"], d["cmid"] * S, B, d["cmid"], S, True, False,
+                b2_.gamma, b2_.scale, b2_.shift, b2_.saved, d["gw"], d["cmid"] * S, b2_.dgamma, b2_.dbeta)
+      cc = cv[p + "c1."]
+      tr1 = Transform(b1_.scale, b1_.shift, pre_relu=True)
+      self._wgrad(cc, V.view_of(d["u"]), tr1, V.view_of(d["gw"]))
+      self._bias_grad(cc, d["gw"], S, d["cmid"] * S)
+      self._dgrad(cc, V.view_of(d["gw"]), V.view_of(d["gv1"]))
+      be.bn_bwd(d["u"], d["cin"] * S, d["gv1"], d["cin"] * S, B, d["cin"], S, True, False,
+                b1_.gamma, b1_.scale, b1_.shift, b1_.saved, d["gu"], d["cin"] * S, b1_.dgamma, b1_.dbeta)
+      g_out = d["gu"]
+    # stage_1 / stage_0
+    c1 = cv["decoder.stage_1.t1."]
+    b = bn["decoder.stage_1.b1."]
+    zv = V.view_of(self.z0.view(B, L + 3, 1, 1, 1))
+    gv = V.flat_channel_view(V.view_of(g_out))
+    self._wgrad(c1, zv, Transform(b.scale, b.shift, pre_relu=True), gv)
+    self._bias_grad(c1, g_out, 64, 256 * 64)
+    self._dgrad(c1, gv, V.view_of(self.gv0.view(B, L + 3, 1, 1, 1)))
+    be.bn_bwd(self.z0, L + 3, self.gv0, L + 3, B, L + 3, 1, True, False, b.gamma, b.scale, b.shift,
+              b.saved, self.gz0, L + 3, b.dgamma, b.dbeta)
+    s = eng.store
+    be.linear_bwd(self.avg, s.view("decoder.stage_0.weight"), self.gz0, L + 3, B, 2048, L, self.gavg,
+                  s.view("decoder.stage_0.weight", grad=True), s.view("decoder.stage_0.bias", grad=True))
+    # encoder
+    f5, g5 = self.feat["stage5"], self.gfeat["stage5"]
+    last = self.blocks[-1]
+    be.relu_mean_bwd(f5, self.gavg, B, 2048, 64, f5.stride(0), last["gpre"], 2048 * 64, False)
+    be.affine_add_relu(last["gpre"], None, None, g5, None, None, B, 2048, 64, 2048 * 64, g5.stride(0),
+                       None, 0, last["gpre"], 2048 * 64, False)
+    g_in = None          # gradient wrt the block's output (post-ReLU), None for the last block
+    for blk in reversed(self.blocks):
+      g_in = self._block_bwd(blk, g_in)
+    # stem: g_in = d p1
+    b1 = bn["encoder.stage1_part2.bn."]
+    be.maxpool_bwd(g_in, self.p1_arg, B, 64, 128, 128, self.gy1)
+    S1 = 128 * 128
+    be.bn_bwd(self.y1, 64 * S1, self.gy1, 64 * S1, B, 64, S1, False, False, b1.gamma, b1.scale, b1.shift,
+              b1.saved, self.gy1b, 64 * S1, b1.dgamma, b1.dbeta)
+    cs = cv["encoder.stage1.conv."]
+    self._wgrad(cs, V.space_to_depth_view(V.view_of(self.img), (1, 2, 2)), None, V.view_of(self.gy1b))
+    self._bias_grad(cs, self.gy1b, S1, 64 * S1)
+    # packed weight grads -> reference layout inside the flat grad slab (1 launch)
+    be.scatter(eng.gpacked, eng.gscatter_index, eng.store.grads, False)
+
+  def _block_bwd(self, blk, g_out: Optional[t.Tensor]) -> t.Tensor:
+    eng, be, B = self.eng, self.be, self.B
+    cv, bn = eng.convs, eng.bns
+    p = blk["prefix"]
+    h = blk["h"]; S = h * h
+    f1, f2, f3 = blk["f"]
+    ba, bb, bc = bn[p + "op_a.bn."], bn[p + "op_b.bn."], bn[p + "op_c.bn."]
+    gpre = blk["gpre"]
+    if g_out is not None:
+      if blk["final"]:
+        ft, gf = self.feat[blk["stage"]], self.gfeat[blk["stage"]]
+        be.relu_bwd_add(g_out, ft, gf, B, f3, S, f3 * S, ft.stride(0), gf.stride(0), gpre, f3 * S)
+      else:
+        be.relu_bwd_add(g_out, blk["out"], None, B, f3, S, f3 * S, f3 * S, 0, gpre, f3 * S)
+    # else: gpre already holds d pre (last block of the encoder)
+    be.bn_bwd(blk["yc"], f3 * S, gpre, f3 * S, B, f3, S, False, False, bc.gamma, bc.scale, bc.shift,
+              bc.saved, blk["gyc"], f3 * S, bc.dgamma, bc.dbeta)
+    trb = Transform(bb.scale, bb.shift, post_relu=True)
+    tra = Transform(ba.scale, ba.shift, post_relu=True)
+    cc, cb, ca = cv[p + "op_c.conv."], cv[p + "op_b.conv."], cv[p + "op_a.conv."]
+    self._wgrad(cc, V.view_of(blk["yb"]), trb, V.view_of(blk["gyc"]))
+    self._bias_grad(cc, blk["gyc"], S, f3 * S)
+    self._dgrad(cc, V.view_of(blk["gyc"]), V.view_of(blk["gab"]))
+    be.bn_bwd(blk["yb"], f2 * S, blk["gab"], f2 * S, B, f2, S, False, True, bb.gamma, bb.scale, bb.shift,
+              bb.saved, blk["gyb"], f2 * S, bb.dgamma, bb.dbeta)
+    self._wgrad(cb, V.view_of(blk["ya"]), tra, V.view_of(blk["gyb"]))
+    self._bias_grad(cb, blk["gyb"], S, f2 * S)
+    self._dgrad(cb, V.view_of(blk["gyb"]), V.view_of(blk["gaa"]))
+    be.bn_bwd(blk["ya"], f1 * S, blk["gaa"], f1 * S, B, f1, S, False, True, ba.gamma, ba.scale, ba.shift,
+              ba.saved, blk["gya"], f1 * S, ba.dgamma, ba.dbeta)
+    cur = blk["in"]
+    xin = V.view_of(cur)
+    if blk["stride"] == 2:
+      xin = V.strided_view(xin, (1, 2, 2))
+    self._wgrad(ca, xin, None, V.view_of(blk["gya"]))
+    self._bias_grad(ca, blk["gya"], S, f1 * S)
+    if blk["down"]:
+      bs = bn[p + "shortcut.bn."]
+      csn = cv[p + "shortcut.conv."]
+      be.bn_bwd(blk["ys"], f3 * S, gpre, f3 * S, B, f3, S, False, False, bs.gamma, bs.scale, bs.shift,
+                bs.saved, blk["gys"], f3 * S, bs.dgamma, bs.dbeta)
+      self._wgrad(csn, xin, None, V.view_of(blk["gys"]))
+      self._bias_grad(csn, blk["gys"], S, f3 * S)
+      gin = blk["gin"]
+      gv = V.view_of(gin)
+      if blk["stride"] == 2:
+        be.zero(gin)
+        gv = V.strided_view(gv, (1, 2, 2))
+        self._dgrad(ca, V.view_of(blk["gya"]), gv, accumulate=True)
+      else:
+        self._dgrad(ca, V.view_of(blk["gya"]), gv)
+      self._dgrad(csn, V.view_of(blk["gys"]), gv, accumulate=True)
+      return gin
+    # identity block: d in = d pre + dgrad(op_a)
+    self._dgrad(ca, V.view_of(blk["gya"]), V.view_of(gpre), accumulate=True)
+    return gpre

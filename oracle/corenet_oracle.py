@@ -262,7 +262,7 @@ def decoder_forward(feats, avg, sd: State, v2s: Tensor, offset: Tensor,
     key = f"{p}rt_skip_{stage}.compress_channels."
     if key + "weight" not in sd:
       return x
-    o = offset[:, :, None, None].expand(src2d.shape[0], 3, *src2d.shape[2:])
+    o = offset.to(src2d.dtype)[:, :, None, None].expand(src2d.shape[0], 3, *src2d.shape[2:])
     s2 = t.cat([src2d, o], 1)
     r1 = t.tensor(x.shape[2:], dtype=t.float32)
     layer_matrix = v2s.matmul(scale(res / r1))          # Q8
@@ -274,7 +274,7 @@ def decoder_forward(feats, avg, sd: State, v2s: Tensor, offset: Tensor,
     return batch_renorm(x.relu(), sd, f"{p}{name}.", training)
 
   x = F.linear(avg, sd[p + "stage_0.weight"], sd[p + "stage_0.bias"])
-  x = t.cat([x, offset], 1)[:, :, None, None, None]
+  x = t.cat([x, offset.to(x.dtype)], 1)[:, :, None, None, None]
   x = bn(x, "stage_1.b1")
   ir = resolution[0] // (16 * _last_upscale(sd, p))
   x = F.conv_transpose3d(x, sd[p + "stage_1.t1.weight"], sd[p + "stage_1.t1.bias"],

@@ -1,0 +1,275 @@
+"""Executable SPECIFICATION of the libcorenet_hip.so kernel contracts, written
+with torch-CPU ops.  TEST INFRASTRUCTURE ONLY.
+
+It mirrors corenet_amd.backend.HipBackend method for method so that the host
+wiring of corenet_amd/model/engine.py (views, packed-weight tables, buffer
+plumbing, the forward/backward sequence) can be validated against the oracle
+in this GPU-less container.  The product never imports this module: on a GPU
+box every one of these methods is a HIP kernel, and the `-m gpu` tests compare
+the HIP kernels against these contracts / the oracle.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch as t
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import corenet_oracle as O   # noqa: E402
+from corenet_amd.views import View        # noqa: E402
+
+
+def _chan(view: View, c: int) -> t.Tensor:
+  off = int(view.chan_off[c]) if view.chan_off is not None else c * view.sC
+  return t.as_strided(view.storage, (view.B, view.D, view.H, view.W),
+                      (view.sB, view.sD, view.sH, view.sW), view.offset + off)
+
+
+def logical(view: View) -> t.Tensor:
+  if view.chan_off is None:
+    return t.as_strided(view.storage, (view.B, view.C, view.D, view.H, view.W),
+                        (view.sB, view.sC, view.sD, view.sH, view.sW), view.offset)
+  return t.stack([_chan(view, c) for c in range(view.C)], 1)
+
+
+def write_logical(view: View, val: t.Tensor, accumulate=False):
+  if view.chan_off is None:
+    dst = t.as_strided(view.storage, (view.B, view.C, view.D, view.H, view.W),
+                       (view.sB, view.sC, view.sD, view.sH, view.sW), view.offset)
+    if accumulate: dst += val
+    else: dst.copy_(val)
+    return
+  for c in range(view.C):
+    dst = _chan(view, c)
+    if accumulate: dst += val[:, c]
+    else: dst.copy_(val[:, c])
+
+
+def _transform(x, tr):
+  if tr is None or tr.scale is None:
+    return x
+  if tr.pre_relu: x = x.relu()
+  shape = [1, -1] + [1] * (x.dim() - 2)
+  x = x * tr.scale.view(shape) + tr.shift.view(shape)
+  if tr.post_relu: x = x.relu()
+  return x
+
+
+def _padded(x, window, pad_lo, out_dims):
+  pads = []
+  for dim in (2, 1, 0):     # F.pad order: W, H, D
+    lo = pad_lo[dim]
+    hi = out_dims[dim] + window[dim] - 1 - lo - x.shape[2 + dim]
+    pads += [lo, hi]
+  return F.pad(x, pads)     # negative pads crop
+
+
+class EmuBackend:
+  name = "emu"
+
+  # -- convolution engine -----------------------------------------------------
+  def conv_fwd(self, x, tr, w, npad, bias, bias_sB, y, window, pad_lo, splits=1, accumulate=False):
+    xl = _transform(logical(x), tr)
+    xp = _padded(xl, window, pad_lo, (y.D, y.H, y.W))
+    T = window[0] * window[1] * window[2]
+    wk = w.view(x.C, window[0], window[1], window[2], npad).permute(4, 0, 1, 2, 3)
+    out = F.conv3d(xp, wk)[:, :y.C]
+    if bias is not None:
+      if bias_sB:
+        out = out + bias.view(x.B, -1)[:, :y.C, None, None, None]
+      else:
+        out = out + bias[:y.C].view(1, -1, 1, 1, 1)
+    write_logical(y, out, accumulate)
+
+  def conv_wgrad(self, x, tr, dy, dw, npad, window, pad_lo, zero_first=True):
+    xl = _transform(logical(x), tr)
+    xp = _padded(xl, window, pad_lo, (dy.D, dy.H, dy.W))
+    dyl = logical(dy)
+    wk = t.zeros(dy.C, x.C, *window, requires_grad=True, dtype=xp.dtype)
+    out = F.conv3d(xp, wk)
+    (g,) = t.autograd.grad(out, wk, dyl)                 # [N, C, kd,kh,kw]
+    T = window[0] * window[1] * window[2]
+    full = t.zeros(x.C, T, npad, dtype=xp.dtype)
+    full[:, :, :dy.C] = g.permute(1, 2, 3, 4, 0).reshape(x.C, T, dy.C)
+    if zero_first: dw.zero_()
+    dw += full.reshape(-1)
+
+  def gather(self, src, idx, dst):
+    i = idx.long()
+    dst.copy_(t.where(i >= 0, src[i.clamp(min=0)], t.zeros((), dtype=src.dtype)))
+
+  def scatter(self, src, idx, dst, accumulate=False):
+    i = idx.long(); m = i >= 0
+    if accumulate: dst.index_add_(0, i[m], src[m])
+    else: dst[i[m]] = src[m]
+
+  def bias_grad(self, dy, B, Cn, S, sB, db, accumulate=False):
+    v = t.as_strided(dy, (B, Cn, S), (sB, S, 1), dy.storage_offset()).double().sum((0, 2)).to(dy.dtype)
+    if accumulate: db += v
+    else: db.copy_(v)
+
+  # -- BatchRenorm --------------------------------------------------------------
+  def bn_stats(self, x, B, Cn, S, sB, pre_relu, gamma, beta, rmean, rvar, nbt, eps, momentum,
+               training, scale, shift, saved):
+    if not training:
+      rstd = 1.0 / (rvar + eps).sqrt()
+      scale.copy_(gamma * rstd); shift.copy_(beta - gamma * rmean * rstd)
+      return
+    v = t.as_strided(x, (B, Cn, S), (sB, S, 1), x.storage_offset())
+    if pre_relu: v = v.relu()
+    vd = v.double()
+    mean = vd.mean((0, 2)); var = (vd * vd).mean((0, 2)) - mean * mean
+    b_mean, b_var = mean.to(x.dtype), var.clamp(min=0).to(x.dtype)
+    b_std = (b_var + eps).sqrt(); run_std = (rvar + eps).sqrt()
+    nt = nbt.reshape(())          # float32 schedule arithmetic, as batch_renorm.py:41-42
+    d_max = float((5.0 * (nt - 5000) / (25000 - 5000)).clamp(0.0, 5.0))
+    r_max = float(1.0 + (2.0 * (nt - 5000) / (40000 - 5000)).clamp(0.0, 2.0))
+    r = (b_std / run_std).clamp(1 / r_max, r_max)
+    d = ((b_mean - rmean) / run_std).clamp(-d_max, d_max)
+    rstd = 1.0 / b_std
+    scale.copy_(gamma * r * rstd); shift.copy_(beta + gamma * (d - b_mean * r * rstd))
+    saved.view(4, Cn).copy_(t.stack([b_mean, rstd, r, d]))
+    rvar += momentum * (b_var * Cn / (Cn - 1) - rvar)
+    rmean += momentum * (b_mean - rmean)
+
+  def bn_bwd(self, x, sB_x, dy, sB_dy, B, Cn, S, pre_relu, post_relu, gamma, scale, shift, saved,
+             dx, sB_dx, dgamma, dbeta, accumulate=False):
+    xs = t.as_strided(x, (B, Cn, S), (sB_x, S, 1), x.storage_offset())
+    g = t.as_strided(dy, (B, Cn, S), (sB_dy, S, 1), dy.storage_offset()).clone()
+    mu, rstd, r, d = [u.view(1, Cn, 1) for u in saved.view(4, Cn)]
+    xv = xs.relu() if pre_relu else xs
+    if post_relu:
+      g = g * ((xv * scale.view(1, Cn, 1) + shift.view(1, Cn, 1)) > 0)
+    xn = (xv - mu) * rstd
+    n = B * S
+    s1 = g.double().sum((0, 2)); s2 = (g.double() * xn.double()).sum((0, 2))
+    dg = (r.view(-1).double() * s2 + d.view(-1).double() * s1).to(x.dtype); db = s1.to(x.dtype)
+    if accumulate: dgamma += dg; dbeta += db
+    else: dgamma.copy_(dg); dbeta.copy_(db)
+    mg = (s1 / n).to(x.dtype).view(1, Cn, 1); mgx = (s2 / n).to(x.dtype).view(1, Cn, 1)
+    o = gamma.view(1, Cn, 1) * r * rstd * (g - mg - xn * mgx)
+    if pre_relu: o = o * (xs > 0)
+    t.as_strided(dx, (B, Cn, S), (sB_dx, S, 1), dx.storage_offset()).copy_(o)
+
+  def affine_add_relu(self, x, scale, shift, r, rscale, rshift, B, Cn, S, sB_x, sB_r, y_pre, sB_pre,
+                      y, sB_y, relu):
+    v = t.as_strided(x, (B, Cn, S), (sB_x, S, 1), x.storage_offset())
+    one = t.ones(Cn, dtype=x.dtype); zero = t.zeros(Cn, dtype=x.dtype)
+    o = v * (scale if scale is not None else one).view(1, Cn, 1) + (shift if shift is not None else zero).view(1, Cn, 1)
+    if r is not None:
+      rv = t.as_strided(r, (B, Cn, S), (sB_r, S, 1), r.storage_offset())
+      o = o + rv * (rscale if rscale is not None else one).view(1, Cn, 1) + (rshift if rshift is not None else zero).view(1, Cn, 1)
+    if y_pre is not None:
+      t.as_strided(y_pre, (B, Cn, S), (sB_pre, S, 1), y_pre.storage_offset()).copy_(o)
+    if y is not None:
+      t.as_strided(y, (B, Cn, S), (sB_y, S, 1), y.storage_offset()).copy_(o.relu() if relu else o)
+
+  def relu_bwd_add(self, dy, y_pre, dy2, B, Cn, S, sB_dy, sB_pre, sB_dy2, dx, sB_dx):
+    p = t.as_strided(y_pre, (B, Cn, S), (sB_pre, S, 1), y_pre.storage_offset())
+    o = t.zeros(B, Cn, S, dtype=dx.dtype)
+    if dy is not None:
+      o = t.as_strided(dy, (B, Cn, S), (sB_dy, S, 1), dy.storage_offset()) * (p > 0)
+    if dy2 is not None:
+      o = o + t.as_strided(dy2, (B, Cn, S), (sB_dy2, S, 1), dy2.storage_offset())
+    t.as_strided(dx, (B, Cn, S), (sB_dx, S, 1), dx.storage_offset()).copy_(o)
+
+  # -- encoder odds and ends -------------------------------------------------------
+  def preprocess(self, img_u8, out):
+    out.copy_(O.preprocess_image_caffe(img_u8))
+
+  def maxpool_fwd(self, x, scale, shift, B, Cn, H, W, y, argmax):
+    a = (x * scale.view(1, Cn, 1, 1) + shift.view(1, Cn, 1, 1)).relu()
+    ap = F.pad(a, [1, 1, 1, 1])
+    v, idx = F.max_pool2d(ap, 3, 2, return_indices=True)
+    ih = idx // (W + 2) - 1; iw = idx % (W + 2) - 1
+    ok = (ih >= 0) & (ih < H) & (iw >= 0) & (iw < W) & (v > 0)
+    y.copy_(v)
+    argmax.copy_(t.where(ok, ih * W + iw, -t.ones_like(ih)).to(t.int32))
+
+  def maxpool_bwd(self, dy, argmax, B, Cn, H, W, dx):
+    dxf = t.zeros(B * Cn, H * W, dtype=dy.dtype)
+    am = argmax.reshape(B * Cn, -1).long(); g = dy.reshape(B * Cn, -1)
+    dxf.scatter_add_(1, am.clamp(min=0), g * (am >= 0))
+    dx.copy_(dxf.view(B, Cn, H, W))
+
+  def relu_mean_fwd(self, x_pre, B, Cn, S, sB, avg):
+    v = t.as_strided(x_pre, (B, Cn, S), (sB, S, 1), x_pre.storage_offset())
+    avg.copy_(v.relu().double().mean(2).to(avg.dtype))
+
+  def relu_mean_bwd(self, x_pre, davg, B, Cn, S, sB, dx, sB_dx, accumulate=False):
+    v = t.as_strided(x_pre, (B, Cn, S), (sB, S, 1), x_pre.storage_offset())
+    g = (v > 0) * (davg.view(B, Cn, 1) / float(S))
+    dst = t.as_strided(dx, (B, Cn, S), (sB_dx, S, 1), dx.storage_offset())
+    if accumulate: dst += g
+    else: dst.copy_(g)
+
+  def linear_fwd(self, x, w, bias, B, K, N, y, ldy):
+    t.as_strided(y, (B, N), (ldy, 1), y.storage_offset()).copy_(F.linear(x.view(B, K), w, bias))
+
+  def linear_bwd(self, x, w, dy, lddy, B, K, N, dx, dw, db):
+    g = t.as_strided(dy, (B, N), (lddy, 1), dy.storage_offset())
+    if dx is not None: dx.view(B, K).copy_(g @ w)
+    if dw is not None: dw.copy_(g.t() @ x.view(B, K))
+    if db is not None: db.copy_(g.sum(0))
+
+  def fill_offset_channels(self, x, B, sB, S, c0, offset):
+    t.as_strided(x, (B, 3, S), (sB, S, 1), x.storage_offset() + c0 * S).copy_(
+        offset.view(B, 3, 1).expand(B, 3, S))
+
+  # -- ray-traced skip ------------------------------------------------------------------
+  def ray_sample_fwd(self, fmap, map_sB, B, Cn, h, w, matrix, offset, out, out_sB, D, H, W):
+    m = t.as_strided(fmap, (B, Cn, h, w), (map_sB, h * w, w, 1), fmap.storage_offset())
+    res = O.ray_sample(m, matrix.view(B, 4, 4).float(), offset.view(B, 3).float(), (D, H, W))
+    t.as_strided(out, (B, Cn, D, H, W), (out_sB, D * H * W, H * W, W, 1), out.storage_offset()).copy_(res)
+
+  def ray_sample_bwd(self, dout, dout_sB, B, Cn, D, H, W, matrix, offset, dmap, dmap_sB, h, w,
+                     zero_first=True):
+    g = t.as_strided(dout, (B, Cn, D, H, W), (dout_sB, D * H * W, H * W, W, 1), dout.storage_offset())
+    iy, ix, keep = O.ray_sample_indices(matrix.view(B, 4, 4).float(), offset.view(B, 3).float(), (D, H, W), (w, h))
+    pad = t.zeros(B, Cn, h + 2, w + 2, dtype=g.dtype)
+    bb = t.arange(B)[:, None, None, None].expand_as(iy)
+    gm = (g * keep[:, None]).permute(0, 2, 3, 4, 1)
+    flat = pad.permute(0, 2, 3, 1).reshape(-1, Cn)
+    lin = ((bb * (h + 2) + iy) * (w + 2) + ix).reshape(-1)
+    flat.index_add_(0, lin, gm.reshape(-1, Cn))
+    res = flat.view(B, h + 2, w + 2, Cn).permute(0, 3, 1, 2)[:, :, 1:-1, 1:-1]
+    dst = t.as_strided(dmap, (B, Cn, h, w), (dmap_sB, h * w, w, 1), dmap.storage_offset())
+    if zero_first: dst.copy_(res)
+    else: dst += res
+
+  # -- losses / metrics / optimizer ---------------------------------------------------------
+  LOSSES = {0: "iou_fgbg", 1: "xent_times_iou_agnostic", 2: "iou_agnostic", 3: "xent",
+            4: "xent_times_iou_fgbg"}
+
+  def loss_fwd_bwd(self, kind, logits, gt_i32, B, Cn, S, loss, dlogits, grad_scale=1.0):
+    l = logits.detach().clone().requires_grad_(dlogits is not None)
+    v = getattr(O, self.LOSSES[kind])(gt_i32.long().view(l.shape[0], *l.shape[2:]), l)
+    loss.fill_(float(v))
+    if dlogits is not None:
+      v.backward()
+      dlogits.copy_(l.grad * grad_scale)
+
+  def argmax_confusion(self, logits, gt_i32, B, Cn, S, labels, cm):
+    lab = logits.argmax(1)
+    if labels is not None: labels.copy_(lab.to(t.int32))
+    if gt_i32 is not None:
+      cm += O.confusion_matrix(gt_i32, lab, Cn).reshape(-1)
+
+  def adam_step(self, p, g, m, v, n, lr, b1, b2, eps, grad_scale, step):
+    gg = g * grad_scale
+    m.add_((gg - m) * (1 - b1))
+    v.mul_(b2).add_(gg * gg * (1 - b2))
+    bc1 = 1 - b1 ** step; bc2 = 1 - b2 ** step
+    p.sub_((lr / bc1) * (m / (v.sqrt() / np.sqrt(bc2) + eps)))
+
+  def add_i64(self, p, n, v):
+    p += v
+
+  def zero(self, x):
+    x.zero_()
+
+  def fill_voxels(self, grid, out):
+    out.copy_(t.as_tensor(O.fill_inside_voxels(grid.numpy())))
