@@ -1,0 +1,185 @@
+"""Drop-in for `corenet.model.core_net.CoreNet` (core_net.py:25-61) on MI355X.
+
+Same constructor (`CoreNet(config)` with `config.decoder.{resolution,
+num_output_channels,last_upscale_factor,latent_channels,skip_fraction}`), same
+`forward(image uint8[B,3,H,W], voxel_projection_matrix f32[B,4,4],
+voxel_sample_locations f32[B,3]) -> logits f32[B,C,D,H,W]`, same
+`state_dict()` keys and shapes (so the published checkpoints and
+`model.encoder.load_state_dict(resnet50_checkpoint)` of state.py:69 load), works
+under autograd (`loss.backward()` fills `.grad` of every parameter) and can be
+wrapped by DistributedDataParallel.  All arithmetic runs in libcorenet_hip.so.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Any, Dict, Optional, Tuple
+
+import torch as t
+from torch import nn
+
+from corenet_amd.model.engine import Engine
+
+
+@dataclasses.dataclass(frozen=True)
+class DecoderConfig:
+  """Mirror of corenet.configuration.DecoderConfig (configuration.py:278-294)."""
+  resolution: Tuple[int, int, int]
+  num_output_channels: int
+  last_upscale_factor: int = 2
+  latent_channels: int = 64
+  skip_fraction: float = 0.75
+
+
+@dataclasses.dataclass(frozen=True)
+class CoreNetConfig:
+  """Mirror of corenet.configuration.CoreNetConfig (configuration.py:298-299)."""
+  decoder: DecoderConfig
+
+  def to_dict(self) -> Dict[str, Any]:
+    return {"decoder": dataclasses.asdict(self.decoder)}
+
+  @classmethod
+  def from_dict(cls, d) -> "CoreNetConfig":
+    dd = dict(d["decoder"])
+    dd["resolution"] = tuple(dd["resolution"])
+    return cls(decoder=DecoderConfig(**dd))
+
+
+class _Tree(nn.Module):
+  """Nested container so that parameters get the reference's dotted names."""
+
+  def add(self, path, tensor: t.Tensor, kind: str):
+    head, *rest = path
+    if rest:
+      if head not in self._modules:
+        self.add_module(head, _Tree())
+      self._modules[head].add(rest, tensor, kind)
+    elif kind == "param":
+      self.register_parameter(head, nn.Parameter(tensor))
+    else:
+      self.register_buffer(head, tensor)
+
+
+class _CoreNetFn(t.autograd.Function):
+  """Whole-network autograd node: forward/backward are the engine's HIP plans."""
+
+  @staticmethod
+  def forward(ctx, model, image, v2s, offset, *params):
+    plan = model.engine.plan(image.shape[0])
+    logits = plan.forward(image, v2s, offset, training=model.training)
+    ctx.model, ctx.plan = model, plan
+    return logits.clone()      # the plan's buffer is reused by the next forward
+
+  @staticmethod
+  def backward(ctx, glogits):
+    model, plan = ctx.model, ctx.plan
+    plan.backward(glogits.contiguous())
+    grads = tuple(model.engine.store.view(k, grad=True) for k in model._param_keys)
+    return (None, None, None, None) + grads
+
+
+class CoreNet(nn.Module):
+  """Image to 3D reconstruction with CoReNet (MI355X-native)."""
+
+  def __init__(self, config, device: Optional[str] = None, backend=None):
+    super().__init__()
+    self.config = config
+    dc = config.decoder
+    if device is None:
+      device = f"cuda:{t.cuda.current_device()}" if t.cuda.is_available() else "cuda"
+    self.engine = Engine(dc.num_output_channels, resolution=tuple(dc.resolution),
+                         latent_channels=dc.latent_channels, skip_fraction=dc.skip_fraction,
+                         last_upscale_factor=dc.last_upscale_factor, device=device, backend=backend)
+    self._tree_root = _Tree()
+    self._param_keys = []
+    for key, shape, kind in self.engine.specs:
+      self._tree_root.add(key.split("."), self.engine.store.view(key), kind)
+      if kind == "param":
+        self._param_keys.append(key)
+    # expose encoder / decoder exactly like the reference module tree
+    self.encoder = self._tree_root._modules["encoder"]
+    self.decoder = self._tree_root._modules["decoder"]
+    del self._tree_root
+    self.reset_parameters()
+    self.register_load_state_dict_post_hook(lambda m, k: m._mark_dirty())
+    self.encoder.register_load_state_dict_post_hook(lambda m, k: self._mark_dirty())
+
+  def _mark_dirty(self):
+    self.engine.weights_dirty = True
+
+  def reset_parameters(self, seed: int = 0):
+    """resnet50.py:40-47 (kaiming-normal convs, BN gamma=1 beta=0) and torch's
+    default initialisers for the decoder layers, drawn on the host."""
+    g = t.Generator().manual_seed(seed)
+    s = self.engine.store
+    with t.no_grad():
+      for key, shape, kind in self.engine.specs:
+        v = s.view(key)
+        if key.endswith("running_var"):
+          v.fill_(1.0)
+        elif kind != "param":
+          v.zero_()
+        elif len(shape) >= 2:
+          fan_in = shape[1] * int(math.prod(shape[2:])) if len(shape) > 2 else shape[1]
+          if key.startswith("encoder."):
+            w = t.randn(shape, generator=g) * math.sqrt(2.0 / fan_in)
+          else:
+            bound = 1.0 / math.sqrt(fan_in)
+            w = (t.rand(shape, generator=g) * 2 - 1) * bound
+          v.copy_(w)
+        elif ".bn." in key or ".b1." in key or ".b2." in key:
+          v.fill_(1.0 if key.endswith("weight") else 0.0)
+        else:
+          v.zero_()
+    self._mark_dirty()
+
+  # nn.Module plumbing -------------------------------------------------------
+  def _apply(self, fn, recurse=True):
+    # Parameters are views into the engine's flat device slabs; moving them
+    # would silently detach them from the kernels.
+    probe = fn(t.zeros(1, device=self.engine.device))
+    if probe.device != self.engine.device or probe.dtype != t.float32:
+      raise RuntimeError("corenet_amd.CoreNet lives on its construction device in fp32; "
+                         "construct it with CoreNet(config, device=...) instead of .to()/.half()")
+    return self
+
+  def forward(self, image: t.Tensor, voxel_projection_matrix: t.Tensor,
+              voxel_sample_locations: t.Tensor) -> t.Tensor:
+    # same argument checks as resnet50.py:198-199 / ray_traced_skip_connection.py:81-89
+    assert image.dtype == t.uint8 and image.dim() == 4 and image.shape[1] == 3
+    B = image.shape[0]
+    assert voxel_projection_matrix.shape == (B, 4, 4)
+    assert voxel_sample_locations.shape == (B, 3)
+    if not image.is_cuda:
+      raise ValueError("Only CUDA(HIP) tensors are supported by corenet_amd.CoreNet")
+    self.engine.weights_dirty = True     # parameters may have been stepped by an external optimizer
+    image = image.contiguous()
+    v2s = voxel_projection_matrix.to(t.float32).contiguous()
+    off = voxel_sample_locations.to(t.float32).contiguous()
+    if t.is_grad_enabled() and self.training:
+      params = [self.get_parameter(k) for k in self._param_keys]
+      return _CoreNetFn.apply(self, image, v2s, off, *params)
+    plan = self.engine.plan(B)
+    return plan.forward(image, v2s, off, training=self.training).clone()
+
+  # fused training step (bench.py / the train hot loop pipeline.py:215-240) ------
+  def train_step(self, image: t.Tensor, voxel_projection_matrix: t.Tensor,
+                 voxel_sample_locations: t.Tensor, grid: t.Tensor, loss: str = "iou_fgbg",
+                 lr: float = 4e-4, adam_eps: float = 1e-4, world_size: int = 1,
+                 all_reduce=None) -> t.Tensor:
+    """forward -> loss -> backward -> (gradient all-reduce) -> Adam, without
+    autograd bookkeeping.  Returns the loss as a 1-element device tensor (no sync)."""
+    from corenet_amd.model.engine import LOSS_KINDS
+    eng = self.engine
+    B, C = image.shape[0], eng.num_classes
+    plan = eng.plan(B)
+    plan.forward(image.contiguous(), voxel_projection_matrix, voxel_sample_locations, training=True)
+    plan.gt.copy_(grid)
+    eng.be.loss_fwd_bwd(LOSS_KINDS[loss], plan.logits, plan.gt, B, C, 128 ** 3, plan.loss,
+                        plan.glogits, 1.0)
+    plan.backward(plan.glogits)
+    if all_reduce is not None:
+      all_reduce(eng.store.grads)
+    eng.adam_step(lr, adam_eps, grad_scale=1.0 / world_size)
+    return plan.loss

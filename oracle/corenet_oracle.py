@@ -646,11 +646,11 @@ def make_state(seed: int = 0, num_classes: int = 2, nbt: int = 0,
     elif kind == "bias":
       sd[key] = t.randn(shape, generator=g) * 0.05
     elif kind == "bn_w":
-      sd[key] = 1.0 + (t.randn(shape, generator=g) * 0.1 if perturb_bn else 0)
+      sd[key] = 1.0 + (t.randn(shape, generator=g) * 0.1 if perturb_bn else t.zeros(shape))
     elif kind in ("bn_b", "rm"):
       sd[key] = t.randn(shape, generator=g) * 0.1 if perturb_bn else t.zeros(shape)
     elif kind == "rv":
-      sd[key] = 1.0 + (t.rand(shape, generator=g) * 0.5 if perturb_bn else 0)
+      sd[key] = 1.0 + (t.rand(shape, generator=g) * 0.5 if perturb_bn else t.zeros(shape))
     elif kind == "nbt":
       sd[key] = t.tensor(nbt, dtype=t.int64)
   return sd

@@ -1,0 +1,487 @@
+"""GPU parity tests: every HIP kernel (through the C ABI) against its contract
+(tests/kernel_contract_emu.py) / the oracle on the same seeded inputs.
+Integer/index work must be bit-exact; fp32 work within the stated tolerance."""
+import numpy as np
+import pytest
+import torch as t
+
+from oracle import corenet_oracle as O
+from kernel_contract_emu import EmuBackend
+
+pytestmark = pytest.mark.gpu
+
+
+import os
+EMU = EmuBackend()
+# CRN_TEST_SELFCHECK=1 runs the test LOGIC against the contract emulator on CPU
+# (a dry run of the tests themselves in the GPU-less container; never on the GPU box).
+_SELF = os.environ.get("CRN_TEST_SELFCHECK") == "1"
+DEV = "cpu" if _SELF else "cuda"
+
+
+@pytest.fixture(scope="module")
+def be():
+  if _SELF:
+    return EMU
+  from corenet_amd.backend import HipBackend
+  assert t.cuda.is_available(), "gpu tests need an MI355X"
+  return HipBackend()
+
+
+def close(a, b, rtol, name=""):
+  a = a.detach().cpu().double(); b = b.detach().cpu().double()
+  den = float(b.abs().max()) + 1e-30
+  err = float((a - b).abs().max()) / den
+  assert err <= rtol, f"{name}: max-abs-err/max = {err:.3e} > {rtol}"
+
+
+# ------------------------------------------------------------------ conv engine
+def _views(xc, make_view):
+  """Build the same view over the CPU tensor and over its CUDA copy."""
+  xg = xc.to(DEV)
+  return make_view(xc), make_view(xg), xg
+
+
+CONV_CASES = [
+    # name, kind, wshape, pad, in dims (D,H,W), batch
+    ("conv1x1", "conv", (64, 256, 1, 1), 0, (1, 64, 64), 2),
+    ("conv3x3", "conv", (128, 128, 3, 3), 1, (1, 32, 32), 2),
+    ("conv3x3_small", "conv", (512, 512, 3, 3), 1, (1, 8, 8), 2),
+    ("conv1x1_odd", "conv", (24, 515, 1, 1), 0, (1, 32, 32), 2),
+    ("conv3d_k3", "conv", (256, 256, 3, 3, 3), 1, (4, 4, 4), 2),
+    ("conv3d_k5_8", "conv", (128, 224, 5, 5, 5), 2, (8, 8, 8), 1),
+    ("conv3d_k5_32", "conv", (32, 56, 5, 5, 5), 2, (32, 32, 32), 1),
+    ("conv3d_k5_64", "conv", (16, 28, 5, 5, 5), 2, (64, 64, 64), 1),
+    ("convT_k3", "convT", (256, 128, 3, 3, 3), 1, (4, 4, 4), 2),
+    ("convT_k7_16", "convT", (64, 32, 7, 7, 7), 3, (16, 16, 16), 1),
+    ("convT_k7_64_c2", "convT", (16, 2, 7, 7, 7), 3, (64, 64, 64), 1),
+    ("convT_k7_32_c14", "convT", (16, 14, 7, 7, 7), 3, (32, 32, 32), 1),
+]
+
+
+@pytest.mark.parametrize("name,kind,wshape,pad,dims,B", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(be, name, kind, wshape, pad, dims, B):
+  from corenet_amd import views as V
+  from corenet_amd.backend import Transform
+  from corenet_amd.model import conv_geometry as G
+  g = t.Generator().manual_seed(hash(name) % 1000)
+  w = t.randn(wshape, generator=g) / np.sqrt(np.prod(wshape[1:]))
+  D, H, W = dims
+  is2d = len(wshape) == 4
+  if kind == "conv":
+    cin, cout = wshape[1], wshape[0]
+    fwd, dgr = G.conv_fwd(wshape, pad), G.conv_dgrad(wshape, pad)
+    odims = dims
+  else:
+    cin, cout = wshape[0], wshape[1]
+    fwd, dgr = G.convt_fwd(wshape, pad), G.convt_dgrad(wshape, pad)
+    odims = (2 * D, 2 * H, 2 * W)
+  x = t.randn((B, cin) + ((H, W) if is2d else dims), generator=g)
+  scale = t.rand(cin, generator=g) + 0.5; shift = t.randn(cin, generator=g) * 0.3
+  bias = t.randn(cout, generator=g)
+  y = t.zeros((B, cout + 3) + ((H, W) if is2d else odims))     # written into a channel slice
+  wf = EMU_pack(w, fwd); wd = EMU_pack(w, dgr)
+  bpack = EMU_pack(bias, None, G.bias_index(cout, 8 if kind == "convT" else 1, fwd.npad))
+
+  def yview(tens):
+    v = V.view_of(tens).channels(0, cout)
+    return V.space_to_depth_view(v, (2, 2, 2)) if kind == "convT" else v
+
+  # forward with a fused pre-ReLU affine transform
+  xg, yg = x.to(DEV), y.to(DEV)
+  trc = Transform(scale, shift, pre_relu=True); trg = Transform(scale.to(DEV), shift.to(DEV), pre_relu=True)
+  EMU.conv_fwd(V.view_of(x), trc, wf, fwd.npad, bpack, 0, yview(y), fwd.window, fwd.pad_lo)
+  be.conv_fwd(V.view_of(xg), trg, wf.to(DEV), fwd.npad, bpack.to(DEV), 0, yview(yg), fwd.window, fwd.pad_lo, 0)
+  close(yg, y, 3e-5, name + " fwd")
+  assert float(yg[:, cout:].abs().max()) == 0.0        # untouched channels of the concat buffer
+  # cross-check the contract itself against torch's own op
+  xt = x.relu() * scale.view(1, -1, *([1] * (x.dim() - 2))) + shift.view(1, -1, *([1] * (x.dim() - 2)))
+  if kind == "conv":
+    ref = (t.nn.functional.conv2d if is2d else t.nn.functional.conv3d)(xt, w, bias, padding=pad)
+  else:
+    ref = t.nn.functional.conv_transpose3d(xt, w, bias, stride=2, padding=pad, output_padding=1)
+  close(y[:, :cout], ref, 2e-5, name + " contract-vs-torch")
+  # data gradient (accumulating into an existing buffer)
+  dy = t.randn(ref.shape, generator=g)
+  dyb = t.zeros_like(y); dyb[:, :cout] = dy
+  dx = t.randn(x.shape, generator=g); dxg = dx.to(DEV)
+  dyg = dyb.to(DEV)
+  EMU.conv_fwd(yview(dyb), None, wd, dgr.npad, None, 0, V.view_of(dx), dgr.window, dgr.pad_lo, accumulate=True)
+  be.conv_fwd(yview(dyg), None, wd.to(DEV), dgr.npad, None, 0, V.view_of(dxg), dgr.window, dgr.pad_lo, 0, True)
+  close(dxg, dx, 3e-5, name + " dgrad")
+  # weight gradient
+  dw = t.zeros(wf.numel()); dwg = t.zeros(wf.numel(), device=DEV)
+  EMU.conv_wgrad(V.view_of(x), trc, yview(dyb), dw, fwd.npad, fwd.window, fwd.pad_lo, True)
+  be.conv_wgrad(V.view_of(xg), trg, yview(dyg), dwg, fwd.npad, fwd.window, fwd.pad_lo, True)
+  close(dwg, dw, 5e-5, name + " wgrad")
+  # un-packed gradient equals autograd's
+  wref = w.clone().requires_grad_(True)
+  if kind == "conv":
+    out = (t.nn.functional.conv2d if is2d else t.nn.functional.conv3d)(xt, wref, None, padding=pad)
+  else:
+    out = t.nn.functional.conv_transpose3d(xt, wref, None, stride=2, padding=pad, output_padding=1)
+  out.backward(dy)
+  gw = t.zeros(w.numel())
+  EMU.scatter(dw, t.as_tensor(fwd.index), gw)
+  close(gw.view(wshape), wref.grad, 5e-5, name + " wgrad-vs-autograd")
+
+
+def EMU_pack(w, geom, index=None):
+  idx = t.as_tensor(geom.index if index is None else index)
+  out = t.zeros(idx.numel())
+  EMU.gather(w.reshape(-1), idx, out)
+  return out
+
+
+def test_conv_stem_and_strided(be):
+  """7x7/2 stem on the space-to-depth view and the stride-2 1x1 convs (views)."""
+  from corenet_amd import views as V
+  from corenet_amd.model import conv_geometry as G
+  g = t.Generator().manual_seed(3)
+  x = t.randn(2, 3, 64, 64, generator=g); w = t.randn(64, 3, 7, 7, generator=g) * 0.1; b = t.randn(64, generator=g)
+  geo = G.stem_fwd(w.shape, 3)
+  wf = EMU_pack(w, geo); bp = EMU_pack(b, None, G.bias_index(64, 1, geo.npad))
+  yg = t.zeros(2, 64, 32, 32, device=DEV); xg = x.to(DEV)
+  be.conv_fwd(V.space_to_depth_view(V.view_of(xg), (1, 2, 2)), None, wf.to(DEV), geo.npad, bp.to(DEV), 0,
+              V.view_of(yg), geo.window, geo.pad_lo, 0)
+  ref = t.nn.functional.conv2d(t.nn.functional.pad(x, [3, 3, 3, 3]), w, b, stride=2)
+  close(yg, ref, 2e-5, "stem")
+  # stride-2 1x1: forward through a strided input view, dgrad through a strided output view
+  x = t.randn(2, 96, 16, 16, generator=g); w = t.randn(40, 96, 1, 1, generator=g) * 0.1
+  geo, dgeo = G.conv_fwd(w.shape, 0), G.conv_dgrad(w.shape, 0)
+  wf, wd = EMU_pack(w, geo), EMU_pack(w, dgeo)
+  xg = x.to(DEV); yg = t.zeros(2, 40, 8, 8, device=DEV)
+  be.conv_fwd(V.strided_view(V.view_of(xg), (1, 2, 2)), None, wf.to(DEV), geo.npad, None, 0, V.view_of(yg),
+              geo.window, geo.pad_lo, 0)
+  ref = t.nn.functional.conv2d(x, w, None, stride=2)
+  close(yg, ref, 2e-5, "1x1 s2 fwd")
+  dy = t.randn(ref.shape, generator=g)
+  dxg = t.zeros(2, 96, 16, 16, device=DEV)
+  be.conv_fwd(V.view_of(dy.to(DEV)), None, wd.to(DEV), dgeo.npad, None, 0,
+              V.strided_view(V.view_of(dxg), (1, 2, 2)), dgeo.window, dgeo.pad_lo, 0, True)
+  xr = x.clone().requires_grad_(True)
+  t.nn.functional.conv2d(xr, w, None, stride=2).backward(dy)
+  close(dxg, xr.grad, 2e-5, "1x1 s2 dgrad")
+  dwg = t.zeros(wf.numel(), device=DEV)
+  be.conv_wgrad(V.strided_view(V.view_of(xg), (1, 2, 2)), None, V.view_of(dy.to(DEV)), dwg, geo.npad, geo.window,
+                geo.pad_lo, True)
+  wr = w.clone().requires_grad_(True)
+  t.nn.functional.conv2d(x, wr, None, stride=2).backward(dy)
+  gw = t.zeros(w.numel()); EMU.scatter(dwg.cpu(), t.as_tensor(geo.index), gw)
+  close(gw.view(w.shape), wr.grad, 3e-5, "1x1 s2 wgrad")
+
+
+def test_conv_1to4(be):
+  from corenet_amd import views as V
+  from corenet_amd.model import conv_geometry as G
+  g = t.Generator().manual_seed(4)
+  B = 4
+  x = t.randn(B, 67, generator=g); w = t.randn(67, 256, 4, 4, 4, generator=g) * 0.1; b = t.randn(256, generator=g)
+  geo, dgeo = G.convt_1to4_fwd(w.shape), G.convt_1to4_dgrad(w.shape)
+  wf, wd = EMU_pack(w, geo), EMU_pack(w, dgeo)
+  bp = EMU_pack(b, None, G.bias_index(256, 64, geo.npad))
+  yg = t.zeros(B, 256, 4, 4, 4, device=DEV); xg = x.to(DEV)
+  be.conv_fwd(V.view_of(xg.view(B, 67, 1, 1, 1)), None, wf.to(DEV), geo.npad, bp.to(DEV), 0,
+              V.flat_channel_view(V.view_of(yg)), geo.window, geo.pad_lo, 0)
+  ref = t.nn.functional.conv_transpose3d(x.view(B, 67, 1, 1, 1), w, b, stride=4)
+  close(yg, ref, 2e-5, "1->4 fwd")
+  dy = t.randn(ref.shape, generator=g); dyg = dy.to(DEV)
+  dxg = t.zeros(B, 67, device=DEV)
+  be.conv_fwd(V.flat_channel_view(V.view_of(dyg)), None, wd.to(DEV), dgeo.npad, None, 0,
+              V.view_of(dxg.view(B, 67, 1, 1, 1)), dgeo.window, dgeo.pad_lo, 0)
+  xr = x.clone().requires_grad_(True)
+  t.nn.functional.conv_transpose3d(xr.view(B, 67, 1, 1, 1), w, None, stride=4).backward(dy)
+  close(dxg, xr.grad, 2e-5, "1->4 dgrad")
+
+
+# ------------------------------------------------------------------ BatchRenorm & elementwise
+@pytest.mark.parametrize("B,C,S,pre,post,nbt", [(3, 5, 24, False, False, 0), (2, 28, 4096, True, False, 30000),
+                                               (4, 64, 1024, False, True, 12000), (4, 67, 1, True, False, 0),
+                                               (2, 7, 33, True, False, 7000)])
+def test_batch_renorm(be, B, C, S, pre, post, nbt):
+  g = t.Generator().manual_seed(B * 100 + C)
+  Ct = C + 2
+  x = t.randn(B, Ct, S, generator=g) * 2 + 0.4           # channel slice of a wider buffer
+  gy = t.randn(B, C, S, generator=g)
+  gamma = t.rand(C, generator=g) + 0.5; beta = t.randn(C, generator=g)
+  rm0 = t.randn(C, generator=g); rv0 = t.rand(C, generator=g) * 3 + 0.1
+  nb = t.tensor([nbt], dtype=t.int64)
+  res = []
+  for dev, bk in (("cpu", EMU), (DEV, be)):
+    xx = x.to(dev); rm, rv = rm0.clone().to(dev), rv0.clone().to(dev)
+    sc, sh, sv = t.zeros(C, device=dev), t.zeros(C, device=dev), t.zeros(4 * C, device=dev)
+    bk.bn_stats(xx, B, C, S, Ct * S, pre, gamma.to(dev), beta.to(dev), rm, rv, nb.to(dev), 1e-3, 0.01, True,
+                sc, sh, sv)
+    dx = t.zeros(B, C, S, device=dev); dg = t.zeros(C, device=dev); db = t.zeros(C, device=dev)
+    bk.bn_bwd(xx, Ct * S, gy.to(dev), C * S, B, C, S, pre, post, gamma.to(dev), sc, sh, sv, dx, C * S, dg, db)
+    res.append([v.cpu() for v in (sc, sh, sv, rm, rv, dx, dg, db)])
+  for a, b, nm in zip(res[1], res[0], ["scale", "shift", "saved", "rmean", "rvar", "dx", "dgamma", "dbeta"]):
+    close(a, b, 2e-5, nm)
+  # and against autograd of the oracle
+  sd = {"weight": gamma.clone().requires_grad_(True), "bias": beta.clone().requires_grad_(True),
+        "running_mean": rm0.clone(), "running_var": rv0.clone(), "num_batches_tracked": t.tensor(nbt)}
+  xi = x[:, :C].clone().requires_grad_(True)
+  y = O.batch_renorm(xi.relu() if pre else xi, sd, "", True)
+  if post: y = y.relu()
+  y.backward(gy)
+  close(res[1][5], xi.grad, 1e-4, "dx vs autograd")
+  close(res[1][6], sd["weight"].grad, 1e-4, "dgamma vs autograd")
+  close(res[1][4], sd["running_var"], 1e-5, "running_var vs oracle")
+
+
+def test_elementwise(be):
+  g = t.Generator().manual_seed(9)
+  B, C, S = 2, 6, 100
+  x = t.randn(B, C, S, generator=g); r = t.randn(B, C, S, generator=g)
+  sc, sh, rsc, rsh = [t.randn(C, generator=g) for _ in range(4)]
+  out = {}
+  for dev, bk in (("cpu", EMU), (DEV, be)):
+    pre = t.zeros(B, C + 3, S, device=dev); y = t.zeros(B, C, S, device=dev)
+    bk.affine_add_relu(x.to(dev), sc.to(dev), sh.to(dev), r.to(dev), rsc.to(dev), rsh.to(dev), B, C, S, C * S, C * S,
+                       pre, (C + 3) * S, y, C * S, True)
+    dx = t.zeros(B, C, S, device=dev)
+    bk.relu_bwd_add(r.to(dev), pre, x.to(dev), B, C, S, C * S, (C + 3) * S, C * S, dx, C * S)
+    db = t.zeros(C, device=dev)
+    bk.bias_grad(x.to(dev), B, C, S, C * S, db)
+    out[dev] = [v.cpu() for v in (pre, y, dx, db)]
+  for a, b in zip(out[DEV], out["cpu"]):
+    close(a, b, 1e-6)
+
+
+def test_encoder_misc(be):
+  g = t.Generator().manual_seed(10)
+  B, C, H = 2, 8, 16
+  img = t.randint(0, 256, (B, 3, 12, 20), generator=g, dtype=t.uint8)
+  x = t.randn(B, C, H, H, generator=g); sc = t.rand(C, generator=g) + 0.5; sh = t.randn(C, generator=g) * 0.2
+  dy = t.randn(B, C, H // 2, H // 2, generator=g)
+  w = t.randn(5, 32, generator=g); bias = t.randn(5, generator=g); xl = t.randn(B, 32, generator=g)
+  off = t.rand(B, 3, generator=g)
+  out = {}
+  for dev, bk in (("cpu", EMU), (DEV, be)):
+    f = t.zeros(B, 3, 12, 20, device=dev); bk.preprocess(img.to(dev), f)
+    y = t.zeros(B, C, H // 2, H // 2, device=dev); am = t.zeros(B, C, H // 2, H // 2, dtype=t.int32, device=dev)
+    bk.maxpool_fwd(x.to(dev), sc.to(dev), sh.to(dev), B, C, H, H, y, am)
+    dx = t.zeros(B, C, H, H, device=dev); bk.maxpool_bwd(dy.to(dev), am, B, C, H, H, dx)
+    avg = t.zeros(B, C, device=dev); bk.relu_mean_fwd(x.to(dev), B, C, H * H, C * H * H, avg)
+    dm = t.ones(B, C, H * H, device=dev); bk.relu_mean_bwd(x.to(dev), avg, B, C, H * H, C * H * H, dm, C * H * H, True)
+    yl = t.zeros(B, 8, device=dev); bk.linear_fwd(xl.to(dev), w.to(dev), bias.to(dev), B, 32, 5, yl, 8)
+    dxl = t.zeros(B, 32, device=dev); dw = t.zeros(5, 32, device=dev); dbb = t.zeros(5, device=dev)
+    bk.linear_bwd(xl.to(dev), w.to(dev), yl, 8, B, 32, 5, dxl, dw, dbb)
+    fo = t.zeros(B, 7, 9, device=dev); bk.fill_offset_channels(fo, B, 63, 9, 4, off.to(dev))
+    out[dev] = [v.cpu().float() for v in (f, y, am, dx, avg, dm, yl, dxl, dw, dbb, fo)]
+  for i, (a, b) in enumerate(zip(out[DEV], out["cpu"])):
+    close(a, b, 1e-6, f"misc[{i}]")
+  ref = t.nn.functional.max_pool2d(t.nn.functional.pad((x * sc.view(1, C, 1, 1) + sh.view(1, C, 1, 1)).relu(), [1] * 4), 3, 2)
+  close(out[DEV][1], ref, 1e-6, "maxpool vs torch")
+
+
+# ------------------------------------------------------------------ ray-traced skip
+def test_ray_sample_golden_and_edge(be, golden_dir):
+  import os
+  z = np.load(os.path.join(golden_dir, "sample_grid2d.npz"))
+  src, w, b = t.tensor(z["src"]), t.tensor(z["weight"]), t.tensor(z["bias"])
+  mats, off = t.tensor(z["mats"]), t.tensor(z["off"])
+  cmap = t.nn.functional.conv2d(src, w, b)
+  B, C = cmap.shape[:2]
+  out = t.full((B, C + 2, 16, 16, 16), 7.0, device=DEV)
+  be.ray_sample_fwd(cmap.to(DEV), C * 256, B, C, 16, 16, mats.reshape(B, 16).to(DEV), off.to(DEV),
+                    out[:, 2:], (C + 2) * 4096, 16, 16, 16)
+  assert int((out[:, 2:].cpu() != t.tensor(z["y"])).sum()) == 0        # bit-exact incl. edge-case camera
+  assert float((out[:, :2] - 7.0).abs().max()) == 0
+  gy = t.tensor(z["gy"])
+  dmap = t.zeros(B, C, 16, 16, device=DEV)
+  be.ray_sample_bwd(gy.to(DEV), C * 4096, B, C, 16, 16, 16, mats.reshape(B, 16).to(DEV), off.to(DEV), dmap, C * 256,
+                    16, 16, True)
+  cm = cmap.clone().requires_grad_(True)
+  O.ray_sample(cm, mats, off, (16, 16, 16)).backward(gy)
+  close(dmap, cm.grad, 1e-5, "ray bwd")
+
+
+@pytest.mark.parametrize("res,C", [(8, 96), (16, 48), (32, 24), (64, 12)])
+def test_ray_sample_decoder_scales(be, res, C):
+  """Index parity (mismatch count 0) at the four decoder scales, canonical camera, B=2."""
+  g = t.Generator().manual_seed(res)
+  B = 2
+  cmap = t.randn(B, C, res, res, generator=g)
+  m = (O.canonical_camera() @ O.scale([1.0 / 128] * 3) @ O.scale([128.0 / res] * 3))[None].expand(B, 4, 4).contiguous()
+  off = t.tensor([[0.5, 0.5, 0.5], [0.25, 0.5, 0.75]])
+  out = t.zeros(B, C, res, res, res, device=DEV)
+  be.ray_sample_fwd(cmap.to(DEV), C * res * res, B, C, res, res, m.reshape(B, 16).to(DEV), off.to(DEV), out,
+                    C * res ** 3, res, res, res)
+  ref = O.ray_sample(cmap, m, off, (res,) * 3)
+  assert int((out.cpu() != ref).sum()) == 0
+
+
+# ------------------------------------------------------------------ losses / metrics / adam
+@pytest.mark.parametrize("C,kind", [(2, 0), (5, 0), (5, 1), (14, 1), (5, 2), (5, 3), (5, 4)])
+def test_losses(be, C, kind):
+  g = t.Generator().manual_seed(C * 10 + kind)
+  B, dims = 2, (6, 7, 8)
+  S = int(np.prod(dims))
+  logits = t.randn(B, C, *dims, generator=g) * 2
+  gt = t.randint(0, C, (B,) + dims, generator=g)
+  name = EmuBackend.LOSSES[kind]
+  l = logits.clone().requires_grad_(True)
+  v = getattr(O, name)(gt, l); v.backward()
+  loss = t.zeros(1, device=DEV); dl = t.zeros(B, C, *dims, device=DEV)
+  be.loss_fwd_bwd(kind, logits.to(DEV), gt.to(t.int32).to(DEV), B, C, S, loss, dl, 1.0)
+  assert abs(float(loss) - float(v)) <= 1e-5 * max(1.0, abs(float(v)))
+  close(dl, l.grad, 2e-5, name)
+
+
+def test_losses_reference_known_answers(be):
+  from reference_known_answers import LOSS_LOGITS, LOSS_GT
+  logits = t.tensor(LOSS_LOGITS).permute(0, 4, 1, 2, 3).contiguous()
+  gt = t.tensor(LOSS_GT, dtype=t.int32)
+  for kind, want in ((2, 0.8060565), (0, 0.3579613), (3, 1.4547757)):
+    loss = t.zeros(1, device=DEV)
+    be.loss_fwd_bwd(kind, logits.to(DEV), gt.to(DEV), 2, 4, 12, loss, None, 1.0)
+    np.testing.assert_allclose(float(loss), want, rtol=1e-5, atol=1e-6)
+
+
+def test_argmax_confusion_and_adam(be):
+  g = t.Generator().manual_seed(5)
+  B, C, S = 2, 5, 1000
+  logits = t.randn(B, C, S, generator=g); gt = t.randint(0, C, (B, S), generator=g).to(t.int32)
+  lab = t.zeros(B, S, dtype=t.int32, device=DEV); cm = t.zeros(C * C, dtype=t.int64, device=DEV)
+  be.argmax_confusion(logits.to(DEV), gt.to(DEV), B, C, S, lab, cm)
+  assert t.equal(lab.cpu().long(), logits.argmax(1))
+  assert t.equal(cm.cpu().view(C, C), O.confusion_matrix(gt, logits.argmax(1), C))
+  n = 1003
+  p = t.randn(n, generator=g); gr = t.randn(n, generator=g)
+  pt = p.clone().requires_grad_(True); opt = t.optim.Adam([pt], lr=4e-4, eps=1e-4)
+  pg, m, v = p.to(DEV), t.zeros(n, device=DEV), t.zeros(n, device=DEV)
+  for step in range(1, 4):
+    pt.grad = gr * step; opt.step()
+    be.adam_step(pg, (gr * step * 2).to(DEV), m, v, n, 4e-4, 0.9, 0.999, 1e-4, 0.5, step)
+  close(pg, pt.detach(), 1e-6, "adam")
+
+
+# ------------------------------------------------------------------ ground-truth side
+def _shells(N, R, radii, dtype=np.float32):
+  zz, yy, xx = np.meshgrid(np.arange(R), np.arange(R), np.arange(R), indexing="ij")
+  g = np.zeros((N, R, R, R), dtype)
+  for n in range(N):
+    r = radii[n % len(radii)]
+    d = np.sqrt((xx - R / 2 + 0.5) ** 2 + (yy - R / 2 + 0.5) ** 2 + (zz - R / 2 + 0.5) ** 2)
+    g[n][(d <= r) & (d > r - 1.5)] = 1
+  return g
+
+
+def test_fill_known_answers(be):
+  from reference_known_answers import fill_grids
+  from corenet_amd.cc import fill_voxels
+  g1, g2, e1, e2 = fill_grids()
+  for dt in (t.float32, t.uint8, t.int32, t.float64, t.int64):
+    grid = t.tensor(np.stack([g1, g2])).to(dt).to(DEV)
+    out = fill_voxels.fill_inside_voxels_gpu(grid, inplace=False)
+    assert out.data_ptr() != grid.data_ptr() and out.dtype == dt
+    np.testing.assert_array_equal(out.cpu().numpy(), np.stack([e1, e2]).astype(out.cpu().numpy().dtype))
+    out2 = fill_voxels.fill_inside_voxels_gpu(grid, inplace=True)
+    assert out2.data_ptr() == grid.data_ptr()
+    np.testing.assert_array_equal(grid.cpu().numpy(), np.stack([e1, e2]).astype(out.cpu().numpy().dtype))
+  with pytest.raises(ValueError):
+    fill_voxels.fill_inside_voxels_gpu(t.zeros(2, 2, 2, 2), inplace=False)          # CPU tensor
+  with pytest.raises(ValueError):
+    fill_voxels.fill_inside_voxels_gpu(t.zeros(2, 2, 2, device=DEV), inplace=False)  # rank 3
+
+
+@pytest.mark.parametrize("shape,seed", [((3, 5, 6, 7), 0), ((2, 33, 31, 65), 1), ((1, 9, 9, 130), 2),
+                                        ((4, 64, 64, 64), 3), ((2, 7, 7, 7), 4)])
+def test_fill_random_bit_exact(be, shape, seed):
+  import fill_oracle_c
+  rng = np.random.RandomState(seed)
+  for dens in (0.2, 0.45, 0.7):
+    g = (rng.rand(*shape) < dens).astype(np.float32)
+    g[0].flat[::7] = -3.0                    # non-positive values count as empty (data > 0)
+    out = t.empty(shape, device=DEV)
+    be.fill_voxels(t.tensor(g).to(DEV), out)
+    np.testing.assert_array_equal(out.cpu().numpy(), fill_oracle_c.fill(g))
+
+
+def test_fill_full_size_shells(be):
+  """BASELINE sizes: 12 x 128^3 hollow shells -> solid balls, low-face semantics, idempotence."""
+  import fill_oracle_c
+  g = _shells(12, 128, (10, 30, 50))
+  g[5, 100:, 100:, 100:] = 0; g[5, 99, 99:, 99:] = 1; g[5, 99:, 99, 99:] = 1; g[5, 99:, 99:, 99] = 1   # high-face pocket
+  grid = t.tensor(g).to(DEV)
+  out = t.empty_like(grid)
+  be.fill_voxels(grid, out)
+  o = out.cpu().numpy()
+  np.testing.assert_array_equal(o[:6], fill_oracle_c.fill(g[:6]))
+  assert o[5, 100:, 100:, 100:].min() == 1
+  out2 = t.empty_like(grid); be.fill_voxels(out, out2)
+  assert t.equal(out, out2)                                  # idempotent
+  assert set(np.unique(o)) <= {0.0, 1.0}
+
+
+def test_voxelizer_known_answers(be):
+  from corenet_amd.cc import fill_voxels
+  from corenet_amd.geometry import voxelization
+  from test_oracle_cpu import _cube
+  quad = t.tensor([[[0, 0, 0], [1, 0, 1], [0, 1, 0]], [[1, 0, 1], [0, 1, 0], [1, 1, 1]]], dtype=t.float32)
+  grid = voxelization.voxelize_mesh(quad, [2], (4, 4, 4), O.scale([4, 4, 4]), image_resolution_multiplier=16)
+  fill_voxels.fill_inside_voxels_gpu(grid, inplace=True)
+  e = np.zeros((4, 4, 4), np.float32)
+  for i in range(4): e[i, :, i] = 1
+  np.testing.assert_array_equal(grid.cpu().numpy(), e[None])
+  cube = t.tensor(_cube(0.99))
+  g = voxelization.voxelize_mesh(cube, [12], (3, 3, 3), t.eye(4), image_resolution_multiplier=1)
+  e = np.zeros((3, 3, 3), np.float32); e[1, 1, [0, 2]] = e[1, [0, 2], 1] = e[[0, 2], 1, 1] = 1
+  np.testing.assert_array_equal(g.cpu().numpy(), e[None])
+  g = voxelization.voxelize_mesh(cube, [12], (3, 3, 3), t.eye(4), image_resolution_multiplier=1,
+                                 conservative_rasterization=True)
+  e = np.ones((3, 3, 3), np.float32); e[1, 1, 1] = 0
+  np.testing.assert_array_equal(g.cpu().numpy(), e[None])
+  g = voxelization.voxelize_mesh(cube, [12], (3, 3, 3), t.eye(4), sub_grid_sampling=True,
+                                 image_resolution_multiplier=9, conservative_rasterization=True)
+  g = fill_voxels.fill_inside_voxels_gpu(g, inplace=False)
+  e = np.zeros((1, 7, 7, 7), np.float32); e[0, 2:5, 2:5, 2:5] = 1
+  np.testing.assert_array_equal(g.cpu().numpy(), e)
+  cubes = t.cat([cube, cube - 0.5])
+  tr = t.stack([O.translate([-0.5, 0, 0]), O.translate([0.5, 1, 1])])
+  g = voxelization.voxelize_mesh(cubes, [12, 12], (3, 3, 3), tr, sub_grid_sampling=True,
+                                 image_resolution_multiplier=9, conservative_rasterization=True)
+  c = voxelization.get_sub_grid_centers(fill_voxels.fill_inside_voxels_gpu(g)).cpu().numpy()
+  e1 = np.zeros((3, 3, 3)); e1[1, 1, [0, 1]] = 1
+  e2 = np.zeros((3, 3, 3)); e2[1, [1, 2], 1] = e2[2, [1, 2], 1] = 1
+  np.testing.assert_array_equal(c[0], e1); np.testing.assert_array_equal(c[1], e2)
+  with pytest.raises(ValueError):
+    voxelization.voxelize_mesh(cube, [12], (3, 3, 3), t.eye(4), sub_grid_sampling=True, image_resolution_multiplier=8)
+
+
+def _uv_sphere(n_lat, n_lon, center, radius):
+  th = np.linspace(0, np.pi, n_lat + 1); ph = np.linspace(0, 2 * np.pi, n_lon + 1)
+  p = lambda a, b: center + radius * np.array([np.sin(a) * np.cos(b), np.sin(a) * np.sin(b), np.cos(a)])
+  tris = []
+  for i in range(n_lat):
+    for j in range(n_lon):
+      a, b, c, d = p(th[i], ph[j]), p(th[i + 1], ph[j]), p(th[i + 1], ph[j + 1]), p(th[i], ph[j + 1])
+      tris += [[a, b, c], [a, c, d]]
+  return np.array(tris, np.float32)
+
+
+def test_voxelizer_sphere_vs_oracle_and_labels(be):
+  """Sphere meshes at 32^3 (oracle finishes in seconds): HIP == oracle restatement up to
+  the fp32-vs-fp64 rasteriser tolerance the reference itself accepts (<=0.05% voxels);
+  after fill: a solid ball; label merge: larger class id wins on overlap (Q11)."""
+  from corenet_amd.data import batched_example
+  R = 32
+  tris = np.concatenate([_uv_sphere(24, 48, np.array([0.45, 0.5, 0.5]), 0.25),
+                         _uv_sphere(24, 48, np.array([0.6, 0.5, 0.5]), 0.2)])
+  nt = [24 * 48 * 2, 24 * 48 * 2]
+  off = t.full((1, 3), 0.5)
+  v2v = batched_example.view2voxel_matrices(off, (R, R, R))
+  np.testing.assert_allclose(v2v.numpy(), O.view2voxel_matrices(off, (R, R, R)).numpy())
+  from corenet_amd.geometry import voxelization
+  g = voxelization.voxelize_mesh(t.tensor(tris), nt, (R, R, R), v2v[0], image_resolution_multiplier=8).cpu().numpy()
+  ref = O.voxelize_mesh(tris, nt, (R, R, R), v2v[0].numpy(), image_resolution_multiplier=8)
+  assert (g != ref).mean() <= 5e-4
+  labels = batched_example.voxelize(t.tensor(tris), [t.tensor(nt, dtype=t.int32)], [[3, 5]], off, (R, R, R),
+                                    image_resolution_multiplier=8).cpu().numpy()
+  filled = O.fill_inside_voxels(ref)
+  want = O.merge_labels(filled, [2], [[3, 5]])
+  assert (labels != want).mean() <= 1e-3
+  zz, yy, xx = np.meshgrid(*[np.arange(R) + 0.5] * 3, indexing="ij")
+  inside2 = ((xx / R - 0.6) ** 2 + (yy / R - 0.5) ** 2 + (zz / R - 0.5) ** 2) < 0.17 ** 2
+  assert (labels[0][inside2] == 5).all()

@@ -1,0 +1,126 @@
+"""GPU parity of the whole model path through the drop-in boundary
+(corenet_amd.model.core_net.CoreNet) against the golden vectors generated from the
+imported reference and against the oracle.
+
+Tolerances.  north_star: logits within 1e-3 relative (fp32).  The reference model
+itself, in fp32 vs fp64 on these synthetic inputs, moves by 2e-6 (eval) / 3e-4
+(train, B=1) in the logits and by 4e-5 (stage_6.t1) ... 5e-2 (encoder) in the
+gradients (measured with the oracle, DESIGN.md "Conditioning"), so gradient checks
+deeper than the last layers are norm/cosine checks; the tight backward checks are
+per kernel (test_kernels_gpu.py) plus the fp64 host-wiring test (test_host_cpu.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch as t
+
+from oracle import corenet_oracle as O
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _model(nc, sd):
+  from corenet_amd.model.core_net import CoreNet, CoreNetConfig, DecoderConfig
+  m = CoreNet(CoreNetConfig(DecoderConfig((128, 128, 128), nc, 2, 64, 0.75)), device="cuda")
+  missing = m.load_state_dict(sd)
+  assert not missing.missing_keys and not missing.unexpected_keys
+  return m
+
+
+def relerr(a, b):
+  a = t.as_tensor(a).double().cpu(); b = t.as_tensor(b).double().cpu()
+  return float((a - b).abs().max() / b.abs().max().clamp(min=1e-30))
+
+
+def test_state_dict_surface():
+  sd = O.make_state(0, 2)
+  m = _model(2, sd)
+  got = m.state_dict()
+  assert list(got.keys()) == list(sd.keys())
+  for k in sd:
+    assert tuple(got[k].shape) == tuple(sd[k].shape) and got[k].dtype == sd[k].dtype, k
+    assert t.equal(got[k].cpu(), sd[k]), k
+  assert sum(p.numel() for p in m.parameters()) == 36141888
+  enc = {k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}
+  m.encoder.load_state_dict(enc)                                      # state.py:69
+  assert m.config.to_dict()["decoder"]["resolution"] == (128, 128, 128)
+
+
+def test_forward_eval_golden():
+  z = np.load(os.path.join(G, "model_h7_eval_b1.npz"))
+  m = _model(2, O.make_state(0, 2, nbt=100)).eval()
+  image, v2s, off, grid = O.synthetic_batch(1, 0, 2)
+  with t.no_grad():
+    logits = m(image.cuda(), v2s.cuda(), off.cuda())
+  assert logits.shape == (1, 2, 128, 128, 128) and logits.dtype == t.float32
+  assert relerr(logits[:, :, ::16, ::16, ::16], z["logits_sub"]) < 1e-4
+  assert abs(float(logits.double().sum()) - float(z["logits_sum"])) < 1e-4 * float(z["logits_abs_sum"])
+  from corenet_amd.model import losses
+  assert abs(float(losses.iou_fgbg(grid.cuda(), logits)) - float(z["loss"])) < 1e-5
+
+
+@pytest.mark.parametrize("tag,nc,nbt,B,lossname", [("h7_train_b1", 2, 0, 1, "iou_fgbg"),
+                                                   ("m9_train_b1", 14, 0, 1, "xent_times_iou_agnostic")])
+def test_train_forward_backward_golden(tag, nc, nbt, B, lossname):
+  from corenet_amd.model import losses
+  z = np.load(os.path.join(G, f"model_{tag}.npz"))
+  sd = O.make_state(0, nc, nbt=nbt)
+  m = _model(nc, sd).train()
+  image, v2s, off, grid = O.synthetic_batch(B, 0, nc)
+  logits = m(image.cuda(), v2s.cuda(), off.cuda())
+  assert relerr(logits[:, :, ::16, ::16, ::16], z["logits_sub"]) < 1e-3          # north_star tolerance
+  loss = getattr(losses, lossname)(grid.cuda(), logits)
+  assert abs(float(loss) - float(z["loss"])) < 2e-4 * max(1.0, abs(float(z["loss"])))
+  loss.backward()
+  params = dict(m.named_parameters())
+  # last layers: well-conditioned -> element-wise
+  assert relerr(params["decoder.stage_6.t1.weight"].grad, z["grad::decoder.stage_6.t1.weight"]) < 2e-3
+  names, norms = list(z["grad_names"]), z["grad_norms"]
+  bad = []
+  for n, want in zip(names, norms):
+    if n.endswith("conv.bias") or n.endswith("c1.bias") or ".t1.bias" in n and "stage_6" not in n:
+      continue                     # biases in front of a train-mode BatchRenorm: true gradient is 0
+    got = float(params[n].grad.double().norm())
+    if abs(got - want) > 0.25 * want + 1e-12:
+      bad.append((n, got, float(want)))
+  assert not bad, bad[:8]
+  # running statistics were stepped like the reference's
+  sdn = m.state_dict()
+  for k in z.files:
+    if k.startswith("buf::"):
+      assert relerr(sdn[k[5:]], z[k]) < 1e-4, k
+  assert int(sdn["decoder.stage_1.b1.num_batches_tracked"]) == nbt + 1
+
+
+def test_backward_matches_oracle_cosine():
+  """Direction of every parameter gradient vs the oracle's autograd (B=1, h7)."""
+  from corenet_amd.model import losses
+  sd = O.make_state(0, 2, nbt=0)
+  m = _model(2, sd).train()
+  image, v2s, off, grid = O.synthetic_batch(1, 0, 2)
+  loss = losses.iou_fgbg(grid.cuda(), m(image.cuda(), v2s.cuda(), off.cuda()))
+  loss.backward()
+  so = {k: v.clone() for k, v in sd.items()}
+  for k in so:
+    if so[k].dtype == t.float32 and "running" not in k: so[k].requires_grad_(True)
+  O.iou_fgbg(grid, O.corenet_forward(so, image, v2s, off, training=True)).backward()
+  worst = 1.0
+  for n, p in m.named_parameters():
+    if n.endswith("conv.bias") or n.endswith("c1.bias") or (".t1.bias" in n and "stage_6" not in n):
+      continue
+    a, b = p.grad.double().cpu().reshape(-1), so[n].grad.double().reshape(-1)
+    cos = float((a @ b) / (a.norm() * b.norm() + 1e-300))
+    worst = min(worst, cos)
+    assert cos > 0.98, (n, cos)
+  print("worst gradient cosine vs oracle:", worst)
+
+
+def test_train_step_reduces_loss_and_matches_autograd_path():
+  sd = O.make_state(0, 2, nbt=0)
+  m = _model(2, sd).train()
+  image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(2, 0, 2)]
+  l0 = float(m.train_step(image, v2s, off, grid, "iou_fgbg", lr=4e-4))
+  for _ in range(3):
+    l = float(m.train_step(image, v2s, off, grid, "iou_fgbg", lr=4e-4))
+  assert np.isfinite(l) and l < l0

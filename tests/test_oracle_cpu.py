@@ -1,0 +1,171 @@
+"""CPU tests: the oracle against the reference's own known-answer vectors and
+the golden fixtures generated from the imported reference (oracle/gen_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch as t
+
+from oracle import corenet_oracle as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ---- reference known answers (test/losses_test.py:25-95) -----------------------
+def _losses_fixture():
+  from reference_known_answers import LOSS_LOGITS, LOSS_GT, LOSS_WEIGHTS
+  return (t.tensor(LOSS_LOGITS).permute(0, 4, 1, 2, 3).contiguous(), t.tensor(LOSS_GT),
+          t.tensor(LOSS_WEIGHTS))
+
+
+def test_losses_known_answers():
+  logits, gt, w = _losses_fixture()
+  np.testing.assert_allclose(O.iou_agnostic(gt, logits), 0.8060565, rtol=1e-5, atol=1e-6)
+  np.testing.assert_allclose(O.iou_agnostic(gt, logits, w), 0.8174121, rtol=1e-5, atol=1e-6)
+  np.testing.assert_allclose(O.iou_fgbg(gt, logits), 0.3579613, rtol=1e-5, atol=1e-6)
+  np.testing.assert_allclose(O.iou_fgbg(gt, logits, w), 0.4265449, rtol=1e-5, atol=1e-6)
+  np.testing.assert_allclose(O.xent(gt, logits), 1.4547757, rtol=1e-5, atol=1e-6)
+  np.testing.assert_allclose(O.xent(gt, logits, w), 0.7043564, rtol=1e-5, atol=1e-6)
+
+
+# ---- fill (test/voxelization_test.py:150-248) -----------------------------------------
+def test_fill_known_answers():
+  from reference_known_answers import fill_grids
+  g1, g2, e1, e2 = fill_grids()
+  out = O.fill_inside_voxels(np.stack([g1, g2]))
+  np.testing.assert_array_equal(out, np.stack([e1, e2]))
+  out8 = O.fill_inside_voxels(np.stack([g1, g2]).astype(np.uint8))
+  np.testing.assert_array_equal(out8, np.stack([e1, e2]).astype(np.uint8))
+
+
+def test_fill_low_face_semantics():
+  """outside is reachable only through the x=0/y=0/z=0 faces."""
+  g = np.zeros((1, 4, 4, 4), np.float32)
+  g[0, 1, :, :] = g[0, :, 1, :] = g[0, :, :, 1] = 1     # walls: the x,y,z>=2 pocket touches only HIGH faces
+  out = O.fill_inside_voxels(g)
+  assert out[0, 2:, 2:, 2:].min() == 1       # filled although it touches the grid boundary
+  assert out[0, 0, 0, 0] == 0 and out[0, 0, 3, 3] == 0   # regions touching a low face stay outside
+
+
+def test_fill_c_oracle_matches_python():
+  import fill_oracle_c
+  rng = np.random.RandomState(0)
+  for shape in [(2, 5, 6, 7), (1, 9, 9, 9), (3, 4, 4, 4)]:
+    g = (rng.rand(*shape) < 0.45).astype(np.float32)
+    np.testing.assert_array_equal(fill_oracle_c.fill(g), O.fill_inside_voxels(g))
+
+
+# ---- voxel metrics (test/voxel_metrics_test.py) ------------------------------------------
+def test_confusion_matrix_known_answer():
+  gt = t.tensor([[[3, 2, 2, 4], [4, 3, 2, 2], [3, 1, 3, 0]], [[3, 0, 1, 3], [2, 3, 1, 1], [2, 3, 0, 4]]])
+  pred = t.tensor([[[0, 2, 3, 1], [1, 1, 1, 3], [4, 0, 2, 3]], [[1, 0, 1, 4], [2, 4, 4, 0], [4, 2, 4, 2]]])
+  cm = O.confusion_matrix(gt, pred, 5)
+  np.testing.assert_array_equal(cm.numpy(), [[1, 0, 0, 1, 1], [2, 1, 0, 0, 1], [0, 1, 2, 2, 1],
+                                             [1, 2, 2, 0, 3], [0, 2, 1, 0, 0]])
+
+
+# ---- voxelizer (test/voxelization_test.py:53-147) ---------------------------------------------
+def _cube(d):
+  m, x = d, 3 - d
+  return np.array([
+      [[m, m, m], [m, x, m], [m, m, x]], [[m, x, x], [m, x, m], [m, m, x]],
+      [[x, m, m], [x, x, m], [x, m, x]], [[x, x, x], [x, x, m], [x, m, x]],
+      [[m, m, m], [m, m, x], [x, m, m]], [[x, m, x], [m, m, x], [x, m, m]],
+      [[m, x, m], [m, x, x], [x, x, m]], [[x, x, x], [m, x, x], [x, x, m]],
+      [[m, m, m], [m, x, m], [x, m, m]], [[x, x, m], [m, x, m], [x, m, m]],
+      [[m, m, x], [m, x, x], [x, m, x]], [[x, x, x], [m, x, x], [x, m, x]]], np.float32)
+
+
+def test_voxelizer_simple_example():
+  quad = np.array([[[0, 0, 0], [1, 0, 1], [0, 1, 0]], [[1, 0, 1], [0, 1, 0], [1, 1, 1]]], np.float32)
+  grid = O.voxelize_mesh(quad, [2], (4, 4, 4), O.scale([4, 4, 4]).numpy(), image_resolution_multiplier=16)
+  grid = O.fill_inside_voxels(grid)
+  e = np.zeros((4, 4, 4), np.float32)
+  for i in range(4):
+    e[i, :, i] = 1
+  np.testing.assert_array_equal(grid, e[None])
+
+
+def test_voxelizer_conservative():
+  cube = _cube(0.99)
+  g = O.voxelize_mesh(cube, [12], (3, 3, 3), np.eye(4, dtype=np.float32), image_resolution_multiplier=1)
+  e = np.zeros((3, 3, 3), np.float32)
+  e[1, 1, [0, 2]] = e[1, [0, 2], 1] = e[[0, 2], 1, 1] = 1
+  np.testing.assert_array_equal(g, e[None])
+  g = O.voxelize_mesh(cube, [12], (3, 3, 3), np.eye(4, dtype=np.float32), image_resolution_multiplier=1,
+                      conservative_rasterization=True)
+  e = np.ones((3, 3, 3), np.float32); e[1, 1, 1] = 0
+  np.testing.assert_array_equal(g, e[None])
+
+
+def test_voxelizer_sub_grid():
+  cube = _cube(0.99)
+  g = O.voxelize_mesh(cube, [12], (3, 3, 3), np.eye(4, dtype=np.float32), sub_grid_sampling=True,
+                      image_resolution_multiplier=9, conservative_rasterization=True)
+  g = O.fill_inside_voxels(g)
+  e = np.zeros((1, 7, 7, 7), np.float32); e[0, 2:5, 2:5, 2:5] = 1
+  np.testing.assert_array_equal(g, e)
+  c = O.get_sub_grid_centers(g)
+  e = np.zeros((1, 3, 3, 3), np.float32); e[0, 1, 1, 1] = 1
+  np.testing.assert_array_equal(c, e)
+  cubes = np.concatenate([cube, cube - 0.5])
+  tr = np.stack([O.translate([-0.5, 0, 0]).numpy(), O.translate([0.5, 1, 1]).numpy()])
+  g = O.voxelize_mesh(cubes, [12, 12], (3, 3, 3), tr, sub_grid_sampling=True, image_resolution_multiplier=9,
+                      conservative_rasterization=True)
+  c = O.get_sub_grid_centers(O.fill_inside_voxels(g))
+  e1 = np.zeros((3, 3, 3)); e1[1, 1, [0, 1]] = 1
+  e2 = np.zeros((3, 3, 3)); e2[1, [1, 2], 1] = e2[2, [1, 2], 1] = 1
+  np.testing.assert_array_equal(c[0], e1)
+  np.testing.assert_array_equal(c[1], e2)
+  with pytest.raises(ValueError):
+    O.voxelize_mesh(cube, [12], (3, 3, 3), np.eye(4), sub_grid_sampling=True, image_resolution_multiplier=8)
+
+
+# ---- golden fixtures generated from the imported reference --------------------------------------
+def test_batch_renorm_golden():
+  z = np.load(os.path.join(G, "batch_renorm.npz"))
+  x = t.tensor(z["x"])
+  for tag, nbt, training in (("train0", 0, True), ("train30k", 30000, True), ("eval", 123, False)):
+    sd = {"weight": t.tensor([1.0, 0.5, 2.0, 1.5, 0.8]), "bias": t.tensor([0.0, 0.1, -0.2, 0.3, 1.0]),
+          "running_mean": t.tensor([0.5, 0.9, -0.3, 2.5, 0.7]), "running_var": t.tensor([4.0, 0.2, 9.0, 1.0, 30.0]),
+          "num_batches_tracked": t.tensor(nbt)}
+    y = O.batch_renorm(x, sd, "", training)
+    np.testing.assert_allclose(y.numpy(), z[f"{tag}_y"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(sd["running_var"].numpy(), z[f"{tag}_rv"], rtol=1e-6)
+    np.testing.assert_allclose(sd["running_mean"].numpy(), z[f"{tag}_rm"], rtol=1e-6)
+
+
+def test_sample_grid2d_golden():
+  z = np.load(os.path.join(G, "sample_grid2d.npz"))
+  y = O.sample_grid2d(t.tensor(z["src"]), t.tensor(z["weight"]), t.tensor(z["bias"]), t.tensor(z["mats"]),
+                      t.tensor(z["off"]), (16, 16, 16))
+  assert int((y.numpy() != z["y"]).sum()) == 0
+  cam = O.canonical_camera()
+  for res in (8, 16, 32, 64):
+    idmap = t.arange(res * res, dtype=t.float32).reshape(1, 1, res, res) + 1
+    m = (cam @ O.scale([1.0 / 128] * 3) @ O.scale([128.0 / res] * 3))[None]
+    yo = O.ray_sample(idmap, m, t.full((1, 3), 0.5), (res,) * 3)
+    assert int((yo[0, 0].numpy().astype(np.int32) != z[f"idx_{res}"]).sum()) == 0
+
+
+def test_losses_golden():
+  z = np.load(os.path.join(G, "losses.npz"))
+  logits, gt = t.tensor(z["logits"]), t.tensor(z["gt"])
+  for name in ("iou_agnostic", "iou_fgbg", "xent", "xent_times_iou_agnostic", "xent_times_iou_fgbg"):
+    l = logits.clone().requires_grad_(True)
+    v = getattr(O, name)(gt, l)
+    v.backward()
+    np.testing.assert_allclose(float(v), z[name], rtol=1e-6)
+    np.testing.assert_allclose(l.grad.numpy(), z[name + "_grad"], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("tag,nc,nbt,batch,training", [("h7_eval_b1", 2, 100, 1, False),
+                                                       ("h7_train_b1", 2, 0, 1, True)])
+def test_model_golden(tag, nc, nbt, batch, training):
+  z = np.load(os.path.join(G, f"model_{tag}.npz"))
+  sd = O.make_state(0, nc, nbt=nbt)
+  image, v2s, off, grid = O.synthetic_batch(batch, 0, nc)
+  with t.no_grad():
+    logits = O.corenet_forward(sd, image, v2s, off, training=training)
+  np.testing.assert_allclose(logits[:, :, ::16, ::16, ::16].numpy(), z["logits_sub"], rtol=1e-4, atol=1e-5)
+  np.testing.assert_allclose(float(O.iou_fgbg(grid, logits)), z["loss"], rtol=1e-5)
