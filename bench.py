@@ -1,0 +1,137 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json: voxels/sec fwd+bwd @128^3).
+
+One "step" = the reference's training hot loop body (pipeline.py:224-233) on one
+synthetic batch already resident in HBM: CoReNet forward -> iou_fgbg loss ->
+backward -> gradient all-reduce (RCCL, N>1) -> Adam, B=4 samples of 256x256 RGB
+-> 128^3 voxels per GPU (configs/models/h7.json5:42,62-67), fp32 like the
+reference.  value = global_batch * 128^3 * steps / time.
+
+  python bench.py --gpus 1 --steps 10 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+      --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch as t  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic work: per sample
+CONV6_FLOP = 2 * 64 ** 3 * 28 * 125 * 16          # stage_6 c1: Conv3d 28->16 k5 @64^3
+RAY64_BYTES = 64 ** 3 * 12 * 4 + 64 * 64 * 12 * 4  # ray-sample 64^3 x 12ch: output + map
+PEAK_F32_MFMA = 157.3e12                           # MI355X_MICROARCH.md: fp32 matrix peak
+PEAK_HBM = 8.0e12                                  # HBM3E spec peak
+
+
+def cpu_baseline(num_classes, loss_name, seconds_budget=25.0):
+  """The oracle (torch-CPU restatement of the reference, validated against the imported
+  reference in oracle/gen_golden.py) timed on this host's cores: B=1 fwd+loss+bwd."""
+  from oracle import corenet_oracle as O
+  nthreads = os.cpu_count() or 1
+  t.set_num_threads(nthreads)
+  sd = O.make_state(0, num_classes, nbt=0)
+  for k in sd:
+    if sd[k].dtype == t.float32 and "running" not in k:
+      sd[k].requires_grad_(True)
+  image, v2s, off, grid = O.synthetic_batch(1, 0, num_classes)
+  def step():
+    for v in sd.values():
+      v.grad = None
+    loss = getattr(O, loss_name)(grid, O.corenet_forward(sd, image, v2s, off, training=True))
+    loss.backward()
+  step()                                  # warm-up
+  n, t0 = 0, time.time()
+  while n < 3 or (time.time() - t0 < seconds_budget and n < 20):
+    step(); n += 1
+  dt = (time.time() - t0) / n
+  return {"value": 128 ** 3 / dt, "unit": "voxels/s", "cores": nthreads, "kind": "port",
+          "sample": f"{n} steps of B=1 fwd+loss+bwd (oracle/corenet_oracle.py, torch-CPU fp32)"}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=10)
+  ap.add_argument("--warmup", type=int, default=3)
+  ap.add_argument("--batch", type=int, default=4, help="samples per GPU (h7.json5:42)")
+  ap.add_argument("--classes", type=int, default=2, help="2 = h7 (FG/BG); 14 = m7/m9")
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  args = ap.parse_args()
+
+  from corenet_amd import distributed as D
+  from corenet_amd.model.core_net import CoreNet, CoreNetConfig, DecoderConfig
+  from oracle import corenet_oracle as O     # synthetic inputs / deterministic weights only
+
+  rank, local, world = D.init_from_env()
+  assert world == args.gpus or world == 1, (world, args.gpus)
+  t.cuda.set_device(local)
+  dev = f"cuda:{local}"
+  C, B = args.classes, args.batch
+  loss_name = "iou_fgbg" if C == 2 else "xent_times_iou_agnostic"
+  model = CoreNet(CoreNetConfig(DecoderConfig((128, 128, 128), C, 2, 64, 0.75)), device=dev)
+  model.load_state_dict(O.make_state(0, C, nbt=0))
+  model.train()
+  image, v2s, off, grid = [x.to(dev) for x in O.synthetic_batch(B, seed=rank, num_classes=C)]
+  grid = grid.to(t.int32)
+  sync = D.GradientSync(world)
+  plan = model.engine.plan(B)
+
+  def step():
+    D.broadcast_buffers(model.engine.store)
+    return model.train_step(image, v2s, off, grid, loss_name, lr=4e-4, adam_eps=1e-4, world_size=world,
+                            all_reduce=sync if world > 1 else None)
+
+  for _ in range(args.warmup):
+    step()
+  plan.probes = {"conv3d_stage6_c1_fwd": [], "ray_sample_fwd_64": []}
+  if world > 1:
+    dist.barrier()
+  t.cuda.synchronize()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    loss = step()
+  t.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  dt = time.perf_counter() - t0
+  tt = t.tensor([dt], dtype=t.float64, device=dev)
+  if world > 1:
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+  dt = float(tt)
+  probes = {k: sum(a.elapsed_time(b) for a, b in v) / max(1, len(v)) * 1e-3 for k, v in plan.probes.items()}
+  plan.probes = None
+  if rank != 0:
+    return
+  conv_s, ray_s = probes["conv3d_stage6_c1_fwd"], probes["ray_sample_fwd_64"]
+  out = {
+      "metric": "voxels/sec fwd+bwd @128^3", "value": world * B * 128 ** 3 * args.steps / dt,
+      "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+      "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+      "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+      "config": {"workload": f"h7: CoReNet train step (fwd+{loss_name}+bwd+allreduce+Adam), "
+                             f"256x256 RGB -> 128^3, C={C}, B={B}/GPU, fp32, random-init weights",
+                 "global_batch": world * B, "parallelism": f"dp{world}"},
+      "loss": float(loss),
+      "roofline": {"kernel": "conv_fwd_kernel<8,1> (stage_6.c1 Conv3d 28->16 k5 @64^3, fwd)",
+                   "bound": "mfma", "achieved": CONV6_FLOP * B / conv_s / 1e12, "peak": PEAK_F32_MFMA / 1e12,
+                   "unit": "TFLOP/s", "frac": CONV6_FLOP * B / conv_s / PEAK_F32_MFMA, "traffic": None,
+                   "avg_launch_ms": conv_s * 1e3},
+      "roofline_ray_sample": {"kernel": "ray_sample_fwd_kernel<4> (64^3 x 12 ch)", "bound": "hbm",
+                              "achieved": RAY64_BYTES * B / ray_s / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                              "frac": RAY64_BYTES * B / ray_s / PEAK_HBM, "traffic": None,
+                              "avg_launch_ms": ray_s * 1e3},
+  }
+  if not args.no_cpu_baseline and world == 1:
+    out["cpu_baseline"] = cpu_baseline(C, loss_name)
+  print(json.dumps(out))
+
+
+if __name__ == "__main__":
+  main()

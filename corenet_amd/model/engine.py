@@ -350,6 +350,15 @@ class Plan:
     self.gt = t.zeros(B, 128, 128, 128, dtype=t.int32, device=dev)
 
   # ------------------------------------------------------------------ helpers
+  probes = None     # bench.py: {name: [(start_event, end_event), ...]} around selected launches
+
+  def _probe(self, name: str, fn):
+    if self.probes is None or name not in self.probes:
+      return fn()
+    a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+    a.record(); fn(); b.record()
+    self.probes[name].append((a, b))
+
   def _stats(self, bn: BN, x: t.Tensor, S: int, sB: int, pre_relu: bool, training: bool):
     self.be.bn_stats(x, self.B, bn.C, S, sB, pre_relu, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.nbt,
                      BN_EPS, BN_MOMENTUM, training, bn.scale, bn.shift, bn.saved)
@@ -413,8 +422,8 @@ class Plan:
       p = f"decoder.stage_{k}."
       b1_, b2_ = bn[p + "b1."], bn[p + "b2."]
       self._stats(b1_, d["u"], S, d["cin"] * S, True, training)
-      self._conv(cv[p + "c1."], V.view_of(d["u"]), Transform(b1_.scale, b1_.shift, pre_relu=True),
-                 V.view_of(d["w"]))
+      self._probe(f"conv3d_stage{k}_c1_fwd", lambda: self._conv(
+          cv[p + "c1."], V.view_of(d["u"]), Transform(b1_.scale, b1_.shift, pre_relu=True), V.view_of(d["w"])))
       self._stats(b2_, d["w"], S, d["cmid"] * S, True, training)
       out = self.dec[k + 1]["u"] if k < 6 else self.logits
       ov = V.space_to_depth_view(V.view_of(out).channels(0, d["cout"]), (2, 2, 2))
@@ -425,9 +434,9 @@ class Plan:
         self._conv(cv[f"decoder.rt_skip_{k}.compress_channels."], V.view_of(ft), None,
                    V.view_of(self.smap[k]))
         ro = 2 * r
-        be.ray_sample_fwd(self.smap[k], self.smap[k].stride(0), B, eng.skip_ch[k], hw, hw,
-                          self.layer_mats[k - 2], self.offset,
-                          out[:, d["cout"]:], out.stride(0), ro, ro, ro)
+        self._probe(f"ray_sample_fwd_{ro}", lambda: be.ray_sample_fwd(
+            self.smap[k], self.smap[k].stride(0), B, eng.skip_ch[k], hw, hw, self.layer_mats[k - 2],
+            self.offset, out[:, d["cout"]:], out.stride(0), ro, ro, ro))
     if training:
       be.add_i64(eng.store.nbt, eng.store.nbt.numel(), 1)     # batch_renorm.py:57
     return self.logits
