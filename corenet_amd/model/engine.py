@@ -363,17 +363,29 @@ class Plan:
     self.be.bn_stats(x, self.B, bn.C, S, sB, pre_relu, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.nbt,
                      BN_EPS, BN_MOMENTUM, training, bn.scale, bn.shift, bn.saved)
 
+  trace = None      # tools/layer_times.py: list of (label, start_event, end_event) for every conv launch
+
+  def _timed(self, label, fn):
+    if self.trace is None:
+      return fn()
+    a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+    a.record(); fn(); b.record()
+    self.trace.append((label, a, b))
+
   def _conv(self, cv: Conv, x: V.View, tr, y: V.View, accumulate=False):
     g = cv.fwd
-    self.be.conv_fwd(x, tr, cv.wf, g.npad, cv.bias, 0, y, g.window, g.pad_lo, 0, accumulate)
+    self._timed("fwd   " + cv.name, lambda: self.be.conv_fwd(
+        x, tr, cv.wf, g.npad, cv.bias, 0, y, g.window, g.pad_lo, 0, accumulate))
 
   def _dgrad(self, cv: Conv, dy: V.View, dx: V.View, accumulate=False):
     g = cv.dgrad
-    self.be.conv_fwd(dy, None, cv.wd, g.npad, None, 0, dx, g.window, g.pad_lo, 0, accumulate)
+    self._timed("dgrad " + cv.name, lambda: self.be.conv_fwd(
+        dy, None, cv.wd, g.npad, None, 0, dx, g.window, g.pad_lo, 0, accumulate))
 
   def _wgrad(self, cv: Conv, x: V.View, tr, dy: V.View):
     g = cv.fwd
-    self.be.conv_wgrad(x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False)
+    self._timed("wgrad " + cv.name, lambda: self.be.conv_wgrad(
+        x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False))
 
   def _bias_grad(self, cv: Conv, dy: t.Tensor, S: int, sB: int):
     self.be.bias_grad(dy, self.B, cv.n_ref, S, sB, cv.dbias)
