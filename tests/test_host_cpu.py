@@ -1,0 +1,162 @@
+"""CPU tests of the host side: conv geometries (views + packed weights) against
+torch.nn.functional, the complete forward/backward plan of engine.py against the
+oracle in float64 (far below fp32 rounding noise), and the C ABI surface."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch as t
+import torch.nn.functional as F
+
+from oracle import corenet_oracle as O
+from kernel_contract_emu import EmuBackend
+from corenet_amd import views as V
+from corenet_amd.model import conv_geometry as G
+
+EMU = EmuBackend()
+DT = t.float64
+
+
+def pack(w, index):
+  out = t.zeros(len(index), dtype=w.dtype)
+  EMU.gather(w.reshape(-1), t.as_tensor(index), out)
+  return out
+
+
+def err(a, b):
+  return float((a - b).abs().max() / b.abs().max())
+
+
+@pytest.mark.parametrize("k,p", [(7, 3), (3, 1)])
+def test_convtranspose_as_window_correlation(k, p):
+  g = t.Generator().manual_seed(k)
+  B, Cin, Cout, D = 2, 5, 3, 6
+  x = t.randn(B, Cin, D, D, D, generator=g, dtype=DT)
+  w = t.randn(Cin, Cout, k, k, k, generator=g, dtype=DT)
+  bias = t.randn(Cout, generator=g, dtype=DT)
+  fwd, dgr = G.convt_fwd(w.shape, p), G.convt_dgrad(w.shape, p)
+  y = t.zeros(B, Cout + 2, 2 * D, 2 * D, 2 * D, dtype=DT)
+  yv = V.space_to_depth_view(V.view_of(y).channels(0, Cout), (2, 2, 2))
+  EMU.conv_fwd(V.view_of(x), None, pack(w, fwd.index), fwd.npad, pack(bias, G.bias_index(Cout, 8, fwd.npad)), 0,
+               yv, fwd.window, fwd.pad_lo)
+  ref = F.conv_transpose3d(x, w, bias, stride=2, padding=p, output_padding=1)
+  assert err(y[:, :Cout], ref) < 1e-12 and float(y[:, Cout:].abs().max()) == 0
+  dy = t.randn(ref.shape, generator=g, dtype=DT)
+  dyb = t.zeros_like(y); dyb[:, :Cout] = dy
+  dyv = V.space_to_depth_view(V.view_of(dyb).channels(0, Cout), (2, 2, 2))
+  dx = t.zeros_like(x)
+  EMU.conv_fwd(dyv, None, pack(w, dgr.index), dgr.npad, None, 0, V.view_of(dx), dgr.window, dgr.pad_lo)
+  xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+  F.conv_transpose3d(xr, wr, None, stride=2, padding=p, output_padding=1).backward(dy)
+  assert err(dx, xr.grad) < 1e-12
+  dw = t.zeros(len(fwd.index), dtype=DT)
+  EMU.conv_wgrad(V.view_of(x), None, dyv, dw, fwd.npad, fwd.window, fwd.pad_lo, True)
+  gw = t.zeros(w.numel(), dtype=DT); EMU.scatter(dw, t.as_tensor(fwd.index), gw)
+  assert err(gw.view(w.shape), wr.grad) < 1e-12
+  # the forward pack index is injective on the reference weight (doubles as the un-pack scatter)
+  valid = fwd.index[fwd.index >= 0]
+  assert len(np.unique(valid)) == len(valid) == w.numel()
+
+
+def test_conv_stem_strided_and_1to4():
+  g = t.Generator().manual_seed(1)
+  x = t.randn(2, 3, 20, 20, generator=g, dtype=DT); w = t.randn(8, 3, 7, 7, generator=g, dtype=DT)
+  geo = G.stem_fwd(w.shape, 3)
+  y = t.zeros(2, 8, 10, 10, dtype=DT)
+  EMU.conv_fwd(V.space_to_depth_view(V.view_of(x), (1, 2, 2)), None, pack(w, geo.index), geo.npad, None, 0,
+               V.view_of(y), geo.window, geo.pad_lo)
+  assert err(y, F.conv2d(F.pad(x, [3, 3, 3, 3]), w, None, stride=2)) < 1e-12
+  x = t.randn(2, 6, 8, 8, generator=g, dtype=DT); w = t.randn(5, 6, 1, 1, generator=g, dtype=DT)
+  geo, dgeo = G.conv_fwd(w.shape, 0), G.conv_dgrad(w.shape, 0)
+  y = t.zeros(2, 5, 4, 4, dtype=DT)
+  EMU.conv_fwd(V.strided_view(V.view_of(x), (1, 2, 2)), None, pack(w, geo.index), geo.npad, None, 0, V.view_of(y),
+               geo.window, geo.pad_lo)
+  assert err(y, F.conv2d(x, w, None, stride=2)) < 1e-12
+  dy = t.randn(y.shape, generator=g, dtype=DT); dx = t.zeros_like(x)
+  EMU.conv_fwd(V.view_of(dy), None, pack(w, dgeo.index), dgeo.npad, None, 0, V.strided_view(V.view_of(dx), (1, 2, 2)),
+               dgeo.window, dgeo.pad_lo, accumulate=True)
+  xr = x.clone().requires_grad_(True); F.conv2d(xr, w, None, stride=2).backward(dy)
+  assert err(dx, xr.grad) < 1e-12
+  x = t.randn(3, 7, generator=g, dtype=DT); w = t.randn(7, 4, 4, 4, 4, generator=g, dtype=DT)
+  geo = G.convt_1to4_fwd(w.shape)
+  y = t.zeros(3, 4, 4, 4, 4, dtype=DT)
+  EMU.conv_fwd(V.view_of(x.view(3, 7, 1, 1, 1)), None, pack(w, geo.index), geo.npad, None, 0,
+               V.flat_channel_view(V.view_of(y)), geo.window, geo.pad_lo)
+  assert err(y, F.conv_transpose3d(x.view(3, 7, 1, 1, 1), w, None, stride=4)) < 1e-12
+
+
+def test_conv3d_k5_dgrad_geometry():
+  g = t.Generator().manual_seed(2)
+  x = t.randn(1, 4, 6, 6, 6, generator=g, dtype=DT); w = t.randn(3, 4, 5, 5, 5, generator=g, dtype=DT)
+  dgeo = G.conv_dgrad(w.shape, 2)
+  dy = t.randn(1, 3, 6, 6, 6, generator=g, dtype=DT); dx = t.zeros_like(x)
+  EMU.conv_fwd(V.view_of(dy), None, pack(w, dgeo.index), dgeo.npad, None, 0, V.view_of(dx), dgeo.window, dgeo.pad_lo)
+  xr = x.clone().requires_grad_(True); F.conv3d(xr, w, None, padding=2).backward(dy)
+  assert err(dx, xr.grad) < 1e-12
+
+
+def test_engine_plan_matches_oracle_fp64():
+  """Whole forward + loss + backward plan (views, packs, fused BN transforms, skips,
+  residuals, scatter of packed grads) vs the oracle, float64, r/d clamps active."""
+  from corenet_amd.model.engine import Engine, LOSS_KINDS
+  t.set_num_threads(min(8, os.cpu_count() or 1))
+  B, C = 1, 2
+  eng = Engine(C, device="cpu", backend=EmuBackend(), dtype=DT)
+  sd = O.make_state(0, C, nbt=30000)
+  for k, v in sd.items():
+    eng.store.view(k).copy_(v)
+  image, v2s, off, grid = O.synthetic_batch(B, 0, C)
+  plan = eng.plan(B)
+  logits = plan.forward(image, v2s, off, training=True)
+  s = {k: (v.detach().clone().to(DT) if v.dtype == t.float32 else v.clone()) for k, v in sd.items()}
+  for k in s:
+    if s[k].dtype == DT and "running" not in k:
+      s[k].requires_grad_(True)
+  feats, avg = O.resnet50_features(O.preprocess_image_caffe(image).to(DT), s, True)
+  lo = O.decoder_forward(feats, avg, s, v2s, off, (128, 128, 128), True)
+  assert err(logits, lo.detach()) < 1e-6
+  O.iou_fgbg(grid, lo).backward()
+  plan.gt.copy_(grid.to(t.int32))
+  eng.be.loss_fwd_bwd(LOSS_KINDS["iou_fgbg"], plan.logits, plan.gt, B, C, 128 ** 3, plan.loss, plan.glogits, 1.0)
+  plan.backward(plan.glogits)
+  for k, v in s.items():
+    if v.grad is None or k.endswith("conv.bias") or k.endswith("c1.bias"):
+      continue          # biases feeding a train-mode BatchRenorm have zero true gradient
+    gmax = float(v.grad.abs().max())
+    if gmax < 1e-14:
+      continue
+    assert err(eng.store.view(k, grad=True), v.grad) < 1e-5, k
+  for k in ("decoder.stage_6.b1.running_mean", "encoder.stage5.c.op_c.bn.running_var"):
+    assert float((eng.store.view(k) - s[k]).abs().max()) < 1e-8
+  assert int(eng.store.view("decoder.stage_1.b1.num_batches_tracked")) == 30001
+
+
+def test_c_abi_surface():
+  """The shared library loads (no GPU needed) and exports every symbol of include/corenet_hip.h."""
+  import re
+  from corenet_amd import _lib, build as B
+  if not os.path.exists(B.LIB):
+    B.build(verbose=False)
+  lib = ctypes.CDLL(B.LIB)
+  hdr = open(os.path.join(os.path.dirname(B.HERE), "include", "corenet_hip.h")).read()
+  declared = set(re.findall(r"\b(crn_[a-z0-9_]+)\s*\(", hdr))
+  assert declared == set(_lib.ALL_SYMBOLS), declared ^ set(_lib.ALL_SYMBOLS)
+  for sym in declared:
+    getattr(lib, sym)
+  lib.crn_version.restype = ctypes.c_char_p
+  assert b"gfx950" in lib.crn_version()
+
+
+def test_product_has_no_cpu_fallback():
+  """corenet_amd never imports the oracle / emulator, and CPU tensors are rejected."""
+  import corenet_amd.cc.fill_voxels as fv
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  for dp, _, files in os.walk(os.path.join(root, "corenet_amd")):
+    for f in files:
+      if f.endswith(".py"):
+        src = open(os.path.join(dp, f)).read()
+        import re
+        assert not re.search(r"^\s*(from|import)\s+(oracle|kernel_contract_emu|tests)\b", src, re.M), f
+  with pytest.raises(ValueError):
+    fv.fill_inside_voxels_gpu(t.zeros(1, 2, 2, 2))
