@@ -24,6 +24,8 @@
 //    (crnInTransform), so normalised activations are never written to HBM.
 #include "crn_common.h"
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -48,111 +50,203 @@ struct ConvGeom {
   int tilesD, tilesH, tilesW;
   int nchunks, chunks_per_split;
   int mode;                // 0 store, 1 accumulate (rmw), 2 atomic add
-  float inv_PW, inv_PH, inv_PD, inv_T;
+  int lg2, npass;          // patch staging: plane padded to 2^lg2 slots, passes of 256 slots
+  unsigned magic_PW, magic_PD, magic_T;
 };
-
-__device__ __forceinline__ int fdiv(int e, float inv) {  // floor(e / d), exact for e < 2^21
-  return (int)(((float)e + 0.5f) * inv);
-}
 
 __device__ __forceinline__ int64_t view_chan(const crnView& v, int c) {
   return v.chan_off ? (int64_t)v.chan_off[c] : (int64_t)c * v.sC;
 }
 
 // ---- patch staging: global -> registers (issue) and registers -> LDS (commit) ----
+// The patch of one chunk is CC*PD planes of PH*PW elements.  Staging slots are laid out as
+// planes padded to PLP = 2^lg2 elements so that slot -> (plane q, in-plane r) is shift/mask:
+//   lg2 >= 8: q is wave-uniform (scalar unit) and r takes PLP/256 per-thread values,
+//   lg2 <  8: r is a per-thread constant.
+// Everything that depends only on r (ph, pw, h/w bounds, h/w address part) is loop invariant
+// and hoisted by the compiler; per slot ~6 VALU remain for issue and ~8 for commit.
 struct PatchDesc {
   crnView x;
   crnInTransform tr;
-  int pd, ph, pw, PD, PH, PW, PS, PSP;
-  float inv_PW, inv_PH, inv_PD;
+  int pd, ph, pw, PD, PH, PW, plane, lg2, PSP;
+  unsigned magic_PW, magic_PD;       // ceil(2^20 / d)
 };
 
 typedef __amdgpu_buffer_rsrc_t crn_rsrc;   // buffer resource (V#)
 
-// Decompose staged element e -> (channel_local, LDS offset, in-bounds, byte offset in the sample).
-// Pure function of e: evaluated at issue time for the address and again at commit time for the
-// LDS slot, so that only the loaded VALUE lives in registers across the MFMA loop.
-struct PatchElem { int cl, lds; bool in; unsigned goff; };
-__device__ __forceinline__ PatchElem patch_elem(const PatchDesc& g, const unsigned* choff, int e, int c0,
-                                                int d0, int h0, int w0) {
-  PatchElem r;
-  const int r1 = fdiv(e, g.inv_PW);
-  const int pw = e - r1 * g.PW;
-  const int r2 = fdiv(r1, g.inv_PH);
-  const int ph = r1 - r2 * g.PH;
-  r.cl = fdiv(r2, g.inv_PD);
-  const int pd = r2 - r.cl * g.PD;
-  const int c = c0 + r.cl;
-  const int gd = d0 + pd - g.pd, gh = h0 + ph - g.ph, gw = w0 + pw - g.pw;
-  r.in = c < g.x.C && (unsigned)gd < (unsigned)g.x.D && (unsigned)gh < (unsigned)g.x.H &&
-         (unsigned)gw < (unsigned)g.x.W;
-  r.lds = r.cl * g.PSP + (pd * g.PH + ph) * g.PW + pw;
-  const unsigned co = choff[r.cl];      // per-chunk channel offsets staged in LDS
-  r.goff = r.in ? (co + (unsigned)gd * (unsigned)g.x.sD + (unsigned)gh * (unsigned)g.x.sH +
-                   (unsigned)gw * (unsigned)g.x.sW) * 4u
-                : 0xFFFFFFFFu;        // out of range of the descriptor -> the load returns 0
-  return r;
-}
+__device__ __forceinline__ int mdiv(int x, unsigned magic) { return (int)(((unsigned)x * magic) >> 20); }
 
 __device__ __forceinline__ crn_rsrc make_rsrc(const float* base) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0xFFFFFFF0u, 0x00020000);
 }
 
-// channel offsets (elements) of chunk [c0, c0+nch) -> LDS table (threads 0..nch-1)
-__device__ __forceinline__ void stage_choff(const crnView& v, unsigned* choff, int c0, int nch) {
+// per-chunk channel tables in LDS: [0,64) element offsets, [64,128) BRN scale, [128,192) BRN shift
+constexpr int kChTab = 192;
+__device__ __forceinline__ void stage_choff(const crnView& v, const crnInTransform& tr, unsigned* choff, int c0,
+                                            int nch) {
   const int t = threadIdx.x;
   if (t < nch) {
     const int c = min(c0 + t, v.C - 1);
     choff[t] = v.chan_off ? (unsigned)v.chan_off[c] : (unsigned)c * (unsigned)v.sC;
-  }
-}
-
-__device__ __forceinline__ void patch_issue(const PatchDesc& g, const unsigned* choff, int b, int c0, int d0,
-                                            int h0, int w0, int nch, float (&val)[PREG]) {
-  const int total = nch * g.PS;
-  const crn_rsrc rs = make_rsrc(g.x.base + (int64_t)b * g.x.sB);
-#pragma unroll
-  for (int j = 0; j < PREG; ++j) {
-    int e = threadIdx.x + j * 256;
-    asm volatile("" : "+v"(e));          // defeat LICM: recompute per chunk instead of 100+ live VGPRs
-    float v = 0.f;
-    if (e < total) {
-      const PatchElem pe = patch_elem(g, choff, e, c0, d0, h0, w0);
-      v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)pe.goff, 0, 0));
+    if (tr.scale) {
+      reinterpret_cast<float*>(choff)[64 + t] = tr.scale[c];
+      reinterpret_cast<float*>(choff)[128 + t] = tr.shift[c];
     }
-    val[j] = v;
-    __builtin_amdgcn_sched_barrier(0);   // one address in flight at a time: keeps VGPR pressure flat
   }
 }
 
-__device__ __forceinline__ void patch_commit(const PatchDesc& g, const unsigned* choff, float* ldsA, int c0,
-                                             int d0, int h0, int w0, int nch, const float (&val)[PREG]) {
-  const int total = nch * g.PS;
+// In-plane slot variant: everything that depends only on (thread, tile) and not on the plane.
+// U = slots of 256 per padded plane (1, 2 or 4: compile time) -> U variants per thread; U == 0:
+// planes smaller than 256 slots -> one variant, the plane index is per thread.
+struct HWVar { int r; unsigned off; int in; };   // r = in-plane index (or -1), off = gh*sH + gw*sW
+
+template <int U>
+__device__ __forceinline__ void patch_hw(const PatchDesc& g, int h0, int w0, HWVar (&hw)[U ? U : 1]) {
+  const int tid = threadIdx.x;
 #pragma unroll
-  for (int j = 0; j < PREG; ++j) {
-    int e = threadIdx.x + j * 256;
-    asm volatile("" : "+v"(e));        // opaque: recompute here, do not keep issue-time values live
-    if (e < total) {
-      const PatchElem pe = patch_elem(g, choff, e, c0, d0, h0, w0);
-      float v = val[j];
-      if (pe.in && g.tr.scale) {
-        const int c = c0 + pe.cl;
+  for (int u = 0; u < (U ? U : 1); ++u) {
+    const int r = U ? tid + u * 256 : (tid & ((1 << g.lg2) - 1));
+    const bool valid = r < g.plane;
+    const int ph = mdiv(r, g.magic_PW), pw = r - ph * g.PW;
+    const int gh = h0 + ph - g.ph, gw = w0 + pw - g.pw;
+    hw[u].r = valid ? r : -1;
+    hw[u].in = valid && (unsigned)gh < (unsigned)g.x.H && (unsigned)gw < (unsigned)g.x.W;
+    hw[u].off = (unsigned)gh * (unsigned)g.x.sH + (unsigned)gw * (unsigned)g.x.sW;
+  }
+}
+
+__device__ __forceinline__ unsigned chan_off_s(const crnView& v, int c) {   // c wave-uniform -> scalar load
+  return v.chan_off ? (unsigned)v.chan_off[c] : (unsigned)c * (unsigned)v.sC;
+}
+
+template <int J, int U>
+__device__ __forceinline__ void patch_issue_one(const PatchDesc& g, const unsigned* choff,
+                                                const HWVar (&hw)[U ? U : 1], const crn_rsrc& rs, int nplanes,
+                                                int c0, int d0, float& v) {
+  unsigned goff = 0xFFFFFFFFu;               // outside the descriptor range -> the load returns 0
+  if constexpr (U >= 1) {
+    int q = J / U;
+    asm volatile("" : "+s"(q));              // recompute per chunk on the scalar unit
+    const HWVar& h = hw[J % U];
+    const int cl = mdiv(q, g.magic_PD), pd = q - cl * g.PD;
+    const int c = c0 + cl, gd = d0 + pd - g.pd;
+    if (q < nplanes && c < g.x.C && (unsigned)gd < (unsigned)g.x.D) {       // wave-uniform
+      const unsigned sbase = chan_off_s(g.x, c) + (unsigned)gd * (unsigned)g.x.sD;
+      goff = h.in ? (sbase + h.off) * 4u : 0xFFFFFFFFu;
+    }
+  } else {
+    int jq = J * (256 >> g.lg2);
+    asm volatile("" : "+s"(jq));
+    const HWVar& h = hw[0];
+    const int q = jq + ((int)threadIdx.x >> g.lg2);
+    const int cl = mdiv(q, g.magic_PD), pd = q - cl * g.PD;
+    const int gd = d0 + pd - g.pd;
+    const bool in = h.in && q < nplanes && (c0 + cl < g.x.C) && (unsigned)gd < (unsigned)g.x.D;
+    if (in) goff = (choff[cl] + (unsigned)gd * (unsigned)g.x.sD + h.off) * 4u;
+  }
+  v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)goff, 0, 0));
+}
+
+template <int J, int U>
+__device__ __forceinline__ void patch_commit_one(const PatchDesc& g, const unsigned* choff,
+                                                 const HWVar (&hw)[U ? U : 1], float* ldsA, int nplanes, int c0,
+                                                 int d0, float v) {
+  if constexpr (U >= 1) {
+    int q = J / U;
+    asm volatile("" : "+s"(q));
+    const HWVar& h = hw[J % U];
+    if (q < nplanes) {                                   // wave-uniform
+      const int cl = mdiv(q, g.magic_PD), pd = q - cl * g.PD;
+      const int c = c0 + cl, gd = d0 + pd - g.pd;
+      if (g.tr.scale && c < g.x.C && (unsigned)gd < (unsigned)g.x.D) {
+        const float sc = g.tr.scale[c], sh = g.tr.shift[c];           // scalar loads
+        float t = v;
+        if (g.tr.pre_relu) t = fmaxf(t, 0.f);
+        t = t * sc + sh;
+        if (g.tr.post_relu) t = fmaxf(t, 0.f);
+        v = h.in ? t : v;                                // zero padding stays zero
+      }
+      if (h.r >= 0) ldsA[cl * g.PSP + pd * g.plane + h.r] = v;
+    }
+  } else {
+    int jq = J * (256 >> g.lg2);
+    asm volatile("" : "+s"(jq));
+    const HWVar& h = hw[0];
+    const int q = jq + ((int)threadIdx.x >> g.lg2);
+    if (q < nplanes && h.r >= 0) {
+      const int cl = mdiv(q, g.magic_PD), pd = q - cl * g.PD;
+      const int gd = d0 + pd - g.pd;
+      const bool in = h.in && (c0 + cl < g.x.C) && (unsigned)gd < (unsigned)g.x.D;
+      if (in && g.tr.scale) {
+        const float* tab = reinterpret_cast<const float*>(choff);
         if (g.tr.pre_relu) v = fmaxf(v, 0.f);
-        v = v * g.tr.scale[c] + g.tr.shift[c];
+        v = v * tab[64 + cl] + tab[128 + cl];
         if (g.tr.post_relu) v = fmaxf(v, 0.f);
       }
-      ldsA[pe.lds] = v;
+      ldsA[cl * g.PSP + pd * g.plane + h.r] = v;
     }
-    __builtin_amdgcn_sched_barrier(0);
   }
 }
+
+template <int U, int J = 0>
+__device__ __forceinline__ void patch_issue_u(const PatchDesc& g, const unsigned* choff,
+                                              const HWVar (&hw)[U ? U : 1], const crn_rsrc& rs, int nplanes,
+                                              int npass, int c0, int d0, float (&val)[PREG]) {
+  if constexpr (J < PREG) {
+    if (J < npass) patch_issue_one<J, U>(g, choff, hw, rs, nplanes, c0, d0, val[J]);
+    patch_issue_u<U, J + 1>(g, choff, hw, rs, nplanes, npass, c0, d0, val);
+  }
+}
+template <int U, int J = 0>
+__device__ __forceinline__ void patch_commit_u(const PatchDesc& g, const unsigned* choff,
+                                               const HWVar (&hw)[U ? U : 1], float* ldsA, int nplanes, int npass,
+                                               int c0, int d0, const float (&val)[PREG]) {
+  if constexpr (J < PREG) {
+    if (J < npass) patch_commit_one<J, U>(g, choff, hw, ldsA, nplanes, c0, d0, val[J]);
+    patch_commit_u<U, J + 1>(g, choff, hw, ldsA, nplanes, npass, c0, d0, val);
+  }
+}
+
+// Runtime (wave-uniform) dispatch on the plane padding; HWVar storage is sized for the largest U.
+struct PatchHW { HWVar v[4]; };
+__device__ __forceinline__ void patch_prepare(const PatchDesc& g, int h0, int w0, PatchHW& p) {
+  switch (g.lg2) {
+    case 8: patch_hw<1>(g, h0, w0, reinterpret_cast<HWVar(&)[1]>(p.v)); break;
+    case 9: patch_hw<2>(g, h0, w0, reinterpret_cast<HWVar(&)[2]>(p.v)); break;
+    case 10: patch_hw<4>(g, h0, w0, p.v); break;
+    default: patch_hw<0>(g, h0, w0, reinterpret_cast<HWVar(&)[1]>(p.v)); break;
+  }
+}
+__device__ __forceinline__ void patch_issue(const PatchDesc& g, const unsigned* choff, const PatchHW& p,
+                                            const crn_rsrc& rs, int nplanes, int npass, int c0, int d0,
+                                            float (&val)[PREG]) {
+  switch (g.lg2) {   // wave-uniform
+    case 8: patch_issue_u<1>(g, choff, reinterpret_cast<const HWVar(&)[1]>(p.v), rs, nplanes, npass, c0, d0, val); break;
+    case 9: patch_issue_u<2>(g, choff, reinterpret_cast<const HWVar(&)[2]>(p.v), rs, nplanes, npass, c0, d0, val); break;
+    case 10: patch_issue_u<4>(g, choff, p.v, rs, nplanes, npass, c0, d0, val); break;
+    default: patch_issue_u<0>(g, choff, reinterpret_cast<const HWVar(&)[1]>(p.v), rs, nplanes, npass, c0, d0, val); break;
+  }
+}
+__device__ __forceinline__ void patch_commit(const PatchDesc& g, const unsigned* choff, const PatchHW& p,
+                                             float* ldsA, int nplanes, int npass, int c0, int d0,
+                                             const float (&val)[PREG]) {
+  switch (g.lg2) {
+    case 8: patch_commit_u<1>(g, choff, reinterpret_cast<const HWVar(&)[1]>(p.v), ldsA, nplanes, npass, c0, d0, val); break;
+    case 9: patch_commit_u<2>(g, choff, reinterpret_cast<const HWVar(&)[2]>(p.v), ldsA, nplanes, npass, c0, d0, val); break;
+    case 10: patch_commit_u<4>(g, choff, p.v, ldsA, nplanes, npass, c0, d0, val); break;
+    default: patch_commit_u<0>(g, choff, reinterpret_cast<const HWVar(&)[1]>(p.v), ldsA, nplanes, npass, c0, d0, val); break;
+  }
+}
+
+template <int V>
+struct IntC { static constexpr int value = V; };
 
 // ------------------------------- forward -----------------------------------
 template <int MSUB, int NSUB>
-__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
+__global__ __launch_bounds__(256, (MSUB * NSUB > 8 ? 1 : 2)) void conv_fwd_kernel(ConvGeom g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  unsigned* choff = reinterpret_cast<unsigned*>(lds);      // 2 x 64 channel offsets (double buffered)
-  float* ldsA = lds + 128;
+  unsigned* choff = reinterpret_cast<unsigned*>(lds);      // 2 x kChTab per-chunk channel tables
+  float* ldsA = lds + 2 * kChTab;
   float* ldsB = ldsA + g.CC * g.PSP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kk = lane >> 4;
@@ -171,8 +265,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
 
   PatchDesc pdsc;
   pdsc.x = g.x; pdsc.tr = g.tr; pdsc.pd = g.pd; pdsc.ph = g.ph; pdsc.pw = g.pw;
-  pdsc.PD = g.PD; pdsc.PH = g.PH; pdsc.PW = g.PW; pdsc.PS = g.PS; pdsc.PSP = g.PSP;
-  pdsc.inv_PW = g.inv_PW; pdsc.inv_PH = g.inv_PH; pdsc.inv_PD = g.inv_PD;
+  pdsc.PD = g.PD; pdsc.PH = g.PH; pdsc.PW = g.PW; pdsc.plane = g.PH * g.PW; pdsc.lg2 = g.lg2;
+  pdsc.PSP = g.PSP; pdsc.magic_PW = g.magic_PW; pdsc.magic_PD = g.magic_PD;
+  const int nplanes = g.CC * g.PD, npass = g.npass;
+  const crn_rsrc xrs = make_rsrc(g.x.base + (int64_t)b * g.x.sB);
+  PatchHW phw;
+  patch_prepare(pdsc, h0, w0, phw);
 
   // lane's LDS offset of output position (sub-tile s, row i16) at tap (0,0,0)
   int posbase[MSUB];
@@ -201,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
   auto weight_elem = [&](int f, int c0, int& ldso, int64_t& go) {
     const int j4 = f % (NB / 4);
     const int ct = f / (NB / 4);
-    const int cl = fdiv(ct, g.inv_T);
+    const int cl = mdiv(ct, g.magic_T);
     const int t = ct - cl * g.T;
     const int c = c0 + cl;
     const int n = n0 + j4 * 4;
@@ -220,7 +318,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
         if (go >= 0) v = *reinterpret_cast<const f32x4*>(g.w + go);
       }
       wval[j] = v;
-      __builtin_amdgcn_sched_barrier(0);
     }
   };
   auto weights_commit = [&](int c0) {
@@ -233,47 +330,64 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
         weight_elem(f, c0, ldso, go);
         *reinterpret_cast<f32x4*>(ldsB + ldso) = wval[j];
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
   if (cbeg < cend) {
-    stage_choff(g.x, choff + (cbeg & 1) * 64, cbeg * g.CC, g.CC);
+    stage_choff(g.x, g.tr, choff + (cbeg & 1) * kChTab, cbeg * g.CC, g.CC);
     __syncthreads();
-    patch_issue(pdsc, choff + (cbeg & 1) * 64, b, cbeg * g.CC, d0, h0, w0, g.CC, pval);
+    patch_issue(pdsc, choff + (cbeg & 1) * kChTab, phw, xrs, nplanes, npass, cbeg * g.CC, d0, pval);
     weights_issue(cbeg * g.CC);
   }
   for (int chunk = cbeg; chunk < cend; ++chunk) {
     const int c0 = chunk * g.CC;
     __syncthreads();                       // previous chunk's MFMA reads are done
-    patch_commit(pdsc, choff + (chunk & 1) * 64, ldsA, c0, d0, h0, w0, g.CC, pval);
+    patch_commit(pdsc, choff + (chunk & 1) * kChTab, phw, ldsA, nplanes, npass, c0, d0, pval);
     weights_commit(c0);
-    if (chunk + 1 < cend) stage_choff(g.x, choff + ((chunk + 1) & 1) * 64, c0 + g.CC, g.CC);
+    if (chunk + 1 < cend) stage_choff(g.x, g.tr, choff + ((chunk + 1) & 1) * kChTab, c0 + g.CC, g.CC);
     __syncthreads();
     if (chunk + 1 < cend) {                // next chunk's loads fly under this chunk's MFMAs
-      patch_issue(pdsc, choff + ((chunk + 1) & 1) * 64, b, c0 + g.CC, d0, h0, w0, g.CC, pval);
+      patch_issue(pdsc, choff + ((chunk + 1) & 1) * kChTab, phw, xrs, nplanes, npass, c0 + g.CC, d0, pval);
       weights_issue(c0 + g.CC);
     }
 
+    // MFMA loop.  One (k-step, zd, zh) row of KW taps is straight-line code: the tap offsets
+    // along W are ds_read immediates, so a row costs MSUB+1 address adds for KW*MSUB*NSUB MFMAs.
     const int ksteps = g.CC >> 2;
-    int t = 0;
-    for (int zd = 0; zd < g.kd; ++zd)
-      for (int zh = 0; zh < g.kh; ++zh)
-        for (int zw = 0; zw < g.kw; ++zw, ++t) {
-          const int tapoff = (zd * g.PH + zh) * g.PW + zw;
-          for (int ks = 0; ks < ksteps; ++ks) {
-            float a[MSUB], bv[NSUB];
-            const float* pa = ldsA + ks * 4 * g.PSP + tapoff;
-            const float* pb = ldsB + ks * 4 * g.WSP + t * NB + bbase;
+    auto row = [&](auto kwc, int aoff, int boff) {
+      constexpr int KW = decltype(kwc)::value;
+      const float* pa[MSUB];
 #pragma unroll
-            for (int ms = 0; ms < MSUB; ++ms) a[ms] = pa[posbase[ms]];
+      for (int ms = 0; ms < MSUB; ++ms) pa[ms] = ldsA + aoff + posbase[ms];
+      const float* pb = ldsB + boff + bbase;
 #pragma unroll
-            for (int ns = 0; ns < NSUB; ++ns) bv[ns] = pb[ns * 16];
+      for (int zw = 0; zw < KW; ++zw) {
+        float a[MSUB], bv[NSUB];
 #pragma unroll
-            for (int ms = 0; ms < MSUB; ++ms)
+        for (int ms = 0; ms < MSUB; ++ms) a[ms] = pa[ms][zw];
 #pragma unroll
-              for (int ns = 0; ns < NSUB; ++ns)
-                acc[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ms], bv[ns], acc[ms][ns], 0, 0, 0);
+        for (int ns = 0; ns < NSUB; ++ns) bv[ns] = pb[zw * NB + ns * 16];
+#pragma unroll
+        for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+          for (int ns = 0; ns < NSUB; ++ns)
+            acc[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ms], bv[ns], acc[ms][ns], 0, 0, 0);
+      }
+    };
+    for (int ks = 0; ks < ksteps; ++ks)
+      for (int zd = 0; zd < g.kd; ++zd)
+        for (int zh = 0; zh < g.kh; ++zh) {
+          const int aoff = ks * 4 * g.PSP + (zd * g.PH + zh) * g.PW;
+          const int boff = ks * 4 * g.WSP + (zd * g.kh + zh) * g.kw * NB;
+          switch (g.kw) {
+            case 1: row(IntC<1>{}, aoff, boff); break;
+            case 2: row(IntC<2>{}, aoff, boff); break;
+            case 3: row(IntC<3>{}, aoff, boff); break;
+            case 4: row(IntC<4>{}, aoff, boff); break;
+            case 5: row(IntC<5>{}, aoff, boff); break;
+            case 7: row(IntC<7>{}, aoff, boff); break;
+            default:
+              for (int zw = 0; zw < g.kw; ++zw) row(IntC<1>{}, aoff + zw, boff + zw * NB);
           }
         }
   }
@@ -294,8 +408,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
       const int sd = s;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = kk * 4 + r;
-        const int rr = row / g.mw, rc = row - rr * g.mw;
+        const int row_ = kk * 4 + r;
+        const int rr = row_ / g.mw, rc = row_ - rr * g.mw;
         const int od = d0 + sd, oh = h0 + sh * g.mh + rr, ow = w0 + sw * g.mw + rc;
         if (od < g.y.D && oh < g.y.H && ow < g.y.W) {
           float* dst = yb + co + (int64_t)od * g.y.sD + (int64_t)oh * g.y.sH + (int64_t)ow * g.y.sW;
@@ -317,23 +431,24 @@ struct WgradGeom {
   int Npad;
   int kd, kh, kw, pd, ph, pw, T;
   int TD, TH, TW;
-  int PD, PH, PW, PS, PSP;
-  int NBP;                 // LDS dy row stride (NB + 1)
+  int PD, PH, PW, PSP;
+  int lg2, npass;          // patch staging slots
+  int dlg2, dnpass;        // dy staging slots (plane = TD*TH*TW positions of one channel)
   int CC;                  // channels per block (rows = CC*T <= 64*RSUB)
   int tilesD, tilesH, tilesW, ntiles;   // ntiles includes batch
   int tiles_per_split;
-  float inv_PW, inv_PH, inv_PD, inv_T, inv_TW, inv_TH, inv_TD;
+  unsigned magic_PW, magic_PD, magic_T, magic_TW, magic_TH;
 };
 
 template <int RSUB, int NSUB>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
+__global__ __launch_bounds__(256, (RSUB * NSUB > 8 ? 1 : 2)) void conv_wgrad_kernel(WgradGeom g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  unsigned* choff = reinterpret_cast<unsigned*>(lds);   // channel offsets of this block's CC channels
-  float* ldsA = lds + 128;                  // CC * PSP   (input patch)
+  unsigned* choff = reinterpret_cast<unsigned*>(lds);   // x channel table; dy channel offsets at [192,256)
+  float* ldsA = lds + 2 * kChTab;           // CC * PSP   (input patch)
   float* ldsB = ldsA + g.CC * g.PSP;        // TD*TH*TW * NBP (dy, [pos][n])
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kk = lane >> 4;
-  constexpr int NB = NSUB * 16;
+  constexpr int NB = NSUB * 16, NBP = NB + 1;
   const int c0 = blockIdx.x * g.CC;
   const int n0 = blockIdx.y * NB;
   const int split = blockIdx.z;
@@ -341,8 +456,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
 
   PatchDesc pdsc;
   pdsc.x = g.x; pdsc.tr = g.tr; pdsc.pd = g.pd; pdsc.ph = g.ph; pdsc.pw = g.pw;
-  pdsc.PD = g.PD; pdsc.PH = g.PH; pdsc.PW = g.PW; pdsc.PS = g.PS; pdsc.PSP = g.PSP;
-  pdsc.inv_PW = g.inv_PW; pdsc.inv_PH = g.inv_PH; pdsc.inv_PD = g.inv_PD;
+  pdsc.PD = g.PD; pdsc.PH = g.PH; pdsc.PW = g.PW; pdsc.plane = g.PH * g.PW; pdsc.lg2 = g.lg2;
+  pdsc.PSP = g.PSP; pdsc.magic_PW = g.magic_PW; pdsc.magic_PD = g.magic_PD;
+  const int nplanes = g.CC * g.PD, npass = g.npass;
 
   // row (c_local, tap) -> LDS offset inside the patch
   int rowbase[RSUB];
@@ -350,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
   for (int rs = 0; rs < RSUB; ++rs) {
     int row = (wave * RSUB + rs) * 16 + i16;
     if (row >= nrows) row = 0;                       // never stored
-    const int cl = fdiv(row, g.inv_T);
+    const int cl = mdiv(row, g.magic_T);
     int t = row - cl * g.T;
     const int zw = t % g.kw; t /= g.kw;
     const int zh = t % g.kh; t /= g.kh;
@@ -366,7 +482,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
   const int tbeg = split * g.tiles_per_split;
   const int tend = min(tbeg + g.tiles_per_split, g.ntiles);
   const int npos = g.TD * g.TH * g.TW;
-  const int dytotal = NB * npos;
 
   float pval[PREG];
   float dval[DREG];
@@ -378,104 +493,150 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
     const int tdi = tile % g.tilesD; tile /= g.tilesD;
     b = tile; d0 = tdi * g.TD; h0 = thi * g.TH; w0 = twi * g.TW;
   };
-  // dy tile -> registers; LDS layout [pos][n] (lanes run along w: coalesced global, odd LDS stride)
-  auto dy_elem = [&](int e, int d0, int h0, int w0, int& ldso, unsigned& goff) {
-    const int r1 = fdiv(e, g.inv_TW);
-    const int tw = e - r1 * g.TW;
-    const int r2 = fdiv(r1, g.inv_TH);
-    const int th = r1 - r2 * g.TH;
-    const int nl = fdiv(r2, g.inv_TD);
-    const int td = r2 - nl * g.TD;
-    const int n = n0 + nl;
-    const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
-    const bool in = n < g.dy.C && od < g.dy.D && oh < g.dy.H && ow < g.dy.W;
-    ldso = ((td * g.TH + th) * g.TW + tw) * g.NBP + nl;
-    const int nn = in ? n : 0;
-    const unsigned co = g.dy.chan_off ? (unsigned)g.dy.chan_off[nn] : (unsigned)nn * (unsigned)g.dy.sC;
-    goff = in ? (co + (unsigned)od * (unsigned)g.dy.sD + (unsigned)oh * (unsigned)g.dy.sH +
-                 (unsigned)ow * (unsigned)g.dy.sW) * 4u
-              : 0xFFFFFFFFu;
+  // dy tile: planes = channels nl, in-plane index r = position (td,th,tw); LDS layout [pos][n]
+  // (lanes run along w: coalesced global reads, odd LDS stride NBP: conflict-free writes).
+  // Per-thread position variants (npos <= 512 -> at most 2) are hoisted per tile.
+  HWVar dhw0, dhw1;
+  auto dy_prepare = [&](int d0, int h0, int w0) {
+    auto one = [&](int u, HWVar& out) {
+      const int r = g.dlg2 >= 8 ? tid + u * 256 : (tid & ((1 << g.dlg2) - 1));
+      const bool valid = r < npos && (u == 0 || g.dlg2 == 9);
+      const int r1 = mdiv(r, g.magic_TW), tw = r - r1 * g.TW;
+      const int td = mdiv(r1, g.magic_TH), th = r1 - td * g.TH;
+      const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
+      out.r = valid ? r : -1;
+      out.in = valid && od < g.dy.D && oh < g.dy.H && ow < g.dy.W;
+      out.off = (unsigned)od * (unsigned)g.dy.sD + (unsigned)oh * (unsigned)g.dy.sH +
+                (unsigned)ow * (unsigned)g.dy.sW;
+    };
+    one(0, dhw0);
+    one(1, dhw1);
   };
-  auto dy_issue = [&](int b, int d0, int h0, int w0) {
-    const crn_rsrc rs = make_rsrc(g.dy.base + (int64_t)b * g.dy.sB);
-#pragma unroll
-    for (int j = 0; j < DREG; ++j) {
-      int e = tid + j * 256;
-      asm volatile("" : "+v"(e));
-      float v = 0.f;
-      if (e < dytotal) {
-        int ldso; unsigned goff;
-        dy_elem(e, d0, h0, w0, ldso, goff);
-        v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)goff, 0, 0));
-      }
-      dval[j] = v;
-      __builtin_amdgcn_sched_barrier(0);
+  // slot J -> (channel q, variant u); q wave-uniform when a plane spans >= 256 slots
+  auto dy_issue = [&](const crn_rsrc& rs, auto jc, float& v) {
+    constexpr int J = decltype(jc)::value;
+    unsigned goff = 0xFFFFFFFFu;
+    if (g.dlg2 >= 8) {
+      int q = __builtin_amdgcn_readfirstlane(g.dlg2 == 9 ? J / 2 : J);
+      asm volatile("" : "+s"(q));
+      const HWVar h = (J % 2 == 1 && g.dlg2 == 9) ? dhw1 : dhw0;
+      if (q < NB && n0 + q < g.dy.C) goff = h.in ? (chan_off_s(g.dy, n0 + q) + h.off) * 4u : 0xFFFFFFFFu;
+    } else {
+      int jq = J * (256 >> g.dlg2);
+      asm volatile("" : "+s"(jq));
+      const int q = jq + (tid >> g.dlg2);
+      if (dhw0.in && q < NB && n0 + q < g.dy.C) goff = (choff[kChTab + q] + dhw0.off) * 4u;
+    }
+    v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)goff, 0, 0));
+  };
+  auto dy_commit = [&](auto jc, float v) {
+    constexpr int J = decltype(jc)::value;
+    if (g.dlg2 >= 8) {
+      int q = __builtin_amdgcn_readfirstlane(g.dlg2 == 9 ? J / 2 : J);
+      asm volatile("" : "+s"(q));
+      const HWVar h = (J % 2 == 1 && g.dlg2 == 9) ? dhw1 : dhw0;
+      if (q < NB && h.r >= 0) ldsB[h.r * NBP + q] = v;
+    } else {
+      int jq = J * (256 >> g.dlg2);
+      asm volatile("" : "+s"(jq));
+      const int q = jq + (tid >> g.dlg2);
+      if (q < NB && dhw0.r >= 0) ldsB[dhw0.r * NBP + q] = v;
     }
   };
-  auto dy_commit = [&](int d0, int h0, int w0) {
-#pragma unroll
-    for (int j = 0; j < DREG; ++j) {
-      int e = tid + j * 256;
-      asm volatile("" : "+v"(e));
-      if (e < dytotal) {
-        int ldso; unsigned goff;
-        dy_elem(e, d0, h0, w0, ldso, goff);
-        ldsB[ldso] = dval[j];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
+#define CRN_DY_8(OP, A, B0)                                                                        \
+  if (g.dnpass > B0) {                                                                             \
+    OP(A IntC<B0 + 0>{}, dval[B0 + 0]); OP(A IntC<B0 + 1>{}, dval[B0 + 1]);                        \
+    OP(A IntC<B0 + 2>{}, dval[B0 + 2]); OP(A IntC<B0 + 3>{}, dval[B0 + 3]);                        \
+    OP(A IntC<B0 + 4>{}, dval[B0 + 4]); OP(A IntC<B0 + 5>{}, dval[B0 + 5]);                        \
+    OP(A IntC<B0 + 6>{}, dval[B0 + 6]); OP(A IntC<B0 + 7>{}, dval[B0 + 7]);                        \
+  }
+#define CRN_DY_ISSUE(rs) do { CRN_DY_8(dy_issue, rs CRN_COMMA, 0) CRN_DY_8(dy_issue, rs CRN_COMMA, 8) \
+                              CRN_DY_8(dy_issue, rs CRN_COMMA, 16) CRN_DY_8(dy_issue, rs CRN_COMMA, 24) } while (0)
+#define CRN_DY_COMMIT() do { CRN_DY_8(dy_commit, , 0) CRN_DY_8(dy_commit, , 8) CRN_DY_8(dy_commit, , 16) \
+                             CRN_DY_8(dy_commit, , 24) } while (0)
+#define CRN_COMMA ,
 
   int cb = 0, cd0 = 0, ch0 = 0, cw0 = 0;     // origin of the tile currently held in registers
-  stage_choff(g.x, choff, c0, g.CC);
+  PatchHW phw;
+  stage_choff(g.x, g.tr, choff, c0, g.CC);
+  if (tid < NB) {
+    const int n = min(n0 + tid, g.dy.C - 1);
+    choff[kChTab + tid] = g.dy.chan_off ? (unsigned)g.dy.chan_off[n] : (unsigned)n * (unsigned)g.dy.sC;
+  }
   __syncthreads();
   if (tbeg < tend) {
     tile_origin(tbeg, cb, cd0, ch0, cw0);
-    patch_issue(pdsc, choff, cb, c0, cd0, ch0, cw0, g.CC, pval);
-    dy_issue(cb, cd0, ch0, cw0);
+    const crn_rsrc xrs = make_rsrc(g.x.base + (int64_t)cb * g.x.sB);
+    const crn_rsrc drs = make_rsrc(g.dy.base + (int64_t)cb * g.dy.sB);
+    patch_prepare(pdsc, ch0, cw0, phw);
+    dy_prepare(cd0, ch0, cw0);
+    patch_issue(pdsc, choff, phw, xrs, nplanes, npass, c0, cd0, pval);
+    CRN_DY_ISSUE(drs);
   }
   for (int tl = tbeg; tl < tend; ++tl) {
     __syncthreads();
-    patch_commit(pdsc, choff, ldsA, c0, cd0, ch0, cw0, g.CC, pval);
-    dy_commit(cd0, ch0, cw0);
+    patch_commit(pdsc, choff, phw, ldsA, nplanes, npass, c0, cd0, pval);
+    CRN_DY_COMMIT();
     __syncthreads();
     if (tl + 1 < tend) {
       tile_origin(tl + 1, cb, cd0, ch0, cw0);
-      patch_issue(pdsc, choff, cb, c0, cd0, ch0, cw0, g.CC, pval);
-      dy_issue(cb, cd0, ch0, cw0);
+      const crn_rsrc xrs = make_rsrc(g.x.base + (int64_t)cb * g.x.sB);
+      const crn_rsrc drs = make_rsrc(g.dy.base + (int64_t)cb * g.dy.sB);
+      patch_prepare(pdsc, ch0, cw0, phw);
+      dy_prepare(cd0, ch0, cw0);
+      patch_issue(pdsc, choff, phw, xrs, nplanes, npass, c0, cd0, pval);
+      CRN_DY_ISSUE(drs);
     }
-    // reduction over the tile's positions, 4 consecutive w per MFMA k-step
+    // reduction over the tile's positions: one (td,th) row of TW/4 k-steps is straight-line code
+    auto row = [&](auto wsc, int aoff, int boff) {
+      constexpr int WS = decltype(wsc)::value;
+      const float* pa[RSUB];
+#pragma unroll
+      for (int rs = 0; rs < RSUB; ++rs) pa[rs] = ldsA + aoff + rowbase[rs];
+      const float* pb = ldsB + boff;
+#pragma unroll
+      for (int ws = 0; ws < WS; ++ws) {
+        float a[RSUB], bv[NSUB];
+#pragma unroll
+        for (int rs = 0; rs < RSUB; ++rs) a[rs] = pa[rs][ws * 4];
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) bv[ns] = pb[ws * 4 * NBP + ns * 16];
+#pragma unroll
+        for (int rs = 0; rs < RSUB; ++rs)
+#pragma unroll
+          for (int ns = 0; ns < NSUB; ++ns)
+            acc[rs][ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rs], bv[ns], acc[rs][ns], 0, 0, 0);
+      }
+    };
     for (int td = 0; td < g.TD; ++td)
       for (int th = 0; th < g.TH; ++th) {
-        const float* pa = ldsA + (td * g.PH + th) * g.PW;
-        const float* pb = ldsB + ((td * g.TH + th) * g.TW + kk) * g.NBP + i16;
-        for (int tw = 0; tw < g.TW; tw += 4) {
-          float a[RSUB], bv[NSUB];
-#pragma unroll
-          for (int rs = 0; rs < RSUB; ++rs) a[rs] = pa[rowbase[rs] + tw];
-#pragma unroll
-          for (int ns = 0; ns < NSUB; ++ns) bv[ns] = pb[tw * g.NBP + ns * 16];
-#pragma unroll
-          for (int rs = 0; rs < RSUB; ++rs)
-#pragma unroll
-            for (int ns = 0; ns < NSUB; ++ns)
-              acc[rs][ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rs], bv[ns], acc[rs][ns], 0, 0, 0);
+        const int aoff = (td * g.PH + th) * g.PW;
+        const int boff = ((td * g.TH + th) * g.TW + kk) * NBP + i16;
+        switch (g.TW >> 2) {
+          case 1: row(IntC<1>{}, aoff, boff); break;
+          case 2: row(IntC<2>{}, aoff, boff); break;
+          case 3: row(IntC<3>{}, aoff, boff); break;
+          default: row(IntC<4>{}, aoff, boff); break;
         }
       }
   }
+#undef CRN_DY_8
+#undef CRN_DY_ISSUE
+#undef CRN_DY_COMMIT
+#undef CRN_COMMA
 
   // D row = kk*4 + r -> weight row (c_local*T + tap); col = i16 -> n
 #pragma unroll
   for (int rs = 0; rs < RSUB; ++rs)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = (wave * RSUB + rs) * 16 + kk * 4 + r;
-      if (row >= nrows) continue;
+      const int row_ = (wave * RSUB + rs) * 16 + kk * 4 + r;
+      if (row_ >= nrows) continue;
 #pragma unroll
       for (int ns = 0; ns < NSUB; ++ns) {
         const int n = n0 + ns * 16 + i16;
         if (n < g.Npad)
-          atomicAdd(g.dw + ((int64_t)c0 * g.T + row) * g.Npad + n, acc[rs][ns][r]);
+          atomicAdd(g.dw + ((int64_t)c0 * g.T + row_) * g.Npad + n, acc[rs][ns][r]);
       }
     }
 }
@@ -493,6 +654,14 @@ __global__ void zero_view_kernel(crnView v) {
     const int64_t co = v.chan_off ? (int64_t)v.chan_off[c] : (int64_t)c * v.sC;
     v.base[r * v.sB + co + (int64_t)d * v.sD + (int64_t)h * v.sH + (int64_t)w * v.sW] = 0.f;
   }
+}
+
+int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+unsigned magic20(int d) { return (unsigned)(((1u << 20) + d - 1) / d); }
+// staging slots (planes padded to a power of two) needed for nplanes planes of `plane` elements
+int stage_passes(int nplanes, int plane) {
+  if (plane > 1024) return 1 << 30;     // staging handles planes padded to at most 1024 slots
+  return crn_cdiv((int64_t)nplanes << ilog2_ceil(plane), 256);
 }
 
 int pad16mod32(int v) {  // smallest v' >= v with v' % 32 == 16
@@ -530,18 +699,19 @@ bool fwd_cfg(int MSUB, int NSUB, int B, int Cin, int Npad, int D, int H, int W, 
       if (cost < best) { best = cost; c.tsd = a; c.tsh = bq; c.tsw = cw; }
     }
   const int TD = c.tsd, TH = c.tsh * c.mh, TW = c.tsw * c.mw;
-  const int PS = (TD + kd - 1) * (TH + kh - 1) * (TW + kw - 1);
+  const int PDp = TD + kd - 1, plane = (TH + kh - 1) * (TW + kw - 1);
+  const int PS = PDp * plane;
   const int PSP = pad16mod32(PS), WSP = pad16mod32(T * NSUB * 16);
   auto fits = [&](int cc) {
-    return (size_t)cc * (PSP + WSP) * 4 + 512 <= kLdsBudget && (int64_t)cc * PS <= kMaxStage &&
-           (int64_t)cc * T * NSUB * 16 <= 256 * WREG * 4;
+    return (size_t)cc * (PSP + WSP) * 4 + 2 * kChTab * 4 <= kLdsBudget &&
+           stage_passes(cc * PDp, plane) <= PREG && (int64_t)cc * T * NSUB * 16 <= 256 * WREG * 4;
   };
   if (!fits(4)) return false;
   int CC = 4;
   const int cin4 = (Cin + 3) & ~3;
   while (CC * 2 <= cin4 && CC * 2 <= 64 && fits(CC * 2)) CC *= 2;
   c.CC = CC;
-  c.lds = (size_t)CC * (PSP + WSP) * 4 + 512;
+  c.lds = (size_t)CC * (PSP + WSP) * 4 + 2 * kChTab * 4;
   c.blocks = (int64_t)B * crn_cdiv(D, TD) * crn_cdiv(H, TH) * crn_cdiv(W, TW) * crn_cdiv(Npad, NSUB * 16);
   *out = c;
   return true;
@@ -585,11 +755,11 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   for (int mi = 0; mi < 4; ++mi)
     for (int ni = 0; ni < 3; ++ni) {
       if (kN[ni] > 1 && kN[ni] * 16 > Npad) continue;
-      if (kM[mi] * kN[ni] > 16) continue;            // 128 accumulator VGPRs would spill
+      if (kM[mi] * kN[ni] > 16) continue;
       FwdCfg c;
       if (!fwd_cfg(kM[mi], kN[ni], y->B, x->C, Npad, y->D, y->H, y->W, kd, kh, kw, &c)) continue;
       const int area = kM[mi] * kN[ni];
-      const double reuse = area >= 32 ? 1.0 : area >= 16 ? 0.92 : area >= 8 ? 0.82 : area >= 4 ? 0.66 : area >= 2 ? 0.5 : 0.4;
+      const double reuse = area >= 16 ? 0.85 : area >= 8 ? 0.82 : area >= 4 ? 0.66 : area >= 2 ? 0.5 : 0.4;
       const double npos_tiles = (double)c.blocks / crn_cdiv(Npad, kN[ni] * 16) * (64.0 * kM[mi]);
       const double useful = ((double)y->B * y->D * y->H * y->W) / npos_tiles *
                             ((double)Npad / (crn_cdiv(Npad, kN[ni] * 16) * kN[ni] * 16.0));
@@ -620,7 +790,8 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   g.chunks_per_split = crn_cdiv(g.nchunks, splits);
   splits = crn_cdiv(g.nchunks, g.chunks_per_split);
   g.mode = splits > 1 ? 2 : (accumulate ? 1 : 0);
-  g.inv_PW = 1.f / g.PW; g.inv_PH = 1.f / g.PH; g.inv_PD = 1.f / g.PD; g.inv_T = 1.f / g.T;
+  g.lg2 = ilog2_ceil(g.PH * g.PW); g.npass = stage_passes(CC * g.PD, g.PH * g.PW);
+  g.magic_PW = magic20(g.PW); g.magic_PD = magic20(g.PD); g.magic_T = magic20(g.T);
   if (g.mode == 2 && !accumulate) {
     const int64_t tot = (int64_t)y->B * y->C * y->D * y->H * y->W;
     hipLaunchKernelGGL(zero_view_kernel, dim3((unsigned)std::min<int64_t>(crn_cdiv(tot, 256), 4096)),
@@ -630,6 +801,11 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   dim3 grid((unsigned)(g.tilesD * g.tilesH * g.tilesW * y->B), (unsigned)crn_cdiv(Npad, NSUB * 16),
             (unsigned)splits);
   const size_t lds_bytes = best.lds;
+  static const bool dbg = getenv("CRN_DEBUG") != nullptr;
+  if (dbg)
+    fprintf(stderr, "[crn_conv_fwd] x(C%d %dx%dx%d) y(C%d %dx%dx%d) k%dx%dx%d: MSUB %d NSUB %d CC %d tile %dx%dx%d "
+            "grid %ux%ux%u lds %zu npass %d lg2 %d\n", x->C, x->D, x->H, x->W, y->C, y->D, y->H, y->W, kd, kh, kw,
+            best.MSUB, NSUB, CC, g.TD, g.TH, g.TW, grid.x, grid.y, grid.z, lds_bytes, g.npass, g.lg2);
 #define CRN_FWD_CASE(M, N) if (best.MSUB == M && NSUB == N) return launch_fwd<M, N>(g, grid, lds_bytes, st);
   CRN_FWD_CASE(8, 1) CRN_FWD_CASE(8, 2)
   CRN_FWD_CASE(4, 1) CRN_FWD_CASE(4, 2) CRN_FWD_CASE(4, 4)
@@ -665,17 +841,18 @@ extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const 
       lastTH = TH;
       const int npos = TD * TH * TW;
       if (npos > 512) continue;
-      const int PS = (TD + kd - 1) * (TH + kh - 1) * (TW + kw - 1), PSP = PS + 1;
+      const int PDp = TD + kd - 1, plane = (TH + kh - 1) * (TW + kw - 1);
+      const int PS = PDp * plane, PSP = PS + 1;
       for (int NSUB = 4; NSUB >= 1; NSUB >>= 1) {
         if (NSUB > 1 && NSUB * 16 > Npad) continue;
         const int NB = NSUB * 16;
-        if ((int64_t)NB * npos > 256 * DREG) continue;
+        if (stage_passes(NB, npos) > DREG) continue;
         for (int RSUB = 8; RSUB >= 1; RSUB >>= 1) {
-          if (RSUB * NSUB > 16) continue;               // accumulator registers
+          if (RSUB * NSUB > 16) continue;
           int CC = std::min(std::min(std::max(1, (64 * RSUB) / T), (int)x->C), 64);
-          while (CC > 1 && (int64_t)CC * PS > kMaxStage) --CC;
-          const size_t lds = (size_t)CC * PSP * 4 + (size_t)npos * (NB + 1) * 4 + 512;
-          if (lds > kLdsBudget || (int64_t)CC * PS > kMaxStage) continue;
+          while (CC > 1 && stage_passes(CC * PDp, plane) > PREG) --CC;
+          const size_t lds = (size_t)CC * PSP * 4 + (size_t)npos * (NB + 1) * 4 + 2 * kChTab * 4;
+          if (lds > kLdsBudget || stage_passes(CC * PDp, plane) > PREG) continue;
           const int rows = CC * T;
           if (rows > 64 * RSUB) continue;
           if (RSUB > 1 && rows <= 32 * RSUB) continue;  // a smaller RSUB covers it
@@ -688,6 +865,33 @@ extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const 
       }
     }
   }
+  if (const char* f = getenv("CRN_WG_FORCE")) {      // tuning aid: "TD,TH,RSUB,NSUB"
+    int fTD, fTH, fR, fN;
+    if (sscanf(f, "%d,%d,%d,%d", &fTD, &fTH, &fR, &fN) == 4) {
+      fTD = std::min(fTD, Dy); fTH = std::min(fTH, Hy);
+      const int PDp = fTD + kd - 1, plane = (fTH + kh - 1) * (TWc + kw - 1);
+      int CC = std::min(std::min(std::max(1, (64 * fR) / T), (int)x->C), 64);
+      while (CC > 1 && stage_passes(CC * PDp, plane) > PREG) --CC;
+      const size_t lds = (size_t)CC * (PDp * plane + 1) * 4 + (size_t)fTD * fTH * TWc * (fN * 16 + 1) * 4 + 2 * kChTab * 4;
+      if (stage_passes(fN * 16, fTD * fTH * TWc) <= DREG && CC * T <= 64 * fR && lds <= 150 * 1024) {
+        best = Cand{fTD, fTH, TWc, fR, fN, CC, 0.0, lds}; have = true;
+      }
+    }
+  }
+  else if (Dy >= 4 && Wy >= 16) {
+    // 3-D decoder layers: measured sweep on MI355X (tools/sweep_wgrad.sh): k5 convs run best with the
+    // 4x8x16 tile and 512 (channel,tap) rows; the window-4 transposed-conv geometry with a flat 4x2x16
+    // tile (small halo, plane <= 128 slots).
+    const int fTD = 4, fTH = T >= 100 ? std::min(8, Hy) : std::min(2, Hy);
+    const int fN = (T < 100 && Npad >= 32) ? 2 : 1, fR = (T < 100 && Npad >= 32) ? 4 : 8;
+    const int PDp = fTD + kd - 1, plane = (fTH + kh - 1) * (TWc + kw - 1);
+    int CC = std::min(std::min(std::max(1, (64 * fR) / T), (int)x->C), 64);
+    while (CC > 1 && stage_passes(CC * PDp, plane) > PREG) --CC;
+    const size_t lds = (size_t)CC * (PDp * plane + 1) * 4 + (size_t)fTD * fTH * TWc * (fN * 16 + 1) * 4 + 2 * kChTab * 4;
+    if (stage_passes(fN * 16, fTD * fTH * TWc) <= DREG && CC * T <= 64 * fR && lds <= kLdsBudget) {
+      best = Cand{fTD, fTH, TWc, fR, fN, CC, 0.0, lds}; have = true;
+    }
+  }
   if (!have) return CRN_EINVAL;
   WgradGeom g{};
   g.x = *x; g.dy = *dy;
@@ -696,20 +900,28 @@ extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const 
   g.kd = kd; g.kh = kh; g.kw = kw; g.pd = pd; g.ph = ph; g.pw = pw; g.T = T;
   g.TD = best.TD; g.TH = best.TH; g.TW = best.TW;
   g.PD = g.TD + kd - 1; g.PH = g.TH + kh - 1; g.PW = g.TW + kw - 1;
-  g.PS = g.PD * g.PH * g.PW; g.PSP = g.PS + 1;
+  g.PSP = g.PD * g.PH * g.PW + 1;
   const int NSUB = best.NSUB, RSUB = best.RSUB, NB = NSUB * 16, CC = best.CC;
-  g.NBP = NB + 1; g.CC = CC;
+  g.CC = CC;
   g.tilesD = crn_cdiv(Dy, g.TD); g.tilesH = crn_cdiv(Hy, g.TH); g.tilesW = crn_cdiv(Wy, g.TW);
   g.ntiles = g.tilesD * g.tilesH * g.tilesW * dy->B;
   const int cblocks = crn_cdiv(x->C, CC), nblocks = crn_cdiv(Npad, NB);
   int splits = std::max(1, std::min(g.ntiles, crn_cdiv(768, cblocks * nblocks)));
   g.tiles_per_split = crn_cdiv(g.ntiles, splits);
   splits = crn_cdiv(g.ntiles, g.tiles_per_split);
-  g.inv_PW = 1.f / g.PW; g.inv_PH = 1.f / g.PH; g.inv_PD = 1.f / g.PD; g.inv_T = 1.f / T;
-  g.inv_TW = 1.f / g.TW; g.inv_TH = 1.f / g.TH; g.inv_TD = 1.f / g.TD;
+  g.lg2 = ilog2_ceil(g.PH * g.PW); g.npass = stage_passes(CC * g.PD, g.PH * g.PW);
+  g.dlg2 = ilog2_ceil(g.TD * g.TH * g.TW); g.dnpass = stage_passes(NB, g.TD * g.TH * g.TW);
+  g.magic_PW = magic20(g.PW); g.magic_PD = magic20(g.PD); g.magic_T = magic20(T);
+  g.magic_TW = magic20(g.TW); g.magic_TH = magic20(g.TH);
   if (zero_first) CRN_HIP(hipMemsetAsync(dw, 0, (size_t)x->C * T * Npad * 4, st));
   dim3 grid((unsigned)cblocks, (unsigned)nblocks, (unsigned)splits);
   const size_t lds_bytes = best.lds;
+  static const bool dbg = getenv("CRN_DEBUG") != nullptr;
+  if (dbg)
+    fprintf(stderr, "[crn_conv_wgrad] x(C%d %dx%dx%d) dy(C%d %dx%dx%d) k%dx%dx%d: RSUB %d NSUB %d CC %d tile %dx%dx%d "
+            "grid %ux%ux%u lds %zu npass %d dnpass %d tiles/split %d\n", x->C, x->D, x->H, x->W, dy->C, dy->D, dy->H,
+            dy->W, kd, kh, kw, RSUB, NSUB, CC, g.TD, g.TH, g.TW, grid.x, grid.y, grid.z, lds_bytes, g.npass, g.dnpass,
+            g.tiles_per_split);
 #define CRN_WG_CASE(R, N) if (RSUB == R && NSUB == N) return launch_wgrad<R, N>(g, grid, lds_bytes, st);
   CRN_WG_CASE(8, 1) CRN_WG_CASE(8, 2)
   CRN_WG_CASE(4, 1) CRN_WG_CASE(4, 2) CRN_WG_CASE(4, 4)

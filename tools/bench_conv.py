@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""Micro-benchmark of one conv layer through the C ABI (for rocprofv3 --pmc runs).
+usage: bench_conv.py <fwd|dgrad|wgrad> <layer-key> [iters] [B]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch as t
+from corenet_amd import views as V
+from corenet_amd.backend import HipBackend, Transform
+from corenet_amd.model import conv_geometry as G
+
+LAYERS = {  # name: (kind, wshape, pad, in dims)
+    "s6c1": ("conv", (16, 28, 5, 5, 5), 2, (64, 64, 64)),
+    "s5c1": ("conv", (32, 56, 5, 5, 5), 2, (32, 32, 32)),
+    "s6t1": ("convT", (16, 2, 7, 7, 7), 3, (64, 64, 64)),
+    "s5t1": ("convT", (32, 16, 7, 7, 7), 3, (32, 32, 32)),
+    "e2c": ("conv", (256, 64, 1, 1), 0, (1, 64, 64)),
+    "e3b": ("conv", (128, 128, 3, 3), 1, (1, 32, 32)),
+}
+mode, key = sys.argv[1], sys.argv[2]
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+kind, wshape, pad, dims = LAYERS[key]
+be = HipBackend()
+g = t.Generator().manual_seed(0)
+is2d = len(wshape) == 4
+if kind == "conv":
+  cin, cout = wshape[1], wshape[0]; fwd, dgr = G.conv_fwd(wshape, pad), G.conv_dgrad(wshape, pad); odims = dims
+else:
+  cin, cout = wshape[0], wshape[1]; fwd, dgr = G.convt_fwd(wshape, pad), G.convt_dgrad(wshape, pad)
+  odims = tuple(2 * d for d in dims)
+sh = lambda c, d: (B, c) + (d[1:] if is2d else d)
+x = t.randn(sh(cin, dims), generator=g).cuda(); y = t.zeros(sh(cout, odims)).cuda()
+w = t.randn(wshape, generator=g) * 0.05
+pk = lambda idx: t.where(t.as_tensor(idx) >= 0, w.reshape(-1)[t.as_tensor(idx).clamp(min=0).long()], t.zeros(())).cuda()
+wf, wd = pk(fwd.index), pk(dgr.index)
+sc, shf = (t.rand(cin) + 0.5).cuda(), t.randn(cin).cuda()
+tr = Transform(sc, shf, pre_relu=True)
+yv = V.space_to_depth_view(V.view_of(y), (2, 2, 2)) if kind == "convT" else V.view_of(y)
+dw = t.zeros(wf.numel()).cuda()
+def run():
+  if mode == "fwd": be.conv_fwd(V.view_of(x), tr, wf, fwd.npad, None, 0, yv, fwd.window, fwd.pad_lo, 0)
+  elif mode == "dgrad": be.conv_fwd(yv, None, wd, dgr.npad, None, 0, V.view_of(x), dgr.window, dgr.pad_lo, 0)
+  else: be.conv_wgrad(V.view_of(x), tr, yv, dw, fwd.npad, fwd.window, fwd.pad_lo, True)
+for _ in range(3): run()
+t.cuda.synchronize(); a = t.cuda.Event(enable_timing=True); b = t.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(iters): run()
+b.record(); t.cuda.synchronize()
+ms = a.elapsed_time(b) / iters
+import numpy as np
+flop = 2.0 * B * np.prod(dims) * cin * cout * np.prod(wshape[2:])
+print(f"{mode} {key} B={B}: {ms*1e3:.1f} us  {flop/ms/1e9:.1f} TFLOP/s (real flops)")
