@@ -641,6 +641,97 @@ __global__ __launch_bounds__(256, (RSUB * NSUB > 8 ? 1 : 2)) void conv_wgrad_ker
     }
 }
 
+// --------------------------- pointwise (1x1x1) convolutions ---------------------------------
+// Y[b][n][m] = bias[n] + sum_c W[c][n] * T(X[b][c][m]) for plain views with contiguous positions:
+// a GEMM whose A operand is already K-major in memory (NCHW), so global loads are float4 rows
+// and no index arithmetic is needed.  Block = 64 positions x 32 channels, K chunks of 32 staged
+// through LDS with register prefetch; wave w owns positions [16w, 16w+16) x 32 channels.
+// Used for ResNet 1x1 convs and their data gradients (resnet50.py:62-69,95-107) and the skip
+// compress convs (ray_traced_skip_connection.py:38).
+struct PwGeom {
+  const float* x; float* y; const float* w; const float* bias;
+  crnInTransform tr;
+  int B, C, N, Npad, S;            // S = positions per sample
+  int64_t xsB, ysB;                // batch strides; channel stride = S for both
+  int bias_sB, mode;
+};
+
+__global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
+  constexpr int BM = 64, BN = 32, KC = 32, SA = BM + 16, SB = BN + 16;
+  __shared__ __attribute__((aligned(16))) float ldsA[KC * SA];
+  __shared__ __attribute__((aligned(16))) float ldsB[KC * SB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kk = lane >> 4;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, b = blockIdx.z;
+  const float* xb = g.x + (int64_t)b * g.xsB;
+  // staging roles: A: 2 float4 per thread (rows ka0, ka0+16), B: 1 float4 per thread
+  const int ka = tid >> 4, ca = (tid & 15) * 4;       // A row / column
+  const int kb = tid >> 3, cb = (tid & 7) * 4;        // B row / column
+  const bool a_ok = (m0 + ca) < g.S;                  // S % 4 == 0 (checked on the host)
+  const bool b_ok = (n0 + cb) < g.Npad;
+  f32x4 ra0, ra1, rb;
+  auto issue = [&](int c0) {
+    const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int c_a0 = c0 + ka, c_a1 = c0 + ka + 16, c_b = c0 + kb;
+    ra0 = (a_ok && c_a0 < g.C) ? *reinterpret_cast<const f32x4*>(xb + (int64_t)c_a0 * g.S + m0 + ca) : z;
+    ra1 = (a_ok && c_a1 < g.C) ? *reinterpret_cast<const f32x4*>(xb + (int64_t)c_a1 * g.S + m0 + ca) : z;
+    rb = (b_ok && c_b < g.C) ? *reinterpret_cast<const f32x4*>(g.w + (int64_t)c_b * g.Npad + n0 + cb) : z;
+  };
+  auto xform = [&](f32x4 v, int c) -> f32x4 {
+    if (g.tr.scale && a_ok && c < g.C) {
+      const float sc = g.tr.scale[c], sh = g.tr.shift[c];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float t = v[i];
+        if (g.tr.pre_relu) t = fmaxf(t, 0.f);
+        t = t * sc + sh;
+        if (g.tr.post_relu) t = fmaxf(t, 0.f);
+        v[i] = t;
+      }
+    }
+    return v;
+  };
+  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  issue(0);
+  for (int c0 = 0; c0 < g.C; c0 += KC) {
+    __syncthreads();
+    *reinterpret_cast<f32x4*>(ldsA + ka * SA + ca) = xform(ra0, c0 + ka);
+    *reinterpret_cast<f32x4*>(ldsA + (ka + 16) * SA + ca) = xform(ra1, c0 + ka + 16);
+    *reinterpret_cast<f32x4*>(ldsB + kb * SB + cb) = rb;
+    __syncthreads();
+    if (c0 + KC < g.C) issue(c0 + KC);
+    const float* pa = ldsA + kk * SA + wave * 16 + i16;
+    const float* pb = ldsB + kk * SB + i16;
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ++ks) {
+      const float a = pa[ks * 4 * SA];
+      const float b0 = pb[ks * 4 * SB], b1 = pb[ks * 4 * SB + 16];
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[1], 0, 0, 0);
+    }
+  }
+  // D: rows kk*4..kk*4+3 = 4 consecutive positions, col i16 = channel -> one float4 per lane
+  const int m = m0 + wave * 16 + kk * 4;
+  if (m < g.S) {
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns) {
+      const int n = n0 + ns * 16 + i16;
+      if (n < g.N) {
+        const float bsv = g.bias ? g.bias[(int64_t)b * g.bias_sB + n] : 0.f;
+        float* dst = g.y + (int64_t)b * g.ysB + (int64_t)n * g.S + m;
+        f32x4 v = acc[ns] + bsv;
+        if (g.mode == 1) v += *reinterpret_cast<const f32x4*>(dst);
+        *reinterpret_cast<f32x4*>(dst) = v;
+      }
+    }
+  }
+}
+
+bool plain_view(const crnView& v) {
+  return v.chan_off == nullptr && v.sW == 1 && v.sH == v.W && (v.D == 1 || v.sD == v.H * v.W) &&
+         v.sC == (int64_t)v.D * v.H * v.W && (((uintptr_t)v.base) & 15) == 0 && (v.sB & 3) == 0;
+}
+
 __global__ void zero_view_kernel(crnView v) {
   const int64_t per_b = (int64_t)v.C * v.D * v.H * v.W;
   const int64_t total = per_b * v.B;
@@ -747,6 +838,19 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
     return CRN_EINVAL;
   if (y->C > Npad) return CRN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  const int64_t Sx = (int64_t)x->D * x->H * x->W;
+  if (kd * kh * kw == 1 && pd == 0 && ph == 0 && pw == 0 && splits <= 1 && plain_view(*x) && plain_view(*y) &&
+      Sx == (int64_t)y->D * y->H * y->W && (Sx & 3) == 0 && (((uintptr_t)w) & 15) == 0) {
+    PwGeom p{};
+    p.x = x->base; p.y = y->base; p.w = w; p.bias = bias;
+    p.tr = tr ? *tr : crnInTransform{nullptr, nullptr, 0, 0};
+    p.B = x->B; p.C = x->C; p.N = y->C; p.Npad = Npad; p.S = (int)Sx;
+    p.xsB = x->sB; p.ysB = y->sB; p.bias_sB = bias_sB; p.mode = accumulate ? 1 : 0;
+    dim3 grid((unsigned)crn_cdiv(Sx, 64), (unsigned)crn_cdiv(y->C, 32), (unsigned)x->B);
+    hipLaunchKernelGGL(pointwise_fwd_kernel, grid, dim3(256), 0, st, p);
+    CRN_CHECK_LAUNCH();
+    return CRN_OK;
+  }
   // Score every (MSUB, NSUB) tile: useful MFMA rows x operand reuse of the tile x how well
   // the grid (with split-K as a fallback) fills 256 CUs.
   static const int kM[4] = {8, 4, 2, 1};

@@ -71,19 +71,27 @@ __global__ __launch_bounds__(kThreads) void loss_pass1_kernel(const float* logit
 // coef layout (floats): [0]=loss, [1]=kIouFg, [2]=kIouAg, [3]=kX, then per b: I_fg,U_fg,I_ag,U_ag
 __global__ void loss_finalize_kernel(const double* part, int nblk, int B, int64_t S, int kind,
                                      float grad_scale, float* loss, float* coef) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // one wave: lanes stride over the per-block partials of each (sample, quantity)
+  const int lane = threadIdx.x;
   double iou_fg = 0.0, iou_ag = 0.0, xs = 0.0;
   for (int b = 0; b < B; ++b) {
-    double q[kNQ] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < nblk; ++i)
-      for (int k = 0; k < kNQ; ++k) q[k] += part[((int64_t)b * nblk + i) * kNQ + k];
+    double q[kNQ];
+    for (int k = 0; k < kNQ; ++k) {
+      double s = 0.0;
+      for (int i = lane; i < nblk; i += 64) s += part[((int64_t)b * nblk + i) * kNQ + k];
+      s = crn_wave_sum(s);
+      q[k] = __shfl(s, 0, 64);
+    }
     // losses.py:57,110: union==0 -> divide by 1
     const float ifg = (float)q[0], ufg = (float)q[1] == 0.f ? 1.f : (float)q[1];
     const float iag = (float)q[2], uag = (float)q[3] == 0.f ? 1.f : (float)q[3];
     iou_fg += (double)(ifg / ufg); iou_ag += (double)(iag / uag);
     xs += q[4];
-    coef[4 + b * 4 + 0] = ifg; coef[4 + b * 4 + 1] = ufg; coef[4 + b * 4 + 2] = iag; coef[4 + b * 4 + 3] = uag;
+    if (lane == 0) {
+      coef[4 + b * 4 + 0] = ifg; coef[4 + b * 4 + 1] = ufg; coef[4 + b * 4 + 2] = iag; coef[4 + b * 4 + 3] = uag;
+    }
   }
+  if (lane != 0) return;
   const float Lfg = 1.f - (float)(iou_fg / B), Lag = 1.f - (float)(iou_ag / B);
   const float X = (float)(xs / ((double)B * (double)S));
   float L = 0.f, kfg = 0.f, kag = 0.f, kx = 0.f;

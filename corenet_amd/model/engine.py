@@ -288,6 +288,7 @@ class Plan:
   def __init__(self, eng: Engine, B: int):
     self.eng, self.B = eng, B
     self.be = eng.be
+    self._views = {}
     dev = eng.device
     self.dev = dev
     f = lambda *shape: t.zeros(*shape, dtype=eng.dtype, device=dev)
@@ -349,6 +350,28 @@ class Plan:
     self.loss = f(1)
     self.gt = t.zeros(B, 128, 128, 128, dtype=t.int32, device=dev)
 
+  # ------------------------------------------------------------------ cached views
+  def _cached(self, key, fn):
+    v = self._views.get(key)
+    if v is None:
+      v = fn()
+      self._views[key] = v
+    return v
+
+  def vw(self, x: t.Tensor) -> V.View:
+    return self._cached(("v", x.data_ptr(), tuple(x.shape), tuple(x.stride())), lambda: V.view_of(x))
+
+  def s2d(self, x: t.Tensor, c1: int, r) -> V.View:
+    """space-to-depth / pixel-shuffle view of channels [0, c1) of x."""
+    return self._cached(("s2d", x.data_ptr(), tuple(x.shape), tuple(x.stride()), c1, r),
+                        lambda: V.space_to_depth_view(self.vw(x).channels(0, c1), r))
+
+  def flat(self, x: t.Tensor) -> V.View:
+    return self._cached(("flat", x.data_ptr(), tuple(x.shape)), lambda: V.flat_channel_view(self.vw(x)))
+
+  def strided(self, x: t.Tensor, step) -> V.View:
+    return self._cached(("str", x.data_ptr(), tuple(x.shape), step), lambda: V.strided_view(self.vw(x), step))
+
   # ------------------------------------------------------------------ helpers
   probes = None     # bench.py: {name: [(start_event, end_event), ...]} around selected launches
 
@@ -404,7 +427,7 @@ class Plan:
     be.preprocess(image_u8, self.img)
     # stem (resnet50.py:122-131)
     c1 = cv["encoder.stage1.conv."]
-    self._conv(c1, V.space_to_depth_view(V.view_of(self.img), (1, 2, 2)), None, V.view_of(self.y1))
+    self._conv(c1, self.s2d(self.img, 3, (1, 2, 2)), None, self.vw(self.y1))
     b1 = bn["encoder.stage1_part2.bn."]
     self._stats(b1, self.y1, 128 * 128, 64 * 128 * 128, False, training)
     be.maxpool_fwd(self.y1, b1.scale, b1.shift, B, 64, 128, 128, self.p1, self.p1_arg)
@@ -424,10 +447,10 @@ class Plan:
     be.fill_offset_channels(self.z0, B, L + 3, 1, L, self.offset)
     b = bn["decoder.stage_1.b1."]
     self._stats(b, self.z0, 1, L + 3, True, training)
-    zv = V.view_of(self.z0.view(B, L + 3, 1, 1, 1))
+    zv = self.vw(self.z0.view(B, L + 3, 1, 1, 1))
     u2 = self.dec[2]["u"]
     self._conv(cv["decoder.stage_1.t1."], zv, Transform(b.scale, b.shift, pre_relu=True),
-               V.flat_channel_view(V.view_of(u2)))
+               self.flat(u2))
     for k in range(2, 7):
       d = self.dec[k]
       r, S = d["r"], d["r"] ** 3
@@ -435,16 +458,16 @@ class Plan:
       b1_, b2_ = bn[p + "b1."], bn[p + "b2."]
       self._stats(b1_, d["u"], S, d["cin"] * S, True, training)
       self._probe(f"conv3d_stage{k}_c1_fwd", lambda: self._conv(
-          cv[p + "c1."], V.view_of(d["u"]), Transform(b1_.scale, b1_.shift, pre_relu=True), V.view_of(d["w"])))
+          cv[p + "c1."], self.vw(d["u"]), Transform(b1_.scale, b1_.shift, pre_relu=True), self.vw(d["w"])))
       self._stats(b2_, d["w"], S, d["cmid"] * S, True, training)
       out = self.dec[k + 1]["u"] if k < 6 else self.logits
-      ov = V.space_to_depth_view(V.view_of(out).channels(0, d["cout"]), (2, 2, 2))
-      self._conv(cv[p + "t1."], V.view_of(d["w"]), Transform(b2_.scale, b2_.shift, pre_relu=True), ov)
+      ov = self.s2d(out, d["cout"], (2, 2, 2))
+      self._conv(cv[p + "t1."], self.vw(d["w"]), Transform(b2_.scale, b2_.shift, pre_relu=True), ov)
       if k < 6:
         ft = self.feat[self.skip_src[k]]
         hw = self.skip_hw[k]
-        self._conv(cv[f"decoder.rt_skip_{k}.compress_channels."], V.view_of(ft), None,
-                   V.view_of(self.smap[k]))
+        self._conv(cv[f"decoder.rt_skip_{k}.compress_channels."], self.vw(ft), None,
+                   self.vw(self.smap[k]))
         ro = 2 * r
         self._probe(f"ray_sample_fwd_{ro}", lambda: be.ray_sample_fwd(
             self.smap[k], self.smap[k].stride(0), B, eng.skip_ch[k], hw, hw, self.layer_mats[k - 2],
@@ -459,17 +482,15 @@ class Plan:
     p = blk["prefix"]
     h = blk["h"]; S = h * h
     f1, f2, f3 = blk["f"]
-    xin = V.view_of(cur)
-    if blk["stride"] == 2:
-      xin = V.strided_view(xin, (1, 2, 2))
+    xin = self.strided(cur, (1, 2, 2)) if blk["stride"] == 2 else self.vw(cur)
     ba, bb, bc = bn[p + "op_a.bn."], bn[p + "op_b.bn."], bn[p + "op_c.bn."]
-    self._conv(cv[p + "op_a.conv."], xin, None, V.view_of(blk["ya"]))
+    self._conv(cv[p + "op_a.conv."], xin, None, self.vw(blk["ya"]))
     self._stats(ba, blk["ya"], S, f1 * S, False, training)
-    self._conv(cv[p + "op_b.conv."], V.view_of(blk["ya"]), Transform(ba.scale, ba.shift, post_relu=True),
-               V.view_of(blk["yb"]))
+    self._conv(cv[p + "op_b.conv."], self.vw(blk["ya"]), Transform(ba.scale, ba.shift, post_relu=True),
+               self.vw(blk["yb"]))
     self._stats(bb, blk["yb"], S, f2 * S, False, training)
-    self._conv(cv[p + "op_c.conv."], V.view_of(blk["yb"]), Transform(bb.scale, bb.shift, post_relu=True),
-               V.view_of(blk["yc"]))
+    self._conv(cv[p + "op_c.conv."], self.vw(blk["yb"]), Transform(bb.scale, bb.shift, post_relu=True),
+               self.vw(blk["yc"]))
     self._stats(bc, blk["yc"], S, f3 * S, False, training)
     if blk["final"]:
       pre, sB_pre = self.feat[blk["stage"]], self.feat[blk["stage"]].stride(0)
@@ -477,7 +498,7 @@ class Plan:
       pre, sB_pre = None, 0
     if blk["down"]:
       bs = bn[p + "shortcut.bn."]
-      self._conv(cv[p + "shortcut.conv."], xin, None, V.view_of(blk["ys"]))
+      self._conv(cv[p + "shortcut.conv."], xin, None, self.vw(blk["ys"]))
       self._stats(bs, blk["ys"], S, f3 * S, False, training)
       be.affine_add_relu(blk["yc"], bc.scale, bc.shift, blk["ys"], bs.scale, bs.shift, B, f3, S,
                          f3 * S, f3 * S, pre, sB_pre, blk["out"], f3 * S, True)
@@ -511,33 +532,33 @@ class Plan:
                           hw, hw, True)
         cs = cv[f"decoder.rt_skip_{k}.compress_channels."]
         ft = self.feat[self.skip_src[k]]
-        self._wgrad(cs, V.view_of(ft), None, V.view_of(self.gsmap[k]))
+        self._wgrad(cs, self.vw(ft), None, self.vw(self.gsmap[k]))
         self._bias_grad(cs, self.gsmap[k], hw * hw, ns * hw * hw)
-        self._dgrad(cs, V.view_of(self.gsmap[k]), V.view_of(self.gfeat[self.skip_src[k]]))
+        self._dgrad(cs, self.vw(self.gsmap[k]), self.vw(self.gfeat[self.skip_src[k]]))
       ct = cv[p + "t1."]
-      gv = V.space_to_depth_view(V.view_of(g_out).channels(0, d["cout"]), (2, 2, 2))
+      gv = self.s2d(g_out, d["cout"], (2, 2, 2))
       tr2 = Transform(b2_.scale, b2_.shift, pre_relu=True)
-      self._wgrad(ct, V.view_of(d["w"]), tr2, gv)
+      self._wgrad(ct, self.vw(d["w"]), tr2, gv)
       self._bias_grad(ct, g_out, So, ctot * So)
-      self._dgrad(ct, gv, V.view_of(d["gv2"]))
+      self._dgrad(ct, gv, self.vw(d["gv2"]))
       be.bn_bwd(d["w"], d["cmid"] * S, d["gv2"], d["cmid"] * S, B, d["cmid"], S, True, False,
                 b2_.gamma, b2_.scale, b2_.shift, b2_.saved, d["gw"], d["cmid"] * S, b2_.dgamma, b2_.dbeta)
       cc = cv[p + "c1."]
       tr1 = Transform(b1_.scale, b1_.shift, pre_relu=True)
-      self._wgrad(cc, V.view_of(d["u"]), tr1, V.view_of(d["gw"]))
+      self._wgrad(cc, self.vw(d["u"]), tr1, self.vw(d["gw"]))
       self._bias_grad(cc, d["gw"], S, d["cmid"] * S)
-      self._dgrad(cc, V.view_of(d["gw"]), V.view_of(d["gv1"]))
+      self._dgrad(cc, self.vw(d["gw"]), self.vw(d["gv1"]))
       be.bn_bwd(d["u"], d["cin"] * S, d["gv1"], d["cin"] * S, B, d["cin"], S, True, False,
                 b1_.gamma, b1_.scale, b1_.shift, b1_.saved, d["gu"], d["cin"] * S, b1_.dgamma, b1_.dbeta)
       g_out = d["gu"]
     # stage_1 / stage_0
     c1 = cv["decoder.stage_1.t1."]
     b = bn["decoder.stage_1.b1."]
-    zv = V.view_of(self.z0.view(B, L + 3, 1, 1, 1))
-    gv = V.flat_channel_view(V.view_of(g_out))
+    zv = self.vw(self.z0.view(B, L + 3, 1, 1, 1))
+    gv = self.flat(g_out)
     self._wgrad(c1, zv, Transform(b.scale, b.shift, pre_relu=True), gv)
     self._bias_grad(c1, g_out, 64, 256 * 64)
-    self._dgrad(c1, gv, V.view_of(self.gv0.view(B, L + 3, 1, 1, 1)))
+    self._dgrad(c1, gv, self.vw(self.gv0.view(B, L + 3, 1, 1, 1)))
     be.bn_bwd(self.z0, L + 3, self.gv0, L + 3, B, L + 3, 1, True, False, b.gamma, b.scale, b.shift,
               b.saved, self.gz0, L + 3, b.dgamma, b.dbeta)
     s = eng.store
@@ -559,7 +580,7 @@ class Plan:
     be.bn_bwd(self.y1, 64 * S1, self.gy1, 64 * S1, B, 64, S1, False, False, b1.gamma, b1.scale, b1.shift,
               b1.saved, self.gy1b, 64 * S1, b1.dgamma, b1.dbeta)
     cs = cv["encoder.stage1.conv."]
-    self._wgrad(cs, V.space_to_depth_view(V.view_of(self.img), (1, 2, 2)), None, V.view_of(self.gy1b))
+    self._wgrad(cs, self.s2d(self.img, 3, (1, 2, 2)), None, self.vw(self.gy1b))
     self._bias_grad(cs, self.gy1b, S1, 64 * S1)
     # packed weight grads -> reference layout inside the flat grad slab (1 launch)
     be.scatter(eng.gpacked, eng.gscatter_index, eng.store.grads, False)
@@ -584,39 +605,37 @@ class Plan:
     trb = Transform(bb.scale, bb.shift, post_relu=True)
     tra = Transform(ba.scale, ba.shift, post_relu=True)
     cc, cb, ca = cv[p + "op_c.conv."], cv[p + "op_b.conv."], cv[p + "op_a.conv."]
-    self._wgrad(cc, V.view_of(blk["yb"]), trb, V.view_of(blk["gyc"]))
+    self._wgrad(cc, self.vw(blk["yb"]), trb, self.vw(blk["gyc"]))
     self._bias_grad(cc, blk["gyc"], S, f3 * S)
-    self._dgrad(cc, V.view_of(blk["gyc"]), V.view_of(blk["gab"]))
+    self._dgrad(cc, self.vw(blk["gyc"]), self.vw(blk["gab"]))
     be.bn_bwd(blk["yb"], f2 * S, blk["gab"], f2 * S, B, f2, S, False, True, bb.gamma, bb.scale, bb.shift,
               bb.saved, blk["gyb"], f2 * S, bb.dgamma, bb.dbeta)
-    self._wgrad(cb, V.view_of(blk["ya"]), tra, V.view_of(blk["gyb"]))
+    self._wgrad(cb, self.vw(blk["ya"]), tra, self.vw(blk["gyb"]))
     self._bias_grad(cb, blk["gyb"], S, f2 * S)
-    self._dgrad(cb, V.view_of(blk["gyb"]), V.view_of(blk["gaa"]))
+    self._dgrad(cb, self.vw(blk["gyb"]), self.vw(blk["gaa"]))
     be.bn_bwd(blk["ya"], f1 * S, blk["gaa"], f1 * S, B, f1, S, False, True, ba.gamma, ba.scale, ba.shift,
               ba.saved, blk["gya"], f1 * S, ba.dgamma, ba.dbeta)
     cur = blk["in"]
-    xin = V.view_of(cur)
-    if blk["stride"] == 2:
-      xin = V.strided_view(xin, (1, 2, 2))
-    self._wgrad(ca, xin, None, V.view_of(blk["gya"]))
+    xin = self.strided(cur, (1, 2, 2)) if blk["stride"] == 2 else self.vw(cur)
+    self._wgrad(ca, xin, None, self.vw(blk["gya"]))
     self._bias_grad(ca, blk["gya"], S, f1 * S)
     if blk["down"]:
       bs = bn[p + "shortcut.bn."]
       csn = cv[p + "shortcut.conv."]
       be.bn_bwd(blk["ys"], f3 * S, gpre, f3 * S, B, f3, S, False, False, bs.gamma, bs.scale, bs.shift,
                 bs.saved, blk["gys"], f3 * S, bs.dgamma, bs.dbeta)
-      self._wgrad(csn, xin, None, V.view_of(blk["gys"]))
+      self._wgrad(csn, xin, None, self.vw(blk["gys"]))
       self._bias_grad(csn, blk["gys"], S, f3 * S)
       gin = blk["gin"]
-      gv = V.view_of(gin)
+      gv = self.vw(gin)
       if blk["stride"] == 2:
         be.zero(gin)
-        gv = V.strided_view(gv, (1, 2, 2))
-        self._dgrad(ca, V.view_of(blk["gya"]), gv, accumulate=True)
+        gv = self.strided(gin, (1, 2, 2))
+        self._dgrad(ca, self.vw(blk["gya"]), gv, accumulate=True)
       else:
-        self._dgrad(ca, V.view_of(blk["gya"]), gv)
-      self._dgrad(csn, V.view_of(blk["gys"]), gv, accumulate=True)
+        self._dgrad(ca, self.vw(blk["gya"]), gv)
+      self._dgrad(csn, self.vw(blk["gys"]), gv, accumulate=True)
       return gin
     # identity block: d in = d pre + dgrad(op_a)
-    self._dgrad(ca, V.view_of(blk["gya"]), V.view_of(gpre), accumulate=True)
+    self._dgrad(ca, self.vw(blk["gya"]), self.vw(gpre), accumulate=True)
     return gpre

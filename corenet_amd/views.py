@@ -67,9 +67,19 @@ def strided_view(v: View, step: Tuple[int, int, int]) -> View:
       sD=v.sD * sd, sH=v.sH * sh, sW=v.sW * sw)
 
 
+_TABLES = {}
+
+
 def _table(vals: np.ndarray, like: t.Tensor) -> t.Tensor:
+  """Device copy of a channel-offset table, cached: the same few tables are needed every step."""
   assert vals.max(initial=0) < 2 ** 31
-  return t.as_tensor(vals.astype(np.int32), device=like.device)
+  v = np.ascontiguousarray(vals.astype(np.int32))
+  key = (str(like.device), v.shape[0], hash(v.tobytes()))
+  tab = _TABLES.get(key)
+  if tab is None:
+    tab = t.as_tensor(v, device=like.device)
+    _TABLES[key] = tab
+  return tab
 
 
 def space_to_depth_view(v: View, r: Tuple[int, int, int]) -> View:
