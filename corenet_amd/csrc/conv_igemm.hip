@@ -873,6 +873,12 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
       const double score = useful * reuse * fill;
       if (score > best_score) { best_score = score; best = c; have = true; }
     }
+  if (const char* f = getenv("CRN_FWD_FORCE")) {     // tuning aid: "MSUB,NSUB"
+    int fM, fN; FwdCfg c;
+    if (sscanf(f, "%d,%d", &fM, &fN) == 2 && fwd_cfg(fM, fN, y->B, x->C, Npad, y->D, y->H, y->W, kd, kh, kw, &c)) {
+      best = c; have = true;
+    }
+  }
   if (!have) return CRN_EINVAL;
   ConvGeom g{};
   g.x = *x; g.y = *y;

@@ -66,8 +66,30 @@ __global__ __launch_bounds__(256) void ray_sample_fwd_kernel(
   const int64_t hw = (int64_t)h * w;
   const float* mb = map + (int64_t)b * map_sB;
   float* ob = out + (int64_t)b * out_sB + ((int64_t)z * H + y) * W + x0;
-#pragma unroll 4
-  for (int c = 0; c < C; ++c) {
+  // 12 channels per iteration (every skip width 96/48/24/12 is a multiple): 48 independent gathers in
+  // flight per lane, then 12 streaming (non-temporal) float4 stores -- the output is consumed much
+  // later by the next decoder stage, so it should not displace the feature map from L2.
+  int c = 0;
+  for (; c + 12 <= C; c += 12) {
+    float v[12][VX];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      const float* mc = mb + (c + u) * hw;
+#pragma unroll
+      for (int k = 0; k < VX; ++k) v[u][k] = po[k] >= 0 ? mc[po[k]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      if (VX == 4) {
+        __builtin_nontemporal_store((f32x4){v[u][0], v[u][1], v[u][2], v[u][3]},
+                                    reinterpret_cast<f32x4*>(ob + (c + u) * S));
+      } else {
+#pragma unroll
+        for (int k = 0; k < VX; ++k) ob[(c + u) * S + k] = v[u][k];
+      }
+    }
+  }
+  for (; c < C; ++c) {
     const float* mc = mb + c * hw;
     float v[VX];
 #pragma unroll

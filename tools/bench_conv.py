@@ -15,6 +15,13 @@ LAYERS = {  # name: (kind, wshape, pad, in dims)
     "s5t1": ("convT", (32, 16, 7, 7, 7), 3, (32, 32, 32)),
     "e2c": ("conv", (256, 64, 1, 1), 0, (1, 64, 64)),
     "e3b": ("conv", (128, 128, 3, 3), 1, (1, 32, 32)),
+    "e2b": ("conv", (64, 64, 3, 3), 1, (1, 64, 64)),
+    "e4b": ("conv", (256, 256, 3, 3), 1, (1, 16, 16)),
+    "e5b": ("conv", (512, 512, 3, 3), 1, (1, 8, 8)),
+    "s4c1": ("conv", (64, 112, 5, 5, 5), 2, (16, 16, 16)),
+    "s4t1": ("convT", (64, 32, 7, 7, 7), 3, (16, 16, 16)),
+    "s3c1": ("conv", (128, 224, 5, 5, 5), 2, (8, 8, 8)),
+    "s3t1": ("convT", (128, 64, 7, 7, 7), 3, (8, 8, 8)),
 }
 mode, key = sys.argv[1], sys.argv[2]
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
