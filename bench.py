@@ -119,6 +119,16 @@ def main():
   if rank != 0:
     return
   conv_s, ray_s = probes["conv3d_stage6_c1_fwd"], probes["ray_sample_fwd_64"]
+  # HBM bytes per launch from the PMC passes of this same command (profiles/*_pmc_traffic.json;
+  # FETCH_SIZE / WRITE_SIZE need their own rocprofv3 runs and cannot be read from inside the process)
+  traffic = {}
+  try:
+    tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+    for k, v in tj.items():
+      if isinstance(v, dict) and "hbm_bytes" in v:
+        traffic["ray" if k.startswith("ray") else "conv"] = v["hbm_bytes"] * (B / 4.0)
+  except Exception:
+    pass
   out = {
       "metric": "voxels/sec fwd+bwd @128^3", "value": world * B * 128 ** 3 * args.steps / dt,
       "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -130,11 +140,11 @@ def main():
       "loss": float(loss),
       "roofline": {"kernel": "conv_fwd_kernel<8,1> (stage_6.c1 Conv3d 28->16 k5 @64^3, fwd)",
                    "bound": "mfma", "achieved": CONV6_FLOP * B / conv_s / 1e12, "peak": PEAK_F32_MFMA / 1e12,
-                   "unit": "TFLOP/s", "frac": CONV6_FLOP * B / conv_s / PEAK_F32_MFMA, "traffic": None,
+                   "unit": "TFLOP/s", "frac": CONV6_FLOP * B / conv_s / PEAK_F32_MFMA, "traffic": traffic.get("conv"),
                    "avg_launch_ms": conv_s * 1e3},
       "roofline_ray_sample": {"kernel": "ray_sample_fwd_kernel<4> (64^3 x 12 ch)", "bound": "hbm",
                               "achieved": RAY64_BYTES * B / ray_s / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                              "frac": RAY64_BYTES * B / ray_s / PEAK_HBM, "traffic": None,
+                              "frac": RAY64_BYTES * B / ray_s / PEAK_HBM, "traffic": traffic.get("ray"),
                               "avg_launch_ms": ray_s * 1e3},
   }
   if not args.no_cpu_baseline and world == 1:
