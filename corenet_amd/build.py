@@ -11,7 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcorenet_hip.so")
-SOURCES = ["conv_igemm.hip", "batch_renorm.hip", "ray_sample.hip", "misc_ops.hip",
+SOURCES = ["conv_igemm.hip", "conv_inst_fwd_a.hip", "conv_inst_fwd_b.hip", "conv_inst_fwd_c.hip",
+           "conv_inst_wg_a.hip", "conv_inst_wg_b.hip", "conv_inst_wg_c.hip", "batch_renorm.hip", "ray_sample.hip", "misc_ops.hip",
            "losses.hip", "fill_voxels.hip", "voxelize.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-ffp-contract=off", "-Wno-unused-result"]
@@ -21,7 +22,7 @@ def _stale(obj, src):
   if not os.path.exists(obj):
     return True
   m = os.path.getmtime(obj)
-  deps = [src, os.path.join(CSRC, "crn_common.h"),
+  deps = [src, os.path.join(CSRC, "crn_common.h"), os.path.join(CSRC, "conv_kernels.h"),
           os.path.join(HERE, "..", "include", "corenet_hip.h")]
   return any(os.path.getmtime(d) > m for d in deps)
 

@@ -1,0 +1,6 @@
+// Explicit instantiations of the conv engine kernels (split for parallel compilation).
+#include "conv_kernels.h"
+
+int crn_launch_fwd_4_2(const crnk::ConvGeom& g, dim3 grid, size_t lds, hipStream_t st) { return crnk::launch_fwd<4, 2>(g, grid, lds, st); }
+int crn_launch_fwd_4_1(const crnk::ConvGeom& g, dim3 grid, size_t lds, hipStream_t st) { return crnk::launch_fwd<4, 1>(g, grid, lds, st); }
+int crn_launch_fwd_2_4(const crnk::ConvGeom& g, dim3 grid, size_t lds, hipStream_t st) { return crnk::launch_fwd<2, 4>(g, grid, lds, st); }

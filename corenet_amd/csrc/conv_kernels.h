@@ -1,0 +1,714 @@
+// Device code of the fp32 MFMA implicit-GEMM convolution engine (see conv_igemm.hip for the design).
+// Kernel templates live here; conv_inst_*.hip instantiate them in parallel translation units
+// (one hipcc process each) and export plain launcher functions used by conv_igemm.hip.
+#pragma once
+#include "crn_common.h"
+
+namespace crnk {
+
+constexpr int PREG = 32;    // staged patch floats per thread   (CC*PS   <= 256*PREG)
+constexpr int WREG = 8;     // staged weight float4 per thread  (CC*T*NB <= 256*WREG*4)
+constexpr int DREG = 32;    // staged dy floats per thread      (NB*npos <= 256*DREG)
+constexpr int kMaxStage = 256 * PREG;
+
+struct ConvGeom {
+  crnView x, y;
+  crnInTransform tr;
+  const float* w;
+  const float* bias;
+  int Npad, bias_sB;
+  int kd, kh, kw, pd, ph, pw, T;
+  int TD, TH, TW;          // tile (positions)
+  int mw, mh;              // M-subtile shape, mw*mh == 16
+  int nsh, nsw;            // sub-tiles per tile along H, W
+  int PD, PH, PW, PS, PSP; // patch dims, size, padded channel stride
+  int WSP;                 // LDS weight channel stride
+  int CC;                  // channels per chunk (multiple of 4)
+  int tilesD, tilesH, tilesW;
+  int nchunks, chunks_per_split;
+  int mode;                // 0 store, 1 accumulate (rmw), 2 atomic add
+  int lg2, npass;          // patch staging: plane padded to 2^lg2 slots, passes of 256 slots
+  unsigned magic_PW, magic_PD, magic_T;
+  int vec_store;           // epilogue may use 16-B stores (unit W stride, 4-aligned rows)
+  int dbg;                 // tuning aid (CRN_DBG_MODE): 1 = no MFMA loop, 2 = stage only the first chunk
+};
+
+__device__ __forceinline__ int64_t view_chan(const crnView& v, int c) {
+  return v.chan_off ? (int64_t)v.chan_off[c] : (int64_t)c * v.sC;
+}
+
+// ---- patch staging: global -> registers (issue) and registers -> LDS (commit) ----
+// The patch of one chunk is CC*PD planes of PH*PW elements.  Staging slots are laid out as
+// planes padded to PLP = 2^lg2 elements so that slot -> (plane q, in-plane r) is shift/mask:
+//   lg2 >= 8: q is wave-uniform (scalar unit) and r takes PLP/256 per-thread values,
+//   lg2 <  8: r is a per-thread constant.
+// Everything that depends only on r (ph, pw, h/w bounds, h/w address part) is loop invariant
+// and hoisted by the compiler; per slot ~6 VALU remain for issue and ~8 for commit.
+struct PatchDesc {
+  crnView x;
+  crnInTransform tr;
+  int pd, ph, pw, PD, PH, PW, plane, lg2, PSP;
+  unsigned magic_PW, magic_PD;       // ceil(2^20 / d)
+};
+
+typedef int crn_rsrc __attribute__((ext_vector_type(4)));   // buffer resource (V#) in 4 SGPRs
+
+__device__ __forceinline__ int mdiv(int x, unsigned magic) { return (int)(((unsigned)x * magic) >> 20); }
+
+__device__ __forceinline__ crn_rsrc make_rsrc(const float* base) {   // raw buffer: stride 0, 2 GiB range
+  const unsigned long long a = (unsigned long long)base;
+  return (crn_rsrc){(int)(unsigned)a, (int)((a >> 32) & 0xFFFFu), (int)0x7FFFFFFFu, 0x00020000};   // 2 GiB range: offsets with bit 31 set read 0
+}
+
+// Staging loads are inline asm on purpose: hipcc's waitcnt pass serialises compiler-visible loads
+// whose destination VGPRs are re-used across the chunk loop (one s_waitcnt vmcnt(0) per load,
+// measured 45k cycles per chunk).  The asm loads are invisible to that pass; the matching wait is
+// crn_wait_loads() right before the registers are consumed (cdna guide 5.7).
+// The destination is the staging register itself (no temporary): a compiler-inserted copy between
+// the load and crn_wait_loads() would read the register before the data has landed.  For the same
+// reason every staging slot is loaded unconditionally (inactive slots use the out-of-range offset).
+__device__ __forceinline__ void crn_bload(float& dst, const crn_rsrc& rs, unsigned byte_off) {
+  asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(dst) : "v"(byte_off), "s"(rs));
+}
+__device__ __forceinline__ void crn_bload4(f32x4& dst, const crn_rsrc& rs, unsigned byte_off) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(byte_off), "s"(rs));
+}
+template <int N>
+__device__ __forceinline__ void crn_wait_loads(float (&v)[N]) {
+  static_assert(N % 8 == 0, "");
+#pragma unroll
+  for (int i = 0; i < N; i += 8)
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]), "+v"(v[i + 4]), "+v"(v[i + 5]),
+                   "+v"(v[i + 6]), "+v"(v[i + 7]));
+}
+__device__ __forceinline__ void crn_wait_loads4(f32x4 (&v)[WREG]) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+}
+
+// per-chunk channel tables in LDS: [0,64) element offsets, [64,128) BRN scale, [128,192) BRN shift
+constexpr int kChTab = 192;
+__device__ __forceinline__ void stage_choff(const crnView& v, const crnInTransform& tr, unsigned* choff, int c0,
+                                            int nch) {
+  const int t = threadIdx.x;
+  if (t < nch) {
+    const int c = min(c0 + t, v.C - 1);
+    choff[t] = v.chan_off ? (unsigned)v.chan_off[c] : (unsigned)c * (unsigned)v.sC;
+    if (tr.scale) {
+      reinterpret_cast<float*>(choff)[64 + t] = tr.scale[c];
+      reinterpret_cast<float*>(choff)[128 + t] = tr.shift[c];
+    }
+  }
+}
+
+// In-plane slot variant: everything that depends only on (thread, tile) and not on the plane.
+// U = slots of 256 per padded plane (1, 2 or 4: compile time) -> U variants per thread; U == 0:
+// planes smaller than 256 slots -> one variant, the plane index is per thread.
+struct HWVar { int r; unsigned off; int in; };   // r = in-plane index (or -1), off = gh*sH + gw*sW
+
+template <int U>
+__device__ __forceinline__ void patch_hw(const PatchDesc& g, int h0, int w0, HWVar (&hw)[U ? U : 1]) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < (U ? U : 1); ++u) {
+    const int r = U ? tid + u * 256 : (tid & ((1 << g.lg2) - 1));
+    const bool valid = r < g.plane;
+    const int ph = mdiv(r, g.magic_PW), pw = r - ph * g.PW;
+    const int gh = h0 + ph - g.ph, gw = w0 + pw - g.pw;
+    hw[u].r = valid ? r : -1;
+    hw[u].in = valid && (unsigned)gh < (unsigned)g.x.H && (unsigned)gw < (unsigned)g.x.W;
+    hw[u].off = (unsigned)gh * (unsigned)g.x.sH + (unsigned)gw * (unsigned)g.x.sW;
+  }
+}
+
+__device__ __forceinline__ unsigned chan_off_s(const crnView& v, int c) {   // c wave-uniform -> scalar load
+  return v.chan_off ? (unsigned)v.chan_off[c] : (unsigned)c * (unsigned)v.sC;
+}
+
+template <int J, int U>
+__device__ __forceinline__ void patch_issue_one(const PatchDesc& g, const unsigned* choff,
+                                                const HWVar (&hw)[U ? U : 1], const crn_rsrc& rs, int nplanes,
+                                                int c0, int d0, float& v) {
+  unsigned goff = 0x80000000u;               // outside the descriptor range -> the load returns 0
+  if constexpr (U >= 1) {
+    int q = J / U;
+    asm volatile("" : "+s"(q));              // recompute per chunk on the scalar unit
+    const HWVar& h = hw[J % U];
+    const int cl = mdiv(q, g.magic_PD), pd = q - cl * g.PD;
+    const int c = c0 + cl, gd = d0 + pd - g.pd;
+    if (q < nplanes && c < g.x.C && (unsigned)gd < (unsigned)g.x.D) {       // wave-uniform
+      const unsigned sbase = chan_off_s(g.x, c) + (unsigned)gd * (unsigned)g.x.sD;
+      goff = h.in ? (sbase + h.off) * 4u : 0x80000000u;
+    }
+  } else {
+    int jq = J * (256 >> g.lg2);
+    asm volatile("" : "+s"(jq));
+    const HWVar& h = hw[0];
+    const int q = jq + ((int)threadIdx.x >> g.lg2);
+    const int cl = mdiv(q, g.magic_PD), pd = q - cl * g.PD;
+    const int gd = d0 + pd - g.pd;
+    const bool in = h.in && q < nplanes && (c0 + cl < g.x.C) && (unsigned)gd < (unsigned)g.x.D;
+    if (in) goff = (choff[cl] + (unsigned)gd * (unsigned)g.x.sD + h.off) * 4u;
+  }
+  crn_bload(v, rs, goff);
+}
+
+template <int J, int U>
+__device__ __forceinline__ void patch_commit_one(const PatchDesc& g, const unsigned* choff,
+                                                 const HWVar (&hw)[U ? U : 1], float* ldsA, int nplanes, int c0,
+                                                 int d0, float v) {
+  if constexpr (U >= 1) {
+    int q = J / U;
+    asm volatile("" : "+s"(q));
+    const HWVar& h = hw[J % U];
+    if (q < nplanes) {                                   // wave-uniform
+      const int cl = mdiv(q, g.magic_PD), pd = q - cl * g.PD;
+      const int c = c0 + cl, gd = d0 + pd - g.pd;
+      if (g.tr.scale && c < g.x.C && (unsigned)gd < (unsigned)g.x.D) {
+        const float sc = g.tr.scale[c], sh = g.tr.shift[c];           // scalar loads
+        float t = v;
+        if (g.tr.pre_relu) t = fmaxf(t, 0.f);
+        t = t * sc + sh;
+        if (g.tr.post_relu) t = fmaxf(t, 0.f);
+        v = h.in ? t : v;                                // zero padding stays zero
+      }
+      if (h.r >= 0) ldsA[cl * g.PSP + pd * g.plane + h.r] = v;
+    }
+  } else {
+    int jq = J * (256 >> g.lg2);
+    asm volatile("" : "+s"(jq));
+    const HWVar& h = hw[0];
+    const int q = jq + ((int)threadIdx.x >> g.lg2);
+    if (q < nplanes && h.r >= 0) {
+      const int cl = mdiv(q, g.magic_PD), pd = q - cl * g.PD;
+      const int gd = d0 + pd - g.pd;
+      const bool in = h.in && (c0 + cl < g.x.C) && (unsigned)gd < (unsigned)g.x.D;
+      if (in && g.tr.scale) {
+        const float* tab = reinterpret_cast<const float*>(choff);
+        if (g.tr.pre_relu) v = fmaxf(v, 0.f);
+        v = v * tab[64 + cl] + tab[128 + cl];
+        if (g.tr.post_relu) v = fmaxf(v, 0.f);
+      }
+      ldsA[cl * g.PSP + pd * g.plane + h.r] = v;
+    }
+  }
+}
+
+template <int U, int J = 0>
+__device__ __forceinline__ void patch_issue_u(const PatchDesc& g, const unsigned* choff,
+                                              const HWVar (&hw)[U ? U : 1], const crn_rsrc& rs, int nplanes,
+                                              int npass, int c0, int d0, float (&val)[PREG]) {
+  if constexpr (J < PREG) {
+    patch_issue_one<J, U>(g, choff, hw, rs, J < npass ? nplanes : 0, c0, d0, val[J]);
+    patch_issue_u<U, J + 1>(g, choff, hw, rs, nplanes, npass, c0, d0, val);
+  }
+}
+template <int U, int J = 0>
+__device__ __forceinline__ void patch_commit_u(const PatchDesc& g, const unsigned* choff,
+                                               const HWVar (&hw)[U ? U : 1], float* ldsA, int nplanes, int npass,
+                                               int c0, int d0, const float (&val)[PREG]) {
+  if constexpr (J < PREG) {
+    if (J < npass) patch_commit_one<J, U>(g, choff, hw, ldsA, nplanes, c0, d0, val[J]);
+    patch_commit_u<U, J + 1>(g, choff, hw, ldsA, nplanes, npass, c0, d0, val);
+  }
+}
+
+// Runtime (wave-uniform) dispatch on the plane padding; HWVar storage is sized for the largest U.
+struct PatchHW { HWVar v[2]; };
+__device__ __forceinline__ void patch_prepare(const PatchDesc& g, int h0, int w0, PatchHW& p) {
+  switch (g.lg2) {
+    case 8: patch_hw<1>(g, h0, w0, reinterpret_cast<HWVar(&)[1]>(p.v)); break;
+    case 9: patch_hw<2>(g, h0, w0, reinterpret_cast<HWVar(&)[2]>(p.v)); break;
+    default: patch_hw<0>(g, h0, w0, reinterpret_cast<HWVar(&)[1]>(p.v)); break;
+  }
+}
+__device__ __forceinline__ void patch_issue(const PatchDesc& g, const unsigned* choff, const PatchHW& p,
+                                            const crn_rsrc& rs, int nplanes, int npass, int c0, int d0,
+                                            float (&val)[PREG]) {
+  switch (g.lg2) {   // wave-uniform
+    case 8: patch_issue_u<1>(g, choff, reinterpret_cast<const HWVar(&)[1]>(p.v), rs, nplanes, npass, c0, d0, val); break;
+    case 9: patch_issue_u<2>(g, choff, reinterpret_cast<const HWVar(&)[2]>(p.v), rs, nplanes, npass, c0, d0, val); break;
+    default: patch_issue_u<0>(g, choff, reinterpret_cast<const HWVar(&)[1]>(p.v), rs, nplanes, npass, c0, d0, val); break;
+  }
+}
+__device__ __forceinline__ void patch_commit(const PatchDesc& g, const unsigned* choff, const PatchHW& p,
+                                             float* ldsA, int nplanes, int npass, int c0, int d0,
+                                             const float (&val)[PREG]) {
+  switch (g.lg2) {
+    case 8: patch_commit_u<1>(g, choff, reinterpret_cast<const HWVar(&)[1]>(p.v), ldsA, nplanes, npass, c0, d0, val); break;
+    case 9: patch_commit_u<2>(g, choff, reinterpret_cast<const HWVar(&)[2]>(p.v), ldsA, nplanes, npass, c0, d0, val); break;
+    default: patch_commit_u<0>(g, choff, reinterpret_cast<const HWVar(&)[1]>(p.v), ldsA, nplanes, npass, c0, d0, val); break;
+  }
+}
+
+template <int V>
+struct IntC { static constexpr int value = V; };
+
+// XCD-aware work-item order (cdna guide T1): workgroup b is dispatched to XCD b % 8, each XCD has
+// its own L2; remap so that each XCD walks a CONTIGUOUS range of tiles and the halos shared by
+// neighbouring tiles hit in that XCD's L2 instead of being re-fetched from HBM by another one.
+__device__ __forceinline__ int xcd_remap(int bid, int nb) {
+  const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ------------------------------- forward -----------------------------------
+template <int MSUB, int NSUB>
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  unsigned* choff = reinterpret_cast<unsigned*>(lds);      // 2 x kChTab per-chunk channel tables
+  float* ldsA = lds + 2 * kChTab;
+  float* ldsB = ldsA + g.CC * g.PSP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kk = lane >> 4;
+  constexpr int NB = NSUB * 16;
+
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int twi = tile % g.tilesW; tile /= g.tilesW;
+  const int thi = tile % g.tilesH; tile /= g.tilesH;
+  const int tdi = tile % g.tilesD; tile /= g.tilesD;
+  const int b = tile;
+  const int d0 = tdi * g.TD, h0 = thi * g.TH, w0 = twi * g.TW;
+  const int n0 = blockIdx.y * NB;
+  const int split = blockIdx.z;
+  const int cbeg = split * g.chunks_per_split;
+  const int cend = min(cbeg + g.chunks_per_split, g.nchunks);
+
+  PatchDesc pdsc;
+  pdsc.x = g.x; pdsc.tr = g.tr; pdsc.pd = g.pd; pdsc.ph = g.ph; pdsc.pw = g.pw;
+  pdsc.PD = g.PD; pdsc.PH = g.PH; pdsc.PW = g.PW; pdsc.plane = g.PH * g.PW; pdsc.lg2 = g.lg2;
+  pdsc.PSP = g.PSP; pdsc.magic_PW = g.magic_PW; pdsc.magic_PD = g.magic_PD;
+  const int nplanes = g.CC * g.PD, npass = g.npass;
+  const crn_rsrc xrs = make_rsrc(g.x.base + (int64_t)b * g.x.sB);
+  PatchHW phw;
+  patch_prepare(pdsc, h0, w0, phw);
+
+  // lane's LDS offset of output position (sub-tile s, row i16) at tap (0,0,0)
+  int posbase[MSUB];
+  const int ri = i16 / g.mw, rj = i16 - ri * g.mw;
+#pragma unroll
+  for (int ms = 0; ms < MSUB; ++ms) {
+    int s = wave * MSUB + ms;
+    const int sw = s % g.nsw; s /= g.nsw;
+    const int sh = s % g.nsh; s /= g.nsh;
+    const int sd = s;
+    posbase[ms] = (sd * g.PH + sh * g.mh + ri) * g.PW + sw * g.mw + rj + kk * g.PSP;
+  }
+  const int bbase = kk * g.WSP + i16;
+
+  f32x4 acc[MSUB][NSUB];
+#pragma unroll
+  for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) acc[ms][ns] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float pval[PREG];
+  f32x4 wval[WREG];
+  const int nf4 = g.CC * g.T * (NB / 4);
+
+  const crn_rsrc wrs = make_rsrc(g.w);
+  // weight element f (float4) -> (LDS offset, global float offset or -1)
+  auto weight_elem = [&](int f, int c0, int& ldso, int64_t& go) {
+    const int j4 = f % (NB / 4);
+    const int ct = f / (NB / 4);
+    const int cl = mdiv(ct, g.magic_T);
+    const int t = ct - cl * g.T;
+    const int c = c0 + cl;
+    const int n = n0 + j4 * 4;
+    ldso = cl * g.WSP + t * NB + j4 * 4;
+    go = (c < g.x.C && n < g.Npad) ? ((int64_t)c * g.T + t) * g.Npad + n : -1;
+  };
+  auto weights_issue = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < WREG; ++j) {
+      int f = tid + j * 256;
+      asm volatile("" : "+v"(f));
+      unsigned boff = 0x80000000u;             // out of range -> zeros
+      if (f < nf4) {
+        int ldso; int64_t go;
+        weight_elem(f, c0, ldso, go);
+        if (go >= 0) boff = (unsigned)go * 4u;
+      }
+      crn_bload4(wval[j], wrs, boff);
+    }
+  };
+  auto weights_commit = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < WREG; ++j) {
+      int f = tid + j * 256;
+      asm volatile("" : "+v"(f));
+      if (f < nf4) {
+        int ldso; int64_t go;
+        weight_elem(f, c0, ldso, go);
+        *reinterpret_cast<f32x4*>(ldsB + ldso) = wval[j];
+      }
+    }
+  };
+
+  if (cbeg < cend) {
+    stage_choff(g.x, g.tr, choff + (cbeg & 1) * kChTab, cbeg * g.CC, g.CC);
+    __syncthreads();
+    patch_issue(pdsc, choff + (cbeg & 1) * kChTab, phw, xrs, nplanes, npass, cbeg * g.CC, d0, pval);
+    weights_issue(cbeg * g.CC);
+  }
+  for (int chunk = cbeg; chunk < cend; ++chunk) {
+    const int c0 = chunk * g.CC;
+    const bool stage = !(g.dbg == 2 && chunk > cbeg);
+    if (stage) {
+    crn_wait_loads(pval);
+    crn_wait_loads4(wval);
+    __syncthreads();                       // previous chunk's MFMA reads are done
+    patch_commit(pdsc, choff + (chunk & 1) * kChTab, phw, ldsA, nplanes, npass, c0, d0, pval);
+    weights_commit(c0);
+    if (chunk + 1 < cend) stage_choff(g.x, g.tr, choff + ((chunk + 1) & 1) * kChTab, c0 + g.CC, g.CC);
+    __syncthreads();
+    }
+    if (stage && g.dbg != 2 && chunk + 1 < cend) {                // next chunk's loads fly under this chunk's MFMAs
+      patch_issue(pdsc, choff + ((chunk + 1) & 1) * kChTab, phw, xrs, nplanes, npass, c0 + g.CC, d0, pval);
+      weights_issue(c0 + g.CC);
+    }
+
+    // MFMA loop.  One (k-step, zd, zh) row of KW taps is straight-line code: the tap offsets
+    // along W are ds_read immediates, so a row costs MSUB+1 address adds for KW*MSUB*NSUB MFMAs.
+    const int ksteps = g.CC >> 2;
+    auto row = [&](auto kwc, int aoff, int boff) {
+      constexpr int KW = decltype(kwc)::value;
+      const float* pa[MSUB];
+#pragma unroll
+      for (int ms = 0; ms < MSUB; ++ms) pa[ms] = ldsA + aoff + posbase[ms];
+      const float* pb = ldsB + boff + bbase;
+#pragma unroll
+      for (int zw = 0; zw < KW; ++zw) {
+        float a[MSUB], bv[NSUB];
+#pragma unroll
+        for (int ms = 0; ms < MSUB; ++ms) a[ms] = pa[ms][zw];
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) bv[ns] = pb[zw * NB + ns * 16];
+#pragma unroll
+        for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+          for (int ns = 0; ns < NSUB; ++ns)
+            acc[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ms], bv[ns], acc[ms][ns], 0, 0, 0);
+      }
+    };
+    if (g.dbg != 1)
+    for (int ks = 0; ks < ksteps; ++ks)
+      for (int zd = 0; zd < g.kd; ++zd)
+        for (int zh = 0; zh < g.kh; ++zh) {
+          const int aoff = ks * 4 * g.PSP + (zd * g.PH + zh) * g.PW;
+          const int boff = ks * 4 * g.WSP + (zd * g.kh + zh) * g.kw * NB;
+          switch (g.kw) {
+            case 1: row(IntC<1>{}, aoff, boff); break;
+            case 2: row(IntC<2>{}, aoff, boff); break;
+            case 3: row(IntC<3>{}, aoff, boff); break;
+            case 4: row(IntC<4>{}, aoff, boff); break;
+            case 5: row(IntC<5>{}, aoff, boff); break;
+            case 7: row(IntC<7>{}, aoff, boff); break;
+            default:
+              for (int zw = 0; zw < g.kw; ++zw) row(IntC<1>{}, aoff + zw, boff + zw * NB);
+          }
+        }
+  }
+
+  // epilogue: D row = kk*4 + r (position), col = i16 (channel)
+  float* yb = g.y.base + (int64_t)b * g.y.sB;
+#pragma unroll
+  for (int ns = 0; ns < NSUB; ++ns) {
+    const int n = n0 + ns * 16 + i16;
+    if (n >= g.y.C) continue;
+    const int64_t co = view_chan(g.y, n);
+    const float bsv = (g.bias && split == 0) ? g.bias[(int64_t)b * g.bias_sB + n] : 0.f;
+#pragma unroll
+    for (int ms = 0; ms < MSUB; ++ms) {
+      int s = wave * MSUB + ms;
+      const int sw = s % g.nsw; s /= g.nsw;
+      const int sh = s % g.nsh; s /= g.nsh;
+      const int sd = s;
+      if (g.vec_store) {
+        // the 4 accumulator rows of this lane are 4 consecutive W positions: one 16-B store
+        const int row0 = kk * 4;
+        const int rr = row0 / g.mw, rc = row0 - rr * g.mw;
+        const int od = d0 + sd, oh = h0 + sh * g.mh + rr, ow = w0 + sw * g.mw + rc;
+        if (od < g.y.D && oh < g.y.H && ow < g.y.W) {
+          float* dst = yb + co + (int64_t)od * g.y.sD + (int64_t)oh * g.y.sH + ow;
+          f32x4 v = acc[ms][ns] + bsv;
+          if (g.mode == 1) v += *reinterpret_cast<const f32x4*>(dst);
+          *reinterpret_cast<f32x4*>(dst) = v;
+        }
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row_ = kk * 4 + r;
+        const int rr = row_ / g.mw, rc = row_ - rr * g.mw;
+        const int od = d0 + sd, oh = h0 + sh * g.mh + rr, ow = w0 + sw * g.mw + rc;
+        if (od < g.y.D && oh < g.y.H && ow < g.y.W) {
+          float* dst = yb + co + (int64_t)od * g.y.sD + (int64_t)oh * g.y.sH + (int64_t)ow * g.y.sW;
+          const float v = acc[ms][ns][r] + bsv;
+          if (g.mode == 0) *dst = v;
+          else if (g.mode == 1) *dst += v;
+          else atomicAdd(dst, v);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------ weight grad ---------------------------------
+struct WgradGeom {
+  crnView x, dy;
+  crnInTransform tr;
+  float* dw;
+  int Npad;
+  int kd, kh, kw, pd, ph, pw, T;
+  int TD, TH, TW;
+  int PD, PH, PW, PSP;
+  int lg2, npass;          // patch staging slots
+  int dlg2, dnpass;        // dy staging slots (plane = TD*TH*TW positions of one channel)
+  int CC;                  // channels per block (rows = CC*T <= 64*RSUB)
+  int tilesD, tilesH, tilesW, ntiles;   // ntiles includes batch
+  int tiles_per_split;
+  unsigned magic_PW, magic_PD, magic_T, magic_TW, magic_TH;
+};
+
+template <int RSUB, int NSUB>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  unsigned* choff = reinterpret_cast<unsigned*>(lds);   // x channel table; dy channel offsets at [192,256)
+  float* ldsA = lds + 2 * kChTab;           // CC * PSP   (input patch)
+  float* ldsB = ldsA + g.CC * g.PSP;        // TD*TH*TW * NBP (dy, [pos][n])
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kk = lane >> 4;
+  constexpr int NB = NSUB * 16, NBP = NB + 1;
+  const int c0 = blockIdx.x * g.CC;
+  const int n0 = blockIdx.y * NB;
+  const int split = blockIdx.z;
+  const int nrows = min(g.CC, g.x.C - c0) * g.T;
+
+  PatchDesc pdsc;
+  pdsc.x = g.x; pdsc.tr = g.tr; pdsc.pd = g.pd; pdsc.ph = g.ph; pdsc.pw = g.pw;
+  pdsc.PD = g.PD; pdsc.PH = g.PH; pdsc.PW = g.PW; pdsc.plane = g.PH * g.PW; pdsc.lg2 = g.lg2;
+  pdsc.PSP = g.PSP; pdsc.magic_PW = g.magic_PW; pdsc.magic_PD = g.magic_PD;
+  const int nplanes = g.CC * g.PD, npass = g.npass;
+
+  // row (c_local, tap) -> LDS offset inside the patch
+  int rowbase[RSUB];
+#pragma unroll
+  for (int rs = 0; rs < RSUB; ++rs) {
+    int row = (wave * RSUB + rs) * 16 + i16;
+    if (row >= nrows) row = 0;                       // never stored
+    const int cl = mdiv(row, g.magic_T);
+    int t = row - cl * g.T;
+    const int zw = t % g.kw; t /= g.kw;
+    const int zh = t % g.kh; t /= g.kh;
+    rowbase[rs] = cl * g.PSP + (t * g.PH + zh) * g.PW + zw + kk;
+  }
+
+  f32x4 acc[RSUB][NSUB];
+#pragma unroll
+  for (int rs = 0; rs < RSUB; ++rs)
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) acc[rs][ns] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int tbeg = split * g.tiles_per_split;
+  const int tend = min(tbeg + g.tiles_per_split, g.ntiles);
+  const int npos = g.TD * g.TH * g.TW;
+
+  float pval[PREG];
+  float dval[DREG];
+
+  auto tile_origin = [&](int tl, int& b, int& d0, int& h0, int& w0) {
+    int tile = tl;
+    const int twi = tile % g.tilesW; tile /= g.tilesW;
+    const int thi = tile % g.tilesH; tile /= g.tilesH;
+    const int tdi = tile % g.tilesD; tile /= g.tilesD;
+    b = tile; d0 = tdi * g.TD; h0 = thi * g.TH; w0 = twi * g.TW;
+  };
+  // dy tile: planes = channels nl, in-plane index r = position (td,th,tw); LDS layout [pos][n]
+  // (lanes run along w: coalesced global reads, odd LDS stride NBP: conflict-free writes).
+  // Per-thread position variants (npos <= 512 -> at most 2) are hoisted per tile.
+  HWVar dhw0, dhw1;
+  auto dy_prepare = [&](int d0, int h0, int w0) {
+    auto one = [&](int u, HWVar& out) {
+      const int r = g.dlg2 >= 8 ? tid + u * 256 : (tid & ((1 << g.dlg2) - 1));
+      const bool valid = r < npos && (u == 0 || g.dlg2 == 9);
+      const int r1 = mdiv(r, g.magic_TW), tw = r - r1 * g.TW;
+      const int td = mdiv(r1, g.magic_TH), th = r1 - td * g.TH;
+      const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
+      out.r = valid ? r : -1;
+      out.in = valid && od < g.dy.D && oh < g.dy.H && ow < g.dy.W;
+      out.off = (unsigned)od * (unsigned)g.dy.sD + (unsigned)oh * (unsigned)g.dy.sH +
+                (unsigned)ow * (unsigned)g.dy.sW;
+    };
+    one(0, dhw0);
+    one(1, dhw1);
+  };
+  // slot J -> (channel q, variant u); q wave-uniform when a plane spans >= 256 slots
+  auto dy_issue = [&](const crn_rsrc& rs, auto jc, float& v) {
+    constexpr int J = decltype(jc)::value;
+    unsigned goff = 0x80000000u;
+    if (g.dlg2 >= 8) {
+      int q = __builtin_amdgcn_readfirstlane(g.dlg2 == 9 ? J / 2 : J);
+      asm volatile("" : "+s"(q));
+      const HWVar h = (J % 2 == 1 && g.dlg2 == 9) ? dhw1 : dhw0;
+      if (J < g.dnpass && q < NB && n0 + q < g.dy.C)
+        goff = h.in ? (chan_off_s(g.dy, n0 + q) + h.off) * 4u : 0x80000000u;
+    } else {
+      int jq = J * (256 >> g.dlg2);
+      asm volatile("" : "+s"(jq));
+      const int q = jq + (tid >> g.dlg2);
+      if (J < g.dnpass && dhw0.in && q < NB && n0 + q < g.dy.C) goff = (choff[kChTab + q] + dhw0.off) * 4u;
+    }
+    crn_bload(v, rs, goff);
+  };
+  auto dy_commit = [&](auto jc, float v) {
+    constexpr int J = decltype(jc)::value;
+    if (g.dlg2 >= 8) {
+      int q = __builtin_amdgcn_readfirstlane(g.dlg2 == 9 ? J / 2 : J);
+      asm volatile("" : "+s"(q));
+      const HWVar h = (J % 2 == 1 && g.dlg2 == 9) ? dhw1 : dhw0;
+      if (q < NB && h.r >= 0) ldsB[h.r * NBP + q] = v;
+    } else {
+      int jq = J * (256 >> g.dlg2);
+      asm volatile("" : "+s"(jq));
+      const int q = jq + (tid >> g.dlg2);
+      if (q < NB && dhw0.r >= 0) ldsB[dhw0.r * NBP + q] = v;
+    }
+  };
+#define CRN_DY_8(OP, A, B0)                                                                        \
+  if (g.dnpass > B0) {                                                                             \
+    OP(A IntC<B0 + 0>{}, dval[B0 + 0]); OP(A IntC<B0 + 1>{}, dval[B0 + 1]);                        \
+    OP(A IntC<B0 + 2>{}, dval[B0 + 2]); OP(A IntC<B0 + 3>{}, dval[B0 + 3]);                        \
+    OP(A IntC<B0 + 4>{}, dval[B0 + 4]); OP(A IntC<B0 + 5>{}, dval[B0 + 5]);                        \
+    OP(A IntC<B0 + 6>{}, dval[B0 + 6]); OP(A IntC<B0 + 7>{}, dval[B0 + 7]);                        \
+  }
+#define CRN_DY_8U(OP, A, B0)                                                                       \
+  OP(A IntC<B0 + 0>{}, dval[B0 + 0]); OP(A IntC<B0 + 1>{}, dval[B0 + 1]);                          \
+  OP(A IntC<B0 + 2>{}, dval[B0 + 2]); OP(A IntC<B0 + 3>{}, dval[B0 + 3]);                          \
+  OP(A IntC<B0 + 4>{}, dval[B0 + 4]); OP(A IntC<B0 + 5>{}, dval[B0 + 5]);                          \
+  OP(A IntC<B0 + 6>{}, dval[B0 + 6]); OP(A IntC<B0 + 7>{}, dval[B0 + 7]);
+#define CRN_DY_ISSUE(rs) do { CRN_DY_8U(dy_issue, rs CRN_COMMA, 0) CRN_DY_8U(dy_issue, rs CRN_COMMA, 8) \
+                              CRN_DY_8U(dy_issue, rs CRN_COMMA, 16) CRN_DY_8U(dy_issue, rs CRN_COMMA, 24) } while (0)
+#define CRN_DY_COMMIT() do { CRN_DY_8(dy_commit, , 0) CRN_DY_8(dy_commit, , 8) CRN_DY_8(dy_commit, , 16) \
+                             CRN_DY_8(dy_commit, , 24) } while (0)
+#define CRN_COMMA ,
+
+  int cb = 0, cd0 = 0, ch0 = 0, cw0 = 0;     // origin of the tile currently held in registers
+  PatchHW phw;
+  stage_choff(g.x, g.tr, choff, c0, g.CC);
+  if (tid < NB) {
+    const int n = min(n0 + tid, g.dy.C - 1);
+    choff[kChTab + tid] = g.dy.chan_off ? (unsigned)g.dy.chan_off[n] : (unsigned)n * (unsigned)g.dy.sC;
+  }
+  __syncthreads();
+  if (tbeg < tend) {
+    tile_origin(tbeg, cb, cd0, ch0, cw0);
+    const crn_rsrc xrs = make_rsrc(g.x.base + (int64_t)cb * g.x.sB);
+    const crn_rsrc drs = make_rsrc(g.dy.base + (int64_t)cb * g.dy.sB);
+    patch_prepare(pdsc, ch0, cw0, phw);
+    dy_prepare(cd0, ch0, cw0);
+    patch_issue(pdsc, choff, phw, xrs, nplanes, npass, c0, cd0, pval);
+    CRN_DY_ISSUE(drs);
+  }
+  for (int tl = tbeg; tl < tend; ++tl) {
+    crn_wait_loads(pval);
+    crn_wait_loads(dval);
+    __syncthreads();
+    patch_commit(pdsc, choff, phw, ldsA, nplanes, npass, c0, cd0, pval);
+    CRN_DY_COMMIT();
+    __syncthreads();
+    if (tl + 1 < tend) {
+      tile_origin(tl + 1, cb, cd0, ch0, cw0);
+      const crn_rsrc xrs = make_rsrc(g.x.base + (int64_t)cb * g.x.sB);
+      const crn_rsrc drs = make_rsrc(g.dy.base + (int64_t)cb * g.dy.sB);
+      patch_prepare(pdsc, ch0, cw0, phw);
+      dy_prepare(cd0, ch0, cw0);
+      patch_issue(pdsc, choff, phw, xrs, nplanes, npass, c0, cd0, pval);
+      CRN_DY_ISSUE(drs);
+    }
+    // reduction over the tile's positions: one (td,th) row of TW/4 k-steps is straight-line code
+    auto row = [&](auto wsc, int aoff, int boff) {
+      constexpr int WS = decltype(wsc)::value;
+      const float* pa[RSUB];
+#pragma unroll
+      for (int rs = 0; rs < RSUB; ++rs) pa[rs] = ldsA + aoff + rowbase[rs];
+      const float* pb = ldsB + boff;
+#pragma unroll
+      for (int ws = 0; ws < WS; ++ws) {
+        float a[RSUB], bv[NSUB];
+#pragma unroll
+        for (int rs = 0; rs < RSUB; ++rs) a[rs] = pa[rs][ws * 4];
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) bv[ns] = pb[ws * 4 * NBP + ns * 16];
+#pragma unroll
+        for (int rs = 0; rs < RSUB; ++rs)
+#pragma unroll
+          for (int ns = 0; ns < NSUB; ++ns)
+            acc[rs][ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rs], bv[ns], acc[rs][ns], 0, 0, 0);
+      }
+    };
+    for (int td = 0; td < g.TD; ++td)
+      for (int th = 0; th < g.TH; ++th) {
+        const int aoff = (td * g.PH + th) * g.PW;
+        const int boff = ((td * g.TH + th) * g.TW + kk) * NBP + i16;
+        switch (g.TW >> 2) {
+          case 1: row(IntC<1>{}, aoff, boff); break;
+          case 2: row(IntC<2>{}, aoff, boff); break;
+          case 3: row(IntC<3>{}, aoff, boff); break;
+          default: row(IntC<4>{}, aoff, boff); break;
+        }
+      }
+  }
+#undef CRN_DY_8
+#undef CRN_DY_8U
+#undef CRN_DY_ISSUE
+#undef CRN_DY_COMMIT
+#undef CRN_COMMA
+
+  // D row = kk*4 + r -> weight row (c_local*T + tap); col = i16 -> n
+#pragma unroll
+  for (int rs = 0; rs < RSUB; ++rs)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row_ = (wave * RSUB + rs) * 16 + kk * 4 + r;
+      if (row_ >= nrows) continue;
+#pragma unroll
+      for (int ns = 0; ns < NSUB; ++ns) {
+        const int n = n0 + ns * 16 + i16;
+        if (n < g.Npad)
+          atomicAdd(g.dw + ((int64_t)c0 * g.T + row_) * g.Npad + n, acc[rs][ns][r]);
+      }
+    }
+}
+
+
+template <int MSUB, int NSUB>
+inline int launch_fwd(const ConvGeom& g, dim3 grid, size_t lds_bytes, hipStream_t st) {
+  auto k = conv_fwd_kernel<MSUB, NSUB>;
+  if (lds_bytes > 65536)
+    CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes, st, g);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+template <int RSUB, int NSUB>
+inline int launch_wgrad(const WgradGeom& g, dim3 grid, size_t lds_bytes, hipStream_t st) {
+  auto k = conv_wgrad_kernel<RSUB, NSUB>;
+  if (lds_bytes > 65536)
+    CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes, st, g);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+}  // namespace crnk
+
+// launchers defined in conv_inst_*.hip
+#define CRN_FWD_CONFIGS(X) X(8, 1) X(4, 2) X(4, 1) X(2, 4) X(2, 2) X(2, 1) X(1, 4) X(1, 2) X(1, 1)
+#define CRN_WG_CONFIGS(X) X(8, 1) X(4, 2) X(4, 1) X(2, 4) X(2, 2) X(2, 1) X(1, 4) X(1, 2) X(1, 1)
+#define CRN_DECL_FWD(M, N) int crn_launch_fwd_##M##_##N(const crnk::ConvGeom&, dim3, size_t, hipStream_t);
+#define CRN_DECL_WG(R, N) int crn_launch_wgrad_##R##_##N(const crnk::WgradGeom&, dim3, size_t, hipStream_t);
+CRN_FWD_CONFIGS(CRN_DECL_FWD)
+CRN_WG_CONFIGS(CRN_DECL_WG)
