@@ -388,13 +388,16 @@ extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const 
   g.tilesD = crn_cdiv(Dy, g.TD); g.tilesH = crn_cdiv(Hy, g.TH); g.tilesW = crn_cdiv(Wy, g.TW);
   g.ntiles = g.tilesD * g.tilesH * g.tilesW * dy->B;
   const int cblocks = crn_cdiv(x->C, CC), nblocks = crn_cdiv(Npad, NB);
-  int splits = std::max(1, std::min(g.ntiles, crn_cdiv(768, cblocks * nblocks)));
+  static const int kWgBlocks = getenv("CRN_WG_BLOCKS") ? atoi(getenv("CRN_WG_BLOCKS")) : 768;
+  int splits = std::max(1, std::min(g.ntiles, crn_cdiv(kWgBlocks, cblocks * nblocks)));
   g.tiles_per_split = crn_cdiv(g.ntiles, splits);
   splits = crn_cdiv(g.ntiles, g.tiles_per_split);
   g.lg2 = ilog2_ceil(g.PH * g.PW); g.npass = stage_passes(CC * g.PD, g.PH * g.PW);
   g.dlg2 = ilog2_ceil(g.TD * g.TH * g.TW); g.dnpass = stage_passes(NB, g.TD * g.TH * g.TW);
   g.magic_PW = magic20(g.PW); g.magic_PD = magic20(g.PD); g.magic_T = magic20(T);
   g.magic_TW = magic20(g.TW); g.magic_TH = magic20(g.TH);
+  g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
+  g.skew = getenv("CRN_SKEW") ? atoi(getenv("CRN_SKEW")) : 0;
   if (zero_first) CRN_HIP(hipMemsetAsync(dw, 0, (size_t)x->C * T * Npad * 4, st));
   dim3 grid((unsigned)cblocks, (unsigned)nblocks, (unsigned)splits);
   const size_t lds_bytes = best.lds;

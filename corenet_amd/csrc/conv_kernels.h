@@ -138,7 +138,10 @@ __device__ __forceinline__ void patch_issue_one(const PatchDesc& g, const unsign
     const int cl = mdiv(q, g.magic_PD), pd = q - cl * g.PD;
     const int c = c0 + cl, gd = d0 + pd - g.pd;
     if (q < nplanes && c < g.x.C && (unsigned)gd < (unsigned)g.x.D) {       // wave-uniform
-      const unsigned sbase = chan_off_s(g.x, c) + (unsigned)gd * (unsigned)g.x.sD;
+      // channel offset from the LDS table, NOT from global memory: a compiler-visible global load
+      // here makes hipcc emit s_waitcnt vmcnt(0), which also drains every asm staging load issued so
+      // far (measured: one full memory latency per slot, 27 us per wgrad tile)
+      const unsigned sbase = choff[cl] + (unsigned)gd * (unsigned)g.x.sD;
       goff = h.in ? (sbase + h.off) * 4u : 0x80000000u;
     }
   } else {
@@ -166,7 +169,8 @@ __device__ __forceinline__ void patch_commit_one(const PatchDesc& g, const unsig
       const int cl = mdiv(q, g.magic_PD), pd = q - cl * g.PD;
       const int c = c0 + cl, gd = d0 + pd - g.pd;
       if (g.tr.scale && c < g.x.C && (unsigned)gd < (unsigned)g.x.D) {
-        const float sc = g.tr.scale[c], sh = g.tr.shift[c];           // scalar loads
+        const float* tab = reinterpret_cast<const float*>(choff);
+        const float sc = tab[64 + cl], sh = tab[128 + cl];            // LDS broadcast reads
         float t = v;
         if (g.tr.pre_relu) t = fmaxf(t, 0.f);
         t = t * sc + sh;
@@ -245,12 +249,65 @@ __device__ __forceinline__ void patch_commit(const PatchDesc& g, const unsigned*
 template <int V>
 struct IntC { static constexpr int value = V; };
 
+// Two workgroups share a CU and run the same [stage | MFMA] cycle; started together they stay in
+// phase and fight for the same unit in every phase.  Delaying the workgroup in the odd CU slot by
+// about half a cycle puts them in anti-phase: one stages while the other owns the MFMA pipe.
+__device__ __forceinline__ void phase_skew(int sleeps) {
+  const unsigned tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);   // HW_ID.TG_ID
+  if (tg & 1)
+    for (int i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+}
+
 // XCD-aware work-item order (cdna guide T1): workgroup b is dispatched to XCD b % 8, each XCD has
 // its own L2; remap so that each XCD walks a CONTIGUOUS range of tiles and the halos shared by
 // neighbouring tiles hit in that XCD's L2 instead of being re-fetched from HBM by another one.
 __device__ __forceinline__ int xcd_remap(int bid, int nb) {
   const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// One chunk's MFMAs.  A (k-step, zd, zh) row of KW taps is straight-line code: the tap offsets
+// along W are ds_read immediates, so a row costs MSUB+1 address adds for KW*MSUB*NSUB MFMAs.
+// nzw > 1 (with KW == 1): window widths without an unrolled variant walk the taps one by one.
+template <int KW, int MSUB, int NSUB>
+__device__ __forceinline__ void mfma_rows(f32x4 (&acc)[MSUB][NSUB], const float* ldsA, const float* ldsB,
+                                          const int (&posbase)[MSUB], int bbase, int ksteps, const ConvGeom& g,
+                                          int nzw) {
+  constexpr int NB = NSUB * 16;
+  const float* pa0[MSUB];
+#pragma unroll
+  for (int ms = 0; ms < MSUB; ++ms) pa0[ms] = ldsA + posbase[ms];
+  const float* pb0 = ldsB + bbase;
+  for (int ks = 0; ks < ksteps; ++ks)
+    for (int zd = 0; zd < g.kd; ++zd)
+      for (int zh = 0; zh < g.kh; ++zh)
+        for (int z0 = 0; z0 < nzw; ++z0) {
+          const int aoff = ks * 4 * g.PSP + (zd * g.PH + zh) * g.PW + z0;
+          const int boff = ks * 4 * g.WSP + ((zd * g.kh + zh) * g.kw + z0) * NB;
+          const float* pb = pb0 + boff;
+          float a[KW][MSUB], bv[KW][NSUB];
+#pragma unroll
+          for (int zw = 0; zw < KW; ++zw) {
+#pragma unroll
+            for (int ms = 0; ms < MSUB; ++ms) a[zw][ms] = pa0[ms][aoff + zw];
+#pragma unroll
+            for (int ns = 0; ns < NSUB; ++ns) bv[zw][ns] = pb[zw * NB + ns * 16];
+          }
+#pragma unroll
+          for (int zw = 0; zw < KW; ++zw)
+#pragma unroll
+            for (int ms = 0; ms < MSUB; ++ms)
+#pragma unroll
+              for (int ns = 0; ns < NSUB; ++ns)
+                acc[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[zw][ms], bv[zw][ns], acc[ms][ns], 0, 0, 0);
+          // issue order: reads run one tap ahead of the MFMAs that consume them
+          __builtin_amdgcn_sched_group_barrier(0x100, MSUB + NSUB, 0);
+#pragma unroll
+          for (int zw = 0; zw < KW; ++zw) {
+            __builtin_amdgcn_sched_group_barrier(0x100, MSUB + NSUB, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MSUB * NSUB, 0);
+          }
+        }
 }
 
 // ------------------------------- forward -----------------------------------
@@ -354,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
   }
   for (int chunk = cbeg; chunk < cend; ++chunk) {
     const int c0 = chunk * g.CC;
-    const bool stage = !(g.dbg == 2 && chunk > cbeg);
+    const bool stage = !(g.dbg >= 2 && chunk > cbeg);
     if (stage) {
     crn_wait_loads(pval);
     crn_wait_loads4(wval);
@@ -364,51 +421,27 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
     if (chunk + 1 < cend) stage_choff(g.x, g.tr, choff + ((chunk + 1) & 1) * kChTab, c0 + g.CC, g.CC);
     __syncthreads();
     }
-    if (stage && g.dbg != 2 && chunk + 1 < cend) {                // next chunk's loads fly under this chunk's MFMAs
+    if (stage && g.dbg < 2 && chunk + 1 < cend) {                // next chunk's loads fly under this chunk's MFMAs
       patch_issue(pdsc, choff + ((chunk + 1) & 1) * kChTab, phw, xrs, nplanes, npass, c0 + g.CC, d0, pval);
       weights_issue(c0 + g.CC);
     }
 
-    // MFMA loop.  One (k-step, zd, zh) row of KW taps is straight-line code: the tap offsets
-    // along W are ds_read immediates, so a row costs MSUB+1 address adds for KW*MSUB*NSUB MFMAs.
-    const int ksteps = g.CC >> 2;
-    auto row = [&](auto kwc, int aoff, int boff) {
-      constexpr int KW = decltype(kwc)::value;
-      const float* pa[MSUB];
-#pragma unroll
-      for (int ms = 0; ms < MSUB; ++ms) pa[ms] = ldsA + aoff + posbase[ms];
-      const float* pb = ldsB + boff + bbase;
-#pragma unroll
-      for (int zw = 0; zw < KW; ++zw) {
-        float a[MSUB], bv[NSUB];
-#pragma unroll
-        for (int ms = 0; ms < MSUB; ++ms) a[ms] = pa[ms][zw];
-#pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns) bv[ns] = pb[zw * NB + ns * 16];
-#pragma unroll
-        for (int ms = 0; ms < MSUB; ++ms)
-#pragma unroll
-          for (int ns = 0; ns < NSUB; ++ns)
-            acc[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ms], bv[ns], acc[ms][ns], 0, 0, 0);
+    // MFMA loop (mfma_rows): the switch on the tap-row width sits OUTSIDE the loops, so the
+    // accumulators never cross a control-flow merge inside them (a merge costs 32 v_mov per row,
+    // and on gfx950 every VALU instruction next to an MFMA stream costs 4-8 MFMA cycles:
+    // tools/mfma_peak.hip).
+    if (g.dbg != 1) {
+      const int ksteps = g.CC >> 2;
+      switch (g.kw) {
+        case 1: mfma_rows<1, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, 1); break;
+        case 2: mfma_rows<2, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, 1); break;
+        case 3: mfma_rows<3, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, 1); break;
+        case 4: mfma_rows<4, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, 1); break;
+        case 5: mfma_rows<5, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, 1); break;
+        case 7: mfma_rows<7, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, 1); break;
+        default: mfma_rows<1, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, g.kw); break;
       }
-    };
-    if (g.dbg != 1)
-    for (int ks = 0; ks < ksteps; ++ks)
-      for (int zd = 0; zd < g.kd; ++zd)
-        for (int zh = 0; zh < g.kh; ++zh) {
-          const int aoff = ks * 4 * g.PSP + (zd * g.PH + zh) * g.PW;
-          const int boff = ks * 4 * g.WSP + (zd * g.kh + zh) * g.kw * NB;
-          switch (g.kw) {
-            case 1: row(IntC<1>{}, aoff, boff); break;
-            case 2: row(IntC<2>{}, aoff, boff); break;
-            case 3: row(IntC<3>{}, aoff, boff); break;
-            case 4: row(IntC<4>{}, aoff, boff); break;
-            case 5: row(IntC<5>{}, aoff, boff); break;
-            case 7: row(IntC<7>{}, aoff, boff); break;
-            default:
-              for (int zw = 0; zw < g.kw; ++zw) row(IntC<1>{}, aoff + zw, boff + zw * NB);
-          }
-        }
+    }
   }
 
   // epilogue: D row = kk*4 + r (position), col = i16 (channel)
@@ -470,7 +503,46 @@ struct WgradGeom {
   int tilesD, tilesH, tilesW, ntiles;   // ntiles includes batch
   int tiles_per_split;
   unsigned magic_PW, magic_PD, magic_T, magic_TW, magic_TH;
+  int dbg;                 // tuning aid (CRN_DBG_MODE): 1 = no MFMA loop, 2 = stage only the first tile
+  int skew;                // phase_skew() sleeps
 };
+
+// One tile's MFMAs: a (td,th) row of WS = TW/4 k-steps is straight-line code.
+template <int WS, int RSUB, int NSUB>
+__device__ __forceinline__ void wgrad_rows(f32x4 (&acc)[RSUB][NSUB], const float* ldsA, const float* ldsB,
+                                           const int (&rowbase)[RSUB], int bbase, const WgradGeom& g) {
+  constexpr int NBP = NSUB * 16 + 1;
+  const float* pa0[RSUB];
+#pragma unroll
+  for (int rs = 0; rs < RSUB; ++rs) pa0[rs] = ldsA + rowbase[rs];
+  const float* pb0 = ldsB + bbase;
+  for (int td = 0; td < g.TD; ++td)
+    for (int th = 0; th < g.TH; ++th) {
+      const int aoff = (td * g.PH + th) * g.PW;
+      const float* pb = pb0 + (td * g.TH + th) * g.TW * NBP;
+      float a[WS][RSUB], bv[WS][NSUB];
+#pragma unroll
+      for (int ws = 0; ws < WS; ++ws) {
+#pragma unroll
+        for (int rs = 0; rs < RSUB; ++rs) a[ws][rs] = pa0[rs][aoff + ws * 4];
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) bv[ws][ns] = pb[ws * 4 * NBP + ns * 16];
+      }
+#pragma unroll
+      for (int ws = 0; ws < WS; ++ws)
+#pragma unroll
+        for (int rs = 0; rs < RSUB; ++rs)
+#pragma unroll
+          for (int ns = 0; ns < NSUB; ++ns)
+            acc[rs][ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ws][rs], bv[ws][ns], acc[rs][ns], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, RSUB + NSUB, 0);
+#pragma unroll
+      for (int ws = 0; ws < WS; ++ws) {
+        __builtin_amdgcn_sched_group_barrier(0x100, RSUB + NSUB, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, RSUB * NSUB, 0);
+      }
+    }
+}
 
 template <int RSUB, int NSUB>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
@@ -553,7 +625,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
       asm volatile("" : "+s"(q));
       const HWVar h = (J % 2 == 1 && g.dlg2 == 9) ? dhw1 : dhw0;
       if (J < g.dnpass && q < NB && n0 + q < g.dy.C)
-        goff = h.in ? (chan_off_s(g.dy, n0 + q) + h.off) * 4u : 0x80000000u;
+        goff = h.in ? (choff[kChTab + q] + h.off) * 4u : 0x80000000u;
     } else {
       int jq = J * (256 >> g.dlg2);
       asm volatile("" : "+s"(jq));
@@ -596,6 +668,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
 
   int cb = 0, cd0 = 0, ch0 = 0, cw0 = 0;     // origin of the tile currently held in registers
   PatchHW phw;
+  phase_skew(g.skew);
   stage_choff(g.x, g.tr, choff, c0, g.CC);
   if (tid < NB) {
     const int n = min(n0 + tid, g.dy.C - 1);
@@ -615,10 +688,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
     crn_wait_loads(pval);
     crn_wait_loads(dval);
     __syncthreads();
-    patch_commit(pdsc, choff, phw, ldsA, nplanes, npass, c0, cd0, pval);
-    CRN_DY_COMMIT();
+    if (g.dbg != 2 || tl == tbeg) {
+      patch_commit(pdsc, choff, phw, ldsA, nplanes, npass, c0, cd0, pval);
+      CRN_DY_COMMIT();
+    }
     __syncthreads();
-    if (tl + 1 < tend) {
+    if (tl + 1 < tend && g.dbg != 2) {
       tile_origin(tl + 1, cb, cd0, ch0, cw0);
       const crn_rsrc xrs = make_rsrc(g.x.base + (int64_t)cb * g.x.sB);
       const crn_rsrc drs = make_rsrc(g.dy.base + (int64_t)cb * g.dy.sB);
@@ -627,38 +702,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
       patch_issue(pdsc, choff, phw, xrs, nplanes, npass, c0, cd0, pval);
       CRN_DY_ISSUE(drs);
     }
-    // reduction over the tile's positions: one (td,th) row of TW/4 k-steps is straight-line code
-    auto row = [&](auto wsc, int aoff, int boff) {
-      constexpr int WS = decltype(wsc)::value;
-      const float* pa[RSUB];
-#pragma unroll
-      for (int rs = 0; rs < RSUB; ++rs) pa[rs] = ldsA + aoff + rowbase[rs];
-      const float* pb = ldsB + boff;
-#pragma unroll
-      for (int ws = 0; ws < WS; ++ws) {
-        float a[RSUB], bv[NSUB];
-#pragma unroll
-        for (int rs = 0; rs < RSUB; ++rs) a[rs] = pa[rs][ws * 4];
-#pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns) bv[ns] = pb[ws * 4 * NBP + ns * 16];
-#pragma unroll
-        for (int rs = 0; rs < RSUB; ++rs)
-#pragma unroll
-          for (int ns = 0; ns < NSUB; ++ns)
-            acc[rs][ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rs], bv[ns], acc[rs][ns], 0, 0, 0);
+    // reduction over the tile's positions (wgrad_rows; the row-length switch stays outside the loops)
+    if (g.dbg != 1) {
+      const int bbase = kk * NBP + i16;
+      switch (g.TW >> 2) {
+        case 1: wgrad_rows<1, RSUB, NSUB>(acc, ldsA, ldsB, rowbase, bbase, g); break;
+        case 2: wgrad_rows<2, RSUB, NSUB>(acc, ldsA, ldsB, rowbase, bbase, g); break;
+        case 3: wgrad_rows<3, RSUB, NSUB>(acc, ldsA, ldsB, rowbase, bbase, g); break;
+        default: wgrad_rows<4, RSUB, NSUB>(acc, ldsA, ldsB, rowbase, bbase, g); break;
       }
-    };
-    for (int td = 0; td < g.TD; ++td)
-      for (int th = 0; th < g.TH; ++th) {
-        const int aoff = (td * g.PH + th) * g.PW;
-        const int boff = ((td * g.TH + th) * g.TW + kk) * NBP + i16;
-        switch (g.TW >> 2) {
-          case 1: row(IntC<1>{}, aoff, boff); break;
-          case 2: row(IntC<2>{}, aoff, boff); break;
-          case 3: row(IntC<3>{}, aoff, boff); break;
-          default: row(IntC<4>{}, aoff, boff); break;
-        }
-      }
+    }
   }
 #undef CRN_DY_8
 #undef CRN_DY_8U
