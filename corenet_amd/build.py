@@ -11,9 +11,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcorenet_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_inst_fwd_a.hip", "conv_inst_fwd_b.hip", "conv_inst_fwd_c.hip",
-           "conv_inst_wg_a.hip", "conv_inst_wg_b.hip", "conv_inst_wg_c.hip", "batch_renorm.hip", "ray_sample.hip", "misc_ops.hip",
-           "losses.hip", "fill_voxels.hip", "voxelize.hip"]
+SOURCES = ["conv_igemm.hip", "batch_renorm.hip", "ray_sample.hip", "misc_ops.hip", "losses.hip", "fill_voxels.hip",
+           "voxelize.hip"]
+# conv engine tile configurations (conv_kernels.h CRN_FWD_CONFIGS / CRN_WG_CONFIGS): one object each
+CONV_CONFIGS = [(8, 1), (4, 2), (4, 1), (2, 4), (2, 2), (2, 1), (1, 4), (1, 2), (1, 1)]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-ffp-contract=off", "-Wno-unused-result"]
 
@@ -37,6 +38,13 @@ def build(verbose=True, force=False):
     objs.append(obj)
     if force or _stale(obj, src):
       jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+  inst = os.path.join(CSRC, "conv_inst.hip")
+  for kind, macro in (("wgrad", "CRN_INST_WGRAD"), ("fwd", "CRN_INST_FWD")):   # the slow ones first
+    for m, n in CONV_CONFIGS:
+      obj = os.path.join(LIBDIR, "conv_inst_%s_%d_%d.o" % (kind, m, n))
+      objs.append(obj)
+      if force or _stale(obj, inst):
+        jobs.append([hipcc] + FLAGS + ["-D" + macro, "-DCRN_M=%d" % m, "-DCRN_N=%d" % n, "-c", inst, "-o", obj])
   def run(cmd):
     if verbose:
       print(" ".join(cmd), flush=True)

@@ -116,6 +116,13 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
   }
 }
 
+// 16-byte staging: unit W stride and every offset a multiple of 4 floats
+bool vec_view(const crnView& v) {
+  return v.chan_off == nullptr && v.sW == 1 && (v.W & 3) == 0 && (v.sH & 3) == 0 && (v.sD & 3) == 0 &&
+         (v.sC & 3) == 0 && (v.sB & 3) == 0 && (((uintptr_t)v.base) & 15) == 0;
+}
+int vec_lead(int pw) { return ((-pw) % 4 + 4) % 4; }   // (w0 - pw - lead) % 4 == 0 for 4-aligned tile origins
+
 bool plain_view(const crnView& v) {
   return v.chan_off == nullptr && v.sW == 1 && v.sH == v.W && (v.D == 1 || v.sD == v.H * v.W) &&
          v.sC == (int64_t)v.D * v.H * v.W && (((uintptr_t)v.base) & 15) == 0 && (v.sB & 3) == 0;
@@ -159,7 +166,10 @@ struct FwdCfg {
 };
 
 // Sub-tile = 1 x mh x mw output positions (16 MFMA rows); tile = tsd x tsh x tsw sub-tiles.
-bool fwd_cfg(int MSUB, int NSUB, int B, int Cin, int Npad, int D, int H, int W, int kd, int kh, int kw,
+// lead >= 0: 16-byte staging with `lead` extra patch columns on the left; lead < 0: scalar staging
+int patch_width(int TW, int kw, int lead) { return lead < 0 ? TW + kw - 1 : (lead + TW + kw - 1 + 3) & ~3; }
+
+bool fwd_cfg(int MSUB, int NSUB, int B, int Cin, int Npad, int D, int H, int W, int kd, int kh, int kw, int lead,
              FwdCfg* out) {
   FwdCfg c;
   c.MSUB = MSUB; c.NSUB = NSUB;
@@ -174,17 +184,19 @@ bool fwd_cfg(int MSUB, int NSUB, int B, int Cin, int Npad, int D, int H, int W, 
       const int cw = want / (a * bq);
       const int TD = a, TH = bq * c.mh, TW = cw * c.mw;
       const double tiles = (double)crn_cdiv(D, TD) * crn_cdiv(H, TH) * crn_cdiv(W, TW);
-      const double patch = (double)(TD + kd - 1) * (TH + kh - 1) * (TW + kw - 1);
+      const double patch = (double)(TD + kd - 1) * (TH + kh - 1) * patch_width(TW, kw, lead);
       const double cost = tiles * (patch + 0.25 * TD * TH * TW);   // loads + wasted MFMA rows
       if (cost < best) { best = cost; c.tsd = a; c.tsh = bq; c.tsw = cw; }
     }
   const int TD = c.tsd, TH = c.tsh * c.mh, TW = c.tsw * c.mw;
-  const int PDp = TD + kd - 1, plane = (TH + kh - 1) * (TW + kw - 1);
+  if (lead >= 0 && (TW & 3)) return false;
+  const int PDp = TD + kd - 1, plane = (TH + kh - 1) * patch_width(TW, kw, lead);
   const int PS = PDp * plane;
   const int PSP = pad16mod32(PS), WSP = pad16mod32(T * NSUB * 16);
   auto fits = [&](int cc) {
-    return (size_t)cc * (PSP + WSP) * 4 + 2 * kChTab * 4 <= kLdsBudget &&
-           stage_passes(cc * PDp, plane) <= PREG && (int64_t)cc * T * NSUB * 16 <= 256 * WREG * 4;
+    const bool staged = lead >= 0 ? (int64_t)cc * PS / 4 <= 256 * NV : stage_passes(cc * PDp, plane) <= PREG;
+    return (size_t)cc * (PSP + WSP) * 4 + 2 * kChTab * 4 <= kLdsBudget && staged &&
+           (int64_t)cc * T * NSUB * 16 <= 256 * WREG * 4;
   };
   if (!fits(4)) return false;
   int CC = 4;
@@ -224,13 +236,15 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   // the grid (with split-K as a fallback) fills 256 CUs.
   static const int kM[4] = {8, 4, 2, 1};
   static const int kN[3] = {4, 2, 1};
+  static const bool no_vec = getenv("CRN_NO_VEC") != nullptr;
+  const int lead = (vec_view(*x) && !no_vec) ? vec_lead(pw) : -1;
   FwdCfg best{}; bool have = false; double best_score = -1.0;
   for (int mi = 0; mi < 4; ++mi)
     for (int ni = 0; ni < 3; ++ni) {
       if (kN[ni] > 1 && kN[ni] * 16 > Npad) continue;
       if (kM[mi] * kN[ni] > 8) continue;              // instantiated tiles (conv_kernels.h)
       FwdCfg c;
-      if (!fwd_cfg(kM[mi], kN[ni], y->B, x->C, Npad, y->D, y->H, y->W, kd, kh, kw, &c)) continue;
+      if (!fwd_cfg(kM[mi], kN[ni], y->B, x->C, Npad, y->D, y->H, y->W, kd, kh, kw, lead, &c)) continue;
       const int area = kM[mi] * kN[ni];
       const double reuse = area >= 16 ? 0.85 : area >= 8 ? 0.82 : area >= 4 ? 0.66 : area >= 2 ? 0.5 : 0.4;
       const double npos_tiles = (double)c.blocks / crn_cdiv(Npad, kN[ni] * 16) * (64.0 * kM[mi]);
@@ -244,8 +258,16 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
     }
   if (const char* f = getenv("CRN_FWD_FORCE")) {     // tuning aid: "MSUB,NSUB"
     int fM, fN; FwdCfg c;
-    if (sscanf(f, "%d,%d", &fM, &fN) == 2 && fwd_cfg(fM, fN, y->B, x->C, Npad, y->D, y->H, y->W, kd, kh, kw, &c)) {
+    if (sscanf(f, "%d,%d", &fM, &fN) == 2 && fwd_cfg(fM, fN, y->B, x->C, Npad, y->D, y->H, y->W, kd, kh, kw, lead, &c)) {
       best = c; have = true;
+    }
+  }
+  int xvec = lead >= 0 ? 1 : 0;
+  if (!have && xvec) {       // no 16-byte configuration fits (tiny W): scalar staging
+    xvec = 0;
+    for (int mi = 0; mi < 4 && !have; ++mi) {
+      FwdCfg c;
+      if (fwd_cfg(kM[mi], 1, y->B, x->C, Npad, y->D, y->H, y->W, kd, kh, kw, -1, &c)) { best = c; have = true; }
     }
   }
   if (!have) return CRN_EINVAL;
@@ -253,10 +275,11 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   g.x = *x; g.y = *y;
   if (tr) g.tr = *tr; else g.tr = crnInTransform{nullptr, nullptr, 0, 0};
   g.w = w; g.bias = bias; g.Npad = Npad; g.bias_sB = bias_sB;
-  g.kd = kd; g.kh = kh; g.kw = kw; g.pd = pd; g.ph = ph; g.pw = pw; g.T = kd * kh * kw;
+  g.lead = xvec ? lead : 0;
+  g.kd = kd; g.kh = kh; g.kw = kw; g.pd = pd; g.ph = ph; g.pw = pw + g.lead; g.T = kd * kh * kw;
   g.mw = best.mw; g.mh = best.mh; g.nsh = best.tsh; g.nsw = best.tsw;
   g.TD = best.tsd; g.TH = best.tsh * best.mh; g.TW = best.tsw * best.mw;
-  g.PD = g.TD + kd - 1; g.PH = g.TH + kh - 1; g.PW = g.TW + kw - 1;
+  g.PD = g.TD + kd - 1; g.PH = g.TH + kh - 1; g.PW = patch_width(g.TW, kw, xvec ? lead : -1);
   g.PS = g.PD * g.PH * g.PW; g.PSP = pad16mod32(g.PS);
   g.tilesD = crn_cdiv(y->D, g.TD); g.tilesH = crn_cdiv(y->H, g.TH); g.tilesW = crn_cdiv(y->W, g.TW);
   const int NSUB = best.NSUB, CC = best.CC;
@@ -269,8 +292,12 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   g.chunks_per_split = crn_cdiv(g.nchunks, splits);
   splits = crn_cdiv(g.nchunks, g.chunks_per_split);
   g.mode = splits > 1 ? 2 : (accumulate ? 1 : 0);
-  g.lg2 = ilog2_ceil(g.PH * g.PW); g.npass = stage_passes(CC * g.PD, g.PH * g.PW);
+  g.lg2 = ilog2_ceil(g.PH * g.PW); g.npass = xvec ? 0 : stage_passes(CC * g.PD, g.PH * g.PW);
   g.magic_PW = magic20(g.PW); g.magic_PD = magic20(g.PD); g.magic_T = magic20(g.T);
+  if (xvec) {
+    g.plu = g.PH * g.PW / 4; g.pw4 = g.PW / 4; g.nunits = CC * g.PD * g.plu;
+    g.magic_PLU = magic20(g.plu); g.magic_PW4 = magic20(g.pw4);
+  }
   if (g.mode == 2 && !accumulate) {
     const int64_t tot = (int64_t)y->B * y->C * y->D * y->H * y->W;
     hipLaunchKernelGGL(zero_view_kernel, dim3((unsigned)std::min<int64_t>(crn_cdiv(tot, 256), 4096)),
@@ -289,13 +316,48 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   static const bool dbg = getenv("CRN_DEBUG") != nullptr;
   if (dbg)
     fprintf(stderr, "[crn_conv_fwd] x(C%d %dx%dx%d) y(C%d %dx%dx%d) k%dx%dx%d: MSUB %d NSUB %d CC %d tile %dx%dx%d "
-            "grid %ux%ux%u lds %zu npass %d lg2 %d\n", x->C, x->D, x->H, x->W, y->C, y->D, y->H, y->W, kd, kh, kw,
-            best.MSUB, NSUB, CC, g.TD, g.TH, g.TW, grid.x, grid.y, grid.z, lds_bytes, g.npass, g.lg2);
-#define CRN_FWD_CASE(M, N) if (best.MSUB == M && NSUB == N) return crn_launch_fwd_##M##_##N(g, grid, lds_bytes, st);
+            "grid %ux%ux%u lds %zu npass %d lg2 %d xvec %d units %d\n", x->C, x->D, x->H, x->W, y->C, y->D, y->H, y->W, kd, kh, kw,
+            best.MSUB, NSUB, CC, g.TD, g.TH, g.TW, grid.x, grid.y, grid.z, lds_bytes, g.npass, g.lg2, xvec, g.nunits);
+#define CRN_FWD_CASE(M, N) if (best.MSUB == M && NSUB == N) return crn_launch_fwd_##M##_##N(g, xvec, grid, lds_bytes, st);
   CRN_FWD_CONFIGS(CRN_FWD_CASE)
 #undef CRN_FWD_CASE
   return CRN_EINVAL;
 }
+
+namespace {
+struct WgCand { int TD, TH, TW, RSUB, NSUB, CC, PW, PSP, POSP; double cost; size_t lds; };
+
+// One weight-grad configuration: position tile TDxTHxTW, RSUB x NSUB MFMA tiles per wave.
+// xlead >= 0: x staged in 16-byte units; dvec: dy staged in 16-byte units.
+bool wg_cand(int TD, int TH, int TW, int RSUB, int NSUB, int Cin, int Npad, int kd, int kh, int kw, int xlead,
+             bool dvec, size_t lds_budget, WgCand* out) {
+  const int T = kd * kh * kw, NB = NSUB * 16, npos = TD * TH * TW;
+  if (npos > 512 || RSUB * NSUB > 8 || (NSUB > 1 && NB > Npad)) return false;
+  if ((xlead >= 0 || dvec) && (TW & 3)) return false;
+  if (dvec ? (int64_t)NB * npos / 4 > 256 * NV : stage_passes(NB, npos) > DREG) return false;
+  const int PDp = TD + kd - 1, PH = TH + kh - 1, PW = patch_width(TW, kw, xlead), plane = PH * PW;
+  int CC = std::min(std::min(std::max(1, (64 * RSUB) / T), Cin), 64);
+  auto staged = [&](int cc) {
+    return xlead >= 0 ? (int64_t)cc * PDp * plane / 4 <= 256 * NV : stage_passes(cc * PDp, plane) <= PREG;
+  };
+  while (CC > 1 && !staged(CC)) --CC;
+  if (!staged(CC)) return false;
+  const int PSP = xlead >= 0 ? pad16mod32(PDp * plane) : PDp * plane + 1;
+  const int POSP = npos + 4;
+  const size_t lds = ((size_t)CC * PSP + (size_t)NB * POSP + 2 * kChTab) * 4;
+  if (lds > lds_budget) return false;
+  const int rows = CC * T;
+  if (rows > 64 * RSUB) return false;
+  // cycles per wave and tile: MFMA issue plus staging instructions (they do not overlap: every
+  // VALU/SALU instruction costs MFMA issue time), per useful multiply-add
+  const double mfma = (double)RSUB * NSUB * (npos / 4.0) * 32.0;
+  const double xslots = xlead >= 0 ? (double)CC * PDp * plane / 4 / 256 * 450.0 : (double)CC * PDp * plane / 256 * 350.0;
+  const double dslots = dvec ? (double)NB * npos / 4 / 256 * 300.0 : (double)NB * npos / 256 * 300.0;
+  const double useful = (double)rows * std::min(NB, Npad) * npos;
+  *out = WgCand{TD, TH, TW, RSUB, NSUB, CC, PW, PSP, POSP, (mfma + xslots + dslots + 800.0) / useful, lds};
+  return true;
+}
+}  // namespace
 
 extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const crnView* dy,
                               float* dw, int Npad, int kd, int kh, int kw, int pd, int ph, int pw,
@@ -305,109 +367,91 @@ extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const 
   const int T = kd * kh * kw;
   if (T > 512) return CRN_EINVAL;
   const int Dy = dy->D, Hy = dy->H, Wy = dy->W;
-  // search (position tile, NSUB, RSUB): minimise estimated cycles per useful MAC
   const int TWc = Wy >= 16 ? 16 : ((Wy + 3) & ~3);
-  struct Cand { int TD, TH, TW, RSUB, NSUB, CC; double cost; size_t lds; } best{};
-  bool have = false;
-  static const int kTD[3] = {4, 2, 1};
-  static const int kTH[5] = {16, 8, 4, 2, 1};
-  int lastTD = -1;
-  for (int tdi = 0; tdi < 3; ++tdi) {
-    const int TD = std::min(kTD[tdi], Dy);
-    if (TD == lastTD) continue;
-    lastTD = TD;
-    int lastTH = -1;
-    for (int thi = 0; thi < 5; ++thi) {
-      const int TH = std::min(kTH[thi], Hy), TW = TWc;
-      if (TH == lastTH) continue;
-      lastTH = TH;
-      const int npos = TD * TH * TW;
-      if (npos > 512) continue;
-      const int PDp = TD + kd - 1, plane = (TH + kh - 1) * (TW + kw - 1);
-      const int PS = PDp * plane, PSP = PS + 1;
-      for (int NSUB = 4; NSUB >= 1; NSUB >>= 1) {
-        if (NSUB > 1 && NSUB * 16 > Npad) continue;
-        const int NB = NSUB * 16;
-        if (stage_passes(NB, npos) > DREG) continue;
-        for (int RSUB = 8; RSUB >= 1; RSUB >>= 1) {
-          if (RSUB * NSUB > 8) continue;                // instantiated tiles (conv_kernels.h)
-          int CC = std::min(std::min(std::max(1, (64 * RSUB) / T), (int)x->C), 64);
-          while (CC > 1 && stage_passes(CC * PDp, plane) > PREG) --CC;
-          const size_t lds = (size_t)CC * PSP * 4 + (size_t)npos * (NB + 1) * 4 + 2 * kChTab * 4;
-          if (lds > kLdsBudget || stage_passes(CC * PDp, plane) > PREG) continue;
-          const int rows = CC * T;
-          if (rows > 64 * RSUB) continue;
-          if (RSUB > 1 && rows <= 32 * RSUB) continue;  // a smaller RSUB covers it
-          const double mfma = (double)RSUB * NSUB * (npos / 4.0) * 32.0;          // cycles per wave
-          const double load = ((double)CC * PS + (double)NB * npos) * 4.0 / 6.0;  // ~6 B/clk/CU effective
-          const double useful = (double)rows * std::min(NB, Npad) * npos;
-          const double cost = (std::max(mfma, load) + 0.25 * std::min(mfma, load) + 1500.0) / useful;
-          if (!have || cost < best.cost) { best = Cand{TD, TH, TW, RSUB, NSUB, CC, cost, lds}; have = true; }
-        }
-      }
-    }
-  }
+  static const bool no_vec = getenv("CRN_NO_VEC") != nullptr;
+  int xlead = (vec_view(*x) && !no_vec) ? vec_lead(pw) : -1;
+  bool dvec = vec_view(*dy) && !no_vec;
+  if (!dvec) { /* x-only 16-byte staging is instantiated; dy-only is not */ }
+  WgCand best{}; bool have = false;
+  auto consider = [&](int TD, int TH, int RSUB, int NSUB, size_t budget) {
+    WgCand c;
+    if (!wg_cand(std::min(TD, Dy), std::min(TH, Hy), TWc, RSUB, NSUB, x->C, Npad, kd, kh, kw, xlead, dvec, budget, &c))
+      return false;
+    if (RSUB > 1 && c.CC * T <= 32 * RSUB) return false;   // a smaller RSUB covers it
+    if (!have || c.cost < best.cost) { best = c; have = true; }
+    return true;
+  };
+  auto search = [&]() {
+    static const int kTD[4] = {4, 3, 2, 1};
+    static const int kTH[6] = {16, 8, 6, 4, 2, 1};
+    for (int tdi = 0; tdi < 4; ++tdi)
+      for (int thi = 0; thi < 6; ++thi)
+        for (int NSUB = 4; NSUB >= 1; NSUB >>= 1)
+          for (int RSUB = 8; RSUB >= 1; RSUB >>= 1) consider(kTD[tdi], kTH[thi], RSUB, NSUB, kLdsBudget);
+  };
+  search();
+  if (!have && (xlead >= 0 || dvec)) { xlead = -1; dvec = false; search(); }   // tiny maps: scalar staging
   if (const char* f = getenv("CRN_WG_FORCE")) {      // tuning aid: "TD,TH,RSUB,NSUB"
     int fTD, fTH, fR, fN;
     if (sscanf(f, "%d,%d,%d,%d", &fTD, &fTH, &fR, &fN) == 4) {
-      fTD = std::min(fTD, Dy); fTH = std::min(fTH, Hy);
-      const int PDp = fTD + kd - 1, plane = (fTH + kh - 1) * (TWc + kw - 1);
-      int CC = std::min(std::min(std::max(1, (64 * fR) / T), (int)x->C), 64);
-      while (CC > 1 && stage_passes(CC * PDp, plane) > PREG) --CC;
-      const size_t lds = (size_t)CC * (PDp * plane + 1) * 4 + (size_t)fTD * fTH * TWc * (fN * 16 + 1) * 4 + 2 * kChTab * 4;
-      if (stage_passes(fN * 16, fTD * fTH * TWc) <= DREG && CC * T <= 64 * fR && lds <= 150 * 1024) {
-        best = Cand{fTD, fTH, TWc, fR, fN, CC, 0.0, lds}; have = true;
+      WgCand c;
+      if (wg_cand(std::min(fTD, Dy), std::min(fTH, Hy), TWc, fR, fN, x->C, Npad, kd, kh, kw, xlead, dvec, 150 * 1024, &c)) {
+        best = c; have = true;
       }
     }
   }
-  else if (Dy >= 4 && Wy >= 16) {
-    // 3-D decoder layers: measured sweep on MI355X (tools/sweep_wgrad.sh): k5 convs run best with the
-    // 4x8x16 tile and 512 (channel,tap) rows; the window-4 transposed-conv geometry with a flat 4x2x16
-    // tile (small halo, plane <= 128 slots).
-    const int fTD = 4, fTH = T >= 100 ? std::min(8, Hy) : std::min(2, Hy);
-    const int fN = (T < 100 && Npad >= 32) ? 2 : 1, fR = (T < 100 && Npad >= 32) ? 4 : 8;
-    const int PDp = fTD + kd - 1, plane = (fTH + kh - 1) * (TWc + kw - 1);
-    int CC = std::min(std::min(std::max(1, (64 * fR) / T), (int)x->C), 64);
-    while (CC > 1 && stage_passes(CC * PDp, plane) > PREG) --CC;
-    const size_t lds = (size_t)CC * (PDp * plane + 1) * 4 + (size_t)fTD * fTH * TWc * (fN * 16 + 1) * 4 + 2 * kChTab * 4;
-    if (stage_passes(fN * 16, fTD * fTH * TWc) <= DREG && CC * T <= 64 * fR && lds <= kLdsBudget) {
-      best = Cand{fTD, fTH, TWc, fR, fN, CC, 0.0, lds}; have = true;
+  if (!have) return CRN_EINVAL;
+  if (xlead < 0) dvec = false;                       // instantiated variants: scalar, x, x+dy
+  if (xlead < 0 || !dvec) {
+    // the candidate was costed with dvec; re-derive it with the variant that will run
+    WgCand c;
+    if (!wg_cand(best.TD, best.TH, best.TW, best.RSUB, best.NSUB, x->C, Npad, kd, kh, kw, xlead, dvec, 150 * 1024, &c)) {
+      have = false; search();
+      if (!have) return CRN_EINVAL;
+    } else {
+      best = c;
     }
   }
-  if (!have) return CRN_EINVAL;
   WgradGeom g{};
   g.x = *x; g.dy = *dy;
   if (tr) g.tr = *tr; else g.tr = crnInTransform{nullptr, nullptr, 0, 0};
   g.dw = dw; g.Npad = Npad;
-  g.kd = kd; g.kh = kh; g.kw = kw; g.pd = pd; g.ph = ph; g.pw = pw; g.T = T;
+  g.lead = xlead >= 0 ? xlead : 0;
+  g.kd = kd; g.kh = kh; g.kw = kw; g.pd = pd; g.ph = ph; g.pw = pw + g.lead; g.T = T;
   g.TD = best.TD; g.TH = best.TH; g.TW = best.TW;
-  g.PD = g.TD + kd - 1; g.PH = g.TH + kh - 1; g.PW = g.TW + kw - 1;
-  g.PSP = g.PD * g.PH * g.PW + 1;
+  g.PD = g.TD + kd - 1; g.PH = g.TH + kh - 1; g.PW = best.PW;
+  g.PSP = best.PSP; g.POSP = best.POSP;
   const int NSUB = best.NSUB, RSUB = best.RSUB, NB = NSUB * 16, CC = best.CC;
+  const int npos = g.TD * g.TH * g.TW;
   g.CC = CC;
   g.tilesD = crn_cdiv(Dy, g.TD); g.tilesH = crn_cdiv(Hy, g.TH); g.tilesW = crn_cdiv(Wy, g.TW);
   g.ntiles = g.tilesD * g.tilesH * g.tilesW * dy->B;
   const int cblocks = crn_cdiv(x->C, CC), nblocks = crn_cdiv(Npad, NB);
-  static const int kWgBlocks = getenv("CRN_WG_BLOCKS") ? atoi(getenv("CRN_WG_BLOCKS")) : 768;
+  static const int kWgBlocks = getenv("CRN_WG_BLOCKS") ? atoi(getenv("CRN_WG_BLOCKS")) : 512;
   int splits = std::max(1, std::min(g.ntiles, crn_cdiv(kWgBlocks, cblocks * nblocks)));
   g.tiles_per_split = crn_cdiv(g.ntiles, splits);
   splits = crn_cdiv(g.ntiles, g.tiles_per_split);
-  g.lg2 = ilog2_ceil(g.PH * g.PW); g.npass = stage_passes(CC * g.PD, g.PH * g.PW);
-  g.dlg2 = ilog2_ceil(g.TD * g.TH * g.TW); g.dnpass = stage_passes(NB, g.TD * g.TH * g.TW);
+  g.lg2 = ilog2_ceil(g.PH * g.PW); g.npass = xlead >= 0 ? 0 : stage_passes(CC * g.PD, g.PH * g.PW);
+  g.dlg2 = ilog2_ceil(npos); g.dnpass = dvec ? 0 : stage_passes(NB, npos);
   g.magic_PW = magic20(g.PW); g.magic_PD = magic20(g.PD); g.magic_T = magic20(T);
   g.magic_TW = magic20(g.TW); g.magic_TH = magic20(g.TH);
+  if (xlead >= 0) {
+    g.plu = g.PH * g.PW / 4; g.pw4 = g.PW / 4; g.nunits = CC * g.PD * g.plu;
+    g.magic_PLU = magic20(g.plu); g.magic_PW4 = magic20(g.pw4);
+  }
+  if (dvec) { g.np4 = npos / 4; g.dnunits = NB * g.np4; g.magic_NP4 = magic20(g.np4); }
   g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
-  g.skew = getenv("CRN_SKEW") ? atoi(getenv("CRN_SKEW")) : 0;
   if (zero_first) CRN_HIP(hipMemsetAsync(dw, 0, (size_t)x->C * T * Npad * 4, st));
   dim3 grid((unsigned)cblocks, (unsigned)nblocks, (unsigned)splits);
   const size_t lds_bytes = best.lds;
   static const bool dbg = getenv("CRN_DEBUG") != nullptr;
   if (dbg)
     fprintf(stderr, "[crn_conv_wgrad] x(C%d %dx%dx%d) dy(C%d %dx%dx%d) k%dx%dx%d: RSUB %d NSUB %d CC %d tile %dx%dx%d "
-            "grid %ux%ux%u lds %zu npass %d dnpass %d tiles/split %d\n", x->C, x->D, x->H, x->W, dy->C, dy->D, dy->H,
-            dy->W, kd, kh, kw, RSUB, NSUB, CC, g.TD, g.TH, g.TW, grid.x, grid.y, grid.z, lds_bytes, g.npass, g.dnpass,
-            g.tiles_per_split);
-#define CRN_WG_CASE(R, N) if (RSUB == R && NSUB == N) return crn_launch_wgrad_##R##_##N(g, grid, lds_bytes, st);
+            "grid %ux%ux%u lds %zu npass %d dnpass %d tiles/split %d xvec %d dvec %d units %d/%d\n", x->C, x->D, x->H,
+            x->W, dy->C, dy->D, dy->H, dy->W, kd, kh, kw, RSUB, NSUB, CC, g.TD, g.TH, g.TW, grid.x, grid.y, grid.z,
+            lds_bytes, g.npass, g.dnpass, g.tiles_per_split, xlead >= 0, (int)dvec, g.nunits, g.dnunits);
+#define CRN_WG_CASE(R, N) \
+  if (RSUB == R && NSUB == N) return crn_launch_wgrad_##R##_##N(g, xlead >= 0, dvec, grid, lds_bytes, st);
   CRN_WG_CONFIGS(CRN_WG_CASE)
 #undef CRN_WG_CASE
   return CRN_EINVAL;

@@ -30,6 +30,9 @@ struct ConvGeom {
   int lg2, npass;          // patch staging: plane padded to 2^lg2 slots, passes of 256 slots
   unsigned magic_PW, magic_PD, magic_T;
   int vec_store;           // epilogue may use 16-B stores (unit W stride, 4-aligned rows)
+  int lead;                // extra patch columns on the left (16-byte staging), already included in pw/PW
+  int nunits, plu, pw4;    // 16-byte staging geometry (PatchDesc)
+  unsigned magic_PLU, magic_PW4;
   int dbg;                 // tuning aid (CRN_DBG_MODE): 1 = no MFMA loop, 2 = stage only the first chunk
 };
 
@@ -49,7 +52,16 @@ struct PatchDesc {
   crnInTransform tr;
   int pd, ph, pw, PD, PH, PW, plane, lg2, PSP;
   unsigned magic_PW, magic_PD;       // ceil(2^20 / d)
+  // 16-byte staging (XV kernels): the patch is nunits float4 units, plu per plane, pw4 per row
+  int nunits, plu, pw4;
+  unsigned magic_PLU, magic_PW4;
 };
+
+// 16-byte staging.  Eligible views (unit W stride, everything 4-aligned) are staged as float4
+// units: 4x fewer staging instructions, and on gfx950 every VALU/SALU instruction issued next to an
+// MFMA stream costs MFMA issue time (tools/mfma_peak.hip).  The patch origin along W is moved
+// left by `lead` (0..3) columns so that every row starts 16-byte aligned in global memory.
+constexpr int NV = 8;       // float4 staging slots per thread (the same 32 registers as PREG)
 
 typedef int crn_rsrc __attribute__((ext_vector_type(4)));   // buffer resource (V#) in 4 SGPRs
 
@@ -67,11 +79,13 @@ __device__ __forceinline__ crn_rsrc make_rsrc(const float* base) {   // raw buff
 // The destination is the staging register itself (no temporary): a compiler-inserted copy between
 // the load and crn_wait_loads() would read the register before the data has landed.  For the same
 // reason every staging slot is loaded unconditionally (inactive slots use the out-of-range offset).
+// s_nop 4: the hazard recogniser does not look inside inline asm, and when the descriptor SGPRs were
+// just rebuilt by VALU (v_readlane after an SGPR spill) a VMEM read needs 5 wait states (gfx9 ISA 4.5).
 __device__ __forceinline__ void crn_bload(float& dst, const crn_rsrc& rs, unsigned byte_off) {
-  asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(dst) : "v"(byte_off), "s"(rs));
+  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(dst) : "v"(byte_off), "s"(rs));
 }
 __device__ __forceinline__ void crn_bload4(f32x4& dst, const crn_rsrc& rs, unsigned byte_off) {
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(byte_off), "s"(rs));
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(byte_off), "s"(rs));
 }
 template <int N>
 __device__ __forceinline__ void crn_wait_loads(float (&v)[N]) {
@@ -246,6 +260,69 @@ __device__ __forceinline__ void patch_commit(const PatchDesc& g, const unsigned*
   }
 }
 
+// unit u -> (channel cl, plane row pd, in-plane unit r); tile invariant, recomputed per use so that
+// it does not sit in registers across the MFMA loop
+struct VUnit { int cl, pd, r, ph, p4; bool valid; };
+template <int J>
+__device__ __forceinline__ VUnit vec_unit(const PatchDesc& g) {
+  int u = (int)threadIdx.x + J * 256;
+  asm volatile("" : "+v"(u));
+  VUnit o;
+  o.valid = u < g.nunits;
+  const int q = mdiv(u, g.magic_PLU);
+  o.r = u - q * g.plu;
+  o.ph = mdiv(o.r, g.magic_PW4);
+  o.p4 = o.r - o.ph * g.pw4;
+  o.cl = mdiv(q, g.magic_PD);
+  o.pd = q - o.cl * g.PD;
+  return o;
+}
+template <int J = 0>
+__device__ __forceinline__ void patch_issue_v(const PatchDesc& g, const unsigned* choff, const crn_rsrc& rs, int c0,
+                                              int d0, int h0, int w0, f32x4 (&val)[NV], unsigned& inmask) {
+  if constexpr (J < NV) {
+    unsigned goff = 0x80000000u;
+    const VUnit t = vec_unit<J>(g);
+    if (t.valid) {
+      const int gd = d0 + t.pd - g.pd, gh = h0 + t.ph - g.ph, gw = w0 + 4 * t.p4 - g.pw;
+      const bool in = (c0 + t.cl < g.x.C) && (unsigned)gd < (unsigned)g.x.D && (unsigned)gh < (unsigned)g.x.H &&
+                      (unsigned)gw < (unsigned)g.x.W;
+      if (in) {
+        goff = (choff[t.cl] + (unsigned)gd * (unsigned)g.x.sD + (unsigned)gh * (unsigned)g.x.sH + (unsigned)gw) * 4u;
+        inmask |= 1u << J;
+      }
+    }
+    crn_bload4(val[J], rs, goff);
+    patch_issue_v<J + 1>(g, choff, rs, c0, d0, h0, w0, val, inmask);
+  }
+}
+template <int J = 0>
+__device__ __forceinline__ void patch_commit_v(const PatchDesc& g, const unsigned* choff, float* ldsA,
+                                               const f32x4 (&val)[NV], unsigned inmask) {
+  if constexpr (J < NV) {
+    if (J * 256 < g.nunits) {                            // wave-uniform
+      const VUnit t = vec_unit<J>(g);
+      if (t.valid) {
+        f32x4 v = val[J];
+        if (g.tr.scale && ((inmask >> J) & 1u)) {        // zero padding stays zero
+          const float* tab = reinterpret_cast<const float*>(choff);
+          const float sc = tab[64 + t.cl], sh = tab[128 + t.cl];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = v[e];
+            if (g.tr.pre_relu) x = fmaxf(x, 0.f);
+            x = x * sc + sh;
+            if (g.tr.post_relu) x = fmaxf(x, 0.f);
+            v[e] = x;
+          }
+        }
+        *reinterpret_cast<f32x4*>(ldsA + t.cl * g.PSP + t.pd * g.plane + 4 * t.r) = v;
+      }
+    }
+    patch_commit_v<J + 1>(g, choff, ldsA, val, inmask);
+  }
+}
+
 template <int V>
 struct IntC { static constexpr int value = V; };
 
@@ -311,7 +388,7 @@ __device__ __forceinline__ void mfma_rows(f32x4 (&acc)[MSUB][NSUB], const float*
 }
 
 // ------------------------------- forward -----------------------------------
-template <int MSUB, int NSUB>
+template <int MSUB, int NSUB, bool XV>
 __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned* choff = reinterpret_cast<unsigned*>(lds);      // 2 x kChTab per-chunk channel tables
@@ -336,10 +413,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
   pdsc.x = g.x; pdsc.tr = g.tr; pdsc.pd = g.pd; pdsc.ph = g.ph; pdsc.pw = g.pw;
   pdsc.PD = g.PD; pdsc.PH = g.PH; pdsc.PW = g.PW; pdsc.plane = g.PH * g.PW; pdsc.lg2 = g.lg2;
   pdsc.PSP = g.PSP; pdsc.magic_PW = g.magic_PW; pdsc.magic_PD = g.magic_PD;
+  pdsc.nunits = g.nunits; pdsc.plu = g.plu; pdsc.pw4 = g.pw4; pdsc.magic_PLU = g.magic_PLU; pdsc.magic_PW4 = g.magic_PW4;
   const int nplanes = g.CC * g.PD, npass = g.npass;
   const crn_rsrc xrs = make_rsrc(g.x.base + (int64_t)b * g.x.sB);
   PatchHW phw;
-  patch_prepare(pdsc, h0, w0, phw);
+  if constexpr (!XV) patch_prepare(pdsc, h0, w0, phw);
 
   // lane's LDS offset of output position (sub-tile s, row i16) at tap (0,0,0)
   int posbase[MSUB];
@@ -350,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
     const int sw = s % g.nsw; s /= g.nsw;
     const int sh = s % g.nsh; s /= g.nsh;
     const int sd = s;
-    posbase[ms] = (sd * g.PH + sh * g.mh + ri) * g.PW + sw * g.mw + rj + kk * g.PSP;
+    posbase[ms] = (sd * g.PH + sh * g.mh + ri) * g.PW + sw * g.mw + rj + kk * g.PSP + g.lead;
   }
   const int bbase = kk * g.WSP + i16;
 
@@ -360,7 +438,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
 #pragma unroll
     for (int ns = 0; ns < NSUB; ++ns) acc[ms][ns] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float pval[PREG];
+  float pval[XV ? 1 : PREG];
+  f32x4 pv4[XV ? NV : 1];
+  unsigned inmask = 0;
   f32x4 wval[WREG];
   const int nf4 = g.CC * g.T * (NB / 4);
 
@@ -406,23 +486,26 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
   if (cbeg < cend) {
     stage_choff(g.x, g.tr, choff + (cbeg & 1) * kChTab, cbeg * g.CC, g.CC);
     __syncthreads();
-    patch_issue(pdsc, choff + (cbeg & 1) * kChTab, phw, xrs, nplanes, npass, cbeg * g.CC, d0, pval);
+    if constexpr (XV) patch_issue_v(pdsc, choff + (cbeg & 1) * kChTab, xrs, cbeg * g.CC, d0, h0, w0, pv4, inmask);
+    else patch_issue(pdsc, choff + (cbeg & 1) * kChTab, phw, xrs, nplanes, npass, cbeg * g.CC, d0, pval);
     weights_issue(cbeg * g.CC);
   }
   for (int chunk = cbeg; chunk < cend; ++chunk) {
     const int c0 = chunk * g.CC;
     const bool stage = !(g.dbg >= 2 && chunk > cbeg);
     if (stage) {
-    crn_wait_loads(pval);
+    if constexpr (XV) crn_wait_loads4(pv4); else crn_wait_loads(pval);
     crn_wait_loads4(wval);
     __syncthreads();                       // previous chunk's MFMA reads are done
-    patch_commit(pdsc, choff + (chunk & 1) * kChTab, phw, ldsA, nplanes, npass, c0, d0, pval);
+    if constexpr (XV) { patch_commit_v(pdsc, choff + (chunk & 1) * kChTab, ldsA, pv4, inmask); inmask = 0; }
+    else patch_commit(pdsc, choff + (chunk & 1) * kChTab, phw, ldsA, nplanes, npass, c0, d0, pval);
     weights_commit(c0);
     if (chunk + 1 < cend) stage_choff(g.x, g.tr, choff + ((chunk + 1) & 1) * kChTab, c0 + g.CC, g.CC);
     __syncthreads();
     }
     if (stage && g.dbg < 2 && chunk + 1 < cend) {                // next chunk's loads fly under this chunk's MFMAs
-      patch_issue(pdsc, choff + ((chunk + 1) & 1) * kChTab, phw, xrs, nplanes, npass, c0 + g.CC, d0, pval);
+      if constexpr (XV) patch_issue_v(pdsc, choff + ((chunk + 1) & 1) * kChTab, xrs, c0 + g.CC, d0, h0, w0, pv4, inmask);
+      else patch_issue(pdsc, choff + ((chunk + 1) & 1) * kChTab, phw, xrs, nplanes, npass, c0 + g.CC, d0, pval);
       weights_issue(c0 + g.CC);
     }
 
@@ -497,21 +580,25 @@ struct WgradGeom {
   int kd, kh, kw, pd, ph, pw, T;
   int TD, TH, TW;
   int PD, PH, PW, PSP;
+  int POSP;                // LDS stride of one dy channel ([n][pos] layout), npos + 4
   int lg2, npass;          // patch staging slots
   int dlg2, dnpass;        // dy staging slots (plane = TD*TH*TW positions of one channel)
   int CC;                  // channels per block (rows = CC*T <= 64*RSUB)
   int tilesD, tilesH, tilesW, ntiles;   // ntiles includes batch
   int tiles_per_split;
   unsigned magic_PW, magic_PD, magic_T, magic_TW, magic_TH;
+  int lead;                // 16-byte staging of x (see ConvGeom)
+  int nunits, plu, pw4;
+  unsigned magic_PLU, magic_PW4;
+  int dnunits, np4;        // 16-byte staging of dy: NB * npos/4 units, np4 = npos/4 per channel
+  unsigned magic_NP4;
   int dbg;                 // tuning aid (CRN_DBG_MODE): 1 = no MFMA loop, 2 = stage only the first tile
-  int skew;                // phase_skew() sleeps
 };
 
 // One tile's MFMAs: a (td,th) row of WS = TW/4 k-steps is straight-line code.
 template <int WS, int RSUB, int NSUB>
 __device__ __forceinline__ void wgrad_rows(f32x4 (&acc)[RSUB][NSUB], const float* ldsA, const float* ldsB,
                                            const int (&rowbase)[RSUB], int bbase, const WgradGeom& g) {
-  constexpr int NBP = NSUB * 16 + 1;
   const float* pa0[RSUB];
 #pragma unroll
   for (int rs = 0; rs < RSUB; ++rs) pa0[rs] = ldsA + rowbase[rs];
@@ -519,14 +606,14 @@ __device__ __forceinline__ void wgrad_rows(f32x4 (&acc)[RSUB][NSUB], const float
   for (int td = 0; td < g.TD; ++td)
     for (int th = 0; th < g.TH; ++th) {
       const int aoff = (td * g.PH + th) * g.PW;
-      const float* pb = pb0 + (td * g.TH + th) * g.TW * NBP;
+      const float* pb = pb0 + (td * g.TH + th) * g.TW;
       float a[WS][RSUB], bv[WS][NSUB];
 #pragma unroll
       for (int ws = 0; ws < WS; ++ws) {
 #pragma unroll
         for (int rs = 0; rs < RSUB; ++rs) a[ws][rs] = pa0[rs][aoff + ws * 4];
 #pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns) bv[ws][ns] = pb[ws * 4 * NBP + ns * 16];
+        for (int ns = 0; ns < NSUB; ++ns) bv[ws][ns] = pb[ns * 16 * g.POSP + ws * 4];
       }
 #pragma unroll
       for (int ws = 0; ws < WS; ++ws)
@@ -544,15 +631,57 @@ __device__ __forceinline__ void wgrad_rows(f32x4 (&acc)[RSUB][NSUB], const float
     }
 }
 
-template <int RSUB, int NSUB>
+// 16-byte staging of the dy tile: unit u -> (channel n, 4 consecutive positions along W)
+struct DUnit { int n, pos, td, th, tw; bool valid; };
+template <int J>
+__device__ __forceinline__ DUnit dy_unit(const WgradGeom& g) {
+  int u = (int)threadIdx.x + J * 256;
+  asm volatile("" : "+v"(u));
+  DUnit o;
+  o.valid = u < g.dnunits;
+  o.n = mdiv(u, g.magic_NP4);
+  o.pos = 4 * (u - o.n * g.np4);
+  const int r1 = mdiv(o.pos, g.magic_TW);
+  o.tw = o.pos - r1 * g.TW;
+  o.td = mdiv(r1, g.magic_TH);
+  o.th = r1 - o.td * g.TH;
+  return o;
+}
+template <int J = 0>
+__device__ __forceinline__ void dy_issue_v(const WgradGeom& g, const unsigned* dchoff, const crn_rsrc& rs, int n0,
+                                           int d0, int h0, int w0, f32x4 (&val)[NV]) {
+  if constexpr (J < NV) {
+    unsigned goff = 0x80000000u;
+    const DUnit t = dy_unit<J>(g);
+    if (t.valid) {
+      const int od = d0 + t.td, oh = h0 + t.th, ow = w0 + t.tw;
+      if (n0 + t.n < g.dy.C && od < g.dy.D && oh < g.dy.H && ow < g.dy.W)
+        goff = (dchoff[t.n] + (unsigned)od * (unsigned)g.dy.sD + (unsigned)oh * (unsigned)g.dy.sH + (unsigned)ow) * 4u;
+    }
+    crn_bload4(val[J], rs, goff);
+    dy_issue_v<J + 1>(g, dchoff, rs, n0, d0, h0, w0, val);
+  }
+}
+template <int J = 0>
+__device__ __forceinline__ void dy_commit_v(const WgradGeom& g, float* ldsB, const f32x4 (&val)[NV]) {
+  if constexpr (J < NV) {
+    if (J * 256 < g.dnunits) {
+      const DUnit t = dy_unit<J>(g);
+      if (t.valid) *reinterpret_cast<f32x4*>(ldsB + t.n * g.POSP + t.pos) = val[J];
+    }
+    dy_commit_v<J + 1>(g, ldsB, val);
+  }
+}
+
+template <int RSUB, int NSUB, bool XV, bool DV>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned* choff = reinterpret_cast<unsigned*>(lds);   // x channel table; dy channel offsets at [192,256)
   float* ldsA = lds + 2 * kChTab;           // CC * PSP   (input patch)
-  float* ldsB = ldsA + g.CC * g.PSP;        // TD*TH*TW * NBP (dy, [pos][n])
+  float* ldsB = ldsA + g.CC * g.PSP;        // NB * POSP  (dy, [n][pos])
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kk = lane >> 4;
-  constexpr int NB = NSUB * 16, NBP = NB + 1;
+  constexpr int NB = NSUB * 16;
   const int c0 = blockIdx.x * g.CC;
   const int n0 = blockIdx.y * NB;
   const int split = blockIdx.z;
@@ -562,6 +691,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
   pdsc.x = g.x; pdsc.tr = g.tr; pdsc.pd = g.pd; pdsc.ph = g.ph; pdsc.pw = g.pw;
   pdsc.PD = g.PD; pdsc.PH = g.PH; pdsc.PW = g.PW; pdsc.plane = g.PH * g.PW; pdsc.lg2 = g.lg2;
   pdsc.PSP = g.PSP; pdsc.magic_PW = g.magic_PW; pdsc.magic_PD = g.magic_PD;
+  pdsc.nunits = g.nunits; pdsc.plu = g.plu; pdsc.pw4 = g.pw4; pdsc.magic_PLU = g.magic_PLU; pdsc.magic_PW4 = g.magic_PW4;
   const int nplanes = g.CC * g.PD, npass = g.npass;
 
   // row (c_local, tap) -> LDS offset inside the patch
@@ -574,7 +704,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
     int t = row - cl * g.T;
     const int zw = t % g.kw; t /= g.kw;
     const int zh = t % g.kh; t /= g.kh;
-    rowbase[rs] = cl * g.PSP + (t * g.PH + zh) * g.PW + zw + kk;
+    rowbase[rs] = cl * g.PSP + (t * g.PH + zh) * g.PW + zw + kk + g.lead;
   }
 
   f32x4 acc[RSUB][NSUB];
@@ -587,8 +717,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
   const int tend = min(tbeg + g.tiles_per_split, g.ntiles);
   const int npos = g.TD * g.TH * g.TW;
 
-  float pval[PREG];
-  float dval[DREG];
+  float pval[XV ? 1 : PREG];
+  f32x4 pv4[XV ? NV : 1];
+  unsigned inmask = 0;
+  float dval[DV ? 8 : DREG];
+  f32x4 dv4[DV ? NV : 1];
 
   auto tile_origin = [&](int tl, int& b, int& d0, int& h0, int& w0) {
     int tile = tl;
@@ -597,9 +730,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
     const int tdi = tile % g.tilesD; tile /= g.tilesD;
     b = tile; d0 = tdi * g.TD; h0 = thi * g.TH; w0 = twi * g.TW;
   };
-  // dy tile: planes = channels nl, in-plane index r = position (td,th,tw); LDS layout [pos][n]
-  // (lanes run along w: coalesced global reads, odd LDS stride NBP: conflict-free writes).
-  // Per-thread position variants (npos <= 512 -> at most 2) are hoisted per tile.
+  // scalar dy staging: planes = channels nl, in-plane index r = position (td,th,tw); lanes run
+  // along w: coalesced global reads, consecutive LDS addresses.  Per-thread position variants
+  // (npos <= 512 -> at most 2) are hoisted per tile.
   HWVar dhw0, dhw1;
   auto dy_prepare = [&](int d0, int h0, int w0) {
     auto one = [&](int u, HWVar& out) {
@@ -640,12 +773,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
       int q = __builtin_amdgcn_readfirstlane(g.dlg2 == 9 ? J / 2 : J);
       asm volatile("" : "+s"(q));
       const HWVar h = (J % 2 == 1 && g.dlg2 == 9) ? dhw1 : dhw0;
-      if (q < NB && h.r >= 0) ldsB[h.r * NBP + q] = v;
+      if (q < NB && h.r >= 0) ldsB[q * g.POSP + h.r] = v;
     } else {
       int jq = J * (256 >> g.dlg2);
       asm volatile("" : "+s"(jq));
       const int q = jq + (tid >> g.dlg2);
-      if (q < NB && dhw0.r >= 0) ldsB[dhw0.r * NBP + q] = v;
+      if (q < NB && dhw0.r >= 0) ldsB[q * g.POSP + dhw0.r] = v;
     }
   };
 #define CRN_DY_8(OP, A, B0)                                                                        \
@@ -660,15 +793,43 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
   OP(A IntC<B0 + 2>{}, dval[B0 + 2]); OP(A IntC<B0 + 3>{}, dval[B0 + 3]);                          \
   OP(A IntC<B0 + 4>{}, dval[B0 + 4]); OP(A IntC<B0 + 5>{}, dval[B0 + 5]);                          \
   OP(A IntC<B0 + 6>{}, dval[B0 + 6]); OP(A IntC<B0 + 7>{}, dval[B0 + 7]);
-#define CRN_DY_ISSUE(rs) do { CRN_DY_8U(dy_issue, rs CRN_COMMA, 0) CRN_DY_8U(dy_issue, rs CRN_COMMA, 8) \
-                              CRN_DY_8U(dy_issue, rs CRN_COMMA, 16) CRN_DY_8U(dy_issue, rs CRN_COMMA, 24) } while (0)
-#define CRN_DY_COMMIT() do { CRN_DY_8(dy_commit, , 0) CRN_DY_8(dy_commit, , 8) CRN_DY_8(dy_commit, , 16) \
-                             CRN_DY_8(dy_commit, , 24) } while (0)
 #define CRN_COMMA ,
+  auto stage_issue = [&](int b, int d0, int h0, int w0) {
+    const crn_rsrc xrs = make_rsrc(g.x.base + (int64_t)b * g.x.sB);
+    const crn_rsrc drs = make_rsrc(g.dy.base + (int64_t)b * g.dy.sB);
+    if constexpr (XV) {
+      patch_issue_v(pdsc, choff, xrs, c0, d0, h0, w0, pv4, inmask);
+    } else {
+      PatchHW phw;
+      patch_prepare(pdsc, h0, w0, phw);
+      patch_issue(pdsc, choff, phw, xrs, nplanes, npass, c0, d0, pval);
+    }
+    if constexpr (DV) {
+      dy_issue_v(g, choff + kChTab, drs, n0, d0, h0, w0, dv4);
+    } else {
+      dy_prepare(d0, h0, w0);
+      CRN_DY_8U(dy_issue, drs CRN_COMMA, 0) CRN_DY_8U(dy_issue, drs CRN_COMMA, 8)
+      CRN_DY_8U(dy_issue, drs CRN_COMMA, 16) CRN_DY_8U(dy_issue, drs CRN_COMMA, 24)
+    }
+  };
+  auto stage_commit = [&](int d0, int h0, int w0) {
+    if constexpr (XV) {
+      patch_commit_v(pdsc, choff, ldsA, pv4, inmask);
+      inmask = 0;
+    } else {
+      PatchHW phw;
+      patch_prepare(pdsc, h0, w0, phw);
+      patch_commit(pdsc, choff, phw, ldsA, nplanes, npass, c0, d0, pval);
+    }
+    if constexpr (DV) {
+      dy_commit_v(g, ldsB, dv4);
+    } else {
+      dy_prepare(d0, h0, w0);
+      CRN_DY_8(dy_commit, , 0) CRN_DY_8(dy_commit, , 8) CRN_DY_8(dy_commit, , 16) CRN_DY_8(dy_commit, , 24)
+    }
+  };
 
   int cb = 0, cd0 = 0, ch0 = 0, cw0 = 0;     // origin of the tile currently held in registers
-  PatchHW phw;
-  phase_skew(g.skew);
   stage_choff(g.x, g.tr, choff, c0, g.CC);
   if (tid < NB) {
     const int n = min(n0 + tid, g.dy.C - 1);
@@ -677,34 +838,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
   __syncthreads();
   if (tbeg < tend) {
     tile_origin(tbeg, cb, cd0, ch0, cw0);
-    const crn_rsrc xrs = make_rsrc(g.x.base + (int64_t)cb * g.x.sB);
-    const crn_rsrc drs = make_rsrc(g.dy.base + (int64_t)cb * g.dy.sB);
-    patch_prepare(pdsc, ch0, cw0, phw);
-    dy_prepare(cd0, ch0, cw0);
-    patch_issue(pdsc, choff, phw, xrs, nplanes, npass, c0, cd0, pval);
-    CRN_DY_ISSUE(drs);
+    stage_issue(cb, cd0, ch0, cw0);
   }
   for (int tl = tbeg; tl < tend; ++tl) {
-    crn_wait_loads(pval);
-    crn_wait_loads(dval);
+    if constexpr (XV) crn_wait_loads4(pv4); else crn_wait_loads(pval);
+    if constexpr (DV) crn_wait_loads4(dv4); else crn_wait_loads(dval);
     __syncthreads();
-    if (g.dbg != 2 || tl == tbeg) {
-      patch_commit(pdsc, choff, phw, ldsA, nplanes, npass, c0, cd0, pval);
-      CRN_DY_COMMIT();
-    }
+    if (g.dbg != 2 || tl == tbeg) stage_commit(cd0, ch0, cw0);
     __syncthreads();
     if (tl + 1 < tend && g.dbg != 2) {
       tile_origin(tl + 1, cb, cd0, ch0, cw0);
-      const crn_rsrc xrs = make_rsrc(g.x.base + (int64_t)cb * g.x.sB);
-      const crn_rsrc drs = make_rsrc(g.dy.base + (int64_t)cb * g.dy.sB);
-      patch_prepare(pdsc, ch0, cw0, phw);
-      dy_prepare(cd0, ch0, cw0);
-      patch_issue(pdsc, choff, phw, xrs, nplanes, npass, c0, cd0, pval);
-      CRN_DY_ISSUE(drs);
+      stage_issue(cb, cd0, ch0, cw0);
     }
     // reduction over the tile's positions (wgrad_rows; the row-length switch stays outside the loops)
     if (g.dbg != 1) {
-      const int bbase = kk * NBP + i16;
+      const int bbase = i16 * g.POSP + kk;
       switch (g.TW >> 2) {
         case 1: wgrad_rows<1, RSUB, NSUB>(acc, ldsA, ldsB, rowbase, bbase, g); break;
         case 2: wgrad_rows<2, RSUB, NSUB>(acc, ldsA, ldsB, rowbase, bbase, g); break;
@@ -715,8 +863,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
   }
 #undef CRN_DY_8
 #undef CRN_DY_8U
-#undef CRN_DY_ISSUE
-#undef CRN_DY_COMMIT
 #undef CRN_COMMA
 
   // D row = kk*4 + r -> weight row (c_local*T + tap); col = i16 -> n
@@ -736,9 +882,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
 }
 
 
-template <int MSUB, int NSUB>
+template <int MSUB, int NSUB, bool XV>
 inline int launch_fwd(const ConvGeom& g, dim3 grid, size_t lds_bytes, hipStream_t st) {
-  auto k = conv_fwd_kernel<MSUB, NSUB>;
+  auto k = conv_fwd_kernel<MSUB, NSUB, XV>;
   if (lds_bytes > 65536)
     CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes, st, g);
@@ -746,9 +892,9 @@ inline int launch_fwd(const ConvGeom& g, dim3 grid, size_t lds_bytes, hipStream_
   return CRN_OK;
 }
 
-template <int RSUB, int NSUB>
+template <int RSUB, int NSUB, bool XV, bool DV>
 inline int launch_wgrad(const WgradGeom& g, dim3 grid, size_t lds_bytes, hipStream_t st) {
-  auto k = conv_wgrad_kernel<RSUB, NSUB>;
+  auto k = conv_wgrad_kernel<RSUB, NSUB, XV, DV>;
   if (lds_bytes > 65536)
     CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   hipLaunchKernelGGL(k, grid, dim3(256), lds_bytes, st, g);
@@ -758,10 +904,10 @@ inline int launch_wgrad(const WgradGeom& g, dim3 grid, size_t lds_bytes, hipStre
 
 }  // namespace crnk
 
-// launchers defined in conv_inst_*.hip
+// launchers defined in conv_inst.hip (one object per configuration)
 #define CRN_FWD_CONFIGS(X) X(8, 1) X(4, 2) X(4, 1) X(2, 4) X(2, 2) X(2, 1) X(1, 4) X(1, 2) X(1, 1)
 #define CRN_WG_CONFIGS(X) X(8, 1) X(4, 2) X(4, 1) X(2, 4) X(2, 2) X(2, 1) X(1, 4) X(1, 2) X(1, 1)
-#define CRN_DECL_FWD(M, N) int crn_launch_fwd_##M##_##N(const crnk::ConvGeom&, dim3, size_t, hipStream_t);
-#define CRN_DECL_WG(R, N) int crn_launch_wgrad_##R##_##N(const crnk::WgradGeom&, dim3, size_t, hipStream_t);
+#define CRN_DECL_FWD(M, N) int crn_launch_fwd_##M##_##N(const crnk::ConvGeom&, int xvec, dim3, size_t, hipStream_t);
+#define CRN_DECL_WG(R, N) int crn_launch_wgrad_##R##_##N(const crnk::WgradGeom&, int xvec, int dyvec, dim3, size_t, hipStream_t);
 CRN_FWD_CONFIGS(CRN_DECL_FWD)
 CRN_WG_CONFIGS(CRN_DECL_WG)
