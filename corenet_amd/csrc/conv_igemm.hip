@@ -238,28 +238,36 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   static const int kN[3] = {4, 2, 1};
   static const bool no_vec = getenv("CRN_NO_VEC") != nullptr;
   const int lead = (vec_view(*x) && !no_vec) ? vec_lead(pw) : -1;
-  FwdCfg best{}; bool have = false; double best_score = -1.0;
+  // Estimated cycles per CU (calibrated on tools/sweep_fwd.sh): work that adds up on the SIMDs
+  // (MFMA issue at ~77% + staging instructions, which do not hide under MFMAs) plus one exposed
+  // load->commit->barrier latency per chunk and pair of resident workgroups; split-K pays a
+  // zero-fill launch and an atomic epilogue.
+  FwdCfg best{}; bool have = false; double best_cost = 1e300; int best_splits = 1;
   for (int mi = 0; mi < 4; ++mi)
     for (int ni = 0; ni < 3; ++ni) {
       if (kN[ni] > 1 && kN[ni] * 16 > Npad) continue;
       if (kM[mi] * kN[ni] > 8) continue;              // instantiated tiles (conv_kernels.h)
       FwdCfg c;
       if (!fwd_cfg(kM[mi], kN[ni], y->B, x->C, Npad, y->D, y->H, y->W, kd, kh, kw, lead, &c)) continue;
-      const int area = kM[mi] * kN[ni];
-      const double reuse = area >= 16 ? 0.85 : area >= 8 ? 0.82 : area >= 4 ? 0.66 : area >= 2 ? 0.5 : 0.4;
-      const double npos_tiles = (double)c.blocks / crn_cdiv(Npad, kN[ni] * 16) * (64.0 * kM[mi]);
-      const double useful = ((double)y->B * y->D * y->H * y->W) / npos_tiles *
-                            ((double)Npad / (crn_cdiv(Npad, kN[ni] * 16) * kN[ni] * 16.0));
-      const int nchunks = crn_cdiv(x->C, c.CC);
-      double fill = std::min(1.0, (double)c.blocks / 384.0);
-      if (c.blocks < 192) fill = 0.8 * std::min(1.0, (double)c.blocks * std::min(nchunks, 16) / 384.0);
-      const double score = useful * reuse * fill;
-      if (score > best_score) { best_score = score; best = c; have = true; }
+      const int T = kd * kh * kw, nchunks = crn_cdiv(x->C, c.CC), NB = kN[ni] * 16;
+      const int TD = c.tsd, TH = c.tsh * c.mh, TW = c.tsw * c.mw;
+      const double patch = (double)c.CC * (TD + kd - 1) * (TH + kh - 1) * patch_width(TW, kw, lead);
+      const double slots = (lead >= 0 ? patch / 4 / 256 * 450.0 : patch / 256 * 350.0) +
+                           (double)c.CC * T * NB / 4 / 256 * 300.0;
+      const double chunk_work = (double)kM[mi] * kN[ni] * (c.CC / 4) * T * 32.0 * 1.3 + slots;
+      for (int sp = 1; sp <= (splits < 1 ? std::min(nchunks, 16) : 1); sp *= 2) {
+        if (sp > 1 && c.blocks * (sp / 2) >= 256) break;          // split only to fill the chip
+        const int cps = crn_cdiv(nchunks, sp);
+        const double bpc = std::max(1.0, std::ceil((double)c.blocks * sp / 256.0));
+        double cost = bpc * cps * chunk_work + cps * std::ceil(bpc / 2.0) * 9000.0 + (sp > 1 ? 40000.0 : 0.0);
+        if (cost < best_cost) { best_cost = cost; best = c; have = true; best_splits = sp; }
+      }
     }
+  bool forced = false;
   if (const char* f = getenv("CRN_FWD_FORCE")) {     // tuning aid: "MSUB,NSUB"
     int fM, fN; FwdCfg c;
     if (sscanf(f, "%d,%d", &fM, &fN) == 2 && fwd_cfg(fM, fN, y->B, x->C, Npad, y->D, y->H, y->W, kd, kh, kw, lead, &c)) {
-      best = c; have = true;
+      best = c; have = true; forced = true;
     }
   }
   int xvec = lead >= 0 ? 1 : 0;
@@ -267,7 +275,7 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
     xvec = 0;
     for (int mi = 0; mi < 4 && !have; ++mi) {
       FwdCfg c;
-      if (fwd_cfg(kM[mi], 1, y->B, x->C, Npad, y->D, y->H, y->W, kd, kh, kw, -1, &c)) { best = c; have = true; }
+      if (fwd_cfg(kM[mi], 1, y->B, x->C, Npad, y->D, y->H, y->W, kd, kh, kw, -1, &c)) { best = c; have = true; forced = true; }
     }
   }
   if (!have) return CRN_EINVAL;
@@ -286,7 +294,9 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   g.CC = CC; g.WSP = pad16mod32(g.T * NSUB * 16);
   g.nchunks = crn_cdiv(x->C, CC);
   if (splits < 1) {   // auto split-K (atomic accumulate) only when the output grid cannot fill the chip
-    splits = best.blocks >= 192 ? 1 : (int)std::min<int64_t>(std::min(g.nchunks, 16), crn_cdiv(256, best.blocks));
+    static const char* fs = getenv("CRN_FWD_SPLITS");
+    splits = fs ? atoi(fs) : (forced ? (best.blocks >= 192 ? 1 : (int)std::min<int64_t>(std::min(g.nchunks, 16), crn_cdiv(256, best.blocks)))
+                                     : best_splits);
   }
   if (splits > g.nchunks) splits = g.nchunks;
   g.chunks_per_split = crn_cdiv(g.nchunks, splits);

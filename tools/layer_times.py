@@ -27,3 +27,8 @@ for ms, l in rows[:int(sys.argv[2]) if len(sys.argv) > 2 else 60]:
 agg = {}
 for ms, l in rows: agg[l.split()[0]] = agg.get(l.split()[0], 0) + ms
 print(agg)
+grp = {}
+for ms, l in rows:
+  k = l.split()[0] + ' ' + ('encoder' if 'encoder' in l else l.split()[1].rsplit('.', 2)[0] if 'decoder' in l else 'other')
+  grp[k] = grp.get(k, 0) + ms
+for k in sorted(grp): print(f'{grp[k]*1e3:9.1f} us  {k}')
