@@ -92,12 +92,12 @@ class HipBackend:
                                     ptr(scale), ptr(shift), ptr(saved), ptr(ws), n, _lib.stream())
 
   def bn_bwd(self, x, sB_x, dy, sB_dy, B, Cn, S, pre_relu, post_relu, gamma, scale, shift, saved,
-             dx, sB_dx, dgamma, dbeta, accumulate=False):
+             dx, sB_dx, dgamma, dbeta, accumulate=False, dsum=None, ndsum=0):
     ws, n = self._bn_ws(Cn, x.device)
     self.lib.crn_batch_renorm_bwd(ptr(x), sB_x, ptr(dy), sB_dy, B, Cn, S, int(pre_relu),
                                   int(post_relu), ptr(gamma), ptr(scale), ptr(shift), ptr(saved),
                                   ptr(dx), sB_dx, ptr(dgamma), ptr(dbeta), int(accumulate),
-                                  ptr(ws), n, _lib.stream())
+                                  ptr(dsum), int(ndsum), ptr(ws), n, _lib.stream())
 
   def affine_add_relu(self, x, scale, shift, r, rscale, rshift, B, Cn, S, sB_x, sB_r,
                       y_pre, sB_pre, y, sB_y, relu):

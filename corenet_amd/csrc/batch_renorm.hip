@@ -100,9 +100,12 @@ __global__ void bn_finalize_kernel(const double* ws, int nparts, int C, double c
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void bn_bwd_partial_kernel(
     const float* x, int64_t sBx, const float* dy, int64_t sBdy, int64_t S, int C, int pre_relu,
-    int post_relu, const float* scale, const float* shift, const float* saved, double* ws) {
+    int post_relu, const float* scale, const float* shift, const float* saved, double* ws, float* dsum,
+    int ndsum) {
   __shared__ double red[kThreads / 64];
   const int c = blockIdx.y, b = blockIdx.z;
+  // the apply kernel (next launch on this stream) accumulates sum(dx) here with atomics
+  if (dsum && c < ndsum && blockIdx.x == 0 && b == 0 && threadIdx.x == 0) dsum[c] = 0.f;
   const float* px = x + (int64_t)b * sBx + (int64_t)c * S;
   const float* pg = dy + (int64_t)b * sBdy + (int64_t)c * S;
   const float sc = scale[c], sh = shift[c], mu = saved[c], rstd = saved[C + c];
@@ -132,8 +135,9 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
     const float* x, int64_t sBx, const float* dy, int64_t sBdy, int64_t S, int C, int pre_relu,
     int post_relu, const float* gamma, const float* scale, const float* shift, const float* saved,
     const double* ws, int nparts, double count, float* dx, int64_t sBdx, float* dgamma,
-    float* dbeta, int accumulate) {
+    float* dbeta, int accumulate, float* dsum, int ndsum) {
   __shared__ float sm[2];
+  __shared__ float red[kThreads / 64];
   const int c = blockIdx.y, b = blockIdx.z;
   if (threadIdx.x == 0) {
     double s1 = 0.0, s2 = 0.0;
@@ -152,11 +156,13 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
   const float* px = x + (int64_t)b * sBx + (int64_t)c * S;
   const float* pg = dy + (int64_t)b * sBdy + (int64_t)c * S;
   float* po = dx + (int64_t)b * sBdx + (int64_t)c * S;
+  float lsum = 0.f;
   auto one = [&](float xr, float gv) -> float {
     const float xv = pre_relu ? fmaxf(xr, 0.f) : xr;
     if (post_relu && !(xv * sc + sh > 0.f)) gv = 0.f;
     float o = k * (gv - mg - (xv - mu) * rstd * mgx);
     if (pre_relu && !(xr > 0.f)) o = 0.f;
+    lsum += o;
     return o;
   };
   for_slice<VEC>(block_slice(S),
@@ -166,6 +172,16 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
                                   o.z = one(a.z, g.z); o.w = one(a.w, g.w);
                                   *reinterpret_cast<f32x4*>(po + s) = o; },
                  [&](int64_t s) { po[s] = one(px[s], pg[s]); });
+  if (dsum && c < ndsum) {       // bias gradient of the convolution that produced x: sum of dx
+    const float w = crn_wave_sum(lsum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tsum = 0.f;
+      for (int i = 0; i < kThreads / 64; ++i) tsum += red[i];
+      atomicAdd(dsum + c, tsum);
+    }
+  }
 }
 
 // ---- block tails ---------------------------------------------------------------
@@ -302,8 +318,8 @@ extern "C" int crn_batch_renorm_bwd(const float* x, int64_t sB_x, const float* d
                                     int B, int C, int64_t S, int pre_relu, int post_relu,
                                     const float* gamma, const float* scale, const float* shift,
                                     const float* saved, float* dx, int64_t sB_dx, float* dgamma,
-                                    float* dbeta, int accumulate, double* ws, size_t ws_bytes,
-                                    crnStream stream) {
+                                    float* dbeta, int accumulate, float* dsum, int ndsum, double* ws,
+                                    size_t ws_bytes, crnStream stream) {
   hipStream_t st = (hipStream_t)stream;
   if (B < 1 || C < 1 || S < 1 || B > 64) return CRN_EINVAL;
   const int ns = nsplit_for(S, C, B);
@@ -313,19 +329,19 @@ extern "C" int crn_batch_renorm_bwd(const float* x, int64_t sB_x, const float* d
   const bool v = vec_ok(S, {sB_x, sB_dy, sB_dx}, {x, dy, dx});
   if (v)
     hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, grid, dim3(kThreads), 0, st, x, sB_x, dy, sB_dy, S, C,
-                       pre_relu, post_relu, scale, shift, saved, ws);
+                       pre_relu, post_relu, scale, shift, saved, ws, dsum, ndsum);
   else
     hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, grid, dim3(kThreads), 0, st, x, sB_x, dy, sB_dy, S, C,
-                       pre_relu, post_relu, scale, shift, saved, ws);
+                       pre_relu, post_relu, scale, shift, saved, ws, dsum, ndsum);
   CRN_CHECK_LAUNCH();
   if (v)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(kThreads), 0, st, x, sB_x, dy, sB_dy, S, C,
                        pre_relu, post_relu, gamma, scale, shift, saved, ws, nparts,
-                       (double)B * (double)S, dx, sB_dx, dgamma, dbeta, accumulate);
+                       (double)B * (double)S, dx, sB_dx, dgamma, dbeta, accumulate, dsum, ndsum);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(kThreads), 0, st, x, sB_x, dy, sB_dy, S, C,
                        pre_relu, post_relu, gamma, scale, shift, saved, ws, nparts,
-                       (double)B * (double)S, dx, sB_dx, dgamma, dbeta, accumulate);
+                       (double)B * (double)S, dx, sB_dx, dgamma, dbeta, accumulate, dsum, ndsum);
   CRN_CHECK_LAUNCH();
   return CRN_OK;
 }

@@ -539,17 +539,22 @@ class Plan:
       gv = self.s2d(g_out, d["cout"], (2, 2, 2))
       tr2 = Transform(b2_.scale, b2_.shift, pre_relu=True)
       self._wgrad(ct, self.vw(d["w"]), tr2, gv)
-      self._bias_grad(ct, g_out, So, ctot * So)
+      if k == 6:   # gradient of the logits comes from the loss kernel; below it is a bn_bwd output
+        self._bias_grad(ct, g_out, So, ctot * So)
       self._dgrad(ct, gv, self.vw(d["gv2"]))
-      be.bn_bwd(d["w"], d["cmid"] * S, d["gv2"], d["cmid"] * S, B, d["cmid"], S, True, False,
-                b2_.gamma, b2_.scale, b2_.shift, b2_.saved, d["gw"], d["cmid"] * S, b2_.dgamma, b2_.dbeta)
       cc = cv[p + "c1."]
+      # every conv bias gradient below is sum(dx) of the norm that consumes the conv output: fused
+      # into bn_bwd (dsum) instead of a second pass over dx
+      be.bn_bwd(d["w"], d["cmid"] * S, d["gv2"], d["cmid"] * S, B, d["cmid"], S, True, False,
+                b2_.gamma, b2_.scale, b2_.shift, b2_.saved, d["gw"], d["cmid"] * S, b2_.dgamma, b2_.dbeta,
+                dsum=cc.dbias, ndsum=cc.n_ref)
       tr1 = Transform(b1_.scale, b1_.shift, pre_relu=True)
       self._wgrad(cc, self.vw(d["u"]), tr1, self.vw(d["gw"]))
-      self._bias_grad(cc, d["gw"], S, d["cmid"] * S)
       self._dgrad(cc, self.vw(d["gw"]), self.vw(d["gv1"]))
+      cprev = cv[f"decoder.stage_{k - 1}.t1."]        # produced this stage's input (first n_ref channels)
       be.bn_bwd(d["u"], d["cin"] * S, d["gv1"], d["cin"] * S, B, d["cin"], S, True, False,
-                b1_.gamma, b1_.scale, b1_.shift, b1_.saved, d["gu"], d["cin"] * S, b1_.dgamma, b1_.dbeta)
+                b1_.gamma, b1_.scale, b1_.shift, b1_.saved, d["gu"], d["cin"] * S, b1_.dgamma, b1_.dbeta,
+                dsum=cprev.dbias, ndsum=cprev.n_ref)
       g_out = d["gu"]
     # stage_1 / stage_0
     c1 = cv["decoder.stage_1.t1."]
@@ -557,7 +562,6 @@ class Plan:
     zv = self.vw(self.z0.view(B, L + 3, 1, 1, 1))
     gv = self.flat(g_out)
     self._wgrad(c1, zv, Transform(b.scale, b.shift, pre_relu=True), gv)
-    self._bias_grad(c1, g_out, 64, 256 * 64)
     self._dgrad(c1, gv, self.vw(self.gv0.view(B, L + 3, 1, 1, 1)))
     be.bn_bwd(self.z0, L + 3, self.gv0, L + 3, B, L + 3, 1, True, False, b.gamma, b.scale, b.shift,
               b.saved, self.gz0, L + 3, b.dgamma, b.dbeta)
@@ -577,11 +581,10 @@ class Plan:
     b1 = bn["encoder.stage1_part2.bn."]
     be.maxpool_bwd(g_in, self.p1_arg, B, 64, 128, 128, self.gy1)
     S1 = 128 * 128
-    be.bn_bwd(self.y1, 64 * S1, self.gy1, 64 * S1, B, 64, S1, False, False, b1.gamma, b1.scale, b1.shift,
-              b1.saved, self.gy1b, 64 * S1, b1.dgamma, b1.dbeta)
     cs = cv["encoder.stage1.conv."]
+    be.bn_bwd(self.y1, 64 * S1, self.gy1, 64 * S1, B, 64, S1, False, False, b1.gamma, b1.scale, b1.shift,
+              b1.saved, self.gy1b, 64 * S1, b1.dgamma, b1.dbeta, dsum=cs.dbias, ndsum=cs.n_ref)
     self._wgrad(cs, self.s2d(self.img, 3, (1, 2, 2)), None, self.vw(self.gy1b))
-    self._bias_grad(cs, self.gy1b, S1, 64 * S1)
     # packed weight grads -> reference layout inside the flat grad slab (1 launch)
     be.scatter(eng.gpacked, eng.gscatter_index, eng.store.grads, False)
 
@@ -600,32 +603,29 @@ class Plan:
       else:
         be.relu_bwd_add(g_out, blk["out"], None, B, f3, S, f3 * S, f3 * S, 0, gpre, f3 * S)
     # else: gpre already holds d pre (last block of the encoder)
+    cc, cb, ca = cv[p + "op_c.conv."], cv[p + "op_b.conv."], cv[p + "op_a.conv."]
+    # conv bias gradients = sum(dx) of the following norm, fused into bn_bwd (dsum)
     be.bn_bwd(blk["yc"], f3 * S, gpre, f3 * S, B, f3, S, False, False, bc.gamma, bc.scale, bc.shift,
-              bc.saved, blk["gyc"], f3 * S, bc.dgamma, bc.dbeta)
+              bc.saved, blk["gyc"], f3 * S, bc.dgamma, bc.dbeta, dsum=cc.dbias, ndsum=cc.n_ref)
     trb = Transform(bb.scale, bb.shift, post_relu=True)
     tra = Transform(ba.scale, ba.shift, post_relu=True)
-    cc, cb, ca = cv[p + "op_c.conv."], cv[p + "op_b.conv."], cv[p + "op_a.conv."]
     self._wgrad(cc, self.vw(blk["yb"]), trb, self.vw(blk["gyc"]))
-    self._bias_grad(cc, blk["gyc"], S, f3 * S)
     self._dgrad(cc, self.vw(blk["gyc"]), self.vw(blk["gab"]))
     be.bn_bwd(blk["yb"], f2 * S, blk["gab"], f2 * S, B, f2, S, False, True, bb.gamma, bb.scale, bb.shift,
-              bb.saved, blk["gyb"], f2 * S, bb.dgamma, bb.dbeta)
+              bb.saved, blk["gyb"], f2 * S, bb.dgamma, bb.dbeta, dsum=cb.dbias, ndsum=cb.n_ref)
     self._wgrad(cb, self.vw(blk["ya"]), tra, self.vw(blk["gyb"]))
-    self._bias_grad(cb, blk["gyb"], S, f2 * S)
     self._dgrad(cb, self.vw(blk["gyb"]), self.vw(blk["gaa"]))
     be.bn_bwd(blk["ya"], f1 * S, blk["gaa"], f1 * S, B, f1, S, False, True, ba.gamma, ba.scale, ba.shift,
-              ba.saved, blk["gya"], f1 * S, ba.dgamma, ba.dbeta)
+              ba.saved, blk["gya"], f1 * S, ba.dgamma, ba.dbeta, dsum=ca.dbias, ndsum=ca.n_ref)
     cur = blk["in"]
     xin = self.strided(cur, (1, 2, 2)) if blk["stride"] == 2 else self.vw(cur)
     self._wgrad(ca, xin, None, self.vw(blk["gya"]))
-    self._bias_grad(ca, blk["gya"], S, f1 * S)
     if blk["down"]:
       bs = bn[p + "shortcut.bn."]
       csn = cv[p + "shortcut.conv."]
       be.bn_bwd(blk["ys"], f3 * S, gpre, f3 * S, B, f3, S, False, False, bs.gamma, bs.scale, bs.shift,
-                bs.saved, blk["gys"], f3 * S, bs.dgamma, bs.dbeta)
+                bs.saved, blk["gys"], f3 * S, bs.dgamma, bs.dbeta, dsum=csn.dbias, ndsum=csn.n_ref)
       self._wgrad(csn, xin, None, self.vw(blk["gys"]))
-      self._bias_grad(csn, blk["gys"], S, f3 * S)
       gin = blk["gin"]
       gv = self.vw(gin)
       if blk["stride"] == 2:

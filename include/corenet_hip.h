@@ -104,12 +104,17 @@ size_t crn_batch_renorm_workspace_bytes(int C);
  *   dbeta = sum g ; dgamma = sum g*(r*xn+d)
  *   dx = gamma*r*rstd*(g - mean(g) - xn*mean(g*xn)) * (pre_relu ? x>0 : 1)
  * saved = [4][C]: mu, rstd, r, d written by crn_batch_renorm_stats(training).
- * dgamma/dbeta are accumulated when accumulate != 0.                           */
+ * dgamma/dbeta are accumulated when accumulate != 0.
+ * dsum (optional, may be NULL): dsum[c] = sum_{b,s} dx[b,c,s] for c < ndsum -- the bias
+ * gradient of the convolution whose output x is (autograd's sum over the conv output
+ * gradient, conv bias + norm in resnet50.py:40-61 / reconstruction_decoder.py:33-71),
+ * fused here so that dx is not read again by crn_bias_grad.                        */
 int crn_batch_renorm_bwd(const float* x, int64_t sB_x, const float* dy, int64_t sB_dy,
                          int B, int C, int64_t S, int pre_relu, int post_relu,
                          const float* gamma, const float* scale, const float* shift,
                          const float* saved, float* dx, int64_t sB_dx,
                          float* dgamma, float* dbeta, int accumulate,
+                         float* dsum, int ndsum,
                          double* workspace, size_t workspace_bytes, crnStream s);
 
 /* y = act( x*scale[c]+shift[c] [+ r*rscale[c]+rshift[c]] ) ; optional second

@@ -136,7 +136,7 @@ class EmuBackend:
     rmean += momentum * (b_mean - rmean)
 
   def bn_bwd(self, x, sB_x, dy, sB_dy, B, Cn, S, pre_relu, post_relu, gamma, scale, shift, saved,
-             dx, sB_dx, dgamma, dbeta, accumulate=False):
+             dx, sB_dx, dgamma, dbeta, accumulate=False, dsum=None, ndsum=0):
     xs = t.as_strided(x, (B, Cn, S), (sB_x, S, 1), x.storage_offset())
     g = t.as_strided(dy, (B, Cn, S), (sB_dy, S, 1), dy.storage_offset()).clone()
     mu, rstd, r, d = [u.view(1, Cn, 1) for u in saved.view(4, Cn)]
@@ -153,6 +153,8 @@ class EmuBackend:
     o = gamma.view(1, Cn, 1) * r * rstd * (g - mg - xn * mgx)
     if pre_relu: o = o * (xs > 0)
     t.as_strided(dx, (B, Cn, S), (sB_dx, S, 1), dx.storage_offset()).copy_(o)
+    if dsum is not None:
+      dsum[:ndsum].copy_(o[:, :ndsum].double().sum((0, 2)).to(x.dtype))
 
   def affine_add_relu(self, x, scale, shift, r, rscale, rshift, B, Cn, S, sB_x, sB_r, y_pre, sB_pre,
                       y, sB_y, relu):

@@ -213,8 +213,16 @@ def test_batch_renorm(be, B, C, S, pre, post, nbt):
     bk.bn_stats(xx, B, C, S, Ct * S, pre, gamma.to(dev), beta.to(dev), rm, rv, nb.to(dev), 1e-3, 0.01, True,
                 sc, sh, sv)
     dx = t.zeros(B, C, S, device=dev); dg = t.zeros(C, device=dev); db = t.zeros(C, device=dev)
-    bk.bn_bwd(xx, Ct * S, gy.to(dev), C * S, B, C, S, pre, post, gamma.to(dev), sc, sh, sv, dx, C * S, dg, db)
+    nds = max(1, C - 2)                                   # fused sum(dx) for the first nds channels
+    ds = t.full((C,), 7.0, device=dev)                    # stale content must be overwritten, tail untouched
+    bk.bn_bwd(xx, Ct * S, gy.to(dev), C * S, B, C, S, pre, post, gamma.to(dev), sc, sh, sv, dx, C * S, dg, db,
+              dsum=ds, ndsum=nds)
     res.append([v.cpu() for v in (sc, sh, sv, rm, rv, dx, dg, db)])
+    dsum_ref = dx.double().sum((0, 2)).float().cpu()
+    got = ds.cpu()
+    scale_ = float(dx.abs().sum((0, 2)).max()) + 1e-6     # sum(dx) is ~0 without pre_relu: absolute check
+    assert float((got[:nds] - dsum_ref[:nds]).abs().max()) <= 2e-5 * scale_, (dev, got[:nds], dsum_ref[:nds])
+    assert bool((got[nds:] == 7.0).all())
   for a, b, nm in zip(res[1], res[0], ["scale", "shift", "saved", "rmean", "rvar", "dx", "dgamma", "dbeta"]):
     close(a, b, 2e-5, nm)
   # and against autograd of the oracle
