@@ -20,6 +20,8 @@ Dataflow choices (MI355X-first):
 """
 from __future__ import annotations
 
+import os
+
 import dataclasses
 import math
 from typing import Dict, List, Optional, Tuple
@@ -349,6 +351,10 @@ class Plan:
     self.offset = f(B, 3)
     self.loss = f(1)
     self.gt = t.zeros(B, 128, 128, 128, dtype=t.int32, device=dev)
+    use_side = t.device(dev).type == "cuda" and os.environ.get("CRN_SIDE_STREAM", "1") != "0"
+    self.side = t.cuda.Stream(device=dev) if use_side else None
+    self._side_ev, self._side_i = [], 0
+    self._side_done = t.cuda.Event() if use_side else None
 
   # ------------------------------------------------------------------ cached views
   def _cached(self, key, fn):
@@ -406,9 +412,28 @@ class Plan:
         dy, None, cv.wd, g.npad, None, 0, dx, g.window, g.pad_lo, 0, accumulate))
 
   def _wgrad(self, cv: Conv, x: V.View, tr, dy: V.View):
+    """Weight gradient of one conv.  On the GPU it goes to a second HIP stream: it only reads
+    (saved activation, dy) and writes its own slice of the packed gradient slab, so it can run
+    beside the data-gradient chain; most layers below 32^3 / 64^2 cannot fill 256 CUs alone."""
     g = cv.fwd
-    self._timed("wgrad " + cv.name, lambda: self.be.conv_wgrad(
-        x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False))
+    if self.side is None or self.trace is not None:
+      self._timed("wgrad " + cv.name, lambda: self.be.conv_wgrad(
+          x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False))
+      return
+    if self._side_i == len(self._side_ev):
+      self._side_ev.append(t.cuda.Event())
+    ev = self._side_ev[self._side_i]; self._side_i += 1
+    ev.record()                                   # dy (and the zeroed slab) are ready on the main stream
+    with t.cuda.stream(self.side):
+      self.side.wait_event(ev)
+      self.be.conv_wgrad(x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False)
+
+  def _join_side(self):
+    """Main stream waits for every weight gradient issued on the side stream."""
+    if self.side is not None and self._side_i:
+      self._side_done.record(self.side)
+      t.cuda.current_stream().wait_event(self._side_done)
+      self._side_i = 0
 
   def _bias_grad(self, cv: Conv, dy: t.Tensor, S: int, sB: int):
     self.be.bias_grad(dy, self.B, cv.n_ref, S, sB, cv.dbias)
@@ -586,6 +611,7 @@ class Plan:
               b1.saved, self.gy1b, 64 * S1, b1.dgamma, b1.dbeta, dsum=cs.dbias, ndsum=cs.n_ref)
     self._wgrad(cs, self.s2d(self.img, 3, (1, 2, 2)), None, self.vw(self.gy1b))
     # packed weight grads -> reference layout inside the flat grad slab (1 launch)
+    self._join_side()
     be.scatter(eng.gpacked, eng.gscatter_index, eng.store.grads, False)
 
   def _block_bwd(self, blk, g_out: Optional[t.Tensor]) -> t.Tensor:
