@@ -438,7 +438,8 @@ extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const 
   g.ntiles = g.tilesD * g.tilesH * g.tilesW * dy->B;
   const int cblocks = crn_cdiv(x->C, CC), nblocks = crn_cdiv(Npad, NB);
   static const int kWgBlocks = getenv("CRN_WG_BLOCKS") ? atoi(getenv("CRN_WG_BLOCKS")) : 512;
-  int splits = std::max(1, std::min(g.ntiles, crn_cdiv(kWgBlocks, cblocks * nblocks)));
+  // one resident round: at most kWgBlocks (= 2 per CU) workgroups, or the stragglers double the time
+  int splits = std::max(1, std::min(g.ntiles, kWgBlocks / (cblocks * nblocks)));
   g.tiles_per_split = crn_cdiv(g.ntiles, splits);
   splits = crn_cdiv(g.ntiles, g.tiles_per_split);
   g.lg2 = ilog2_ceil(g.PH * g.PW); g.npass = xlead >= 0 ? 0 : stage_passes(CC * g.PD, g.PH * g.PW);
@@ -451,6 +452,7 @@ extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const 
   }
   if (dvec) { g.np4 = npos / 4; g.dnunits = NB * g.np4; g.magic_NP4 = magic20(g.np4); }
   g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
+  g.xcd = getenv("CRN_WG_XCD") ? atoi(getenv("CRN_WG_XCD")) : 1;
   if (zero_first) CRN_HIP(hipMemsetAsync(dw, 0, (size_t)x->C * T * Npad * 4, st));
   dim3 grid((unsigned)cblocks, (unsigned)nblocks, (unsigned)splits);
   const size_t lds_bytes = best.lds;

@@ -590,6 +590,7 @@ struct WgradGeom {
   int lead;                // 16-byte staging of x (see ConvGeom)
   int nunits, plu, pw4;
   unsigned magic_PLU, magic_PW4;
+  int xcd;                 // XCD-aware block order
   int dnunits, np4;        // 16-byte staging of dy: NB * npos/4 units, np4 = npos/4 per channel
   unsigned magic_NP4;
   int dbg;                 // tuning aid (CRN_DBG_MODE): 1 = no MFMA loop, 2 = stage only the first tile
@@ -682,9 +683,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kk = lane >> 4;
   constexpr int NB = NSUB * 16;
-  const int c0 = blockIdx.x * g.CC;
-  const int n0 = blockIdx.y * NB;
-  const int split = blockIdx.z;
+  // XCD-aware order: the channel blocks that reduce over the same tiles (same split) read the same
+  // dy tiles -> keep them, and neighbouring splits, on one XCD (one L2)
+  const int nbx = gridDim.x, nby = gridDim.y;
+  const int lin0 = blockIdx.x + nbx * (blockIdx.y + nby * blockIdx.z);
+  const int lin = g.xcd ? xcd_remap(lin0, nbx * nby * gridDim.z) : lin0;
+  const int c0 = (lin % nbx) * g.CC;
+  const int n0 = ((lin / nbx) % nby) * NB;
+  const int split = lin / (nbx * nby);
   const int nrows = min(g.CC, g.x.C - c0) * g.T;
 
   PatchDesc pdsc;
