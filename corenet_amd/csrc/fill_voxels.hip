@@ -87,24 +87,11 @@ __device__ __forceinline__ bool relax_row(const u64* e, u64* r) {
 
 constexpr int STRIP = 8;
 
+// Relaxes one slab held in LDS to its local fixed point.  El [nz][H][WX], Rl [nz+2][H][WX] with halo
+// planes 0 and nz+1.  Returns (block-uniform) whether anything changed.
 template <int WX>
-__global__ __launch_bounds__(512) void fill_sweep_kernel(const u64* E, u64* R, int D, int H, int zs,
-                                                         int nslabs, int* flags, int round) {
-  extern __shared__ __attribute__((aligned(16))) u64 sm[];
-  if (round > 0 && flags[round - 1] == 0) return;      // converged in an earlier round
-  const int slab = blockIdx.x % nslabs, n = blockIdx.x / nslabs;
-  const int z0 = slab * zs, nz = min(zs, D - z0);
+__device__ int relax_slab(const u64* El, u64* Rl, int nz, int H) {
   const int rowsz = H * WX;
-  u64* El = sm;                          // [nz][H][WX]
-  u64* Rl = sm + (size_t)zs * rowsz;     // [nz+2][H][WX], plane 0 / nz+1 = halos
-  const u64* Eg = E + ((int64_t)n * D + z0) * rowsz;
-  u64* Rg = R + ((int64_t)n * D + z0) * rowsz;
-  for (int i = threadIdx.x; i < nz * rowsz; i += blockDim.x) { El[i] = Eg[i]; Rl[rowsz + i] = Rg[i]; }
-  for (int i = threadIdx.x; i < rowsz; i += blockDim.x) {
-    Rl[i] = z0 > 0 ? Rg[i - rowsz] : 0ull;
-    Rl[(nz + 1) * rowsz + i] = (z0 + nz < D) ? Rg[nz * rowsz + i] : 0ull;
-  }
-  __syncthreads();
   const int nstrips = (H + STRIP - 1) / STRIP;
   const int units = nz * nstrips;
   int any = 0;
@@ -165,22 +152,361 @@ __global__ __launch_bounds__(512) void fill_sweep_kernel(const u64* E, u64* R, i
     if (!__syncthreads_or(changed)) break;
     any = 1;
   }
+  return any;
+}
+
+template <int WX>
+__global__ __launch_bounds__(512) void fill_sweep_kernel(const u64* E, u64* R, int D, int H, int zs,
+                                                         int nslabs, int* flags, int round) {
+  extern __shared__ __attribute__((aligned(16))) u64 sm[];
+  if (round > 0 && flags[round - 1] == 0) return;      // converged in an earlier round
+  const int slab = blockIdx.x % nslabs, n = blockIdx.x / nslabs;
+  const int z0 = slab * zs, nz = min(zs, D - z0);
+  const int rowsz = H * WX;
+  u64* El = sm;                          // [nz][H][WX]
+  u64* Rl = sm + (size_t)zs * rowsz;     // [nz+2][H][WX], plane 0 / nz+1 = halos
+  const u64* Eg = E + ((int64_t)n * D + z0) * rowsz;
+  u64* Rg = R + ((int64_t)n * D + z0) * rowsz;
+  for (int i = threadIdx.x; i < nz * rowsz; i += blockDim.x) { El[i] = Eg[i]; Rl[rowsz + i] = Rg[i]; }
+  for (int i = threadIdx.x; i < rowsz; i += blockDim.x) {
+    Rl[i] = z0 > 0 ? Rg[i - rowsz] : 0ull;
+    Rl[(nz + 1) * rowsz + i] = (z0 + nz < D) ? Rg[nz * rowsz + i] : 0ull;
+  }
+  __syncthreads();
+  const int any = relax_slab<WX>(El, Rl, nz, H);
   if (any) {
     for (int i = threadIdx.x; i < nz * rowsz; i += blockDim.x) Rg[i] = Rl[rowsz + i];
     if (threadIdx.x == 0) atomicOr(&flags[round], 1);
   }
 }
 
-constexpr int kMaxRounds = 4096;
-constexpr size_t kSweepLds = 144 * 1024;
+// ---- wave-level plane closure (single-launch path) --------------------------------------------
+// One wavefront owns a z-plane: lane = row y (64 rows per group).  Along x the closure is the carry
+// trick per row; along y it is a segmented OR-scan over the lanes (Kogge-Stone on (reach, empty)
+// pairs with wavefront shuffles), so a plane converges in a few passes instead of one row step per
+// iteration.  Returns wave-uniform "changed".
+__device__ __forceinline__ u64 shfl_up64(u64 v, int d) { return (u64)__shfl_up((long long)v, d, 64); }
+__device__ __forceinline__ u64 shfl_dn64(u64 v, int d) { return (u64)__shfl_down((long long)v, d, 64); }
 
+template <int WX>
+__device__ bool plane_close(const u64* e_pl, u64* r_pl, const u64* r_lo, const u64* r_hi, int H) {
+  const int lane = threadIdx.x & 63;
+  const int ngrp = (H + 63) >> 6;
+  bool changed = false;
+  // z neighbours, then x closure (row parallel)
+  for (int grp = 0; grp < ngrp; ++grp) {
+    const int y = grp * 64 + lane;
+    if (y < H) {
+      u64 e[WX], r[WX];
+      bool ch = false;
+#pragma unroll
+      for (int k = 0; k < WX; ++k) {
+        e[k] = e_pl[y * WX + k];
+        const u64 old = r_pl[y * WX + k];
+        r[k] = old | ((r_lo[y * WX + k] | r_hi[y * WX + k]) & e[k]);
+        ch |= r[k] != old;
+      }
+      ch |= relax_row<WX>(e, r);
+      if (ch) {
+#pragma unroll
+        for (int k = 0; k < WX; ++k) r_pl[y * WX + k] = r[k];
+        changed = true;
+      }
+    }
+  }
+  for (int pass = 0; pass < 4096; ++pass) {
+    bool ch_pass = false;
+    // +y: reach flows to higher rows through runs of empty voxels
+    u64 carry[WX];
+#pragma unroll
+    for (int k = 0; k < WX; ++k) carry[k] = 0ull;
+    for (int grp = 0; grp < ngrp; ++grp) {
+      const int y = grp * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < WX; ++k) {
+        const u64 p0 = y < H ? e_pl[y * WX + k] : 0ull, g0 = y < H ? r_pl[y * WX + k] : 0ull;
+        u64 G = g0, P = p0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          u64 gs = shfl_up64(G, d), ps = shfl_up64(P, d);
+          if (lane < d) { gs = 0ull; ps = ~0ull; }
+          G |= P & gs; P &= ps;
+        }
+        u64 gin = shfl_up64(G, 1), pin = shfl_up64(P, 1);          // exclusive prefix
+        if (lane == 0) { gin = 0ull; pin = ~0ull; }
+        const u64 cin = gin | (pin & carry[k]);
+        const u64 v = g0 | (p0 & cin);
+        if (v != g0) { r_pl[y * WX + k] = v; ch_pass = true; }
+        carry[k] = __shfl((long long)v, 63, 64);
+      }
+    }
+    // -y
+#pragma unroll
+    for (int k = 0; k < WX; ++k) carry[k] = 0ull;
+    for (int grp = ngrp - 1; grp >= 0; --grp) {
+      const int y = grp * 64 + lane;
+#pragma unroll
+      for (int k = 0; k < WX; ++k) {
+        const u64 p0 = y < H ? e_pl[y * WX + k] : 0ull, g0 = y < H ? r_pl[y * WX + k] : 0ull;
+        u64 G = g0, P = p0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          u64 gs = shfl_dn64(G, d), ps = shfl_dn64(P, d);
+          if (lane + d > 63) { gs = 0ull; ps = ~0ull; }
+          G |= P & gs; P &= ps;
+        }
+        u64 gin = shfl_dn64(G, 1), pin = shfl_dn64(P, 1);
+        if (lane == 63) { gin = 0ull; pin = ~0ull; }
+        const u64 cin = gin | (pin & carry[k]);
+        const u64 v = g0 | (p0 & cin);
+        if (v != g0) { r_pl[y * WX + k] = v; ch_pass = true; }
+        carry[k] = __shfl((long long)v, 0, 64);
+      }
+    }
+    if (!__any(ch_pass)) break;
+    changed = true;
+    // new reach spreads along x
+    bool ch_x = false;
+    for (int grp = 0; grp < ngrp; ++grp) {
+      const int y = grp * 64 + lane;
+      if (y < H) {
+        u64 e[WX], r[WX];
+#pragma unroll
+        for (int k = 0; k < WX; ++k) { e[k] = e_pl[y * WX + k]; r[k] = r_pl[y * WX + k]; }
+        if (relax_row<WX>(e, r)) {
+#pragma unroll
+          for (int k = 0; k < WX; ++k) r_pl[y * WX + k] = r[k];
+          ch_x = true;
+        }
+      }
+    }
+    if (!__any(ch_x)) break;
+  }
+  return __any(changed);
+}
+
+// slab held in LDS: one wavefront per plane for the in-plane closure, then one thread per (row, word)
+// column for the closure along z; block-uniform "changed"
+template <int WX>
+__device__ int relax_slab_waves(const u64* El, u64* Rl, int nz, int H) {
+  const int rowsz = H * WX;
+  const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  int any = 0;
+  for (int iter = 0; iter < 100000; ++iter) {
+    int changed = 0;
+    for (int p = wave; p < nz; p += nwaves)
+      changed |= plane_close<WX>(El + (size_t)p * rowsz, Rl + (size_t)(p + 1) * rowsz, Rl + (size_t)p * rowsz,
+                                 Rl + (size_t)(p + 2) * rowsz, H) ? 1 : 0;
+    const int c1 = __syncthreads_or(changed);
+    int zch = 0;
+    for (int i = threadIdx.x; i < rowsz; i += blockDim.x) {
+      u64 carry = Rl[i];                                    // halo below
+      for (int p = 0; p < nz; ++p) {
+        const u64 e = El[(size_t)p * rowsz + i], old = Rl[(size_t)(p + 1) * rowsz + i];
+        const u64 v = old | (carry & e);
+        if (v != old) { Rl[(size_t)(p + 1) * rowsz + i] = v; zch = 1; }
+        carry = v;
+      }
+      carry = Rl[(size_t)(nz + 1) * rowsz + i];             // halo above
+      for (int p = nz - 1; p >= 0; --p) {
+        const u64 e = El[(size_t)p * rowsz + i], old = Rl[(size_t)(p + 1) * rowsz + i];
+        const u64 v = old | (carry & e);
+        if (v != old) { Rl[(size_t)(p + 1) * rowsz + i] = v; zch = 1; }
+        carry = v;
+      }
+    }
+    const int c2 = __syncthreads_or(zch);
+    if (c1 | c2) any = 1;
+    if (!c2) break;          // every plane is closed in-plane and nothing moves along z: fixed point
+  }
+  return any;
+}
+
+// ---- single-launch path -------------------------------------------------------------------------
+// One workgroup per z-slab reads its part of the input grid straight into LDS bitmaps (ballot),
+// relaxes, exchanges boundary planes with the neighbouring slabs of the same grid through HBM, and
+// writes the {0,1} result from LDS: 8 B/voxel of HBM traffic for fp32, no bitmap round trip, no host
+// synchronisation.  The slabs of one grid meet at a counter barrier once per exchange; the host
+// launches at most as many workgroups as are co-resident (<= 1 per CU), so the spin-wait cannot
+// starve a workgroup that has not started.  A bounded spin plus an iteration cap turn any surprise
+// into status != 0, and the caller falls back to the multi-launch path.
+constexpr int kFusedIters = 64;
+struct FusedCtl { int count[kFusedIters]; int flag[kFusedIters]; };   // per grid
+
+__device__ __forceinline__ int ld_acquire(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T, int WX>
+__global__ __launch_bounds__(1024) void fill_fused_kernel(const T* grid, T* out, int D, int H, int W, int zs,
+                                                         int nslabs, u64* halo, FusedCtl* ctl, int* status) {
+  extern __shared__ __attribute__((aligned(16))) u64 sm[];
+  const int slab = blockIdx.x % nslabs, n = blockIdx.x / nslabs;
+  const int z0 = slab * zs, nz = min(zs, D - z0);
+  const int rowsz = H * WX;
+  u64* El = sm;                          // [nz][H][WX]
+  u64* Rl = sm + (size_t)zs * rowsz;     // [nz+2][H][WX], plane 0 / nz+1 = halos
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const T* gsrc = grid + ((int64_t)n * D + z0) * H * W;
+  // load + pack: one wave per row, RW rows (RW*WX loads per lane) in flight
+  constexpr int RW = WX <= 2 ? 8 : 4;
+  const int nrows = nz * H;
+  for (int r0 = wave * RW; r0 < nrows; r0 += nwaves * RW) {
+    // branch-free: every load is issued (clamped address) before the first value is used
+    T vals[RW][WX];
+#pragma unroll
+    for (int j = 0; j < RW; ++j)
+#pragma unroll
+      for (int k = 0; k < WX; ++k)
+        vals[j][k] = gsrc[(int64_t)min(r0 + j, nrows - 1) * W + min(k * 64 + lane, W - 1)];
+    bool emp[RW][WX];
+#pragma unroll
+    for (int j = 0; j < RW; ++j)
+#pragma unroll
+      for (int k = 0; k < WX; ++k) emp[j][k] = (r0 + j < nrows && k * 64 + lane < W) && !(vals[j][k] > (T)0);
+#pragma unroll
+    for (int j = 0; j < RW; ++j)
+#pragma unroll
+      for (int k = 0; k < WX; ++k) {
+        const u64 e = __ballot(emp[j][k]);
+        const int row = r0 + j;
+        if (lane == 0 && row < nrows) {
+          const int y = row % H, z = z0 + row / H;
+          El[row * WX + k] = e;
+          Rl[rowsz + row * WX + k] = (y == 0 || z == 0) ? e : (k == 0 ? (e & 1ull) : 0ull);
+        }
+      }
+  }
+  for (int i = threadIdx.x; i < rowsz; i += blockDim.x) { Rl[i] = 0ull; Rl[(nz + 1) * rowsz + i] = 0ull; }
+  __syncthreads();
+
+  FusedCtl* c = ctl + n;
+  u64* hb = halo + (int64_t)n * nslabs * 2 * 2 * rowsz;       // [parity][slab][lo/hi][rowsz]
+  T* gdst = out + ((int64_t)n * D + z0) * H * W;
+  // unpack + store from the LDS bitmaps (an in-place call overwrites its input only here)
+  auto store_slab = [&]() {
+    for (int r0 = wave; r0 < nrows; r0 += nwaves) {
+#pragma unroll
+      for (int k = 0; k < WX; ++k) {
+        const int x = k * 64 + lane;
+        const u64 outside = El[r0 * WX + k] & Rl[rowsz + r0 * WX + k];
+        if (x < W) gdst[(int64_t)r0 * W + x] = ((outside >> lane) & 1ull) ? (T)0 : (T)1;
+      }
+    }
+  };
+  bool ok = true;
+  for (int it = 0; it < kFusedIters; ++it) {
+    const int any = relax_slab_waves<WX>(El, Rl, nz, H);
+    if (nslabs == 1) break;
+    // publish my boundary planes, then meet the other slabs of this grid
+    u64* mine = hb + ((int64_t)(it & 1) * nslabs + slab) * 2 * rowsz;
+    for (int i = threadIdx.x; i < rowsz; i += blockDim.x) {
+      mine[i] = Rl[rowsz + i];
+      mine[rowsz + i] = Rl[(size_t)nz * rowsz + i];
+    }
+    __syncthreads();
+    __shared__ int s_go;
+    if (threadIdx.x == 0) {
+      if (any || it == 0) __hip_atomic_fetch_or(&c->flag[it], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&c->count[it], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      while (ld_acquire(&c->count[it]) < nslabs && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(8);
+      const int arrived = ld_acquire(&c->count[it]);
+      s_go = arrived < nslabs ? -1 : ld_acquire(&c->flag[it]);
+    }
+    __syncthreads();
+    const int go = s_go;
+    __syncthreads();
+    if (go < 0) { ok = false; break; }          // a partner never arrived (should not happen)
+    if (go == 0) break;                         // no slab of this grid changed: fixed point
+    if (it + 1 == kFusedIters) { ok = false; break; }
+    // neighbours' boundary planes -> halos (acquire above made them visible)
+    const u64* par = hb + (int64_t)(it & 1) * nslabs * 2 * rowsz;
+    for (int i = threadIdx.x; i < rowsz; i += blockDim.x) {
+      if (slab > 0) Rl[i] = __builtin_nontemporal_load(par + ((int64_t)(slab - 1) * 2 + 1) * rowsz + i);
+      if (slab + 1 < nslabs) Rl[(size_t)(nz + 1) * rowsz + i] = __builtin_nontemporal_load(par + ((int64_t)(slab + 1) * 2) * rowsz + i);
+    }
+    __syncthreads();
+  }
+  // on failure nothing is written: the caller re-runs the multi-launch path on the untouched input
+  if (!ok) { if (threadIdx.x == 0) atomicOr(status, 1); return; }
+  store_slab();
+}
+
+constexpr int kMaxRounds = 4096;
+
+constexpr int CRN_EAGAIN = -1000;     // internal: use the multi-launch path
+constexpr size_t kSweepLds = 144 * 1024;
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+inline size_t fused_offset(int64_t nwords) { return 2 * align256((size_t)nwords * 8) + 4096 * sizeof(int) + 256; }
+
+template <typename T, int WX>
+int launch_fused(const T* grid, T* out, int G, int D, int H, int W, int zs, int nslabs, size_t lds, u64* halo,
+                 FusedCtl* ctl, int* status, hipStream_t st) {
+  auto k = fill_fused_kernel<T, WX>;
+  if (lds > 65536) CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, dim3(G * nslabs), dim3(1024), lds, st, grid, out, D, H, W, zs, nslabs, halo, ctl, status);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+template <typename T>
+int run_fill_fused(const T* grid, T* out, int N, int D, int H, int W, int WX, void* ws, hipStream_t st) {
+  static const bool off = getenv("CRN_FILL_MULTI") != nullptr;
+  if (off) return CRN_EAGAIN;
+  const size_t plane = (size_t)H * WX * 8;
+  const int zs_max = (int)std::min<size_t>((size_t)D, (kSweepLds / plane - 2) / 2);
+  if (zs_max < 1) return CRN_EAGAIN;
+  const int nslabs_min = (D + zs_max - 1) / zs_max;
+  static const int kResident = [] {                    // workgroups guaranteed co-resident: one per CU
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    return cus;
+  }();
+  if (kResident < 1) return CRN_EAGAIN;
+  if (nslabs_min > kResident) return CRN_EAGAIN;
+  const int G = std::min(N, kResident / nslabs_min);   // grids per launch
+  // at least 4 planes per slab (when the LDS allows it): every slab boundary is a potential exchange round
+  int nslabs = std::min(std::max(nslabs_min, (D + 3) / 4), std::max(nslabs_min, kResident / G));
+  int zs = (D + nslabs - 1) / nslabs;
+  nslabs = (D + zs - 1) / zs;
+  const size_t lds = (size_t)(2 * zs + 2) * plane;
+  const int64_t nwords = (int64_t)N * D * H * WX;
+  char* base = reinterpret_cast<char*>(ws) + fused_offset(nwords);
+  FusedCtl* ctl = reinterpret_cast<FusedCtl*>(base);
+  int* status = reinterpret_cast<int*>(base + align256((size_t)N * sizeof(FusedCtl)));
+  u64* halo = reinterpret_cast<u64*>(base + align256((size_t)N * sizeof(FusedCtl)) + 256);
+  CRN_HIP(hipMemsetAsync(base, 0, align256((size_t)N * sizeof(FusedCtl)) + 256, st));
+  const int64_t gstride = (int64_t)D * H * W;
+  const int64_t hstride = (int64_t)nslabs * 2 * 2 * H * WX;
+  for (int g0 = 0; g0 < N; g0 += G) {
+    const int Gn = std::min(G, N - g0);
+    int rc = CRN_EINVAL;
+#define CRN_FUSED(K) case K: rc = launch_fused<T, K>(grid + g0 * gstride, out + g0 * gstride, Gn, D, H, W, zs, nslabs, lds, \
+                                                     halo + g0 * hstride, ctl + g0, status, st); break;
+    switch (WX) { CRN_FUSED(1) CRN_FUSED(2) CRN_FUSED(3) CRN_FUSED(4) CRN_FUSED(5) CRN_FUSED(6) CRN_FUSED(7) CRN_FUSED(8) }
+#undef CRN_FUSED
+    if (rc != CRN_OK) return rc;
+  }
+  // in-place calls cannot be repeated on failure, so the status is checked only when a retry is possible
+  if ((const void*)grid == (const void*)out) {
+    // the fused kernel leaves the slab untouched on failure: safe to check and fall back
+  }
+  int h_status = 0;
+  CRN_HIP(hipMemcpyAsync(&h_status, status, sizeof(int), hipMemcpyDeviceToHost, st));
+  CRN_HIP(hipStreamSynchronize(st));
+  return h_status ? CRN_EAGAIN : CRN_OK;
+}
 
 template <typename T>
 int run_fill(const T* grid, T* out, int N, int D, int H, int W, void* ws, hipStream_t st) {
   const int WX = (W + 63) / 64;
   if (WX > 8) return CRN_EINVAL;
   const int64_t nwords = (int64_t)N * D * H * WX;
+  {
+    const int rc = run_fill_fused<T>(grid, out, N, D, H, W, WX, ws, st);
+    if (rc != CRN_EAGAIN) return rc;
+  }
   u64* E = reinterpret_cast<u64*>(ws);
   u64* R = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + align256((size_t)nwords * 8));
   int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + 2 * align256((size_t)nwords * 8));
@@ -232,7 +558,10 @@ int run_fill(const T* grid, T* out, int N, int D, int H, int W, void* ws, hipStr
 extern "C" size_t crn_fill_voxels_workspace_bytes(int N, int D, int H, int W) {
   const int WX = (W + 63) / 64;
   const size_t nwords = (size_t)N * D * H * WX;
-  return 2 * align256(nwords * 8) + kMaxRounds * sizeof(int) + 256;
+  const size_t multi = 2 * align256(nwords * 8) + kMaxRounds * sizeof(int) + 256;
+  // single-launch path: control blocks + status + halo planes (2 parities x 2 planes per slab, <= D slabs)
+  const size_t fused = align256((size_t)N * sizeof(FusedCtl)) + 256 + (size_t)N * D * 4 * H * WX * 8 + 256;
+  return multi + fused;
 }
 
 extern "C" int crn_fill_voxels(const void* grid, void* out, int dtype, int N, int D, int H, int W,

@@ -423,6 +423,34 @@ def test_fill_full_size_shells(be):
   assert set(np.unique(o)) <= {0.0, 1.0}
 
 
+def test_fill_serpentine_and_multi_launch_path(be):
+  """A corridor that snakes up and down z behind every wall needs far more slab exchanges than the
+  single-launch kernel allows: it must hand over to the multi-launch path and still be bit-exact.
+  The multi-launch path is also run on its own (CRN_FILL_MULTI) in a fresh process."""
+  import fill_oracle_c, subprocess, sys, os
+  D, H, W = 64, 6, 64
+  g = np.zeros((2, D, H, W), np.float32)
+  g[:, 0] = 1; g[:, :, 0] = 1                  # close the z=0 and y=0 faces: seeds only on x=0
+  for i, x in enumerate(range(2, W - 1, 2)):
+    g[:, :, :, x] = 1
+    g[:, (D - 1) if i % 2 == 0 else 1, 1:, x] = 0      # gap alternates between the top and the bottom
+  g[1, 30:40, 2:5, 50:60] = 1                  # plus a solid block and an enclosed pocket
+  g[1, 33:36, 3, 53:56] = 0
+  want = fill_oracle_c.fill(g)
+  out = t.empty(g.shape, device=DEV)
+  be.fill_voxels(t.tensor(g).to(DEV), out)
+  np.testing.assert_array_equal(out.cpu().numpy(), want)
+  code = ("import sys, numpy as np, torch as t; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+          "import fill_oracle_c; from corenet_amd.backend import HipBackend;"
+          "rng = np.random.RandomState(5); g = (rng.rand(3, 40, 33, 70) < 0.4).astype(np.float32);"
+          "out = t.empty(g.shape, device='cuda'); HipBackend().fill_voxels(t.tensor(g).cuda(), out);"
+          "assert (out.cpu().numpy() == fill_oracle_c.fill(g)).all(); print('multi ok')"
+          % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+  r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CRN_FILL_MULTI="1"), capture_output=True,
+                     text=True, timeout=300)
+  assert r.returncode == 0 and "multi ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_voxelizer_known_answers(be):
   from corenet_amd.cc import fill_voxels
   from corenet_amd.geometry import voxelization
