@@ -103,15 +103,15 @@ __global__ __launch_bounds__(256) void ray_sample_fwd_kernel(
   }
 }
 
-// backward: one thread = one (x,y) column over a z segment, CCH channels;
-// consecutive z usually hit the same pixel -> run-length accumulate in
-// registers, one atomic per run.
-constexpr int CCH = 4;
+// backward: one thread = one (x,y) voxel column over a z segment and CN channels (12 = every skip
+// width, so the projection is evaluated once per voxel like in the forward); consecutive z usually
+// hit the same pixel -> run-length accumulate in registers, one atomic per run and channel.
+template <int CN>
 __global__ __launch_bounds__(256) void ray_sample_bwd_kernel(
     const float* __restrict__ dout, int64_t dout_sB, int C, int D, int H, int W, const float* matrix,
-    const float* offset, float* dmap, int64_t dmap_sB, int h, int w, int zseg) {
+    const float* offset, float* dmap, int64_t dmap_sB, int h, int w, int zseg, int dbg) {
   const int b = blockIdx.z;
-  const int cbase = blockIdx.y * CCH;
+  const int cbase = blockIdx.y * CN;
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t cols = (int64_t)H * W;
   const int nseg = (D + zseg - 1) / zseg;
@@ -122,28 +122,32 @@ __global__ __launch_bounds__(256) void ray_sample_bwd_kernel(
   const int z1 = min(D, z0 + zseg);
   const Cam cam = load_cam(matrix, offset, b);
   const int64_t S = (int64_t)D * H * W, hw = (int64_t)h * w;
-  const float* gb = dout + (int64_t)b * dout_sB + (int64_t)y * W + x;
-  float* mb = dmap + (int64_t)b * dmap_sB;
-  float acc[CCH];
+  const float* gb = dout + (int64_t)b * dout_sB + (int64_t)cbase * S + (int64_t)y * W + x;
+  float* mb = dmap + (int64_t)b * dmap_sB + (int64_t)cbase * hw;
+  float acc[CN];
 #pragma unroll
-  for (int k = 0; k < CCH; ++k) acc[k] = 0.f;
+  for (int k = 0; k < CN; ++k) acc[k] = 0.f;
   int cur = -1;
   auto flush = [&]() {
     if (cur >= 0) {
 #pragma unroll
-      for (int k = 0; k < CCH; ++k)
-        if (cbase + k < C) atomicAdd(mb + (cbase + k) * hw + cur, acc[k]);
+      for (int k = 0; k < CN; ++k)
+        if (cbase + k < C && dbg != 1) atomicAdd(mb + k * hw + cur, acc[k]);
     }
 #pragma unroll
-    for (int k = 0; k < CCH; ++k) acc[k] = 0.f;
+    for (int k = 0; k < CN; ++k) acc[k] = 0.f;
   };
   for (int z = z0; z < z1; ++z) {
-    const int po = project(cam, x, y, z, w, h);
+    // the CN loads of this step do not depend on the projection: issue them first
+    float gv[CN];
+#pragma unroll
+    for (int k = 0; k < CN; ++k)
+      gv[k] = (cbase + k < C && dbg != 2) ? __builtin_nontemporal_load(gb + k * S + (int64_t)z * H * W) : 1.f;
+    const int po = dbg == 3 ? (y * w + x) : project(cam, x, y, z, w, h);
     if (po != cur) { flush(); cur = po; }
     if (po >= 0) {
 #pragma unroll
-      for (int k = 0; k < CCH; ++k)
-        if (cbase + k < C) acc[k] += gb[(cbase + k) * S + (int64_t)z * H * W];
+      for (int k = 0; k < CN; ++k) acc[k] += gv[k];
     }
   }
   flush();
@@ -181,11 +185,18 @@ extern "C" int crn_ray_sample_bwd(const float* dout, int64_t dout_sB, int B, int
       for (int b = 0; b < B; ++b) CRN_HIP(hipMemsetAsync(dmap + b * dmap_sB, 0, (size_t)C * h * w * 4, st));
     }
   }
-  const int zseg = D >= 64 ? 16 : (D >= 16 ? 8 : D);
+  const int dbg = getenv("CRN_RAY_DBG") ? atoi(getenv("CRN_RAY_DBG")) : 0;
+  const int zseg = getenv("CRN_RAY_ZSEG") ? atoi(getenv("CRN_RAY_ZSEG")) : (D >= 16 ? 8 : D);
   const int nseg = (D + zseg - 1) / zseg;
-  dim3 grid((unsigned)crn_cdiv((int64_t)H * W * nseg, 256), (unsigned)crn_cdiv(C, CCH), (unsigned)B);
-  hipLaunchKernelGGL(ray_sample_bwd_kernel, grid, dim3(256), 0, st, dout, dout_sB, C, D, H, W, matrix, offset,
-                     dmap, dmap_sB, h, w, zseg);
+  if (C % 12 == 0) {
+    dim3 grid((unsigned)crn_cdiv((int64_t)H * W * nseg, 256), (unsigned)(C / 12), (unsigned)B);
+    hipLaunchKernelGGL(ray_sample_bwd_kernel<12>, grid, dim3(256), 0, st, dout, dout_sB, C, D, H, W, matrix, offset,
+                       dmap, dmap_sB, h, w, zseg, dbg);
+  } else {
+    dim3 grid((unsigned)crn_cdiv((int64_t)H * W * nseg, 256), (unsigned)crn_cdiv(C, 4), (unsigned)B);
+    hipLaunchKernelGGL(ray_sample_bwd_kernel<4>, grid, dim3(256), 0, st, dout, dout_sB, C, D, H, W, matrix, offset,
+                       dmap, dmap_sB, h, w, zseg, dbg);
+  }
   CRN_CHECK_LAUNCH();
   return CRN_OK;
 }
