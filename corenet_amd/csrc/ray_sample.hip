@@ -123,13 +123,12 @@ __device__ __forceinline__ void project_uv(const Cam& c, float x, float y, float
 // the tile can reach (bounding box of the projected box corners), and the window goes to HBM
 // with one atomic per touched (pixel, channel).  Pixels outside the window (box straddling the
 // camera plane, or a window larger than the LDS budget) fall back to global atomics.
-constexpr int kTMax = 16;                      // tile edge: 16 for grids >= 64, else 8 (more workgroups)
+constexpr int kTMax = 16;                      // tile: 32x8 columns (full 128-B rows) for grids >= 64, else 8x8
 constexpr int kWinFloats = 12 * 1024;          // 48 KiB of LDS
 template <int CN>
 __global__ __launch_bounds__(kTMax * kTMax) void ray_sample_bwd_kernel(
     const float* __restrict__ dout, int64_t dout_sB, int C, int D, int H, int W, const float* matrix,
-    const float* offset, float* dmap, int64_t dmap_sB, int h, int w, int zseg, int tilesX, int tilesY, int kTX) {
-  const int kTY = kTX;
+    const float* offset, float* dmap, int64_t dmap_sB, int h, int w, int zseg, int tilesX, int tilesY, int kTX, int kTY) {
   __shared__ float win[kWinFloats];
   __shared__ int wbox[4];
   const int b = blockIdx.z;
@@ -250,16 +249,17 @@ extern "C" int crn_ray_sample_bwd(const float* dout, int64_t dout_sB, int B, int
   }
   const int zseg = D >= 32 ? 16 : (D >= 16 ? 8 : D);
   const int nseg = (D + zseg - 1) / zseg;
-  const int kT = (W >= 64 && H >= 64) ? 16 : 8;
-  const int tilesX = crn_cdiv(W, kT), tilesY = crn_cdiv(H, kT);
+  const bool big = W >= 64 && H >= 64;
+  const int kTX = big ? 32 : 8, kTY = 8;
+  const int tilesX = crn_cdiv(W, kTX), tilesY = crn_cdiv(H, kTY);
   if (C % 12 == 0) {
     dim3 grid((unsigned)(tilesX * tilesY * nseg), (unsigned)(C / 12), (unsigned)B);
-    hipLaunchKernelGGL(ray_sample_bwd_kernel<12>, grid, dim3(kT * kT), 0, st, dout, dout_sB, C, D, H, W, matrix,
-                       offset, dmap, dmap_sB, h, w, zseg, tilesX, tilesY, kT);
+    hipLaunchKernelGGL(ray_sample_bwd_kernel<12>, grid, dim3(kTX * kTY), 0, st, dout, dout_sB, C, D, H, W, matrix,
+                       offset, dmap, dmap_sB, h, w, zseg, tilesX, tilesY, kTX, kTY);
   } else {
     dim3 grid((unsigned)(tilesX * tilesY * nseg), (unsigned)crn_cdiv(C, 4), (unsigned)B);
-    hipLaunchKernelGGL(ray_sample_bwd_kernel<4>, grid, dim3(kT * kT), 0, st, dout, dout_sB, C, D, H, W, matrix,
-                       offset, dmap, dmap_sB, h, w, zseg, tilesX, tilesY, kT);
+    hipLaunchKernelGGL(ray_sample_bwd_kernel<4>, grid, dim3(kTX * kTY), 0, st, dout, dout_sB, C, D, H, W, matrix,
+                       offset, dmap, dmap_sB, h, w, zseg, tilesX, tilesY, kTX, kTY);
   }
   CRN_CHECK_LAUNCH();
   return CRN_OK;

@@ -16,7 +16,8 @@ def collect(c):
   for f in glob.glob(f"/tmp/pt_{c}/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
       if r["Counter_Name"] != c: continue
-      key = (r["Kernel_Name"].split("(")[0].replace("void ", "").strip(), int(r["Grid_Size"]))
+      nm = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+      key = (nm.split("(")[0].strip(), int(r["Grid_Size"]))
       a = acc.setdefault(key, [0.0, 0]); a[0] += float(r["Counter_Value"]); a[1] += 1
   return {k: v[0] / v[1] for k, v in acc.items()}, {k: v[1] for k, v in acc.items()}
 F, nF = collect("FETCH_SIZE"); W, nW = collect("WRITE_SIZE")
@@ -25,7 +26,7 @@ out = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, -
        "kernels": {}}
 for k in sorted(F, key=lambda k: -F[k] - W.get(k, 0)):
   name, grid = k
-  if not any(s in name for s in ("conv_fwd_kernel", "conv_wgrad_kernel", "ray_sample", "fill", "pointwise")): continue
+  if not any(s in name for s in ("conv_fwd_kernel", "conv_wgrad_kernel", "ray_sample", "fill_fused", "pointwise")): continue
   f_kb = 2.0 * F[k]; w_kb = W.get(k, 0.0)
   out["kernels"][f"{name} grid {grid}"] = {"launches": nF[k], "FETCH_SIZE_KB_x2": round(f_kb, 1), "WRITE_SIZE_KB": round(w_kb, 1),
                                            "hbm_bytes": int((f_kb + w_kb) * 1024)}
