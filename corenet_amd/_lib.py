@@ -65,6 +65,7 @@ _SIGS = {
     "crn_ray_sample_bwd": [vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp],
     "crn_loss_fwd_bwd": [i32, vp, vp, i32, i32, i64, vp, vp, f32, vp, sz, vp],
     "crn_argmax_confusion": [vp, vp, i32, i32, i64, vp, vp, vp],
+    "crn_softmax_superres": [vp, i32, i32, i32, i32, i32, i32, vp, vp],
     "crn_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp],
     "crn_fill_voxels": [vp, vp, i32, i32, i32, i32, i32, vp, sz, vp],
     "crn_voxelize_mesh": [vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp],

@@ -155,6 +155,9 @@ class HipBackend:
     self.lib.crn_loss_fwd_bwd(kind, ptr(logits), ptr(gt_i32), B, Cn, S, ptr(loss), ptr(dlogits),
                               grad_scale, ptr(ws), n, _lib.stream())
 
+  def softmax_superres(self, logits, m, B, Cn, D, H, W, out):
+    self.lib.crn_softmax_superres(ptr(logits), m, B, Cn, D, H, W, ptr(out), _lib.stream())
+
   def argmax_confusion(self, logits, gt_i32, B, Cn, S, labels, cm):
     self.lib.crn_argmax_confusion(ptr(logits), ptr(gt_i32), B, Cn, S, ptr(labels), ptr(cm), _lib.stream())
 

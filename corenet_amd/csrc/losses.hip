@@ -232,3 +232,47 @@ extern "C" int crn_argmax_confusion(const float* logits, const int32_t* gt, int 
   CRN_CHECK_LAUNCH();
   return CRN_OK;
 }
+
+// ---- multi-offset inference epilogue (super_resolution.py:92-125) -----------------------------
+// pmf = softmax over classes of the logits of offset n = (iz*m + iy)*m + ix, written to the
+// interleaved grid out[b][c][z*m+iz][y*m+iy][x*m+ix]: the reference's softmax + stack + reshape +
+// 8-axis permute + reshape as one pass with coalesced writes.  m == 1 is a plain channel softmax.
+namespace {
+template <int CT>
+__global__ __launch_bounds__(256) void softmax_superres_kernel(const float* __restrict__ logits, int m, int B, int C,
+                                                               int D, int H, int W, float* __restrict__ out) {
+  const int64_t So = (int64_t)D * m * H * m * W * m, S = (int64_t)D * H * W;
+  const int b = blockIdx.y;
+  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < So; o += (int64_t)gridDim.x * blockDim.x) {
+    const int Wo = W * m, Ho = H * m;
+    const int X = (int)(o % Wo), Y = (int)((o / Wo) % Ho), Z = (int)(o / ((int64_t)Wo * Ho));
+    const int n = ((Z % m) * m + (Y % m)) * m + (X % m);
+    const int64_t s = ((int64_t)(Z / m) * H + (Y / m)) * W + (X / m);
+    const float* src = logits + (((int64_t)n * B + b) * C) * S + s;
+    float v[CT];
+    float mx = -3.4e38f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) { v[c] = c < C ? src[(int64_t)c * S] : -3.4e38f; mx = fmaxf(mx, v[c]); }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) { v[c] = c < C ? expf(v[c] - mx) : 0.f; sum += v[c]; }
+    float* dst = out + ((int64_t)b * C) * So + o;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) if (c < C) dst[(int64_t)c * So] = v[c] / sum;
+  }
+}
+}  // namespace
+
+extern "C" int crn_softmax_superres(const float* logits, int m, int B, int C, int D, int H, int W, float* out,
+                                    crnStream stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!logits || !out || m < 1 || B < 1 || C < 1 || C > 32 || D < 1 || H < 1 || W < 1) return CRN_EINVAL;
+  const int64_t So = (int64_t)D * H * W * m * m * m;
+  dim3 grid((unsigned)std::min<int64_t>(crn_cdiv(So, 256), 65535), (unsigned)B);
+#define CRN_SM(CT) hipLaunchKernelGGL(softmax_superres_kernel<CT>, grid, dim3(256), 0, st, logits, m, B, C, D, H, W, out)
+  if (C <= 2) CRN_SM(2); else if (C <= 4) CRN_SM(4); else if (C <= 8) CRN_SM(8);
+  else if (C <= 16) CRN_SM(16); else CRN_SM(32);
+#undef CRN_SM
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}

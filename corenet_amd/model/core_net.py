@@ -163,6 +163,46 @@ class CoreNet(nn.Module):
     plan = self.engine.plan(B)
     return plan.forward(image, v2s, off, training=self.training).clone()
 
+  # multi-offset inference (super_resolution.py:114-129) ------------------------------------
+  def multi_offset_pmf(self, image: t.Tensor, voxel_projection_matrix: t.Tensor, grid_offsets: t.Tensor,
+                       resolution_multiplier: int = 0) -> t.Tensor:
+    """softmax(model(image, v2s, offset)) for every offset in grid_offsets [n, B, 3].
+    The reference re-runs the whole network per offset (super_resolution.py:123-125); in eval mode the
+    encoder does not depend on the offset, so it runs ONCE here and only the skip compression, the
+    ray sampling and the 3D decoder run per offset -- identical results, n-1 encoder passes saved.
+    resolution_multiplier m > 0 (with n == m^3 in the reference's offset order): returns the interleaved
+    [B, C, m*D, m*H, m*W] grid directly; 0: returns [n, B, C, D, H, W] like MultiOffsetInferenceFn."""
+    assert not self.training, "multi-offset inference is an eval-mode path (running BatchRenorm statistics)"
+    assert image.dtype == t.uint8 and image.dim() == 4 and image.shape[1] == 3
+    B = image.shape[0]
+    assert voxel_projection_matrix.shape == (B, 4, 4)
+    assert grid_offsets.dim() == 3 and grid_offsets.shape[1:] == (B, 3)
+    if not image.is_cuda:
+      raise ValueError("Only CUDA(HIP) tensors are supported by corenet_amd.CoreNet")
+    n = grid_offsets.shape[0]
+    m = int(resolution_multiplier)
+    if m > 0 and n != m ** 3:
+      raise ValueError("resolution_multiplier**3 offsets expected")
+    self.engine.weights_dirty = True
+    plan = self.engine.plan(B)
+    v2s = voxel_projection_matrix.to(t.float32).contiguous()
+    offs = grid_offsets.to(t.float32).contiguous()
+    C = self.engine.num_classes
+    D, H, W = plan.logits.shape[2:]
+    with t.no_grad():
+      plan.forward_encoder(image.contiguous(), training=False)
+      stash = t.empty((n, B, C, D, H, W), dtype=plan.logits.dtype, device=plan.logits.device)
+      for i in range(n):
+        stash[i].copy_(plan.forward_decoder(v2s, offs[i], training=False))
+      be = self.engine.be
+      if m > 0:
+        out = t.empty((B, C, m * D, m * H, m * W), dtype=stash.dtype, device=stash.device)
+        be.softmax_superres(stash, m, B, C, D, H, W, out)
+        return out
+      out = t.empty_like(stash)
+      be.softmax_superres(stash, 1, n * B, C, D, H, W, out)      # plain channel softmax
+      return out
+
   # fused training step (bench.py / the train hot loop pipeline.py:215-240) ------
   def train_step(self, image: t.Tensor, voxel_projection_matrix: t.Tensor,
                  voxel_sample_locations: t.Tensor, grid: t.Tensor, loss: str = "iou_fgbg",

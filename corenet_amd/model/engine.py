@@ -440,15 +440,17 @@ class Plan:
 
   # ------------------------------------------------------------------ forward
   def forward(self, image_u8: t.Tensor, v2s: t.Tensor, offset: t.Tensor, training: bool) -> t.Tensor:
+    self.forward_encoder(image_u8, training)
+    return self.forward_decoder(v2s, offset, training)
+
+  def forward_encoder(self, image_u8: t.Tensor, training: bool):
+    """ResNet-50 features + global average (resnet50.py:176-186).  In eval mode the result does not depend
+    on the sampling offset, so multi-offset inference (super_resolution.py:123-125) runs it once."""
     eng, be, B = self.eng, self.be, self.B
     if eng.weights_dirty:
       eng.pack_weights()
     cv, bn = eng.convs, eng.bns
     self.training = training
-    self.offset.copy_(offset)
-    # layer matrices v2s @ scale(128 / r) for the four skip grids (reconstruction_decoder.py:111-116)
-    v = v2s.to(self.layer_mats.dtype).reshape(1, B, 4, 4)
-    self.layer_mats.copy_((v * self.layer_scales).reshape(4, B, 16))    # exact: column scaling
     be.preprocess(image_u8, self.img)
     # stem (resnet50.py:122-131)
     c1 = cv["encoder.stage1.conv."]
@@ -461,6 +463,15 @@ class Plan:
       cur = self._block_fwd(blk, cur, training)
     f5 = self.feat["stage5"]
     be.relu_mean_fwd(f5, B, 2048, 64, f5.stride(0), self.avg)
+
+  def forward_decoder(self, v2s: t.Tensor, offset: t.Tensor, training: bool) -> t.Tensor:
+    """Offset channels, skip compression + ray sampling, 3D decoder (reconstruction_decoder.py:97-151)."""
+    eng, be, B = self.eng, self.be, self.B
+    cv, bn = eng.convs, eng.bns
+    self.offset.copy_(offset)
+    # layer matrices v2s @ scale(128 / r) for the four skip grids (reconstruction_decoder.py:111-116)
+    v = v2s.to(self.layer_mats.dtype).reshape(1, B, 4, 4)
+    self.layer_mats.copy_((v * self.layer_scales).reshape(4, B, 16))    # exact: column scaling
     for k in ("stage2", "stage3", "stage4", "stage5"):
       ft = self.feat[k]
       be.fill_offset_channels(ft, B, ft.stride(0), ft.shape[2] * ft.shape[3], ft.shape[1] - 3, self.offset)

@@ -190,6 +190,13 @@ size_t crn_loss_workspace_bytes(int B, int C);
 int crn_argmax_confusion(const float* logits, const int32_t* gt, int B, int C, int64_t S,
                          int32_t* labels, int64_t* cm, crnStream s);
 
+/* Multi-offset inference epilogue (super_resolution.py:92-125): logits [m^3][B][C][D][H][W], one
+ * native-resolution forward per sampling offset n = (iz*m+iy)*m+ix (offset = (ix,iy,iz)/m);
+ * out [B][C][mD][mH][mW] = softmax over C, interleaved: out[b][c][z*m+iz][y*m+iy][x*m+ix].
+ * m == 1: plain channel softmax (pipeline inference_fn, super_resolution.py:121-126).          */
+int crn_softmax_superres(const float* logits, int m, int B, int C, int D, int H, int W, float* out,
+                         crnStream s);
+
 /* ---------------- optimizer --------------------------------------------------
  * torch.optim.Adam step (state.py:65; train hot loop pipeline.py:230) on a flat
  * fp32 parameter slab.  grad_scale multiplies the gradient first (1/world).   */

@@ -676,3 +676,27 @@ def synthetic_batch(batch: int, seed: int = 0, num_classes: int = 2,
       ball = ((xx + 0.5 - cx) ** 2 + (yy + 0.5 - 0.5 * H) ** 2 + (zz + 0.5 - 0.5 * D) ** 2) <= r * r
       grid[b][ball] = 1 if num_classes == 2 else (1 + (3 * b + k) % (num_classes - 1))
   return image, v2s, offset, grid
+
+
+# ----------------------------------------------------------------------------
+# super-resolution inference (super_resolution.py:46-129)
+def super_resolution_offsets(m: int, grid_offsets: t.Tensor) -> t.Tensor:
+  """super_resolution.py:66-90: f32[m^3, B, 3]; index n=(iz*m+iy)*m+ix -> ((ix,iy,iz)+grid_offset)/m."""
+  zz, yy, xx = t.meshgrid([t.arange(m)] * 3, indexing="ij")
+  offsets = (t.stack([xx, yy, zz], -1) / m).reshape([-1, 3])
+  return offsets[:, None] + grid_offsets[None, :] / m
+
+
+def super_resolution(sd, image_u8, camera_transform, view_to_voxel, grid_offsets, m: int):
+  """super_resolution.py:92-126 with the model evaluated in eval mode: pmf f32[B, C, mD, mH, mW].
+  One full forward per offset, exactly like the reference."""
+  native = super_resolution_offsets(m, grid_offsets)
+  v2v = view_to_voxel @ scale([1.0 / m] * 3)
+  v2s = camera_transform @ v2v.inverse()
+  pm = []
+  for off in native:
+    pm.append(corenet_forward(sd, image_u8, v2s, off, training=False).softmax(dim=1))
+  pm = t.stack(pm, 0)
+  _, B, C, d, h, w = pm.shape
+  pm = pm.reshape([m, m, m, B, C, d, h, w]).permute([3, 4, 5, 0, 6, 1, 7, 2])
+  return pm.reshape([B, C, m * d, m * h, m * w])

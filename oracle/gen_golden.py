@@ -201,7 +201,42 @@ def gen_losses():
   print("[losses] ok")
 
 
+def gen_super_resolution():
+  """x2 super-resolution (super_resolution.py:46-129) of the h7 eval model, B=1: the reference's own
+  SuperResolutionInference + super_resolution_from_state, 8 full forwards.  corenet.pipeline / corenet.state
+  cannot be imported here (jq, tensorboard, ...): they are replaced by empty modules that only provide the
+  base class / type name super_resolution.py refers to; every line that computes is the reference's."""
+  pm = types.ModuleType("corenet.pipeline"); pm.InferenceFn = type("InferenceFn", (), {})
+  sm = types.ModuleType("corenet.state"); sm.State = type("State", (), {})
+  sys.modules["corenet.pipeline"] = pm; sys.modules["corenet.state"] = sm
+  import corenet as _c
+  _c.pipeline, _c.state = pm, sm
+  from corenet import super_resolution as SR
+  sd = O.make_state(seed=0, num_classes=2, nbt=100)
+  image, v2s, off, _ = O.synthetic_batch(1, seed=0, num_classes=2)
+  net = ref_model(2, sd); net.eval()
+  state = sm.State(); state.model = net
+  camera = O.canonical_camera()[None]
+  v2v = O.scale([128.0] * 3)[None]                      # view -> voxel of the native grid (pipeline.py:148)
+  go = t.full((1, 3), 0.5)
+  with t.no_grad():
+    sr = SR.super_resolution_from_state(state)
+    pmf = sr(image, camera, v2v, go, (256, 256, 256))
+    po = O.super_resolution(sd, image, camera, v2v, go, 2)
+  print(f"[super_resolution] oracle vs reference pmf max-abs = {float((po - pmf).abs().max()):.3e}")
+  assert float((po - pmf).abs().max()) < 1e-5
+  np.savez_compressed(os.path.join(OUT, "super_resolution_h7_x2.npz"),
+                      pmf_sub=pmf[:, :, ::16, ::16, ::16].numpy(), pmf_odd=pmf[:, :, 1::32, 1::32, 1::32].numpy(),
+                      pmf_sum=np.float64(pmf.double().sum().item()),
+                      fg_sum=np.float64(pmf[:, 1].double().sum().item()),
+                      native_offsets=sr.get_native_offsets((256, 256, 256), go).numpy())
+  print("[super_resolution] ok")
+
+
 if __name__ == "__main__":
+  if "--only-super-resolution" in sys.argv:
+    gen_super_resolution()
+    sys.exit(0)
   gen_batch_renorm()
   gen_sample_grid2d()
   gen_losses()
@@ -209,4 +244,5 @@ if __name__ == "__main__":
   gen_model("h7_train_b2_nbt30k", 2, 30000, 2, "iou_fgbg")
   gen_model("h7_eval_b1", 2, 100, 1, "iou_fgbg", training=False)
   gen_model("m9_train_b1", 14, 0, 1, "xent_times_iou_agnostic")
+  gen_super_resolution()
   print("golden fixtures written to", OUT)

@@ -254,6 +254,11 @@ class EmuBackend:
       v.backward()
       dlogits.copy_(l.grad * grad_scale)
 
+  def softmax_superres(self, logits, m, B, Cn, D, H, W, out):
+    # super_resolution.py:105-112 (reshape/permute) after the per-offset softmax (:124)
+    pm = logits.view(m, m, m, B, Cn, D, H, W).softmax(dim=4)
+    out.view(B, Cn, D * m, H * m, W * m).copy_(pm.permute(3, 4, 5, 0, 6, 1, 7, 2).reshape(B, Cn, m * D, m * H, m * W))
+
   def argmax_confusion(self, logits, gt_i32, B, Cn, S, labels, cm):
     lab = logits.argmax(1)
     if labels is not None: labels.copy_(lab.to(t.int32))

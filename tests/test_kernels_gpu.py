@@ -237,6 +237,19 @@ def test_batch_renorm(be, B, C, S, pre, post, nbt):
   close(res[1][4], sd["running_var"], 1e-5, "running_var vs oracle")
 
 
+@pytest.mark.parametrize("m,B,C,dims", [(1, 3, 2, (5, 6, 7)), (2, 2, 14, (4, 5, 6)), (3, 1, 5, (3, 4, 5)), (2, 1, 2, (16, 16, 16))])
+def test_softmax_superres(be, m, B, C, dims):
+  g = t.Generator().manual_seed(m * 10 + C)
+  D, H, W = dims
+  logits = t.randn(m ** 3, B, C, D, H, W, generator=g) * 4
+  want = t.empty(B, C, m * D, m * H, m * W)
+  EMU.softmax_superres(logits, m, B, C, D, H, W, want)
+  got = t.full((B, C, m * D, m * H, m * W), -1.0, device=DEV)
+  be.softmax_superres(logits.to(DEV), m, B, C, D, H, W, got)
+  close(got, want, 2e-6, "softmax_superres")
+  assert float((got.sum(1) - 1).abs().max()) < 1e-5
+
+
 def test_elementwise(be):
   g = t.Generator().manual_seed(9)
   B, C, S = 2, 6, 100

@@ -127,3 +127,55 @@ def test_train_step_reduces_loss_and_matches_autograd_path():
   for _ in range(3):
     l = float(m.train_step(image, v2s, off, grid, "iou_fgbg", lr=4e-4))
   assert np.isfinite(l) and l < l0
+
+
+def test_super_resolution_x2_golden_and_encoder_reuse():
+  """N1: x2 super-resolution through the drop-in of corenet.super_resolution.
+  (i) golden pmf generated by the reference's SuperResolutionInference (oracle/gen_golden.py);
+  (ii) sub-grid (iz,iy,ix) of the result == softmax of an ordinary eval forward at that offset:
+       running the encoder once instead of 8 times changes nothing beyond run-to-run rounding."""
+  from corenet_amd import super_resolution as SR
+  z = np.load(os.path.join(G, "super_resolution_h7_x2.npz"))
+  m = _model(2, O.make_state(0, 2, nbt=100)).eval()
+  image, v2s, off, _ = O.synthetic_batch(1, 0, 2)
+  camera = O.canonical_camera()[None].cuda()
+  v2v = O.scale([128.0] * 3)[None].cuda()
+  go = t.full((1, 3), 0.5).cuda()
+
+  class State: pass
+  st = State(); st.model = m
+  sr = SR.super_resolution_from_state(st)
+  assert sr.resolution == (128, 128, 128)
+  native = sr.get_native_offsets((256, 256, 256), go)
+  np.testing.assert_allclose(native.cpu().numpy(), z["native_offsets"], rtol=0, atol=0)
+  pmf = sr(image.cuda(), camera, v2v, go, (256, 256, 256))
+  assert pmf.shape == (1, 2, 256, 256, 256) and pmf.dtype == t.float32
+  # random-weight logits reach |x| ~ 1.5e4: a 3e-6-relative difference (two runs of the SAME kernels differ
+  # by that much, split-K partial sums are added with atomics) is 5e-2 in a logit and up to ~1e-2 in a
+  # probability next to the decision boundary (d softmax <= |d logit| / 4); almost all voxels are saturated
+  def pmf_close(got, want, what):
+    d = (got.cpu() - t.as_tensor(want).cpu()).abs()
+    assert float(d.max()) < 5e-2 and float(d.mean()) < 2e-5, (what, float(d.max()), float(d.mean()))
+  pmf_close(pmf[:, :, ::16, ::16, ::16], z["pmf_sub"], "golden even")
+  pmf_close(pmf[:, :, 1::32, 1::32, 1::32], z["pmf_odd"], "golden odd")
+  assert abs(float(pmf.double().sum()) - float(z["pmf_sum"])) < 1e-6 * float(z["pmf_sum"])
+  assert abs(float(pmf[:, 1].double().sum()) - float(z["fg_sum"])) < 1e-4 * float(z["pmf_sum"])
+  # the generic MultiOffsetInferenceFn path (reshape / permute on the host side) gives the same grid
+  generic = SR.SuperResolutionInference(lambda im, cam, vv, offs: SR.CoreNetMultiOffset(m)(im, cam, vv, offs),
+                                        (128, 128, 128))
+  # (two runs of the network differ in the last bits: split-K partial sums are added with atomics)
+  pmf_close(generic(image.cuda(), camera, v2v, go, (256, 256, 256)), pmf, "generic path")
+  # encoder reuse == full forward per offset
+  vs = (camera @ (v2v @ O.scale([0.5] * 3).cuda()).inverse())
+  with t.no_grad():
+    for n in (0, 3, 6, 7):
+      iz, iy, ix = n // 4, (n // 2) % 2, n % 2
+      logits = m(image.cuda(), vs, native[n])
+      one = SR.CoreNetMultiOffset(m)(image.cuda(), camera, v2v @ O.scale([0.5] * 3).cuda(), native[n:n + 1])[0]
+      pmf_close(pmf[:, :, iz::2, iy::2, ix::2], one, "single offset")
+      pmf_close(pmf[:, :, iz::2, iy::2, ix::2], logits.softmax(1), "full forward")
+  with pytest.raises(ValueError):
+    sr(image.cuda(), camera, v2v, go, (192, 256, 256))
+  m.train()
+  with pytest.raises(AssertionError):
+    sr(image.cuda(), camera, v2v, go, (256, 256, 256))

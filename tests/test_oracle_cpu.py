@@ -169,3 +169,40 @@ def test_model_golden(tag, nc, nbt, batch, training):
     logits = O.corenet_forward(sd, image, v2s, off, training=training)
   np.testing.assert_allclose(logits[:, :, ::16, ::16, ::16].numpy(), z["logits_sub"], rtol=1e-4, atol=1e-5)
   np.testing.assert_allclose(float(O.iou_fgbg(grid, logits)), z["loss"], rtol=1e-5)
+
+
+def test_super_resolution_golden_and_host_logic():
+  """x2 super-resolution: oracle restatement vs the reference's SuperResolutionInference output
+  (tests/golden/super_resolution_h7_x2.npz), and the product's host-side class (no GPU: a stand-in
+  inference function) against the same offsets / interleave rule."""
+  z = np.load(os.path.join(os.path.dirname(__file__), "golden", "super_resolution_h7_x2.npz"))
+  sd = O.make_state(0, 2, nbt=100)
+  image, v2s, off, _ = O.synthetic_batch(1, 0, 2)
+  camera = O.canonical_camera()[None]; v2v = O.scale([128.0] * 3)[None]; go = t.full((1, 3), 0.5)
+  np.testing.assert_array_equal(O.super_resolution_offsets(2, go).numpy(), z["native_offsets"])
+  with t.no_grad():
+    pmf = O.super_resolution(sd, image, camera, v2v, go, 2)
+  assert float((pmf[:, :, ::16, ::16, ::16] - t.tensor(z["pmf_sub"])).abs().max()) < 1e-6
+  assert float((pmf[:, :, 1::32, 1::32, 1::32] - t.tensor(z["pmf_odd"])).abs().max()) < 1e-6
+  assert abs(float(pmf.double().sum()) - float(z["pmf_sum"])) < 1e-7 * float(z["pmf_sum"])
+  # host class of the product with a stand-in inference function
+  from corenet_amd import super_resolution as SR
+  seen = {}
+
+  def fake(im, cam, vv, offs):
+    seen["offs"], seen["vv"] = offs, vv
+    n = offs.shape[0]
+    return (t.arange(n, dtype=t.float32).view(n, 1, 1, 1, 1, 1) + t.zeros(n, 1, 2, 4, 4, 4)
+            + t.arange(4.0).view(1, 1, 1, 1, 1, 4) / 10)
+  sr = SR.SuperResolutionInference(fake, (4, 4, 4))
+  assert sr.get_resolution_multiplier((8, 8, 8)) == 2
+  for bad in ((6, 8, 8), (2, 2, 2), (10, 10, 10)):
+    with pytest.raises(ValueError):
+      sr.get_resolution_multiplier(bad)
+  out = sr(t.zeros(1, 3, 8, 8), camera, O.scale([4.0] * 3)[None], go, (8, 8, 8))
+  np.testing.assert_array_equal(seen["offs"].numpy(), z["native_offsets"])
+  np.testing.assert_allclose(seen["vv"].numpy(), O.scale([2.0] * 3)[None].numpy())     # v2v @ scale(1/m)
+  assert out.shape == (1, 2, 8, 8, 8)
+  for n in range(8):
+    iz, iy, ix = n // 4, (n // 2) % 2, n % 2
+    assert float((out[0, 0, iz::2, iy::2, ix::2] - (n + t.arange(4.0) / 10)).abs().max()) == 0.0
