@@ -24,6 +24,12 @@ f32 = C.c_float
 sz = C.c_size_t
 
 
+class CrnTapBoxes(C.Structure):
+  """Mirror of crnTapBoxes (include/corenet_hip.h)."""
+  _fields_ = [("n_groups", C.c_int32), ("c_groups", C.c_int32), ("n_box", (C.c_int8 * 6) * 8),
+              ("c_box", (C.c_int8 * 6) * 8)]
+
+
 class CrnView(C.Structure):
   """Mirror of crnView (include/corenet_hip.h)."""
   _fields_ = [("base", vp), ("B", C.c_int32), ("C", C.c_int32), ("D", C.c_int32),
@@ -41,9 +47,9 @@ class HipError(RuntimeError):
 
 _SIGS = {
     "crn_conv_fwd": [C.POINTER(CrnView), C.POINTER(CrnInTransform), vp, i32, vp, i32,
-                     C.POINTER(CrnView), i32, i32, i32, i32, i32, i32, i32, i32, vp],
+                     C.POINTER(CrnView), i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "crn_conv_wgrad": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32,
-                       i32, i32, i32, i32, i32, i32, i32, vp],
+                       i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "crn_gather_f32": [vp, vp, vp, i64, vp],
     "crn_scatter_f32": [vp, vp, vp, i64, i32, vp],
     "crn_bias_grad": [vp, i32, i32, i64, i64, vp, i32, vp, sz, vp],

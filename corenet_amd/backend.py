@@ -40,6 +40,26 @@ def _ctr(tr: Optional[Transform]):
   return C.byref(CrnInTransform(ptr(tr.scale), ptr(tr.shift), int(tr.pre_relu), int(tr.post_relu)))
 
 
+_TAPBOXES = {}
+
+
+def _ctapboxes(boxes):
+  """(n_boxes, c_boxes) -> cached crnTapBoxes pointer (None -> NULL)."""
+  if not boxes or not (boxes[0] or boxes[1]):
+    return None
+  key = (tuple(boxes[0]), tuple(boxes[1]))
+  tb = _TAPBOXES.get(key)
+  if tb is None:
+    tb = _lib.CrnTapBoxes()
+    tb.n_groups, tb.c_groups = len(key[0]), len(key[1])
+    for g, bx in enumerate(key[0]):
+      for i, v in enumerate(bx): tb.n_box[g][i] = v
+    for g, bx in enumerate(key[1]):
+      for i, v in enumerate(bx): tb.c_box[g][i] = v
+    _TAPBOXES[key] = tb
+  return C.cast(C.pointer(tb), C.c_void_p)
+
+
 class HipBackend:
   name = "hip"
 
@@ -62,16 +82,18 @@ class HipBackend:
   # -- convolution engine -----------------------------------------------------
   def conv_fwd(self, x: View, tr: Optional[Transform], w: t.Tensor, npad: int,
                bias: Optional[t.Tensor], bias_sB: int, y: View, window, pad_lo,
-               splits: int = 1, accumulate: bool = False):
+               splits: int = 1, accumulate: bool = False, boxes=None):
+    """boxes: (n_boxes, c_boxes) tuples of conv_geometry.Geom (structural zeros of transposed convs)."""
     self.lib.crn_conv_fwd(C.byref(_cview(x)), _ctr(tr), ptr(w), npad, ptr(bias), bias_sB,
                           C.byref(_cview(y)), window[0], window[1], window[2],
-                          pad_lo[0], pad_lo[1], pad_lo[2], splits, int(accumulate), _lib.stream())
+                          pad_lo[0], pad_lo[1], pad_lo[2], splits, int(accumulate), _ctapboxes(boxes),
+                          _lib.stream())
 
   def conv_wgrad(self, x: View, tr: Optional[Transform], dy: View, dw: t.Tensor, npad: int,
-                 window, pad_lo, zero_first: bool = True):
+                 window, pad_lo, zero_first: bool = True, boxes=None):
     self.lib.crn_conv_wgrad(C.byref(_cview(x)), _ctr(tr), C.byref(_cview(dy)), ptr(dw), npad,
                             window[0], window[1], window[2], pad_lo[0], pad_lo[1], pad_lo[2],
-                            int(zero_first), _lib.stream())
+                            int(zero_first), _ctapboxes(boxes), _lib.stream())
 
   def gather(self, src: t.Tensor, idx: t.Tensor, dst: t.Tensor):
     self.lib.crn_gather_f32(ptr(src), ptr(idx), ptr(dst), idx.numel(), _lib.stream())

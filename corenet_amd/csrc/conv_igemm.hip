@@ -24,6 +24,7 @@
 //    (crnInTransform), so normalised activations are never written to HBM.
 #include "conv_kernels.h"
 #include <algorithm>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 
@@ -214,7 +215,8 @@ bool fwd_cfg(int MSUB, int NSUB, int B, int Cin, int Npad, int D, int H, int W, 
 extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const float* w, int Npad,
                             const float* bias, int bias_sB, const crnView* y,
                             int kd, int kh, int kw, int pd, int ph, int pw,
-                            int splits, int accumulate, crnStream stream) {
+                            int splits, int accumulate, const crnTapBoxes* boxes, crnStream stream) {
+  if (boxes && (boxes->n_groups < 0 || boxes->n_groups > 8 || boxes->c_groups < 0 || boxes->c_groups > 8)) return CRN_EINVAL;
   if (!x || !y || !w || Npad <= 0 || (Npad & 15) || x->B != y->B || kd < 1 || kh < 1 || kw < 1)
     return CRN_EINVAL;
   if (y->C > Npad) return CRN_EINVAL;
@@ -322,6 +324,12 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
               (y->sC & 3) == 0 && (((uintptr_t)y->base) & 15) == 0 && y->chan_off == nullptr && g.mode != 2;
     g.vec_store = al ? 1 : 0;
   }
+  static const bool no_boxes = getenv("CRN_NO_BOXES") != nullptr;
+  if (boxes && !no_boxes) {
+    // groups must divide the channel counts, otherwise the information is ignored
+    if (boxes->n_groups > 0 && y->C % boxes->n_groups == 0) { g.n_groups = boxes->n_groups; memcpy(g.n_box, boxes->n_box, sizeof(g.n_box)); }
+    if (boxes->c_groups > 0 && x->C % boxes->c_groups == 0) { g.c_groups = boxes->c_groups; memcpy(g.c_box, boxes->c_box, sizeof(g.c_box)); }
+  }
   g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
   static const bool dbg = getenv("CRN_DEBUG") != nullptr;
   if (dbg)
@@ -369,13 +377,14 @@ bool wg_cand(int TD, int TH, int TW, int RSUB, int NSUB, int Cin, int Npad, int 
 }
 }  // namespace
 
-extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const crnView* dy,
-                              float* dw, int Npad, int kd, int kh, int kw, int pd, int ph, int pw,
-                              int zero_first, crnStream stream) {
-  if (!x || !dy || !dw || Npad <= 0 || (Npad & 15) || x->B != dy->B) return CRN_EINVAL;
-  hipStream_t st = (hipStream_t)stream;
+namespace {
+// One weight-gradient launch: window kd x kh x kw, which may be the sub-box (bd0,bh0,bw0) of a packed
+// window khf x kwf with Tfull taps; columns [0, ncols) of dw (row stride Npad).
+int wgrad_launch(const crnView* x, const crnInTransform* tr, const crnView* dy, float* dw, int Npad, int ncols,
+                 int kd, int kh, int kw, int pd, int ph, int pw, int Tfull, int khf, int kwf, int bd0, int bh0,
+                 int bw0, int max_blocks, hipStream_t st) {
   const int T = kd * kh * kw;
-  if (T > 512) return CRN_EINVAL;
+  const int NpadC = (ncols + 15) & ~15;          // columns this launch covers
   const int Dy = dy->D, Hy = dy->H, Wy = dy->W;
   const int TWc = Wy >= 16 ? 16 : ((Wy + 3) & ~3);
   static const bool no_vec = getenv("CRN_NO_VEC") != nullptr;
@@ -385,7 +394,7 @@ extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const 
   WgCand best{}; bool have = false;
   auto consider = [&](int TD, int TH, int RSUB, int NSUB, size_t budget) {
     WgCand c;
-    if (!wg_cand(std::min(TD, Dy), std::min(TH, Hy), TWc, RSUB, NSUB, x->C, Npad, kd, kh, kw, xlead, dvec, budget, &c))
+    if (!wg_cand(std::min(TD, Dy), std::min(TH, Hy), TWc, RSUB, NSUB, x->C, NpadC, kd, kh, kw, xlead, dvec, budget, &c))
       return false;
     if (RSUB > 1 && c.CC * T <= 32 * RSUB) return false;   // a smaller RSUB covers it
     if (!have || c.cost < best.cost) { best = c; have = true; }
@@ -405,7 +414,7 @@ extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const 
     int fTD, fTH, fR, fN;
     if (sscanf(f, "%d,%d,%d,%d", &fTD, &fTH, &fR, &fN) == 4) {
       WgCand c;
-      if (wg_cand(std::min(fTD, Dy), std::min(fTH, Hy), TWc, fR, fN, x->C, Npad, kd, kh, kw, xlead, dvec, 150 * 1024, &c)) {
+      if (wg_cand(std::min(fTD, Dy), std::min(fTH, Hy), TWc, fR, fN, x->C, NpadC, kd, kh, kw, xlead, dvec, 150 * 1024, &c)) {
         best = c; have = true;
       }
     }
@@ -415,7 +424,7 @@ extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const 
   if (xlead < 0 || !dvec) {
     // the candidate was costed with dvec; re-derive it with the variant that will run
     WgCand c;
-    if (!wg_cand(best.TD, best.TH, best.TW, best.RSUB, best.NSUB, x->C, Npad, kd, kh, kw, xlead, dvec, 150 * 1024, &c)) {
+    if (!wg_cand(best.TD, best.TH, best.TW, best.RSUB, best.NSUB, x->C, NpadC, kd, kh, kw, xlead, dvec, 150 * 1024, &c)) {
       have = false; search();
       if (!have) return CRN_EINVAL;
     } else {
@@ -436,10 +445,11 @@ extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const 
   g.CC = CC;
   g.tilesD = crn_cdiv(Dy, g.TD); g.tilesH = crn_cdiv(Hy, g.TH); g.tilesW = crn_cdiv(Wy, g.TW);
   g.ntiles = g.tilesD * g.tilesH * g.tilesW * dy->B;
-  const int cblocks = crn_cdiv(x->C, CC), nblocks = crn_cdiv(Npad, NB);
+  const int cblocks = crn_cdiv(x->C, CC), nblocks = crn_cdiv(NpadC, NB);
   static const int kWgBlocks = getenv("CRN_WG_BLOCKS") ? atoi(getenv("CRN_WG_BLOCKS")) : 512;
   // one resident round: at most kWgBlocks (= 2 per CU) workgroups, or the stragglers double the time
-  int splits = std::max(1, std::min(g.ntiles, kWgBlocks / (cblocks * nblocks)));
+  const int budget = max_blocks > 0 ? std::min(max_blocks, kWgBlocks) : kWgBlocks;
+  int splits = std::max(1, std::min(g.ntiles, budget / (cblocks * nblocks)));
   g.tiles_per_split = crn_cdiv(g.ntiles, splits);
   splits = crn_cdiv(g.ntiles, g.tiles_per_split);
   g.lg2 = ilog2_ceil(g.PH * g.PW); g.npass = xlead >= 0 ? 0 : stage_passes(CC * g.PD, g.PH * g.PW);
@@ -451,9 +461,9 @@ extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const 
     g.magic_PLU = magic20(g.plu); g.magic_PW4 = magic20(g.pw4);
   }
   if (dvec) { g.np4 = npos / 4; g.dnunits = NB * g.np4; g.magic_NP4 = magic20(g.np4); }
+  g.Tfull = Tfull; g.khf = khf; g.kwf = kwf; g.bd0 = bd0; g.bh0 = bh0; g.bw0 = bw0; g.ncols = ncols;
   g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
   g.xcd = getenv("CRN_WG_XCD") ? atoi(getenv("CRN_WG_XCD")) : 1;
-  if (zero_first) CRN_HIP(hipMemsetAsync(dw, 0, (size_t)x->C * T * Npad * 4, st));
   dim3 grid((unsigned)cblocks, (unsigned)nblocks, (unsigned)splits);
   const size_t lds_bytes = best.lds;
   static const bool dbg = getenv("CRN_DEBUG") != nullptr;
@@ -467,4 +477,34 @@ extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const 
   CRN_WG_CONFIGS(CRN_WG_CASE)
 #undef CRN_WG_CASE
   return CRN_EINVAL;
+}
+}  // namespace
+
+extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const crnView* dy,
+                              float* dw, int Npad, int kd, int kh, int kw, int pd, int ph, int pw,
+                              int zero_first, const crnTapBoxes* boxes, crnStream stream) {
+  if (!x || !dy || !dw || Npad <= 0 || (Npad & 15) || x->B != dy->B) return CRN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int T = kd * kh * kw;
+  if (T > 512) return CRN_EINVAL;
+  if (zero_first) CRN_HIP(hipMemsetAsync(dw, 0, (size_t)x->C * T * Npad * 4, st));
+  // Transposed convolutions could run one launch per output parity with that parity's real tap box
+  // (343 instead of 512 taps for k = 7).  Measured on MI355X this LOSES: eight launches of 1/8 of the work
+  // each pay their own prologue and atomic epilogue (s5t1: 1.02 ms vs 0.94 ms for the single full-window
+  // launch), so it stays an experiment (CRN_WG_BOXES=1); forward and data-gradient do use the boxes.
+  static const bool wg_boxes = getenv("CRN_WG_BOXES") != nullptr;
+  if (boxes && wg_boxes && boxes->n_groups > 1 && boxes->n_groups <= 8 && dy->C % boxes->n_groups == 0 &&
+      ((dy->C / boxes->n_groups) & 15) == 0 && dy->chan_off != nullptr) {
+    const int per = dy->C / boxes->n_groups;
+    for (int gi = 0; gi < boxes->n_groups; ++gi) {
+      const signed char* b = boxes->n_box[gi];
+      crnView dyg = *dy;
+      dyg.C = per; dyg.chan_off = dy->chan_off + (size_t)gi * per;
+      const int rc = wgrad_launch(x, tr, &dyg, dw + (size_t)gi * per, Npad, per, b[1] - b[0], b[3] - b[2], b[5] - b[4],
+                                  pd - b[0], ph - b[2], pw - b[4], T, kh, kw, b[0], b[2], b[4], 0, st);
+      if (rc != CRN_OK) return rc;
+    }
+    return CRN_OK;
+  }
+  return wgrad_launch(x, tr, dy, dw, Npad, Npad, kd, kh, kw, pd, ph, pw, T, kh, kw, 0, 0, 0, 0, st);
 }

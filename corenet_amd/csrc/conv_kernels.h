@@ -30,6 +30,8 @@ struct ConvGeom {
   int lg2, npass;          // patch staging: plane padded to 2^lg2 slots, passes of 256 slots
   unsigned magic_PW, magic_PD, magic_T;
   int vec_store;           // epilogue may use 16-B stores (unit W stride, 4-aligned rows)
+  int n_groups, c_groups;  // crnTapBoxes (0 = all taps)
+  signed char n_box[8][6], c_box[8][6];
   int lead;                // extra patch columns on the left (16-byte staging), already included in pw/PW
   int nunits, plu, pw4;    // 16-byte staging geometry (PatchDesc)
   unsigned magic_PLU, magic_PW4;
@@ -346,21 +348,41 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
 // One chunk's MFMAs.  A (k-step, zd, zh) row of KW taps is straight-line code: the tap offsets
 // along W are ds_read immediates, so a row costs MSUB+1 address adds for KW*MSUB*NSUB MFMAs.
 // nzw > 1 (with KW == 1): window widths without an unrolled variant walk the taps one by one.
+// tap box (half open) of the window that can hold non-zero weights
+struct TapBox { int d0, d1, h0, h1, w0, w1; };
+__device__ __forceinline__ TapBox box_union(const signed char (*box)[6], int groups, int nchan, int lo, int hi,
+                                            int kd, int kh, int kw) {
+  TapBox b{0, kd, 0, kh, 0, kw};
+  if (groups <= 0) return b;
+  const int per = max(1, nchan / groups);
+  const int g0 = min(lo / per, groups - 1), g1 = min(hi / per, groups - 1);
+  b = TapBox{kd, 0, kh, 0, kw, 0};
+  for (int g = g0; g <= g1; ++g) {
+    b.d0 = min(b.d0, (int)box[g][0]); b.d1 = max(b.d1, (int)box[g][1]);
+    b.h0 = min(b.h0, (int)box[g][2]); b.h1 = max(b.h1, (int)box[g][3]);
+    b.w0 = min(b.w0, (int)box[g][4]); b.w1 = max(b.w1, (int)box[g][5]);
+  }
+  return b;
+}
+__device__ __forceinline__ TapBox box_intersect(const TapBox& a, const TapBox& b) {
+  return TapBox{max(a.d0, b.d0), min(a.d1, b.d1), max(a.h0, b.h0), min(a.h1, b.h1), max(a.w0, b.w0), min(a.w1, b.w1)};
+}
+
 template <int KW, int MSUB, int NSUB>
 __device__ __forceinline__ void mfma_rows(f32x4 (&acc)[MSUB][NSUB], const float* ldsA, const float* ldsB,
                                           const int (&posbase)[MSUB], int bbase, int ksteps, const ConvGeom& g,
-                                          int nzw) {
+                                          int nzw, const TapBox& tb) {
   constexpr int NB = NSUB * 16;
   const float* pa0[MSUB];
 #pragma unroll
   for (int ms = 0; ms < MSUB; ++ms) pa0[ms] = ldsA + posbase[ms];
   const float* pb0 = ldsB + bbase;
   for (int ks = 0; ks < ksteps; ++ks)
-    for (int zd = 0; zd < g.kd; ++zd)
-      for (int zh = 0; zh < g.kh; ++zh)
+    for (int zd = tb.d0; zd < tb.d1; ++zd)
+      for (int zh = tb.h0; zh < tb.h1; ++zh)
         for (int z0 = 0; z0 < nzw; ++z0) {
-          const int aoff = ks * 4 * g.PSP + (zd * g.PH + zh) * g.PW + z0;
-          const int boff = ks * 4 * g.WSP + ((zd * g.kh + zh) * g.kw + z0) * NB;
+          const int aoff = ks * 4 * g.PSP + (zd * g.PH + zh) * g.PW + tb.w0 + z0;
+          const int boff = ks * 4 * g.WSP + ((zd * g.kh + zh) * g.kw + tb.w0 + z0) * NB;
           const float* pb = pb0 + boff;
           float a[KW][MSUB], bv[KW][NSUB];
 #pragma unroll
@@ -438,6 +460,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
 #pragma unroll
     for (int ns = 0; ns < NSUB; ++ns) acc[ms][ns] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  const TapBox nbox = box_union(g.n_box, g.n_groups, g.y.C, n0, min(n0 + NB, g.y.C) - 1, g.kd, g.kh, g.kw);
   float pval[XV ? 1 : PREG];
   f32x4 pv4[XV ? NV : 1];
   unsigned inmask = 0;
@@ -515,14 +538,18 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
     // tools/mfma_peak.hip).
     if (g.dbg != 1) {
       const int ksteps = g.CC >> 2;
-      switch (g.kw) {
-        case 1: mfma_rows<1, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, 1); break;
-        case 2: mfma_rows<2, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, 1); break;
-        case 3: mfma_rows<3, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, 1); break;
-        case 4: mfma_rows<4, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, 1); break;
-        case 5: mfma_rows<5, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, 1); break;
-        case 7: mfma_rows<7, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, 1); break;
-        default: mfma_rows<1, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, g.kw); break;
+      // taps that can hold non-zero weights for this block's output columns and this chunk's channels
+      const TapBox tb = box_intersect(nbox, box_union(g.c_box, g.c_groups, g.x.C, c0, min(c0 + g.CC, g.x.C) - 1,
+                                                      g.kd, g.kh, g.kw));
+      if (tb.d1 > tb.d0 && tb.h1 > tb.h0 && tb.w1 > tb.w0)
+      switch (tb.w1 - tb.w0) {
+        case 1: mfma_rows<1, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, 1, tb); break;
+        case 2: mfma_rows<2, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, 1, tb); break;
+        case 3: mfma_rows<3, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, 1, tb); break;
+        case 4: mfma_rows<4, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, 1, tb); break;
+        case 5: mfma_rows<5, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, 1, tb); break;
+        case 7: mfma_rows<7, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, 1, tb); break;
+        default: mfma_rows<1, MSUB, NSUB>(acc, ldsA, ldsB, posbase, bbase, ksteps, g, tb.w1 - tb.w0, tb); break;
       }
     }
   }
@@ -591,6 +618,9 @@ struct WgradGeom {
   int nunits, plu, pw4;
   unsigned magic_PLU, magic_PW4;
   int xcd;                 // XCD-aware block order
+  // tap sub-box of a larger packed window (crnTapBoxes): local tap (zd,zh,zw) is packed tap
+  // ((zd+bd0)*khf + zh+bh0)*kwf + zw+bw0 of Tfull; ncols = valid columns of this launch
+  int Tfull, khf, kwf, bd0, bh0, bw0, ncols;
   int dnunits, np4;        // 16-byte staging of dy: NB * npos/4 units, np4 = npos/4 per channel
   unsigned magic_NP4;
   int dbg;                 // tuning aid (CRN_DBG_MODE): 1 = no MFMA loop, 2 = stage only the first tile
@@ -878,11 +908,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
     for (int r = 0; r < 4; ++r) {
       const int row_ = (wave * RSUB + rs) * 16 + kk * 4 + r;
       if (row_ >= nrows) continue;
+      const int cl = mdiv(row_, g.magic_T);
+      int tl = row_ - cl * g.T;
+      const int zw = tl % g.kw; tl /= g.kw;
+      const int zh = tl % g.kh; tl /= g.kh;
+      const int64_t prow = (int64_t)(c0 + cl) * g.Tfull + ((tl + g.bd0) * g.khf + zh + g.bh0) * g.kwf + zw + g.bw0;
 #pragma unroll
       for (int ns = 0; ns < NSUB; ++ns) {
         const int n = n0 + ns * 16 + i16;
-        if (n < g.Npad)
-          atomicAdd(g.dw + ((int64_t)c0 * g.T + row_) * g.Npad + n, acc[rs][ns][r]);
+        if (n < g.ncols)
+          atomicAdd(g.dw + prow * g.Npad + n, acc[rs][ns][r]);
       }
     }
 }

@@ -17,7 +17,10 @@ ray_traced_skip_connection.py:38 (1x1 compress).
 Transposed convolution, stride 2 (per dimension, o = 2 i - p + k):
   write o = 2 q + r.  Forward: i = q + d with k = -2 d + r + p, so the layer is a
   stride-1 correlation over d in [dmin, dmax] producing 8*Cout "parity" channels
-  (n, rd, rh, rw) that the kernel's output view scatters as a pixel shuffle.
+  (rd, rh, rw, n) -- parity major -- that the kernel's output view scatters as a pixel
+  shuffle.  For k = 7 one parity uses 4 of the window's taps per dimension and the other
+  3 (343 = (4+3)^3 real taps in a 8 x 4^3 = 512 window): the per-parity tap boxes let the
+  kernels skip the structural zeros.
   Data gradient: q = i + e with k = 2 e + r + p: a stride-1 correlation of the
   space-to-depth view of dy.  No zero-insertion, no col2im, every MFMA row dense.
 """
@@ -41,6 +44,11 @@ class Geom:
   cin: int               # logical input channels
   nout: int              # logical output channels
   npad: int
+  # structural zeros of transposed convolutions: the logical output (n_boxes) or input (c_boxes)
+  # channels form len(boxes) equal contiguous groups (the 8 parities); group g only has non-zero
+  # weights for taps inside the box (d0, d1, h0, h1, w0, w1) (half-open), see crnTapBoxes
+  n_boxes: Tuple = ()
+  c_boxes: Tuple = ()
 
   @property
   def taps(self) -> int:
@@ -95,6 +103,17 @@ def _convt_ranges(ks: int, p: int):
   return dmin, dmax, emin, emax
 
 
+def _parity_boxes(valid_r_w: np.ndarray):
+  """valid_r_w[r, w]: is window position w a real tap for parity r (one dimension)?  -> the 8 tap boxes
+  (d0,d1,h0,h1,w0,w1) in (rd, rh, rw) order.  The real taps of one parity are contiguous."""
+  rng = []
+  for r in range(2):
+    pos = np.nonzero(valid_r_w[r])[0]
+    assert len(pos) > 0 and (np.diff(pos) == 1).all()
+    rng.append((int(pos[0]), int(pos[-1]) + 1))
+  return tuple(rng[rd] + rng[rh] + rng[rw] for rd in range(2) for rh in range(2) for rw in range(2))
+
+
 def convt_fwd(wshape, padding: int) -> Geom:
   """nn.ConvTranspose3d(stride 2, output_padding 1): Wt[c, n, kd, kh, kw]."""
   Cc, N, ks = wshape[0], wshape[1], wshape[2]
@@ -112,9 +131,11 @@ def convt_fwd(wshape, padding: int) -> Geom:
   kw = kk.reshape(1, 1, 1, nw, 1, 1, 1, 2); vw = valid1.reshape(1, 1, 1, nw, 1, 1, 1, 2)
   flat = (((c * N + n) * ks + kd) * ks + kh) * ks + kw
   flat = np.where(vd & vh & vw, flat, -1)                      # [C, nw,nw,nw, N, 2,2,2]
+  flat = flat.transpose(0, 1, 2, 3, 5, 6, 7, 4)                # parity major: [C, nw,nw,nw, 2,2,2, N]
   idx = np.full((Cc, nw ** 3, npad), -1, np.int64)
   idx[:, :, :N * 8] = flat.reshape(Cc, nw ** 3, N * 8)
-  return Geom((nw,) * 3, (-dmin,) * 3, idx.reshape(-1).astype(np.int32), Cc, N * 8, npad)
+  return Geom((nw,) * 3, (-dmin,) * 3, idx.reshape(-1).astype(np.int32), Cc, N * 8, npad,
+              n_boxes=_parity_boxes(valid1.T))
 
 
 def convt_dgrad(wshape, padding: int) -> Geom:
@@ -133,9 +154,11 @@ def convt_dgrad(wshape, padding: int) -> Geom:
   kw = kk.reshape(1, 1, 1, 2, 1, 1, nw, 1); vw = valid1.reshape(1, 1, 1, 2, 1, 1, nw, 1)
   flat = (((c * N + n) * ks + kd) * ks + kh) * ks + kw
   flat = np.where(vd & vh & vw, flat, -1)                      # [N,2,2,2, nw,nw,nw, C]
+  flat = flat.transpose(1, 2, 3, 0, 4, 5, 6, 7)                # parity major: [2,2,2,N, nw,nw,nw, C]
   idx = np.full((N * 8, nw ** 3, npad), -1, np.int64)
   idx[:, :, :Cc] = flat.reshape(N * 8, nw ** 3, Cc)
-  return Geom((nw,) * 3, (-emin,) * 3, idx.reshape(-1).astype(np.int32), N * 8, Cc, npad)
+  return Geom((nw,) * 3, (-emin,) * 3, idx.reshape(-1).astype(np.int32), N * 8, Cc, npad,
+              c_boxes=_parity_boxes(valid1))
 
 
 def stem_fwd(wshape=(64, 3, 7, 7), padding: int = 3) -> Geom:
@@ -181,8 +204,10 @@ def convt_1to4_dgrad(wshape) -> Geom:
   return Geom((1, 1, 1), (0, 0, 0), idx.reshape(-1).astype(np.int32), nn, Cc, npad)
 
 
-def bias_index(n_ref: int, repeat: int, npad: int) -> np.ndarray:
-  """Packed bias: logical channel j takes bias[j // repeat]."""
+def bias_index(n_ref: int, repeat: int, npad: int, parity_major: bool = False) -> np.ndarray:
+  """Packed bias: logical channel j takes bias[j // repeat] ((n, sub-position) order) or, with
+  parity_major ((sub-position, n) order: transposed convolutions), bias[j % n_ref]."""
   idx = np.full((npad,), -1, np.int64)
-  idx[:n_ref * repeat] = np.arange(n_ref * repeat) // repeat
+  j = np.arange(n_ref * repeat)
+  idx[:n_ref * repeat] = (j % n_ref) if parity_major else (j // repeat)
   return idx.astype(np.int32)

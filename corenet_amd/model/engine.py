@@ -235,7 +235,7 @@ class Engine:
       wo, bo = s.offset(name + "weight"), s.offset(name + "bias")
       def shift(ix, o):
         return np.where(ix >= 0, ix.astype(np.int64) + o, -1)
-      parts = [shift(fwd.index, wo), shift(G.bias_index(nref, repeat, fwd.npad), bo)]
+      parts = [shift(fwd.index, wo), shift(G.bias_index(nref, repeat, fwd.npad, parity_major=(repeat == 8)), bo)]
       if dgrad is not None:
         parts.append(shift(dgrad.index, wo))
       idx_parts.append(parts)
@@ -368,9 +368,11 @@ class Plan:
     return self._cached(("v", x.data_ptr(), tuple(x.shape), tuple(x.stride())), lambda: V.view_of(x))
 
   def s2d(self, x: t.Tensor, c1: int, r) -> V.View:
-    """space-to-depth / pixel-shuffle view of channels [0, c1) of x."""
+    """space-to-depth / pixel-shuffle view of channels [0, c1) of x; the 2x2x2 views of the transposed
+    convolutions are parity major (conv_geometry.convt_fwd), the stem's 1x2x2 view is channel major."""
+    pm = tuple(r) == (2, 2, 2)
     return self._cached(("s2d", x.data_ptr(), tuple(x.shape), tuple(x.stride()), c1, r),
-                        lambda: V.space_to_depth_view(self.vw(x).channels(0, c1), r))
+                        lambda: V.space_to_depth_view(self.vw(x).channels(0, c1), r, parity_major=pm))
 
   def flat(self, x: t.Tensor) -> V.View:
     return self._cached(("flat", x.data_ptr(), tuple(x.shape)), lambda: V.flat_channel_view(self.vw(x)))
@@ -404,12 +406,12 @@ class Plan:
   def _conv(self, cv: Conv, x: V.View, tr, y: V.View, accumulate=False):
     g = cv.fwd
     self._timed("fwd   " + cv.name, lambda: self.be.conv_fwd(
-        x, tr, cv.wf, g.npad, cv.bias, 0, y, g.window, g.pad_lo, 0, accumulate))
+        x, tr, cv.wf, g.npad, cv.bias, 0, y, g.window, g.pad_lo, 0, accumulate, boxes=(g.n_boxes, g.c_boxes)))
 
   def _dgrad(self, cv: Conv, dy: V.View, dx: V.View, accumulate=False):
     g = cv.dgrad
     self._timed("dgrad " + cv.name, lambda: self.be.conv_fwd(
-        dy, None, cv.wd, g.npad, None, 0, dx, g.window, g.pad_lo, 0, accumulate))
+        dy, None, cv.wd, g.npad, None, 0, dx, g.window, g.pad_lo, 0, accumulate, boxes=(g.n_boxes, g.c_boxes)))
 
   def _wgrad(self, cv: Conv, x: V.View, tr, dy: V.View):
     """Weight gradient of one conv.  On the GPU it goes to a second HIP stream: it only reads
@@ -418,7 +420,7 @@ class Plan:
     g = cv.fwd
     if self.side is None or self.trace is not None:
       self._timed("wgrad " + cv.name, lambda: self.be.conv_wgrad(
-          x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False))
+          x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes)))
       return
     if self._side_i == len(self._side_ev):
       self._side_ev.append(t.cuda.Event())
@@ -426,7 +428,7 @@ class Plan:
     ev.record()                                   # dy (and the zeroed slab) are ready on the main stream
     with t.cuda.stream(self.side):
       self.side.wait_event(ev)
-      self.be.conv_wgrad(x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False)
+      self.be.conv_wgrad(x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes))
 
   def _join_side(self):
     """Main stream waits for every weight gradient issued on the side stream."""

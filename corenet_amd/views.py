@@ -82,14 +82,16 @@ def _table(vals: np.ndarray, like: t.Tensor) -> t.Tensor:
   return tab
 
 
-def space_to_depth_view(v: View, r: Tuple[int, int, int]) -> View:
-  """Logical channels (c, rd, rh, rw) of a plain view; logical spatial dims
-  ceil(dim / r).  Element (c,rd,rh,rw | q) = v(c | r*q + (rd,rh,rw))."""
+def space_to_depth_view(v: View, r: Tuple[int, int, int], parity_major: bool = False) -> View:
+  """Logical channels (c, rd, rh, rw) of a plain view -- or (rd, rh, rw, c) with parity_major, which
+  keeps the channels of one sub-position (parity) contiguous -- ; logical spatial dims ceil(dim / r).
+  Element (c,rd,rh,rw | q) = v(c | r*q + (rd,rh,rw))."""
   assert v.chan_off is None
   rd, rh, rw = r
   c = np.arange(v.C)[:, None, None, None] * v.sC
   off = (c + np.arange(rd)[None, :, None, None] * v.sD + np.arange(rh)[None, None, :, None] * v.sH
-         + np.arange(rw)[None, None, None, :] * v.sW).reshape(-1)
+         + np.arange(rw)[None, None, None, :] * v.sW)
+  off = (off.transpose(1, 2, 3, 0) if parity_major else off).reshape(-1)
   return dataclasses.replace(
       v, C=v.C * rd * rh * rw, D=(v.D + rd - 1) // rd, H=(v.H + rh - 1) // rh,
       W=(v.W + rw - 1) // rw, sD=v.sD * rd, sH=v.sH * rh, sW=v.sW * rw,

@@ -50,6 +50,17 @@ typedef struct {
   int32_t pre_relu, post_relu;
 } crnInTransform;
 
+/* Structural zeros of the packed weights (transposed convolutions written as window correlations:
+ * each of the 8 output/input parities only uses a sub-box of the window, 343 of 8*64 taps for k=7).
+ * The logical OUTPUT channels [0, y->C) form n_groups equal contiguous groups, the logical INPUT
+ * channels [0, x->C) c_groups groups; for group g every weight with a tap outside the half-open box
+ * (d0,d1,h0,h1,w0,w1) is zero, and the kernels skip those taps.  0 groups = no information.  Host memory. */
+typedef struct {
+  int32_t n_groups, c_groups;          /* 0..8 */
+  int8_t n_box[8][6];
+  int8_t c_box[8][6];
+} crnTapBoxes;
+
 /* ---------------- convolutions (MFMA fp32 implicit GEMM) -------------------
  * One stride-1 window correlation covers Conv2d / Conv3d / ConvTranspose3d
  * forward and data-gradient of the reference (resnet50.py:62-69,95-107,124;
@@ -63,7 +74,7 @@ int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const float* w, int
                  const float* bias, int bias_sB, const crnView* y,
                  int kd, int kh, int kw, int pd, int ph, int pw,
                  int splits, int accumulate /* y += result instead of y = result */,
-                 crnStream stream);
+                 const crnTapBoxes* boxes /* may be NULL */, crnStream stream);
 
 /* Weight gradient in the same packed layout:
  *   dw[(c*T+t)*Npad+n] = sum_{b,o} T(x)[b,c,o-pad_lo+t] * dy[b,n,o]
@@ -71,7 +82,8 @@ int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const float* w, int
  * modules above.                                                             */
 int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const crnView* dy,
                    float* dw, int Npad, int kd, int kh, int kw, int pd, int ph, int pw,
-                   int zero_first, crnStream stream);
+                   int zero_first, const crnTapBoxes* boxes /* may be NULL; entries of dw at structural zeros may be left untouched */,
+                   crnStream stream);
 
 /* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0        (weight packing)            */
 int crn_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, crnStream s);

@@ -71,7 +71,8 @@ class EmuBackend:
   name = "emu"
 
   # -- convolution engine -----------------------------------------------------
-  def conv_fwd(self, x, tr, w, npad, bias, bias_sB, y, window, pad_lo, splits=1, accumulate=False):
+  def conv_fwd(self, x, tr, w, npad, bias, bias_sB, y, window, pad_lo, splits=1, accumulate=False, boxes=None):
+    # boxes only tell where the packed weights are structurally zero: no effect on the result
     xl = _transform(logical(x), tr)
     xp = _padded(xl, window, pad_lo, (y.D, y.H, y.W))
     T = window[0] * window[1] * window[2]
@@ -84,7 +85,7 @@ class EmuBackend:
         out = out + bias[:y.C].view(1, -1, 1, 1, 1)
     write_logical(y, out, accumulate)
 
-  def conv_wgrad(self, x, tr, dy, dw, npad, window, pad_lo, zero_first=True):
+  def conv_wgrad(self, x, tr, dy, dw, npad, window, pad_lo, zero_first=True, boxes=None):
     xl = _transform(logical(x), tr)
     xp = _padded(xl, window, pad_lo, (dy.D, dy.H, dy.W))
     dyl = logical(dy)

@@ -37,14 +37,14 @@ def test_convtranspose_as_window_correlation(k, p):
   bias = t.randn(Cout, generator=g, dtype=DT)
   fwd, dgr = G.convt_fwd(w.shape, p), G.convt_dgrad(w.shape, p)
   y = t.zeros(B, Cout + 2, 2 * D, 2 * D, 2 * D, dtype=DT)
-  yv = V.space_to_depth_view(V.view_of(y).channels(0, Cout), (2, 2, 2))
-  EMU.conv_fwd(V.view_of(x), None, pack(w, fwd.index), fwd.npad, pack(bias, G.bias_index(Cout, 8, fwd.npad)), 0,
+  yv = V.space_to_depth_view(V.view_of(y).channels(0, Cout), (2, 2, 2), parity_major=True)
+  EMU.conv_fwd(V.view_of(x), None, pack(w, fwd.index), fwd.npad, pack(bias, G.bias_index(Cout, 8, fwd.npad, parity_major=True)), 0,
                yv, fwd.window, fwd.pad_lo)
   ref = F.conv_transpose3d(x, w, bias, stride=2, padding=p, output_padding=1)
   assert err(y[:, :Cout], ref) < 1e-12 and float(y[:, Cout:].abs().max()) == 0
   dy = t.randn(ref.shape, generator=g, dtype=DT)
   dyb = t.zeros_like(y); dyb[:, :Cout] = dy
-  dyv = V.space_to_depth_view(V.view_of(dyb).channels(0, Cout), (2, 2, 2))
+  dyv = V.space_to_depth_view(V.view_of(dyb).channels(0, Cout), (2, 2, 2), parity_major=True)
   dx = t.zeros_like(x)
   EMU.conv_fwd(dyv, None, pack(w, dgr.index), dgr.npad, None, 0, V.view_of(dx), dgr.window, dgr.pad_lo)
   xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)

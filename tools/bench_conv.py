@@ -42,12 +42,12 @@ pk = lambda idx: t.where(t.as_tensor(idx) >= 0, w.reshape(-1)[t.as_tensor(idx).c
 wf, wd = pk(fwd.index), pk(dgr.index)
 sc, shf = (t.rand(cin) + 0.5).cuda(), t.randn(cin).cuda()
 tr = Transform(sc, shf, pre_relu=True)
-yv = V.space_to_depth_view(V.view_of(y), (2, 2, 2)) if kind == "convT" else V.view_of(y)
+yv = V.space_to_depth_view(V.view_of(y), (2, 2, 2), parity_major=True) if kind == "convT" else V.view_of(y)
 dw = t.zeros(wf.numel()).cuda()
 def run():
-  if mode == "fwd": be.conv_fwd(V.view_of(x), tr, wf, fwd.npad, None, 0, yv, fwd.window, fwd.pad_lo, 0)
-  elif mode == "dgrad": be.conv_fwd(yv, None, wd, dgr.npad, None, 0, V.view_of(x), dgr.window, dgr.pad_lo, 0)
-  else: be.conv_wgrad(V.view_of(x), tr, yv, dw, fwd.npad, fwd.window, fwd.pad_lo, True)
+  if mode == "fwd": be.conv_fwd(V.view_of(x), tr, wf, fwd.npad, None, 0, yv, fwd.window, fwd.pad_lo, 0, boxes=(fwd.n_boxes, fwd.c_boxes))
+  elif mode == "dgrad": be.conv_fwd(yv, None, wd, dgr.npad, None, 0, V.view_of(x), dgr.window, dgr.pad_lo, 0, boxes=(dgr.n_boxes, dgr.c_boxes))
+  else: be.conv_wgrad(V.view_of(x), tr, yv, dw, fwd.npad, fwd.window, fwd.pad_lo, True, boxes=(fwd.n_boxes, fwd.c_boxes))
 for _ in range(3): run()
 t.cuda.synchronize(); a = t.cuda.Event(enable_timing=True); b = t.cuda.Event(enable_timing=True)
 a.record()
