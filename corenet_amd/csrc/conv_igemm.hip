@@ -382,7 +382,7 @@ namespace {
 // window khf x kwf with Tfull taps; columns [0, ncols) of dw (row stride Npad).
 int wgrad_launch(const crnView* x, const crnInTransform* tr, const crnView* dy, float* dw, int Npad, int ncols,
                  int kd, int kh, int kw, int pd, int ph, int pw, int Tfull, int khf, int kwf, int bd0, int bh0,
-                 int bw0, int max_blocks, hipStream_t st) {
+                 int bw0, int max_blocks, const crnTapBoxes* boxes, hipStream_t st) {
   const int T = kd * kh * kw;
   const int NpadC = (ncols + 15) & ~15;          // columns this launch covers
   const int Dy = dy->D, Hy = dy->H, Wy = dy->W;
@@ -452,6 +452,28 @@ int wgrad_launch(const crnView* x, const crnInTransform* tr, const crnView* dy, 
   int splits = std::max(1, std::min(g.ntiles, budget / (cblocks * nblocks)));
   g.tiles_per_split = crn_cdiv(g.ntiles, splits);
   splits = crn_cdiv(g.ntiles, g.tiles_per_split);
+  bool balanced = false;
+  if (boxes && boxes->n_groups > 0 && boxes->n_groups <= 8 && dy->C % boxes->n_groups == 0 &&
+      (dy->C / boxes->n_groups) % NB == 0) {           // every block's columns belong to one group
+    balanced = true;
+    g.n_groups = boxes->n_groups; memcpy(g.n_box, boxes->n_box, sizeof(g.n_box));
+    // blocks of a group with fewer real taps do less MFMA work per tile: give them proportionally more
+    // tiles (fewer splits), the heavy groups more splits; the total stays within the resident budget
+    double w[8], wsum = 0.0;
+    for (int gi = 0; gi < g.n_groups; ++gi) {
+      const signed char* b = boxes->n_box[gi];
+      w[gi] = 0.35 * T + std::max(0, b[1] - b[0]) * std::max(0, b[3] - b[2]) * std::max(0, b[5] - b[4]);  // + staging share
+      wsum += w[gi];
+    }
+    g.balanced = 1; g.nbpg = (dy->C / boxes->n_groups) / NB;
+    g.zoff[0] = 0;
+    for (int gi = 0; gi < g.n_groups; ++gi) {
+      const int sgi = std::max(1, std::min(g.ntiles, (int)(splits * w[gi] * g.n_groups / wsum + 0.5)));
+      g.tps[gi] = crn_cdiv(g.ntiles, sgi);
+      g.sg[gi] = crn_cdiv(g.ntiles, g.tps[gi]);
+      g.zoff[gi + 1] = g.zoff[gi] + g.nbpg * g.sg[gi];
+    }
+  }
   g.lg2 = ilog2_ceil(g.PH * g.PW); g.npass = xlead >= 0 ? 0 : stage_passes(CC * g.PD, g.PH * g.PW);
   g.dlg2 = ilog2_ceil(npos); g.dnpass = dvec ? 0 : stage_passes(NB, npos);
   g.magic_PW = magic20(g.PW); g.magic_PD = magic20(g.PD); g.magic_T = magic20(T);
@@ -463,8 +485,9 @@ int wgrad_launch(const crnView* x, const crnInTransform* tr, const crnView* dy, 
   if (dvec) { g.np4 = npos / 4; g.dnunits = NB * g.np4; g.magic_NP4 = magic20(g.np4); }
   g.Tfull = Tfull; g.khf = khf; g.kwf = kwf; g.bd0 = bd0; g.bh0 = bh0; g.bw0 = bw0; g.ncols = ncols;
   g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
+  // (with per-group split counts the idle tail blocks must stay spread over the XCDs: plain round robin)
   g.xcd = getenv("CRN_WG_XCD") ? atoi(getenv("CRN_WG_XCD")) : 1;
-  dim3 grid((unsigned)cblocks, (unsigned)nblocks, (unsigned)splits);
+  dim3 grid((unsigned)cblocks, (unsigned)(g.balanced ? 1 : nblocks), (unsigned)(g.balanced ? g.zoff[g.n_groups] : splits));
   const size_t lds_bytes = best.lds;
   static const bool dbg = getenv("CRN_DEBUG") != nullptr;
   if (dbg)
@@ -488,10 +511,10 @@ extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const 
   const int T = kd * kh * kw;
   if (T > 512) return CRN_EINVAL;
   if (zero_first) CRN_HIP(hipMemsetAsync(dw, 0, (size_t)x->C * T * Npad * 4, st));
-  // Transposed convolutions could run one launch per output parity with that parity's real tap box
-  // (343 instead of 512 taps for k = 7).  Measured on MI355X this LOSES: eight launches of 1/8 of the work
-  // each pay their own prologue and atomic epilogue (s5t1: 1.02 ms vs 0.94 ms for the single full-window
-  // launch), so it stays an experiment (CRN_WG_BOXES=1); forward and data-gradient do use the boxes.
+  // Tap boxes: inside the single launch every block enumerates only the (channel, tap) rows of its output
+  // group's box (conv_wgrad_kernel).  The alternative -- one launch per output parity with a smaller
+  // window -- LOSES on MI355X (eight prologues and atomic epilogues: s5t1 1.02 ms vs 0.94 ms) and stays an
+  // experiment (CRN_WG_BOXES=1).
   static const bool wg_boxes = getenv("CRN_WG_BOXES") != nullptr;
   if (boxes && wg_boxes && boxes->n_groups > 1 && boxes->n_groups <= 8 && dy->C % boxes->n_groups == 0 &&
       ((dy->C / boxes->n_groups) & 15) == 0 && dy->chan_off != nullptr) {
@@ -501,10 +524,11 @@ extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const 
       crnView dyg = *dy;
       dyg.C = per; dyg.chan_off = dy->chan_off + (size_t)gi * per;
       const int rc = wgrad_launch(x, tr, &dyg, dw + (size_t)gi * per, Npad, per, b[1] - b[0], b[3] - b[2], b[5] - b[4],
-                                  pd - b[0], ph - b[2], pw - b[4], T, kh, kw, b[0], b[2], b[4], 0, st);
+                                  pd - b[0], ph - b[2], pw - b[4], T, kh, kw, b[0], b[2], b[4], 0, nullptr, st);
       if (rc != CRN_OK) return rc;
     }
     return CRN_OK;
   }
-  return wgrad_launch(x, tr, dy, dw, Npad, Npad, kd, kh, kw, pd, ph, pw, T, kh, kw, 0, 0, 0, 0, st);
+  static const bool no_boxes = getenv("CRN_NO_BOXES") != nullptr;
+  return wgrad_launch(x, tr, dy, dw, Npad, Npad, kd, kh, kw, pd, ph, pw, T, kh, kw, 0, 0, 0, 0, no_boxes ? nullptr : boxes, st);
 }

@@ -621,43 +621,52 @@ struct WgradGeom {
   // tap sub-box of a larger packed window (crnTapBoxes): local tap (zd,zh,zw) is packed tap
   // ((zd+bd0)*khf + zh+bh0)*kwf + zw+bw0 of Tfull; ncols = valid columns of this launch
   int Tfull, khf, kwf, bd0, bh0, bw0, ncols;
+  int n_groups;            // crnTapBoxes of the output columns (0 = all taps)
+  signed char n_box[8][6];
+  // balanced split counts: output group g (fewer real taps -> cheaper tiles) gets sg[g] splits of tps[g]
+  // tiles; grid.z enumerates (group, n-block in group, split) through the prefix sums zoff[], grid.y = 1, so
+  // that every launched block has work and all of them fit in the single resident round
+  int balanced, nbpg;      // nbpg = n-blocks per group
+  int tps[8], sg[8], zoff[9];
   int dnunits, np4;        // 16-byte staging of dy: NB * npos/4 units, np4 = npos/4 per channel
   unsigned magic_NP4;
   int dbg;                 // tuning aid (CRN_DBG_MODE): 1 = no MFMA loop, 2 = stage only the first tile
 };
 
 // One tile's MFMAs: a (td,th) row of WS = TW/4 k-steps is straight-line code.
-template <int WS, int RSUB, int NSUB>
+// NACT <= RSUB: row sub-tiles of this wave that hold real (channel, tap) rows; the others are skipped
+// (tap boxes of transposed convolutions leave up to 58 % of the 64-tap rows structurally zero).
+template <int WS, int RSUB, int NSUB, int NACT>
 __device__ __forceinline__ void wgrad_rows(f32x4 (&acc)[RSUB][NSUB], const float* ldsA, const float* ldsB,
                                            const int (&rowbase)[RSUB], int bbase, const WgradGeom& g) {
-  const float* pa0[RSUB];
+  const float* pa0[NACT];
 #pragma unroll
-  for (int rs = 0; rs < RSUB; ++rs) pa0[rs] = ldsA + rowbase[rs];
+  for (int rs = 0; rs < NACT; ++rs) pa0[rs] = ldsA + rowbase[rs];
   const float* pb0 = ldsB + bbase;
   for (int td = 0; td < g.TD; ++td)
     for (int th = 0; th < g.TH; ++th) {
       const int aoff = (td * g.PH + th) * g.PW;
       const float* pb = pb0 + (td * g.TH + th) * g.TW;
-      float a[WS][RSUB], bv[WS][NSUB];
+      float a[WS][NACT], bv[WS][NSUB];
 #pragma unroll
       for (int ws = 0; ws < WS; ++ws) {
 #pragma unroll
-        for (int rs = 0; rs < RSUB; ++rs) a[ws][rs] = pa0[rs][aoff + ws * 4];
+        for (int rs = 0; rs < NACT; ++rs) a[ws][rs] = pa0[rs][aoff + ws * 4];
 #pragma unroll
         for (int ns = 0; ns < NSUB; ++ns) bv[ws][ns] = pb[ns * 16 * g.POSP + ws * 4];
       }
 #pragma unroll
       for (int ws = 0; ws < WS; ++ws)
 #pragma unroll
-        for (int rs = 0; rs < RSUB; ++rs)
+        for (int rs = 0; rs < NACT; ++rs)
 #pragma unroll
           for (int ns = 0; ns < NSUB; ++ns)
             acc[rs][ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ws][rs], bv[ws][ns], acc[rs][ns], 0, 0, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, RSUB + NSUB, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NACT + NSUB, 0);
 #pragma unroll
       for (int ws = 0; ws < WS; ++ws) {
-        __builtin_amdgcn_sched_group_barrier(0x100, RSUB + NSUB, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, RSUB * NSUB, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, NACT + NSUB, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NACT * NSUB, 0);
       }
     }
 }
@@ -719,9 +728,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
   const int lin0 = blockIdx.x + nbx * (blockIdx.y + nby * blockIdx.z);
   const int lin = g.xcd ? xcd_remap(lin0, nbx * nby * gridDim.z) : lin0;
   const int c0 = (lin % nbx) * g.CC;
-  const int n0 = ((lin / nbx) % nby) * NB;
-  const int split = lin / (nbx * nby);
-  const int nrows = min(g.CC, g.x.C - c0) * g.T;
+  int n0 = ((lin / nbx) % nby) * NB;
+  int split = lin / (nbx * nby);
+  int tps = g.tiles_per_split;
+  if (g.balanced) {                        // grid.y == 1: z -> (group, n-block in group, split)
+    const int z = lin / nbx;
+    int gi = 0;
+    while (gi + 1 < g.n_groups && z >= g.zoff[gi + 1]) ++gi;
+    const int local = z - g.zoff[gi];
+    const int nbi = local / g.sg[gi];
+    split = local - nbi * g.sg[gi];
+    n0 = (gi * g.nbpg + nbi) * NB;
+    tps = g.tps[gi];
+  }
+  // taps that hold real weights for this block's output columns (crnTapBoxes; the full window otherwise):
+  // rows = (local channel, tap inside the box)
+  const TapBox tb = box_union(g.n_box, g.n_groups, g.dy.C, n0, min(n0 + NB, g.dy.C) - 1, g.kd, g.kh, g.kw);
+  const int bkd = max(tb.d1 - tb.d0, 0), bkh = max(tb.h1 - tb.h0, 0), bkw = max(tb.w1 - tb.w0, 0);
+  const int Tb = bkd * bkh * bkw;
+  const int nrows = min(g.CC, g.x.C - c0) * Tb;
+  // row sub-tile s = rs*4 + wave: the real rows are spread evenly over the four wavefronts
+  const int nact = max(0, ((nrows + 15) / 16 - wave + 3) / 4);
 
   PatchDesc pdsc;
   pdsc.x = g.x; pdsc.tr = g.tr; pdsc.pd = g.pd; pdsc.ph = g.ph; pdsc.pw = g.pw;
@@ -734,13 +761,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
   int rowbase[RSUB];
 #pragma unroll
   for (int rs = 0; rs < RSUB; ++rs) {
-    int row = (wave * RSUB + rs) * 16 + i16;
+    int row = (rs * 4 + wave) * 16 + i16;
     if (row >= nrows) row = 0;                       // never stored
-    const int cl = mdiv(row, g.magic_T);
-    int t = row - cl * g.T;
-    const int zw = t % g.kw; t /= g.kw;
-    const int zh = t % g.kh; t /= g.kh;
-    rowbase[rs] = cl * g.PSP + (t * g.PH + zh) * g.PW + zw + kk + g.lead;
+    const int cl = row / max(Tb, 1);
+    int t = row - cl * Tb;
+    const int zw = t % max(bkw, 1); t /= max(bkw, 1);
+    const int zh = t % max(bkh, 1); t /= max(bkh, 1);
+    rowbase[rs] = cl * g.PSP + ((t + tb.d0) * g.PH + zh + tb.h0) * g.PW + zw + tb.w0 + kk + g.lead;
   }
 
   f32x4 acc[RSUB][NSUB];
@@ -749,8 +776,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
 #pragma unroll
     for (int ns = 0; ns < NSUB; ++ns) acc[rs][ns] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int tbeg = split * g.tiles_per_split;
-  const int tend = min(tbeg + g.tiles_per_split, g.ntiles);
+  const int tbeg = min(split * tps, g.ntiles);
+  const int tend = min(tbeg + tps, g.ntiles);
   const int npos = g.TD * g.TH * g.TW;
 
   float pval[XV ? 1 : PREG];
@@ -886,33 +913,44 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
       tile_origin(tl + 1, cb, cd0, ch0, cw0);
       stage_issue(cb, cd0, ch0, cw0);
     }
-    // reduction over the tile's positions (wgrad_rows; the row-length switch stays outside the loops)
+    // reduction over the tile's positions (wgrad_rows; the switches stay outside the loops)
     if (g.dbg != 1) {
       const int bbase = i16 * g.POSP + kk;
-      switch (g.TW >> 2) {
-        case 1: wgrad_rows<1, RSUB, NSUB>(acc, ldsA, ldsB, rowbase, bbase, g); break;
-        case 2: wgrad_rows<2, RSUB, NSUB>(acc, ldsA, ldsB, rowbase, bbase, g); break;
-        case 3: wgrad_rows<3, RSUB, NSUB>(acc, ldsA, ldsB, rowbase, bbase, g); break;
-        default: wgrad_rows<4, RSUB, NSUB>(acc, ldsA, ldsB, rowbase, bbase, g); break;
+#define CRN_WG_WS(NACT)                                                                           \
+  switch (g.TW >> 2) {                                                                            \
+    case 1: wgrad_rows<1, RSUB, NSUB, NACT>(acc, ldsA, ldsB, rowbase, bbase, g); break;           \
+    case 2: wgrad_rows<2, RSUB, NSUB, NACT>(acc, ldsA, ldsB, rowbase, bbase, g); break;           \
+    case 3: wgrad_rows<3, RSUB, NSUB, NACT>(acc, ldsA, ldsB, rowbase, bbase, g); break;           \
+    default: wgrad_rows<4, RSUB, NSUB, NACT>(acc, ldsA, ldsB, rowbase, bbase, g); break;          \
+  }
+      if constexpr (RSUB >= 4) {
+        if (nact * 8 <= RSUB * 4) { CRN_WG_WS((RSUB * 4) / 8) }
+        else if (nact * 8 <= RSUB * 5) { CRN_WG_WS((RSUB * 5 + 7) / 8) }
+        else if (nact * 8 <= RSUB * 6) { CRN_WG_WS((RSUB * 6) / 8) }
+        else { CRN_WG_WS(RSUB) }
+      } else {
+        CRN_WG_WS(RSUB)
       }
+#undef CRN_WG_WS
     }
   }
 #undef CRN_DY_8
 #undef CRN_DY_8U
 #undef CRN_COMMA
 
-  // D row = kk*4 + r -> weight row (c_local*T + tap); col = i16 -> n
+  // D row = kk*4 + r -> weight row (c_local, tap); col = i16 -> n
 #pragma unroll
   for (int rs = 0; rs < RSUB; ++rs)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row_ = (wave * RSUB + rs) * 16 + kk * 4 + r;
+      const int row_ = (rs * 4 + wave) * 16 + kk * 4 + r;
       if (row_ >= nrows) continue;
-      const int cl = mdiv(row_, g.magic_T);
-      int tl = row_ - cl * g.T;
-      const int zw = tl % g.kw; tl /= g.kw;
-      const int zh = tl % g.kh; tl /= g.kh;
-      const int64_t prow = (int64_t)(c0 + cl) * g.Tfull + ((tl + g.bd0) * g.khf + zh + g.bh0) * g.kwf + zw + g.bw0;
+      const int cl = row_ / max(Tb, 1);
+      int tl = row_ - cl * Tb;
+      const int zw = tl % max(bkw, 1); tl /= max(bkw, 1);
+      const int zh = tl % max(bkh, 1); tl /= max(bkh, 1);
+      const int64_t prow = (int64_t)(c0 + cl) * g.Tfull +
+                           ((tl + tb.d0 + g.bd0) * g.khf + zh + tb.h0 + g.bh0) * g.kwf + zw + tb.w0 + g.bw0;
 #pragma unroll
       for (int ns = 0; ns < NSUB; ++ns) {
         const int n = n0 + ns * 16 + i16;

@@ -160,3 +160,32 @@ def test_product_has_no_cpu_fallback():
         assert not re.search(r"^\s*(from|import)\s+(oracle|kernel_contract_emu|tests)\b", src, re.M), f
   with pytest.raises(ValueError):
     fv.fill_inside_voxels_gpu(t.zeros(1, 2, 2, 2))
+
+
+def test_tap_boxes_cover_every_real_weight():
+  """crnTapBoxes contract (include/corenet_hip.h): for output group g (forward geometry) / input group g
+  (data-gradient geometry) every packed weight with a tap OUTSIDE the box is a structural zero (index -1),
+  and the boxes are tight.  k=7 -> 343 = (4+3)^3 real taps out of 8 * 4^3."""
+  from corenet_amd.model import conv_geometry as G
+  for wshape, pad in (((16, 16, 7, 7, 7), 3), ((32, 2, 7, 7, 7), 3), ((8, 32, 3, 3, 3), 1)):
+    cin, cout = wshape[0], wshape[1]
+    fwd, dgr = G.convt_fwd(wshape, pad), G.convt_dgrad(wshape, pad)
+    nw = fwd.window[0]
+    assert len(fwd.n_boxes) == 8 and not fwd.c_boxes and len(dgr.c_boxes) == 8 and not dgr.n_boxes
+    fi = fwd.index.reshape(cin, nw, nw, nw, fwd.npad)[..., :8 * cout].reshape(cin, nw, nw, nw, 8, cout)
+    di = dgr.index.reshape(8, cout, nw, nw, nw, dgr.npad)[..., :cin]
+    vol = 0
+    for g in range(8):
+      d0, d1, h0, h1, w0, w1 = fwd.n_boxes[g]
+      inside = np.zeros((nw, nw, nw), bool); inside[d0:d1, h0:h1, w0:w1] = True
+      real = (fi[:, :, :, :, g, :] >= 0)
+      assert (real == inside[None, :, :, :, None]).all()          # exactly the box, for every (c, n)
+      vol += inside.sum()
+      d0, d1, h0, h1, w0, w1 = dgr.c_boxes[g]
+      inside = np.zeros((nw, nw, nw), bool); inside[d0:d1, h0:h1, w0:w1] = True
+      assert ((di[g] >= 0) == inside[None, :, :, :, None]).all()
+    assert vol == wshape[2] ** 3                                    # every kernel tap appears exactly once
+    # both packings address every parameter exactly once
+    for idx in (fwd.index, dgr.index):
+      v = np.sort(idx[idx >= 0])
+      assert (v == np.arange(np.prod(wshape))).all()
