@@ -126,7 +126,8 @@ def main():
     tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
     if B == 4:
       for k, v in tj.get("kernels", {}).items():
-        if "conv_fwd_kernel" in k and k.endswith(f"grid {4096 * 256}"):      # stage_6.c1 fwd: 4096 tiles x 1 N-block
+        if "conv_fwd_kernel<8, 1, true>" in k and k.endswith(f"grid {2048 * 256}") and v["launches"] == 4:
+          # stage_6.c1 fwd: 2048 tiles (4x8x16 positions) x 1 N-block, one launch per profiled step
           traffic["conv"] = v["hbm_bytes"]
         if "ray_sample_fwd_kernel" in k and k.endswith("grid 262144"):        # 64^3 x 12 ch
           traffic["ray"] = v["hbm_bytes"]
@@ -160,7 +161,7 @@ def main():
                              f"256x256 RGB -> 128^3, C={C}, B={B}/GPU, fp32, random-init weights",
                  "global_batch": world * B, "parallelism": f"dp{world}"},
       "loss": float(loss),
-      "roofline": {"kernel": "conv_fwd_kernel<4,1,xvec> (stage_6.c1 Conv3d 28->16 k5 @64^3, fwd)",
+      "roofline": {"kernel": "conv_fwd_kernel<8,1,xvec> (stage_6.c1 Conv3d 28->16 k5 @64^3, fwd)",
                    "bound": "mfma", "achieved": CONV6_FLOP * B / conv_s / 1e12, "peak": PEAK_F32_MFMA / 1e12,
                    "unit": "TFLOP/s", "frac": CONV6_FLOP * B / conv_s / PEAK_F32_MFMA, "traffic": traffic.get("conv"),
                    "avg_launch_ms": conv_s * 1e3},

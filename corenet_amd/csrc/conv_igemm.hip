@@ -195,7 +195,7 @@ bool fwd_cfg(int MSUB, int NSUB, int B, int Cin, int Npad, int D, int H, int W, 
   const int PS = PDp * plane;
   const int PSP = pad16mod32(PS), WSP = pad16mod32(T * NSUB * 16);
   auto fits = [&](int cc) {
-    const bool staged = lead >= 0 ? (int64_t)cc * PS / 4 <= 256 * NV : stage_passes(cc * PDp, plane) <= PREG;
+    const bool staged = lead >= 0 ? (int64_t)cc * PS / 4 <= 256 * NVX : stage_passes(cc * PDp, plane) <= PREG;
     return (size_t)cc * (PSP + WSP) * 4 + 2 * kChTab * 4 <= kLdsBudget && staged &&
            (int64_t)cc * T * NSUB * 16 <= 256 * WREG * 4;
   };
@@ -356,7 +356,7 @@ bool wg_cand(int TD, int TH, int TW, int RSUB, int NSUB, int Cin, int Npad, int 
   const int PDp = TD + kd - 1, PH = TH + kh - 1, PW = patch_width(TW, kw, xlead), plane = PH * PW;
   int CC = std::min(std::min(std::max(1, (64 * RSUB) / T), Cin), 64);
   auto staged = [&](int cc) {
-    return xlead >= 0 ? (int64_t)cc * PDp * plane / 4 <= 256 * NV : stage_passes(cc * PDp, plane) <= PREG;
+    return xlead >= 0 ? (int64_t)cc * PDp * plane / 4 <= 256 * NVX : stage_passes(cc * PDp, plane) <= PREG;
   };
   while (CC > 1 && !staged(CC)) --CC;
   if (!staged(CC)) return false;

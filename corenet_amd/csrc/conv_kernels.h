@@ -64,6 +64,7 @@ struct PatchDesc {
 // MFMA stream costs MFMA issue time (tools/mfma_peak.hip).  The patch origin along W is moved
 // left by `lead` (0..3) columns so that every row starts 16-byte aligned in global memory.
 constexpr int NV = 8;       // float4 staging slots per thread (the same 32 registers as PREG)
+constexpr int NVX = 9;      // ... for the x patch: 9 lets the 4x8x16-position tile of a k=5 conv (2304 units) fit
 
 typedef int crn_rsrc __attribute__((ext_vector_type(4)));   // buffer resource (V#) in 4 SGPRs
 
@@ -97,6 +98,11 @@ __device__ __forceinline__ void crn_wait_loads(float (&v)[N]) {
     asm volatile("s_waitcnt vmcnt(0)"
                  : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]), "+v"(v[i + 4]), "+v"(v[i + 5]),
                    "+v"(v[i + 6]), "+v"(v[i + 7]));
+}
+template <int N>
+__device__ __forceinline__ void crn_wait_loads4n(f32x4 (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[i]));
 }
 __device__ __forceinline__ void crn_wait_loads4(f32x4 (&v)[WREG]) {
   asm volatile("s_waitcnt vmcnt(0)"
@@ -281,8 +287,8 @@ __device__ __forceinline__ VUnit vec_unit(const PatchDesc& g) {
 }
 template <int J = 0>
 __device__ __forceinline__ void patch_issue_v(const PatchDesc& g, const unsigned* choff, const crn_rsrc& rs, int c0,
-                                              int d0, int h0, int w0, f32x4 (&val)[NV], unsigned& inmask) {
-  if constexpr (J < NV) {
+                                              int d0, int h0, int w0, f32x4 (&val)[NVX], unsigned& inmask) {
+  if constexpr (J < NVX) {
     unsigned goff = 0x80000000u;
     const VUnit t = vec_unit<J>(g);
     if (t.valid) {
@@ -300,8 +306,8 @@ __device__ __forceinline__ void patch_issue_v(const PatchDesc& g, const unsigned
 }
 template <int J = 0>
 __device__ __forceinline__ void patch_commit_v(const PatchDesc& g, const unsigned* choff, float* ldsA,
-                                               const f32x4 (&val)[NV], unsigned inmask) {
-  if constexpr (J < NV) {
+                                               const f32x4 (&val)[NVX], unsigned inmask) {
+  if constexpr (J < NVX) {
     if (J * 256 < g.nunits) {                            // wave-uniform
       const VUnit t = vec_unit<J>(g);
       if (t.valid) {
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
 
   const TapBox nbox = box_union(g.n_box, g.n_groups, g.y.C, n0, min(n0 + NB, g.y.C) - 1, g.kd, g.kh, g.kw);
   float pval[XV ? 1 : PREG];
-  f32x4 pv4[XV ? NV : 1];
+  f32x4 pv4[XV ? NVX : 1];
   unsigned inmask = 0;
   f32x4 wval[WREG];
   const int nf4 = g.CC * g.T * (NB / 4);
@@ -517,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
     const int c0 = chunk * g.CC;
     const bool stage = !(g.dbg >= 2 && chunk > cbeg);
     if (stage) {
-    if constexpr (XV) crn_wait_loads4(pv4); else crn_wait_loads(pval);
+    if constexpr (XV) crn_wait_loads4n(pv4); else crn_wait_loads(pval);
     crn_wait_loads4(wval);
     __syncthreads();                       // previous chunk's MFMA reads are done
     if constexpr (XV) { patch_commit_v(pdsc, choff + (chunk & 1) * kChTab, ldsA, pv4, inmask); inmask = 0; }
@@ -781,7 +787,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
   const int npos = g.TD * g.TH * g.TW;
 
   float pval[XV ? 1 : PREG];
-  f32x4 pv4[XV ? NV : 1];
+  f32x4 pv4[XV ? NVX : 1];
   unsigned inmask = 0;
   float dval[DV ? 8 : DREG];
   f32x4 dv4[DV ? NV : 1];
@@ -904,7 +910,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
     stage_issue(cb, cd0, ch0, cw0);
   }
   for (int tl = tbeg; tl < tend; ++tl) {
-    if constexpr (XV) crn_wait_loads4(pv4); else crn_wait_loads(pval);
+    if constexpr (XV) crn_wait_loads4n(pv4); else crn_wait_loads(pval);
     if constexpr (DV) crn_wait_loads4(dv4); else crn_wait_loads(dval);
     __syncthreads();
     if (g.dbg != 2 || tl == tbeg) stage_commit(cd0, ch0, cw0);
