@@ -126,9 +126,13 @@ def main():
     tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
     if B == 4:
       for k, v in tj.get("kernels", {}).items():
-        if "conv_fwd_kernel<8, 1, true>" in k and k.endswith(f"grid {2048 * 256}") and v["launches"] == 4:
-          # stage_6.c1 fwd: 2048 tiles (4x8x16 positions) x 1 N-block, one launch per profiled step
-          traffic["conv"] = v["hbm_bytes"]
+        # stage_6.c1 fwd: conv_fwd_kernel<8,1,xvec>, 2048 tiles x 1 N-block.  stage_5.t1 and stage_6.t1 fwd
+        # share that (kernel, grid); per step the dispatch order is s5.t1, s6.c1, s6.t1 -> every 3rd from 1
+        if "conv_fwd_kernel<8, 1, true>" in k and k.endswith(f"grid {2048 * 256}"):
+          pl = v.get("per_launch_hbm_bytes", [])
+          if len(pl) >= 3 and len(pl) % 3 == 0:
+            mine = pl[1::3]
+            traffic["conv"] = sum(mine) / len(mine)
         if "ray_sample_fwd_kernel" in k and k.endswith("grid 262144"):        # 64^3 x 12 ch
           traffic["ray"] = v["hbm_bytes"]
         if "fill_fused_kernel" in k:
