@@ -50,6 +50,7 @@ _SIGS = {
                      C.POINTER(CrnView), i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "crn_conv_wgrad": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32,
                        i32, i32, i32, i32, i32, i32, i32, vp, vp],
+    "crn_copy_tiles_f32": [vp, vp, vp, vp, vp, i64, i32, vp],
     "crn_gather_f32": [vp, vp, vp, i64, vp],
     "crn_scatter_f32": [vp, vp, vp, i64, i32, vp],
     "crn_bias_grad": [vp, i32, i32, i64, i64, vp, i32, vp, sz, vp],

@@ -95,6 +95,12 @@ class HipBackend:
                             window[0], window[1], window[2], pad_lo[0], pad_lo[1], pad_lo[2],
                             int(zero_first), _ctapboxes(boxes), _lib.stream())
 
+  def copy_tiles(self, src: t.Tensor, dst: t.Tensor, tiles, reverse: bool = False):
+    """tiles: (desc int32 [n,6], mask int64 [n], explicit int32 [m]) from conv_geometry.tile_index."""
+    desc, mask, ex = tiles
+    self.lib.crn_copy_tiles_f32(ptr(src), ptr(dst), ptr(desc), ptr(mask), ptr(ex), desc.shape[0], int(reverse),
+                                _lib.stream())
+
   def gather(self, src: t.Tensor, idx: t.Tensor, dst: t.Tensor):
     self.lib.crn_gather_f32(ptr(src), ptr(idx), ptr(dst), idx.numel(), _lib.stream())
 

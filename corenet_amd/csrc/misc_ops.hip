@@ -150,6 +150,34 @@ __global__ void add_i64_kernel(int64_t* p, int n, int64_t v) {
   if (e < n) p[e] += v;
 }
 
+
+// ---- tiled index copies (weight pack / gradient un-pack) -----------------------------------------
+// The packed conv layouts are transposes of the reference layouts: a flat int32 index per element
+// costs 4 B of index traffic per 4 B moved and makes one side of the copy touch a different 32-B sector
+// per lane.  Here the packed side is cut into 8x8 tiles (rows x 8 consecutive columns); a tile whose
+// index map is affine (src = base + r*sr + c*sc, true for every plain conv) is described by 6 ints + a
+// 64-bit validity mask, other tiles (transposed-conv windows, stem, bias) point to 64 explicit indices.
+// One wavefront per tile: both sides move in 8 full 32-B sectors.
+template <bool REVERSE>
+__global__ __launch_bounds__(256) void copy_tiles_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                         const int32_t* __restrict__ desc,
+                                                         const unsigned long long* __restrict__ mask,
+                                                         const int32_t* __restrict__ ex, int64_t ntiles) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane >> 3, c = lane & 7;
+  const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t tIdx = wave0; tIdx < ntiles; tIdx += nwaves) {
+    const int32_t* d = desc + tIdx * 6;
+    const unsigned long long m = mask[tIdx];
+    if (!((m >> lane) & 1ull)) continue;
+    const int64_t tile_pos = (int64_t)d[0] + (int64_t)r * d[1] + c;                   // packed side
+    const int64_t index = d[5] >= 0 ? (int64_t)ex[(int64_t)d[5] + lane] : (int64_t)d[2] + (int64_t)r * d[3] + (int64_t)c * d[4];
+    if (REVERSE) dst[index] = src[tile_pos];     // un-pack: reference layout <- packed
+    else dst[tile_pos] = src[index];             // pack: packed <- reference layout
+  }
+}
+
 // torch.optim.Adam (amsgrad=False, weight_decay=0), fp32, float4 per lane
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n4,
@@ -270,6 +298,21 @@ extern "C" int crn_scatter_f32(const float* src, const int32_t* idx, float* dst,
                                crnStream s) {
   hipLaunchKernelGGL(scatter_kernel, dim3(std::min(nblk(n), 4096u)), dim3(256), 0, (hipStream_t)s, src, idx, dst, n,
                      accumulate);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_copy_tiles_f32(const float* src, float* dst, const int32_t* desc, const uint64_t* mask,
+                                  const int32_t* explicit_idx, int64_t ntiles, int reverse, crnStream s) {
+  if (!src || !dst || !desc || !mask || ntiles < 0) return CRN_EINVAL;
+  if (ntiles == 0) return CRN_OK;
+  const unsigned blocks = (unsigned)std::min<int64_t>(crn_cdiv(ntiles, 4), 16384);
+  if (reverse)
+    hipLaunchKernelGGL(copy_tiles_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)s, src, dst, desc,
+                       reinterpret_cast<const unsigned long long*>(mask), explicit_idx, ntiles);
+  else
+    hipLaunchKernelGGL(copy_tiles_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)s, src, dst, desc,
+                       reinterpret_cast<const unsigned long long*>(mask), explicit_idx, ntiles);
   CRN_CHECK_LAUNCH();
   return CRN_OK;
 }

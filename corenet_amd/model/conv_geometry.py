@@ -211,3 +211,55 @@ def bias_index(n_ref: int, repeat: int, npad: int, parity_major: bool = False) -
   j = np.arange(n_ref * repeat)
   idx[:n_ref * repeat] = (j % n_ref) if parity_major else (j // repeat)
   return idx.astype(np.int32)
+
+
+def tile_index(parts):
+  """8x8 tiling of packed index arrays for crn_copy_tiles_f32.
+  parts: list of (packed_offset, index int array [rows*cols] with -1 = structural zero, cols, group_rows):
+  tiles never straddle a group of `group_rows` consecutive rows (the taps of one output channel in a
+  data-gradient pack), inside which the index map of a plain conv is affine.
+  Returns (desc int32 [n,6], mask uint64 [n], explicit int32 [m]); tiles without any element are dropped."""
+  descs, masks, exs = [], [], []
+  ex_off = 0
+  ar = np.arange(8)
+  for off, idx, cols, grows in parts:
+    idx = np.asarray(idx, np.int64)
+    rows = idx.size // cols
+    grows = rows if not grows else grows
+    assert rows % grows == 0
+    ng = rows // grows
+    R8, C8 = (grows + 7) // 8, (cols + 7) // 8
+    pad = np.full((ng, R8 * 8, C8 * 8), -1, np.int64)
+    pad[:, :grows, :cols] = idx.reshape(ng, grows, cols)
+    tl = pad.reshape(ng, R8, 8, C8, 8).transpose(0, 1, 3, 2, 4).reshape(ng * R8 * C8, 8, 8)
+    valid = tl >= 0
+    keep = valid.any((1, 2))
+    tl, valid = tl[keep], valid[keep]
+    tix = np.nonzero(keep)[0]
+    tg, rem = np.divmod(tix, R8 * C8)
+    tr, tc = np.divmod(rem, C8)
+    base = tl[:, 0, 0]
+    sr = tl[:, 1, 0] - base
+    sc = tl[:, 0, 1] - base
+    # single-row / single-column tiles: the missing stride is irrelevant
+    one_row = ~valid[:, 1:, :].any((1, 2)); one_col = ~valid[:, :, 1:].any((1, 2))
+    sr = np.where(one_row, 0, sr); sc = np.where(one_col, 0, sc)
+    pred = base[:, None, None] + ar[None, :, None] * sr[:, None, None] + ar[None, None, :] * sc[:, None, None]
+    affine = valid[:, 0, 0] & (valid[:, 1, 0] | one_row) & (valid[:, 0, 1] | one_col) & (~valid | (tl == pred)).all((1, 2))
+    affine &= (np.abs(sr) < 2 ** 31) & (np.abs(sc) < 2 ** 31)
+    n = tl.shape[0]
+    d = np.zeros((n, 6), np.int64)
+    d[:, 0] = off + (tg * grows + tr * 8) * cols + tc * 8
+    d[:, 1] = cols
+    d[:, 2] = np.where(affine, base, 0); d[:, 3] = np.where(affine, sr, 0); d[:, 4] = np.where(affine, sc, 0)
+    nex = int((~affine).sum())
+    d[:, 5] = -1
+    d[~affine, 5] = ex_off + np.arange(nex) * 64
+    exs.append(np.where(valid[~affine], tl[~affine], 0).reshape(-1))
+    ex_off += nex * 64
+    bits = (valid.reshape(n, 64).astype(np.uint64) << np.arange(64, dtype=np.uint64)[None, :]).sum(1, dtype=np.uint64)
+    descs.append(d); masks.append(bits)
+  desc = np.concatenate(descs) if descs else np.zeros((0, 6), np.int64)
+  assert np.abs(desc).max(initial=0) < 2 ** 31
+  ex = np.concatenate(exs) if exs else np.zeros((0,), np.int64)
+  return desc.astype(np.int32), (np.concatenate(masks) if masks else np.zeros((0,), np.uint64)), ex.astype(np.int32)

@@ -239,14 +239,26 @@ class Engine:
       if dgrad is not None:
         parts.append(shift(dgrad.index, wo))
       idx_parts.append(parts)
-    flat = np.concatenate([p for parts in idx_parts for p in parts])
-    assert flat.max() < 2 ** 31
-    self.pack_index = t.as_tensor(flat.astype(np.int32), device=self.device)
-    self.packed = t.zeros(flat.shape[0], dtype=self.dtype, device=self.device)
+    flat_len = sum(len(p) for parts in idx_parts for p in parts)
+    assert max(int(p.max()) for parts in idx_parts for p in parts) < 2 ** 31
+    self.packed = t.zeros(flat_len, dtype=self.dtype, device=self.device)
     gsize = sum(len(parts[0]) for parts in idx_parts)
     self.gpacked = t.zeros(gsize, dtype=self.dtype, device=self.device)
-    self.gscatter_index = t.as_tensor(
-        np.concatenate([parts[0] for parts in idx_parts]).astype(np.int32), device=self.device)
+    # 8x8-tile descriptors of the pack (reference -> packed) and un-pack (packed grad -> reference grad)
+    # copies: crn_copy_tiles_f32 moves both sides in full 32-byte sectors and reads ~0.5 B of index per element
+    # instead of 4 (conv_geometry.tile_index)
+    pack_parts, unpack_parts = [], []
+    po, go = 0, 0
+    for (name, fwd, dgrad, repeat, nref), parts in zip(reg, idx_parts):
+      pack_parts.append((po, parts[0], fwd.npad, 0)); po += len(parts[0])
+      pack_parts.append((po, parts[1], len(parts[1]), 0)); po += len(parts[1])
+      if dgrad is not None:
+        pack_parts.append((po, parts[2], dgrad.npad, dgrad.taps if dgrad.taps > 1 else 0)); po += len(parts[2])
+      unpack_parts.append((go, parts[0], fwd.npad, 0)); go += len(parts[0])
+    dev = lambda tl: (t.as_tensor(tl[0], device=self.device), t.as_tensor(tl[1].view(np.int64), device=self.device),
+                      t.as_tensor(tl[2] if tl[2].size else np.zeros(1, np.int32), device=self.device))
+    self.pack_tiles = dev(G.tile_index(pack_parts))
+    self.unpack_tiles = dev(G.tile_index(unpack_parts))
     po, go = 0, 0
     for (name, fwd, dgrad, repeat, nref), parts in zip(reg, idx_parts):
       nwf, nb = len(parts[0]), len(parts[1])
@@ -261,7 +273,7 @@ class Engine:
 
   def pack_weights(self):
     """flat parameter slab -> packed kernel layouts (1 launch)."""
-    self.be.gather(self.store.params, self.pack_index, self.packed)
+    self.be.copy_tiles(self.store.params, self.packed, self.pack_tiles)
     self.weights_dirty = False
 
   # -------------------------------------------------------------------- plans
@@ -625,7 +637,7 @@ class Plan:
     self._wgrad(cs, self.s2d(self.img, 3, (1, 2, 2)), None, self.vw(self.gy1b))
     # packed weight grads -> reference layout inside the flat grad slab (1 launch)
     self._join_side()
-    be.scatter(eng.gpacked, eng.gscatter_index, eng.store.grads, False)
+    be.copy_tiles(eng.gpacked, eng.store.grads, eng.unpack_tiles, reverse=True)
 
   def _block_bwd(self, blk, g_out: Optional[t.Tensor]) -> t.Tensor:
     eng, be, B = self.eng, self.be, self.B

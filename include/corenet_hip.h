@@ -86,6 +86,14 @@ int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const crnView* dy
                    crnStream stream);
 
 /* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0        (weight packing)            */
+/* Tiled index copy between a reference-layout buffer and a packed buffer (weight pack / gradient un-pack).
+ * Tile t covers packed positions desc[t][0] + r*desc[t][1] + c (r, c in 0..7); bit (r*8+c) of mask[t] says
+ * whether the element exists; its reference-layout index is desc[t][2] + r*desc[t][3] + c*desc[t][4], or
+ * explicit_idx[desc[t][5] + r*8 + c] when desc[t][5] >= 0.
+ * reverse == 0: dst[packed position] = src[index];  reverse != 0: dst[index] = src[packed position].       */
+int crn_copy_tiles_f32(const float* src, float* dst, const int32_t* desc /* [ntiles][6] */,
+                       const uint64_t* mask /* [ntiles] */, const int32_t* explicit_idx, int64_t ntiles,
+                       int reverse, crnStream s);
 int crn_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, crnStream s);
 /* dst[idx[i]] (+)= src[i] for idx[i] >= 0      (gradient un-packing)        */
 int crn_scatter_f32(const float* src, const int32_t* idx, float* dst, int64_t n,

@@ -98,6 +98,20 @@ class EmuBackend:
     if zero_first: dw.zero_()
     dw += full.reshape(-1)
 
+  def copy_tiles(self, src, dst, tiles, reverse=False):
+    desc, mask, ex = [x.cpu() for x in tiles]
+    n = desc.shape[0]
+    r = t.arange(8).view(1, 8, 1); c = t.arange(8).view(1, 1, 8)
+    d = desc.long()
+    pos = (d[:, 0].view(n, 1, 1) + r * d[:, 1].view(n, 1, 1) + c).reshape(-1)
+    aff = (d[:, 2].view(n, 1, 1) + r * d[:, 3].view(n, 1, 1) + c * d[:, 4].view(n, 1, 1)).reshape(n, 64)
+    lane = t.arange(64).view(1, 64)
+    exi = ex.long()[(d[:, 5].clamp(min=0).view(n, 1) + lane).clamp(max=max(ex.numel() - 1, 0))] if ex.numel() else aff
+    index = t.where(d[:, 5].view(n, 1) >= 0, exi, aff).reshape(-1)
+    bits = ((mask.view(n, 1) >> lane) & 1).bool().reshape(-1)
+    if reverse: dst[index[bits]] = src[pos[bits]]
+    else: dst[pos[bits]] = src[index[bits]]
+
   def gather(self, src, idx, dst):
     i = idx.long()
     dst.copy_(t.where(i >= 0, src[i.clamp(min=0)], t.zeros((), dtype=src.dtype)))

@@ -540,3 +540,33 @@ def test_voxelizer_sphere_vs_oracle_and_labels(be):
   zz, yy, xx = np.meshgrid(*[np.arange(R) + 0.5] * 3, indexing="ij")
   inside2 = ((xx / R - 0.6) ** 2 + (yy / R - 0.5) ** 2 + (zz / R - 0.5) ** 2) < 0.17 ** 2
   assert (labels[0][inside2] == 5).all()
+
+
+def test_copy_tiles_pack_unpack(be):
+  """crn_copy_tiles_f32 against the flat-index gather / scatter it replaces, on every kind of pack."""
+  from corenet_amd.model import conv_geometry as G
+  g = t.Generator().manual_seed(3)
+  geoms = [(G.conv_fwd((64, 32, 3, 3), 1), 0), (G.conv_dgrad((64, 32, 3, 3), 1), 9), (G.conv_dgrad((24, 515, 1, 1), 0), 0),
+           (G.conv_fwd((16, 28, 5, 5, 5), 2), 0), (G.conv_dgrad((16, 28, 5, 5, 5), 2), 125),
+           (G.convt_fwd((16, 14, 7, 7, 7), 3), 0), (G.convt_dgrad((16, 14, 7, 7, 7), 3), 64), (G.stem_fwd(), 0)]
+  nparam = max(int(ge.index.max()) for ge, _ in geoms) + 1
+  src = t.randn(nparam, generator=g)
+  parts, off = [], 0
+  for ge, grp in geoms:
+    parts.append((off, ge.index, ge.npad, grp)); off += ge.index.size
+  flat = t.as_tensor(np.concatenate([ge.index for ge, _ in geoms]).astype(np.int64))
+  tiles = G.tile_index(parts)
+  tiles_dev = (t.as_tensor(tiles[0]).to(DEV), t.as_tensor(tiles[1].view(np.int64)).to(DEV), t.as_tensor(tiles[2]).to(DEV))
+  want = t.where(flat >= 0, src[flat.clamp(min=0)], t.zeros(()))
+  got = t.zeros(off, device=DEV)
+  be.copy_tiles(src.to(DEV), got, tiles_dev)
+  assert t.equal(got.cpu(), want)
+  # un-pack: every parameter of the forward-geometry packs comes back exactly once
+  gi = t.as_tensor(geoms[3][0].index.astype(np.int64))
+  tl = G.tile_index([(0, geoms[3][0].index, geoms[3][0].npad, 0)])
+  tl_dev = (t.as_tensor(tl[0]).to(DEV), t.as_tensor(tl[1].view(np.int64)).to(DEV), t.as_tensor(tl[2] if tl[2].size else np.zeros(1, np.int32)).to(DEV))
+  packed = t.randn(gi.numel(), generator=g)
+  back = t.full((int(gi.max()) + 1,), -5.0, device=DEV)
+  be.copy_tiles(packed.to(DEV), back, tl_dev, reverse=True)
+  ref = t.full((int(gi.max()) + 1,), -5.0); ref[gi[gi >= 0]] = packed[gi >= 0]
+  assert t.equal(back.cpu(), ref)
