@@ -144,6 +144,38 @@ __global__ void zero_view_kernel(crnView v) {
   }
 }
 
+// y[b,c,pos] (view) = (accumulate ? y : 0) + sum_s scratch[s][b][c][pos] (dense)
+__global__ void splitk_reduce_kernel(crnView v, const float* scratch, int splits, int accumulate) {
+  const int64_t S = (int64_t)v.D * v.H * v.W, per_b = (int64_t)v.C * S;
+  const int64_t total = per_b * v.B;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = e;
+    const int w = r % v.W; r /= v.W;
+    const int h = r % v.H; r /= v.H;
+    const int d = r % v.D; r /= v.D;
+    const int c = r % v.C; r /= v.C;
+    float sum = 0.f;
+    for (int s = 0; s < splits; ++s) sum += scratch[(int64_t)s * total + e];
+    const int64_t co = v.chan_off ? (int64_t)v.chan_off[c] : (int64_t)c * v.sC;
+    float* dst = v.base + r * v.sB + co + (int64_t)d * v.sD + (int64_t)h * v.sH + (int64_t)w * v.sW;
+    *dst = accumulate ? *dst + sum : sum;
+  }
+}
+
+// process-wide scratch for split-K partial sums (calls on different streams must not overlap)
+float* splitk_scratch(size_t floats) {
+  static float* buf = nullptr;
+  static size_t cap = 0;
+  if (floats > cap) {
+    if (floats > ((size_t)256 << 20) / 4) return nullptr;       // larger outputs keep the atomic path
+    if (buf) (void)hipFree(buf);
+    cap = std::max(floats, ((size_t)16 << 20) / 4);
+    if (hipMalloc(&buf, cap * 4) != hipSuccess) { buf = nullptr; cap = 0; }
+  }
+  return buf;
+}
+
 int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 unsigned magic20(int d) { return (unsigned)(((1u << 20) + d - 1) / d); }
 // staging slots (planes padded to a power of two) needed for nplanes planes of `plane` elements
@@ -310,10 +342,22 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
     g.plu = g.PH * g.PW / 4; g.pw4 = g.PW / 4; g.nunits = CC * g.PD * g.plu;
     g.magic_PLU = magic20(g.plu); g.magic_PW4 = magic20(g.pw4);
   }
+  // split-K: partial sums into a dense scratch tensor + one reduction launch (mode 3); atomics (mode 2)
+  // only when the scratch cannot be had
+  const crnView yreal = *y;
+  const int64_t ytot = (int64_t)y->B * y->C * y->D * y->H * y->W;
+  static const bool sk_atomic = getenv("CRN_SPLITK_ATOMIC") != nullptr;
+  float* scratch = (g.mode == 2 && !sk_atomic) ? splitk_scratch((size_t)splits * ytot) : nullptr;
+  if (scratch) {
+    g.mode = 3;
+    const int64_t S = (int64_t)y->D * y->H * y->W;
+    g.y.base = scratch; g.y.chan_off = nullptr;
+    g.y.sW = 1; g.y.sH = y->W; g.y.sD = y->H * y->W; g.y.sC = S; g.y.sB = (int64_t)y->C * S;
+  }
+  y = &g.y;                                // epilogue alignment below refers to the tensor actually written
   if (g.mode == 2 && !accumulate) {
-    const int64_t tot = (int64_t)y->B * y->C * y->D * y->H * y->W;
-    hipLaunchKernelGGL(zero_view_kernel, dim3((unsigned)std::min<int64_t>(crn_cdiv(tot, 256), 4096)),
-                       dim3(256), 0, st, *y);
+    hipLaunchKernelGGL(zero_view_kernel, dim3((unsigned)std::min<int64_t>(crn_cdiv(ytot, 256), 4096)),
+                       dim3(256), 0, st, yreal);
     CRN_CHECK_LAUNCH();
   }
   dim3 grid((unsigned)(g.tilesD * g.tilesH * g.tilesW * y->B), (unsigned)crn_cdiv(Npad, NSUB * 16),
@@ -336,10 +380,16 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
     fprintf(stderr, "[crn_conv_fwd] x(C%d %dx%dx%d) y(C%d %dx%dx%d) k%dx%dx%d: MSUB %d NSUB %d CC %d tile %dx%dx%d "
             "grid %ux%ux%u lds %zu npass %d lg2 %d xvec %d units %d\n", x->C, x->D, x->H, x->W, y->C, y->D, y->H, y->W, kd, kh, kw,
             best.MSUB, NSUB, CC, g.TD, g.TH, g.TW, grid.x, grid.y, grid.z, lds_bytes, g.npass, g.lg2, xvec, g.nunits);
-#define CRN_FWD_CASE(M, N) if (best.MSUB == M && NSUB == N) return crn_launch_fwd_##M##_##N(g, xvec, grid, lds_bytes, st);
+  int rc = CRN_EINVAL;
+#define CRN_FWD_CASE(M, N) if (best.MSUB == M && NSUB == N) rc = crn_launch_fwd_##M##_##N(g, xvec, grid, lds_bytes, st);
   CRN_FWD_CONFIGS(CRN_FWD_CASE)
 #undef CRN_FWD_CASE
-  return CRN_EINVAL;
+  if (rc == CRN_OK && g.mode == 3) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(crn_cdiv(ytot, 256), 4096)), dim3(256), 0, st,
+                       yreal, scratch, splits, accumulate);
+    CRN_CHECK_LAUNCH();
+  }
+  return rc;
 }
 
 namespace {

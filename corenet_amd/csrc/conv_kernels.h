@@ -561,7 +561,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
   }
 
   // epilogue: D row = kk*4 + r (position), col = i16 (channel)
-  float* yb = g.y.base + (int64_t)b * g.y.sB;
+  // mode 3: split-K partial sums go to a dense scratch tensor [split][b][n][pos] (plain stores); a second
+  // launch adds them up.  Device-scope float atomics (mode 2) leave the XCD's L2 and cost ~30 us per launch.
+  float* yb = g.y.base + (int64_t)(g.mode == 3 ? split * g.x.B + b : b) * g.y.sB;
 #pragma unroll
   for (int ns = 0; ns < NSUB; ++ns) {
     const int n = n0 + ns * 16 + i16;
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
         if (od < g.y.D && oh < g.y.H && ow < g.y.W) {
           float* dst = yb + co + (int64_t)od * g.y.sD + (int64_t)oh * g.y.sH + (int64_t)ow * g.y.sW;
           const float v = acc[ms][ns][r] + bsv;
-          if (g.mode == 0) *dst = v;
+          if (g.mode == 0 || g.mode == 3) *dst = v;
           else if (g.mode == 1) *dst += v;
           else atomicAdd(dst, v);
         }
