@@ -276,6 +276,9 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   // (MFMA issue at ~77% + staging instructions, which do not hide under MFMAs) plus one exposed
   // load->commit->barrier latency per chunk and pair of resident workgroups; split-K pays a
   // zero-fill launch and an atomic epilogue.
+  // split-K now costs one small reduction launch (tuned on bench.py: 20000 / 512 beat 40000 / 256 by 0.3 ms)
+  static const double kSplitPenalty = getenv("CRN_SPLIT_PENALTY") ? atof(getenv("CRN_SPLIT_PENALTY")) : 20000.0;
+  static const int kSplitFill = getenv("CRN_SPLIT_FILL") ? atoi(getenv("CRN_SPLIT_FILL")) : 512;
   FwdCfg best{}; bool have = false; double best_cost = 1e300; int best_splits = 1;
   for (int mi = 0; mi < 4; ++mi)
     for (int ni = 0; ni < 3; ++ni) {
@@ -290,10 +293,10 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
                            (double)c.CC * T * NB / 4 / 256 * 300.0;
       const double chunk_work = (double)kM[mi] * kN[ni] * (c.CC / 4) * T * 32.0 * 1.3 + slots;
       for (int sp = 1; sp <= (splits < 1 ? std::min(nchunks, 16) : 1); sp *= 2) {
-        if (sp > 1 && c.blocks * (sp / 2) >= 256) break;          // split only to fill the chip
+        if (sp > 1 && c.blocks * (sp / 2) >= kSplitFill) break;   // split only to fill the chip
         const int cps = crn_cdiv(nchunks, sp);
         const double bpc = std::max(1.0, std::ceil((double)c.blocks * sp / 256.0));
-        double cost = bpc * cps * chunk_work + cps * std::ceil(bpc / 2.0) * 9000.0 + (sp > 1 ? 40000.0 : 0.0);
+        double cost = bpc * cps * chunk_work + cps * std::ceil(bpc / 2.0) * 9000.0 + (sp > 1 ? kSplitPenalty : 0.0);
         if (cost < best_cost) { best_cost = cost; best = c; have = true; best_splits = sp; }
       }
     }
