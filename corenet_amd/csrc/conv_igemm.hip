@@ -399,13 +399,14 @@ namespace {
 struct WgCand { int TD, TH, TW, RSUB, NSUB, CC, PW, PSP, POSP; double cost; size_t lds; };
 
 // One weight-grad configuration: position tile TDxTHxTW, RSUB x NSUB MFMA tiles per wave.
-// xlead >= 0: x staged in 16-byte units; dvec: dy staged in 16-byte units.
+// xlead >= 0: x staged in 16-byte units; dvec: dy staging mode (0 scalar, 1 float4 units, 2 position pairs).
 bool wg_cand(int TD, int TH, int TW, int RSUB, int NSUB, int Cin, int Npad, int kd, int kh, int kw, int xlead,
-             bool dvec, size_t lds_budget, WgCand* out) {
+             int dvec, size_t lds_budget, WgCand* out) {
   const int T = kd * kh * kw, NB = NSUB * 16, npos = TD * TH * TW;
   if (npos > 512 || RSUB * NSUB > 8 || (NSUB > 1 && NB > Npad)) return false;
   if ((xlead >= 0 || dvec) && (TW & 3)) return false;
-  if (dvec ? (int64_t)NB * npos / 4 > 256 * NV : stage_passes(NB, npos) > DREG) return false;
+  if (dvec == 1 ? (int64_t)NB * npos / 4 > 256 * NV
+                : dvec == 2 ? (int64_t)NB * npos / 2 > 256 * NVX : stage_passes(NB, npos) > DREG) return false;
   const int PDp = TD + kd - 1, PH = TH + kh - 1, PW = patch_width(TW, kw, xlead), plane = PH * PW;
   int CC = std::min(std::min(std::max(1, (64 * RSUB) / T), Cin), 64);
   auto staged = [&](int cc) {
@@ -423,7 +424,8 @@ bool wg_cand(int TD, int TH, int TW, int RSUB, int NSUB, int Cin, int Npad, int 
   // VALU/SALU instruction costs MFMA issue time), per useful multiply-add
   const double mfma = (double)RSUB * NSUB * (npos / 4.0) * 32.0;
   const double xslots = xlead >= 0 ? (double)CC * PDp * plane / 4 / 256 * 450.0 : (double)CC * PDp * plane / 256 * 350.0;
-  const double dslots = dvec ? (double)NB * npos / 4 / 256 * 300.0 : (double)NB * npos / 256 * 300.0;
+  const double dslots = dvec == 1 ? (double)NB * npos / 4 / 256 * 300.0
+                                  : dvec == 2 ? (double)NB * npos / 2 / 256 * 300.0 : (double)NB * npos / 256 * 300.0;
   const double useful = (double)rows * std::min(NB, Npad) * npos;
   *out = WgCand{TD, TH, TW, RSUB, NSUB, CC, PW, PSP, POSP, (mfma + xslots + dslots + 800.0) / useful, lds};
   return true;
@@ -442,8 +444,9 @@ int wgrad_launch(const crnView* x, const crnInTransform* tr, const crnView* dy, 
   const int TWc = Wy >= 16 ? 16 : ((Wy + 3) & ~3);
   static const bool no_vec = getenv("CRN_NO_VEC") != nullptr;
   int xlead = (vec_view(*x) && !no_vec) ? vec_lead(pw) : -1;
-  bool dvec = vec_view(*dy) && !no_vec;
-  if (!dvec) { /* x-only 16-byte staging is instantiated; dy-only is not */ }
+  // dy staging: float4 units for unit-stride views, position pairs for the stride-2 space-to-depth views of
+  // the transposed convolutions (one float4 holds two positions of this parity), scalars otherwise
+  int dvec = no_vec ? 0 : (vec_view(*dy) ? 1 : ((dy->sW == 2 && dy->chan_off != nullptr && (dy->W & 1) == 0) ? 2 : 0));
   WgCand best{}; bool have = false;
   auto consider = [&](int TD, int TH, int RSUB, int NSUB, size_t budget) {
     WgCand c;
@@ -462,7 +465,7 @@ int wgrad_launch(const crnView* x, const crnInTransform* tr, const crnView* dy, 
           for (int RSUB = 8; RSUB >= 1; RSUB >>= 1) consider(kTD[tdi], kTH[thi], RSUB, NSUB, kLdsBudget);
   };
   search();
-  if (!have && (xlead >= 0 || dvec)) { xlead = -1; dvec = false; search(); }   // tiny maps: scalar staging
+  if (!have && (xlead >= 0 || dvec)) { xlead = -1; dvec = 0; search(); }   // tiny maps: scalar staging
   if (const char* f = getenv("CRN_WG_FORCE")) {      // tuning aid: "TD,TH,RSUB,NSUB"
     int fTD, fTH, fR, fN;
     if (sscanf(f, "%d,%d,%d,%d", &fTD, &fTH, &fR, &fN) == 4) {
@@ -473,7 +476,7 @@ int wgrad_launch(const crnView* x, const crnInTransform* tr, const crnView* dy, 
     }
   }
   if (!have) return CRN_EINVAL;
-  if (xlead < 0) dvec = false;                       // instantiated variants: scalar, x, x+dy
+  if (xlead < 0) dvec = 0;                           // instantiated variants: scalar, x, x+dy, x+dy pairs
   if (xlead < 0 || !dvec) {
     // the candidate was costed with dvec; re-derive it with the variant that will run
     WgCand c;
@@ -535,7 +538,7 @@ int wgrad_launch(const crnView* x, const crnInTransform* tr, const crnView* dy, 
     g.plu = g.PH * g.PW / 4; g.pw4 = g.PW / 4; g.nunits = CC * g.PD * g.plu;
     g.magic_PLU = magic20(g.plu); g.magic_PW4 = magic20(g.pw4);
   }
-  if (dvec) { g.np4 = npos / 4; g.dnunits = NB * g.np4; g.magic_NP4 = magic20(g.np4); }
+  if (dvec) { g.np4 = npos / (dvec == 2 ? 2 : 4); g.dnunits = NB * g.np4; g.magic_NP4 = magic20(g.np4); }
   g.Tfull = Tfull; g.khf = khf; g.kwf = kwf; g.bd0 = bd0; g.bh0 = bh0; g.bw0 = bw0; g.ncols = ncols;
   g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
   // (with per-group split counts the idle tail blocks must stay spread over the XCDs: plain round robin)

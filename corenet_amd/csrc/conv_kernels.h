@@ -3,6 +3,7 @@
 // (one hipcc process each) and export plain launcher functions used by conv_igemm.hip.
 #pragma once
 #include "crn_common.h"
+#include <type_traits>
 
 namespace crnk {
 
@@ -87,6 +88,10 @@ __device__ __forceinline__ crn_rsrc make_rsrc(const float* base) {   // raw buff
 __device__ __forceinline__ void crn_bload(float& dst, const crn_rsrc& rs, unsigned byte_off) {
   asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(dst) : "v"(byte_off), "s"(rs));
 }
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void crn_bload3(f32x3& dst, const crn_rsrc& rs, unsigned byte_off) {
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx3 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(byte_off), "s"(rs));
+}
 __device__ __forceinline__ void crn_bload4(f32x4& dst, const crn_rsrc& rs, unsigned byte_off) {
   asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(byte_off), "s"(rs));
 }
@@ -98,6 +103,11 @@ __device__ __forceinline__ void crn_wait_loads(float (&v)[N]) {
     asm volatile("s_waitcnt vmcnt(0)"
                  : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]), "+v"(v[i + 4]), "+v"(v[i + 5]),
                    "+v"(v[i + 6]), "+v"(v[i + 7]));
+}
+template <int N>
+__device__ __forceinline__ void crn_wait_loads4n(f32x3 (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[i]));
 }
 template <int N>
 __device__ __forceinline__ void crn_wait_loads4n(f32x4 (&v)[N]) {
@@ -681,47 +691,59 @@ __device__ __forceinline__ void wgrad_rows(f32x4 (&acc)[RSUB][NSUB], const float
 
 // 16-byte staging of the dy tile: unit u -> (channel n, 4 consecutive positions along W)
 struct DUnit { int n, pos, td, th, tw; bool valid; };
-template <int J>
+// PU = positions per unit: 4 (unit-stride dy, one float4) or 2 (dy is a stride-2 space-to-depth view: the
+// float4 at the first position also holds the second one, elements 0 and 2; 1 and 3 belong to the other parity)
+template <int J, int PU>
 __device__ __forceinline__ DUnit dy_unit(const WgradGeom& g) {
   int u = (int)threadIdx.x + J * 256;
   asm volatile("" : "+v"(u));
   DUnit o;
   o.valid = u < g.dnunits;
   o.n = mdiv(u, g.magic_NP4);
-  o.pos = 4 * (u - o.n * g.np4);
+  o.pos = PU * (u - o.n * g.np4);
   const int r1 = mdiv(o.pos, g.magic_TW);
   o.tw = o.pos - r1 * g.TW;
   o.td = mdiv(r1, g.magic_TH);
   o.th = r1 - o.td * g.TH;
   return o;
 }
-template <int J = 0>
+// position pairs load 3 dwords (elements 0 and 2 are ours): a fourth would reach past the tensor's last element
+template <int PU, int NS, int J = 0, typename VT>
 __device__ __forceinline__ void dy_issue_v(const WgradGeom& g, const unsigned* dchoff, const crn_rsrc& rs, int n0,
-                                           int d0, int h0, int w0, f32x4 (&val)[NV]) {
-  if constexpr (J < NV) {
+                                           int d0, int h0, int w0, VT (&val)[NS]) {
+  if constexpr (J < NS) {
     unsigned goff = 0x80000000u;
-    const DUnit t = dy_unit<J>(g);
+    const DUnit t = dy_unit<J, PU>(g);
     if (t.valid) {
       const int od = d0 + t.td, oh = h0 + t.th, ow = w0 + t.tw;
       if (n0 + t.n < g.dy.C && od < g.dy.D && oh < g.dy.H && ow < g.dy.W)
-        goff = (dchoff[t.n] + (unsigned)od * (unsigned)g.dy.sD + (unsigned)oh * (unsigned)g.dy.sH + (unsigned)ow) * 4u;
+        goff = (dchoff[t.n] + (unsigned)od * (unsigned)g.dy.sD + (unsigned)oh * (unsigned)g.dy.sH +
+                (unsigned)ow * (unsigned)(PU == 2 ? 2 : 1)) * 4u;
     }
-    crn_bload4(val[J], rs, goff);
-    dy_issue_v<J + 1>(g, dchoff, rs, n0, d0, h0, w0, val);
+    if constexpr (PU == 4) crn_bload4(val[J], rs, goff); else crn_bload3(val[J], rs, goff);
+    dy_issue_v<PU, NS, J + 1>(g, dchoff, rs, n0, d0, h0, w0, val);
   }
 }
-template <int J = 0>
-__device__ __forceinline__ void dy_commit_v(const WgradGeom& g, float* ldsB, const f32x4 (&val)[NV]) {
-  if constexpr (J < NV) {
+template <int PU, int NS, int J = 0, typename VT>
+__device__ __forceinline__ void dy_commit_v(const WgradGeom& g, float* ldsB, const VT (&val)[NS]) {
+  if constexpr (J < NS) {
     if (J * 256 < g.dnunits) {
-      const DUnit t = dy_unit<J>(g);
-      if (t.valid) *reinterpret_cast<f32x4*>(ldsB + t.n * g.POSP + t.pos) = val[J];
+      const DUnit t = dy_unit<J, PU>(g);
+      if (t.valid) {
+        float* dst = ldsB + t.n * g.POSP + t.pos;
+        if constexpr (PU == 4) {
+          *reinterpret_cast<f32x4*>(dst) = val[J];
+        } else {
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          *reinterpret_cast<f32x2*>(dst) = (f32x2){val[J][0], val[J][2]};
+        }
+      }
     }
-    dy_commit_v<J + 1>(g, ldsB, val);
+    dy_commit_v<PU, NS, J + 1>(g, ldsB, val);
   }
 }
 
-template <int RSUB, int NSUB, bool XV, bool DV>
+template <int RSUB, int NSUB, bool XV, int DV>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned* choff = reinterpret_cast<unsigned*>(lds);   // x channel table; dy channel offsets at [192,256)
@@ -791,8 +813,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
   float pval[XV ? 1 : PREG];
   f32x4 pv4[XV ? NVX : 1];
   unsigned inmask = 0;
+  constexpr int DPU = DV == 2 ? 2 : 4, DNS = DV == 2 ? NVX : NV;     // positions per unit, float4 slots
   float dval[DV ? 8 : DREG];
-  f32x4 dv4[DV ? NV : 1];
+  using DVT = typename std::conditional<DV == 2, f32x3, f32x4>::type;
+  DVT dv4[DV ? DNS : 1];
 
   auto tile_origin = [&](int tl, int& b, int& d0, int& h0, int& w0) {
     int tile = tl;
@@ -875,8 +899,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
       patch_prepare(pdsc, h0, w0, phw);
       patch_issue(pdsc, choff, phw, xrs, nplanes, npass, c0, d0, pval);
     }
-    if constexpr (DV) {
-      dy_issue_v(g, choff + kChTab, drs, n0, d0, h0, w0, dv4);
+    if constexpr (DV != 0) {
+      dy_issue_v<DPU, DNS>(g, choff + kChTab, drs, n0, d0, h0, w0, dv4);
     } else {
       dy_prepare(d0, h0, w0);
       CRN_DY_8U(dy_issue, drs CRN_COMMA, 0) CRN_DY_8U(dy_issue, drs CRN_COMMA, 8)
@@ -892,8 +916,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
       patch_prepare(pdsc, h0, w0, phw);
       patch_commit(pdsc, choff, phw, ldsA, nplanes, npass, c0, d0, pval);
     }
-    if constexpr (DV) {
-      dy_commit_v(g, ldsB, dv4);
+    if constexpr (DV != 0) {
+      dy_commit_v<DPU, DNS>(g, ldsB, dv4);
     } else {
       dy_prepare(d0, h0, w0);
       CRN_DY_8(dy_commit, , 0) CRN_DY_8(dy_commit, , 8) CRN_DY_8(dy_commit, , 16) CRN_DY_8(dy_commit, , 24)
@@ -913,7 +937,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
   }
   for (int tl = tbeg; tl < tend; ++tl) {
     if constexpr (XV) crn_wait_loads4n(pv4); else crn_wait_loads(pval);
-    if constexpr (DV) crn_wait_loads4(dv4); else crn_wait_loads(dval);
+    if constexpr (DV != 0) crn_wait_loads4n(dv4); else crn_wait_loads(dval);
     __syncthreads();
     if (g.dbg != 2 || tl == tbeg) stage_commit(cd0, ch0, cw0);
     __syncthreads();
@@ -979,7 +1003,7 @@ inline int launch_fwd(const ConvGeom& g, dim3 grid, size_t lds_bytes, hipStream_
   return CRN_OK;
 }
 
-template <int RSUB, int NSUB, bool XV, bool DV>
+template <int RSUB, int NSUB, bool XV, int DV>
 inline int launch_wgrad(const WgradGeom& g, dim3 grid, size_t lds_bytes, hipStream_t st) {
   auto k = conv_wgrad_kernel<RSUB, NSUB, XV, DV>;
   if (lds_bytes > 65536)
@@ -995,6 +1019,6 @@ inline int launch_wgrad(const WgradGeom& g, dim3 grid, size_t lds_bytes, hipStre
 #define CRN_FWD_CONFIGS(X) X(8, 1) X(4, 2) X(4, 1) X(2, 4) X(2, 2) X(2, 1) X(1, 4) X(1, 2) X(1, 1)
 #define CRN_WG_CONFIGS(X) X(8, 1) X(4, 2) X(4, 1) X(2, 4) X(2, 2) X(2, 1) X(1, 4) X(1, 2) X(1, 1)
 #define CRN_DECL_FWD(M, N) int crn_launch_fwd_##M##_##N(const crnk::ConvGeom&, int xvec, dim3, size_t, hipStream_t);
-#define CRN_DECL_WG(R, N) int crn_launch_wgrad_##R##_##N(const crnk::WgradGeom&, int xvec, int dyvec, dim3, size_t, hipStream_t);
+#define CRN_DECL_WG(R, N) int crn_launch_wgrad_##R##_##N(const crnk::WgradGeom&, int xvec, int dyvec /* 0 1 2 */, dim3, size_t, hipStream_t);
 CRN_FWD_CONFIGS(CRN_DECL_FWD)
 CRN_WG_CONFIGS(CRN_DECL_WG)
