@@ -199,8 +199,12 @@ struct FwdCfg {
 };
 
 // Sub-tile = 1 x mh x mw output positions (16 MFMA rows); tile = tsd x tsh x tsw sub-tiles.
-// lead >= 0: 16-byte staging with `lead` extra patch columns on the left; lead < 0: scalar staging
-int patch_width(int TW, int kw, int lead) { return lead < 0 ? TW + kw - 1 : (lead + TW + kw - 1 + 3) & ~3; }
+// lead >= 0: vector staging with `lead` extra patch columns on the left (units of `unit` = 4 positions for
+// unit-stride views, 2 for stride-2 space-to-depth views); lead < 0: scalar staging
+thread_local int g_stage_unit = 4;
+int patch_width(int TW, int kw, int lead) {
+  return lead < 0 ? TW + kw - 1 : (lead + TW + kw - 1 + g_stage_unit - 1) / g_stage_unit * g_stage_unit;
+}
 
 bool fwd_cfg(int MSUB, int NSUB, int B, int Cin, int Npad, int D, int H, int W, int kd, int kh, int kw, int lead,
              FwdCfg* out) {
@@ -222,12 +226,12 @@ bool fwd_cfg(int MSUB, int NSUB, int B, int Cin, int Npad, int D, int H, int W, 
       if (cost < best) { best = cost; c.tsd = a; c.tsh = bq; c.tsw = cw; }
     }
   const int TD = c.tsd, TH = c.tsh * c.mh, TW = c.tsw * c.mw;
-  if (lead >= 0 && (TW & 3)) return false;
+  if (lead >= 0 && (TW % g_stage_unit)) return false;
   const int PDp = TD + kd - 1, plane = (TH + kh - 1) * patch_width(TW, kw, lead);
   const int PS = PDp * plane;
   const int PSP = pad16mod32(PS), WSP = pad16mod32(T * NSUB * 16);
   auto fits = [&](int cc) {
-    const bool staged = lead >= 0 ? (int64_t)cc * PS / 4 <= 256 * NVX : stage_passes(cc * PDp, plane) <= PREG;
+    const bool staged = lead >= 0 ? (int64_t)cc * PS / g_stage_unit <= 256 * NVX : stage_passes(cc * PDp, plane) <= PREG;
     return (size_t)cc * (PSP + WSP) * 4 + 2 * kChTab * 4 <= kLdsBudget && staged &&
            (int64_t)cc * T * NSUB * 16 <= 256 * WREG * 4;
   };
@@ -271,7 +275,10 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   static const int kM[4] = {8, 4, 2, 1};
   static const int kN[3] = {4, 2, 1};
   static const bool no_vec = getenv("CRN_NO_VEC") != nullptr;
-  const int lead = (vec_view(*x) && !no_vec) ? vec_lead(pw) : -1;
+  // staging of x: float4 units (unit-stride views), position pairs (stride-2 space-to-depth views), scalars
+  const int xmode = no_vec ? 0 : (vec_view(*x) ? 1 : ((x->sW == 2 && x->chan_off != nullptr && (x->W & 1) == 0) ? 2 : 0));
+  g_stage_unit = xmode == 2 ? 2 : 4;
+  const int lead = xmode == 1 ? vec_lead(pw) : (xmode == 2 ? ((pw % 2) + 2) % 2 : -1);
   // Estimated cycles per CU (calibrated on tools/sweep_fwd.sh): work that adds up on the SIMDs
   // (MFMA issue at ~77% + staging instructions, which do not hide under MFMAs) plus one exposed
   // load->commit->barrier latency per chunk and pair of resident workgroups; split-K pays a
@@ -289,7 +296,7 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
       const int T = kd * kh * kw, nchunks = crn_cdiv(x->C, c.CC), NB = kN[ni] * 16;
       const int TD = c.tsd, TH = c.tsh * c.mh, TW = c.tsw * c.mw;
       const double patch = (double)c.CC * (TD + kd - 1) * (TH + kh - 1) * patch_width(TW, kw, lead);
-      const double slots = (lead >= 0 ? patch / 4 / 256 * 450.0 : patch / 256 * 350.0) +
+      const double slots = (lead >= 0 ? patch / g_stage_unit / 256 * (g_stage_unit == 4 ? 450.0 : 400.0) : patch / 256 * 350.0) +
                            (double)c.CC * T * NB / 4 / 256 * 300.0;
       const double chunk_work = (double)kM[mi] * kN[ni] * (c.CC / 4) * T * 32.0 * 1.3 + slots;
       for (int sp = 1; sp <= (splits < 1 ? std::min(nchunks, 16) : 1); sp *= 2) {
@@ -307,7 +314,7 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
       best = c; have = true; forced = true;
     }
   }
-  int xvec = lead >= 0 ? 1 : 0;
+  int xvec = lead >= 0 ? xmode : 0;
   if (!have && xvec) {       // no 16-byte configuration fits (tiny W): scalar staging
     xvec = 0;
     for (int mi = 0; mi < 4 && !have; ++mi) {
@@ -342,7 +349,7 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   g.lg2 = ilog2_ceil(g.PH * g.PW); g.npass = xvec ? 0 : stage_passes(CC * g.PD, g.PH * g.PW);
   g.magic_PW = magic20(g.PW); g.magic_PD = magic20(g.PD); g.magic_T = magic20(g.T);
   if (xvec) {
-    g.plu = g.PH * g.PW / 4; g.pw4 = g.PW / 4; g.nunits = CC * g.PD * g.plu;
+    g.plu = g.PH * g.PW / g_stage_unit; g.pw4 = g.PW / g_stage_unit; g.nunits = CC * g.PD * g.plu;
     g.magic_PLU = magic20(g.plu); g.magic_PW4 = magic20(g.pw4);
   }
   // split-K: partial sums into a dense scratch tensor + one reduction launch (mode 3); atomics (mode 2)
@@ -439,6 +446,7 @@ int wgrad_launch(const crnView* x, const crnInTransform* tr, const crnView* dy, 
                  int kd, int kh, int kw, int pd, int ph, int pw, int Tfull, int khf, int kwf, int bd0, int bh0,
                  int bw0, int max_blocks, const crnTapBoxes* boxes, hipStream_t st) {
   const int T = kd * kh * kw;
+  g_stage_unit = 4;                              // x patches of the weight gradient: float4 units only
   const int NpadC = (ncols + 15) & ~15;          // columns this launch covers
   const int Dy = dy->D, Hy = dy->H, Wy = dy->W;
   const int TWc = Wy >= 16 ? 16 : ((Wy + 3) & ~3);

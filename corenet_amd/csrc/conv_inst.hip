@@ -9,8 +9,10 @@
 
 #if defined(CRN_INST_FWD)
 int CRN_NAME(crn_launch_fwd_, CRN_M, CRN_N)(const crnk::ConvGeom& g, int xvec, dim3 grid, size_t lds, hipStream_t st) {
-  return xvec ? crnk::launch_fwd<CRN_M, CRN_N, true>(g, grid, lds, st)
-              : crnk::launch_fwd<CRN_M, CRN_N, false>(g, grid, lds, st);
+  // xvec: 0 scalar staging, 1 float4 units (unit-stride x), 2 position pairs (stride-2 space-to-depth x)
+  if (xvec == 1) return crnk::launch_fwd<CRN_M, CRN_N, 1>(g, grid, lds, st);
+  if (xvec == 2) return crnk::launch_fwd<CRN_M, CRN_N, 2>(g, grid, lds, st);
+  return crnk::launch_fwd<CRN_M, CRN_N, 0>(g, grid, lds, st);
 }
 #elif defined(CRN_INST_WGRAD)
 int CRN_NAME(crn_launch_wgrad_, CRN_M, CRN_N)(const crnk::WgradGeom& g, int xvec, int dyvec, dim3 grid, size_t lds,

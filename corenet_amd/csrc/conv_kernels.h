@@ -295,38 +295,44 @@ __device__ __forceinline__ VUnit vec_unit(const PatchDesc& g) {
   o.pd = q - o.cl * g.PD;
   return o;
 }
-template <int J = 0>
+// PU = positions per unit: 4 (unit-stride views, float4) or 2 (stride-2 space-to-depth views: dwordx3 load,
+// elements 0 and 2 are two consecutive positions of this channel's parity; the patch origin is even, so both
+// are inside or both outside, and the load ends exactly at the second one)
+template <int PU, int J = 0, typename VT>
 __device__ __forceinline__ void patch_issue_v(const PatchDesc& g, const unsigned* choff, const crn_rsrc& rs, int c0,
-                                              int d0, int h0, int w0, f32x4 (&val)[NVX], unsigned& inmask) {
+                                              int d0, int h0, int w0, VT (&val)[NVX], unsigned& inmask) {
   if constexpr (J < NVX) {
     unsigned goff = 0x80000000u;
     const VUnit t = vec_unit<J>(g);
     if (t.valid) {
-      const int gd = d0 + t.pd - g.pd, gh = h0 + t.ph - g.ph, gw = w0 + 4 * t.p4 - g.pw;
+      const int gd = d0 + t.pd - g.pd, gh = h0 + t.ph - g.ph, gw = w0 + PU * t.p4 - g.pw;
       const bool in = (c0 + t.cl < g.x.C) && (unsigned)gd < (unsigned)g.x.D && (unsigned)gh < (unsigned)g.x.H &&
                       (unsigned)gw < (unsigned)g.x.W;
       if (in) {
-        goff = (choff[t.cl] + (unsigned)gd * (unsigned)g.x.sD + (unsigned)gh * (unsigned)g.x.sH + (unsigned)gw) * 4u;
+        goff = (choff[t.cl] + (unsigned)gd * (unsigned)g.x.sD + (unsigned)gh * (unsigned)g.x.sH +
+                (unsigned)gw * (unsigned)(PU == 2 ? 2 : 1)) * 4u;
         inmask |= 1u << J;
       }
     }
-    crn_bload4(val[J], rs, goff);
-    patch_issue_v<J + 1>(g, choff, rs, c0, d0, h0, w0, val, inmask);
+    if constexpr (PU == 4) crn_bload4(val[J], rs, goff); else crn_bload3(val[J], rs, goff);
+    patch_issue_v<PU, J + 1>(g, choff, rs, c0, d0, h0, w0, val, inmask);
   }
 }
-template <int J = 0>
+template <int PU, int J = 0, typename VT>
 __device__ __forceinline__ void patch_commit_v(const PatchDesc& g, const unsigned* choff, float* ldsA,
-                                               const f32x4 (&val)[NVX], unsigned inmask) {
+                                               const VT (&val)[NVX], unsigned inmask) {
   if constexpr (J < NVX) {
     if (J * 256 < g.nunits) {                            // wave-uniform
       const VUnit t = vec_unit<J>(g);
       if (t.valid) {
-        f32x4 v = val[J];
+        float v[PU];
+#pragma unroll
+        for (int e = 0; e < PU; ++e) v[e] = val[J][PU == 4 ? e : 2 * e];
         if (g.tr.scale && ((inmask >> J) & 1u)) {        // zero padding stays zero
           const float* tab = reinterpret_cast<const float*>(choff);
           const float sc = tab[64 + t.cl], sh = tab[128 + t.cl];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
+          for (int e = 0; e < PU; ++e) {
             float x = v[e];
             if (g.tr.pre_relu) x = fmaxf(x, 0.f);
             x = x * sc + sh;
@@ -334,10 +340,16 @@ __device__ __forceinline__ void patch_commit_v(const PatchDesc& g, const unsigne
             v[e] = x;
           }
         }
-        *reinterpret_cast<f32x4*>(ldsA + t.cl * g.PSP + t.pd * g.plane + 4 * t.r) = v;
+        float* dst = ldsA + t.cl * g.PSP + t.pd * g.plane + PU * t.r;
+        if constexpr (PU == 4) {
+          *reinterpret_cast<f32x4*>(dst) = (f32x4){v[0], v[1], v[2], v[3]};
+        } else {
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          *reinterpret_cast<f32x2*>(dst) = (f32x2){v[0], v[1]};
+        }
       }
     }
-    patch_commit_v<J + 1>(g, choff, ldsA, val, inmask);
+    patch_commit_v<PU, J + 1>(g, choff, ldsA, val, inmask);
   }
 }
 
@@ -426,7 +438,7 @@ __device__ __forceinline__ void mfma_rows(f32x4 (&acc)[MSUB][NSUB], const float*
 }
 
 // ------------------------------- forward -----------------------------------
-template <int MSUB, int NSUB, bool XV>
+template <int MSUB, int NSUB, int XV>
 __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned* choff = reinterpret_cast<unsigned*>(lds);      // 2 x kChTab per-chunk channel tables
@@ -455,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
   const int nplanes = g.CC * g.PD, npass = g.npass;
   const crn_rsrc xrs = make_rsrc(g.x.base + (int64_t)b * g.x.sB);
   PatchHW phw;
-  if constexpr (!XV) patch_prepare(pdsc, h0, w0, phw);
+  if constexpr (XV == 0) patch_prepare(pdsc, h0, w0, phw);
 
   // lane's LDS offset of output position (sub-tile s, row i16) at tap (0,0,0)
   int posbase[MSUB];
@@ -477,8 +489,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
     for (int ns = 0; ns < NSUB; ++ns) acc[ms][ns] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const TapBox nbox = box_union(g.n_box, g.n_groups, g.y.C, n0, min(n0 + NB, g.y.C) - 1, g.kd, g.kh, g.kw);
+  constexpr int XPU = XV == 2 ? 2 : 4;                  // positions per staged unit
+  using XVT = typename std::conditional<XV == 2, f32x3, f32x4>::type;
   float pval[XV ? 1 : PREG];
-  f32x4 pv4[XV ? NVX : 1];
+  XVT pv4[XV ? NVX : 1];
   unsigned inmask = 0;
   f32x4 wval[WREG];
   const int nf4 = g.CC * g.T * (NB / 4);
@@ -525,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
   if (cbeg < cend) {
     stage_choff(g.x, g.tr, choff + (cbeg & 1) * kChTab, cbeg * g.CC, g.CC);
     __syncthreads();
-    if constexpr (XV) patch_issue_v(pdsc, choff + (cbeg & 1) * kChTab, xrs, cbeg * g.CC, d0, h0, w0, pv4, inmask);
+    if constexpr (XV != 0) patch_issue_v<XPU>(pdsc, choff + (cbeg & 1) * kChTab, xrs, cbeg * g.CC, d0, h0, w0, pv4, inmask);
     else patch_issue(pdsc, choff + (cbeg & 1) * kChTab, phw, xrs, nplanes, npass, cbeg * g.CC, d0, pval);
     weights_issue(cbeg * g.CC);
   }
@@ -533,17 +547,17 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
     const int c0 = chunk * g.CC;
     const bool stage = !(g.dbg >= 2 && chunk > cbeg);
     if (stage) {
-    if constexpr (XV) crn_wait_loads4n(pv4); else crn_wait_loads(pval);
+    if constexpr (XV != 0) crn_wait_loads4n(pv4); else crn_wait_loads(pval);
     crn_wait_loads4(wval);
     __syncthreads();                       // previous chunk's MFMA reads are done
-    if constexpr (XV) { patch_commit_v(pdsc, choff + (chunk & 1) * kChTab, ldsA, pv4, inmask); inmask = 0; }
+    if constexpr (XV != 0) { patch_commit_v<XPU>(pdsc, choff + (chunk & 1) * kChTab, ldsA, pv4, inmask); inmask = 0; }
     else patch_commit(pdsc, choff + (chunk & 1) * kChTab, phw, ldsA, nplanes, npass, c0, d0, pval);
     weights_commit(c0);
     if (chunk + 1 < cend) stage_choff(g.x, g.tr, choff + ((chunk + 1) & 1) * kChTab, c0 + g.CC, g.CC);
     __syncthreads();
     }
     if (stage && g.dbg < 2 && chunk + 1 < cend) {                // next chunk's loads fly under this chunk's MFMAs
-      if constexpr (XV) patch_issue_v(pdsc, choff + ((chunk + 1) & 1) * kChTab, xrs, c0 + g.CC, d0, h0, w0, pv4, inmask);
+      if constexpr (XV != 0) patch_issue_v<XPU>(pdsc, choff + ((chunk + 1) & 1) * kChTab, xrs, c0 + g.CC, d0, h0, w0, pv4, inmask);
       else patch_issue(pdsc, choff + ((chunk + 1) & 1) * kChTab, phw, xrs, nplanes, npass, c0 + g.CC, d0, pval);
       weights_issue(c0 + g.CC);
     }
@@ -893,7 +907,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
     const crn_rsrc xrs = make_rsrc(g.x.base + (int64_t)b * g.x.sB);
     const crn_rsrc drs = make_rsrc(g.dy.base + (int64_t)b * g.dy.sB);
     if constexpr (XV) {
-      patch_issue_v(pdsc, choff, xrs, c0, d0, h0, w0, pv4, inmask);
+      patch_issue_v<4>(pdsc, choff, xrs, c0, d0, h0, w0, pv4, inmask);
     } else {
       PatchHW phw;
       patch_prepare(pdsc, h0, w0, phw);
@@ -909,7 +923,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
   };
   auto stage_commit = [&](int d0, int h0, int w0) {
     if constexpr (XV) {
-      patch_commit_v(pdsc, choff, ldsA, pv4, inmask);
+      patch_commit_v<4>(pdsc, choff, ldsA, pv4, inmask);
       inmask = 0;
     } else {
       PatchHW phw;
@@ -993,7 +1007,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
 }
 
 
-template <int MSUB, int NSUB, bool XV>
+template <int MSUB, int NSUB, int XV>
 inline int launch_fwd(const ConvGeom& g, dim3 grid, size_t lds_bytes, hipStream_t st) {
   auto k = conv_fwd_kernel<MSUB, NSUB, XV>;
   if (lds_bytes > 65536)
