@@ -276,7 +276,7 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   static const int kN[3] = {4, 2, 1};
   static const bool no_vec = getenv("CRN_NO_VEC") != nullptr;
   // staging of x: float4 units (unit-stride views), position pairs (stride-2 space-to-depth views), scalars
-  const int xmode = no_vec ? 0 : (vec_view(*x) ? 1 : ((x->sW == 2 && x->chan_off != nullptr && (x->W & 1) == 0) ? 2 : 0));
+  const int xmode = no_vec ? 0 : (vec_view(*x) ? 1 : ((x->sW == 2 && (x->W & 1) == 0) ? 2 : 0));   // s2d views and stride-2 views
   g_stage_unit = xmode == 2 ? 2 : 4;
   const int lead = xmode == 1 ? vec_lead(pw) : (xmode == 2 ? ((pw % 2) + 2) % 2 : -1);
   // Estimated cycles per CU (calibrated on tools/sweep_fwd.sh): work that adds up on the SIMDs
