@@ -128,7 +128,7 @@ def main():
       for k, v in tj.get("kernels", {}).items():
         # stage_6.c1 fwd: conv_fwd_kernel<8,1,xvec>, 2048 tiles x 1 N-block.  stage_5.t1 and stage_6.t1 fwd
         # share that (kernel, grid); per step the dispatch order is s5.t1, s6.c1, s6.t1 -> every 3rd from 1
-        if "conv_fwd_kernel<8, 1, true>" in k and k.endswith(f"grid {2048 * 256}"):
+        if "conv_fwd_kernel<8, 1, 1>" in k and k.endswith(f"grid {2048 * 256}"):
           pl = v.get("per_launch_hbm_bytes", [])
           if len(pl) >= 3 and len(pl) % 3 == 0:
             mine = pl[1::3]
