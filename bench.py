@@ -156,15 +156,28 @@ def main():
   fill_s = e0.elapsed_time(e1) / 5 * 1e-3
   assert bool((filled == t.stack([(dist3 <= r).float() for r in (10, 30, 50)] * B)).all())
   fill_bytes = 8.0 * shells.numel()
+  # forward-only (eval mode, running BatchRenorm statistics): SURVEY 8(d) asks for it next to the train step
+  model.eval()
+  with t.no_grad():
+    for _ in range(2):
+      model(image, v2s, off)
+    e0.record()
+    for _ in range(5):
+      model(image, v2s, off)
+    e1.record(); t.cuda.synchronize()
+  eval_s = e0.elapsed_time(e1) / 5 * 1e-3
+  model.train()
   out = {
       "metric": "voxels/sec fwd+bwd @128^3", "value": world * B * 128 ** 3 * args.steps / dt,
       "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
       "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
       "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-      "config": {"workload": f"h7: CoReNet train step (fwd+{loss_name}+bwd+allreduce+Adam), "
+      "config": {"workload": f"{'h7' if C == 2 else 'm7/m9'}: CoReNet train step (fwd+{loss_name}+bwd+allreduce+Adam), "
                              f"256x256 RGB -> 128^3, C={C}, B={B}/GPU, fp32, random-init weights",
                  "global_batch": world * B, "parallelism": f"dp{world}"},
       "loss": float(loss),
+      "eval_forward": {"ms_per_batch": eval_s * 1e3, "value": B * 128 ** 3 / eval_s, "unit": "voxels/s",
+                       "note": "rank 0, forward only, eval mode, same inputs"},
       "roofline": {"kernel": "conv_fwd_kernel<8,1,xvec> (stage_6.c1 Conv3d 28->16 k5 @64^3, fwd)",
                    "bound": "mfma", "achieved": CONV6_FLOP * B / conv_s / 1e12, "peak": PEAK_F32_MFMA / 1e12,
                    "unit": "TFLOP/s", "frac": CONV6_FLOP * B / conv_s / PEAK_F32_MFMA, "traffic": traffic.get("conv"),
