@@ -189,3 +189,56 @@ def test_tap_boxes_cover_every_real_weight():
     for idx in (fwd.index, dgr.index):
       v = np.sort(idx[idx >= 0])
       assert (v == np.arange(np.prod(wshape))).all()
+
+
+def test_checkpoint_interop_and_fused_adam():
+  """N4: a checkpoint in the reference's format (state.py:74-97: torch.save of global_step,
+  model_state, model_config, optimizer_state = torch.optim.Adam.state_dict(), extra_metadata) loads into the
+  drop-in; the fused optimizer continues exactly where torch.optim.Adam would; encode -> decode round-trips."""
+  import io
+  from corenet_amd import state as S
+  from corenet_amd.model.core_net import CoreNet, CoreNetConfig, DecoderConfig
+  sd = O.make_state(3, 2, nbt=7)
+  keys = list(sd.keys())
+  pkeys = [k for k in keys if sd[k].dtype == t.float32 and "running" not in k]
+  # what the reference would have saved after two Adam steps on these parameters
+  g = t.Generator().manual_seed(11)
+  params = [sd[k].clone().requires_grad_(True) for k in pkeys]
+  opt = t.optim.Adam(params, lr=4e-4, eps=1e-4)
+  for _ in range(2):
+    for p in params: p.grad = t.randn(p.shape, generator=g) * 0.01
+    opt.step()
+  model_state = {k: (params[pkeys.index(k)].detach().clone() if k in pkeys else sd[k].clone()) for k in keys}
+  cfg = {"decoder": {"resolution": (128, 128, 128), "num_output_channels": 2, "last_upscale_factor": 2,
+                     "latent_channels": 64, "skip_fraction": 0.75}}
+  buf = io.BytesIO()
+  t.save({"global_step": 1234, "model_state": model_state, "model_config": cfg, "optimizer_state": opt.state_dict(),
+          "extra_metadata": {"note": "ref"}}, buf)
+  st = S.decode_state(buf.getvalue(), "cpu", backend=EMU)
+  assert st.global_step == 1234 and st.extra_metadata == {"note": "ref"}
+  assert [k for k, _ in st.model.named_parameters()] == pkeys            # torch's positional optimizer state needs this
+  got = st.model.state_dict()
+  assert list(got.keys()) == keys and all(t.equal(got[k], model_state[k]) for k in keys)
+  assert st.model.engine.adam_t == 2
+  # one more step: fused Adam (kernel contract) vs torch.optim.Adam continuing from the same state
+  grads = [t.randn(p.shape, generator=g) * 0.01 for p in params]
+  for p, gr in zip(params, grads): p.grad = gr
+  opt.step()
+  for k, gr in zip(pkeys, grads): st.model.engine.store.view(k, grad=True).copy_(gr)
+  st.optimizer.step()
+  for k, p in zip(pkeys, params):
+    assert float((st.model.state_dict()[k] - p.detach()).abs().max()) < 1e-6, k
+  # our own checkpoint: same format, round trip, and the saved optimizer state is torch.optim.Adam's
+  raw = S.encode_state(st)
+  d = t.load(io.BytesIO(raw), weights_only=False)
+  assert set(d) == {"global_step", "model_state", "model_config", "optimizer_state", "extra_metadata"}
+  opt2 = t.optim.Adam([p.detach().clone().requires_grad_(True) for p in params], lr=1.0)
+  opt2.load_state_dict(d["optimizer_state"])                             # loads into the reference's optimizer
+  assert opt2.param_groups[0]["lr"] == 4e-4 and opt2.param_groups[0]["eps"] == 1e-4
+  ref_sd = opt.state_dict()
+  for i in range(len(pkeys)):
+    assert float((d["optimizer_state"]["state"][i]["exp_avg"] - ref_sd["state"][i]["exp_avg"]).abs().max()) < 1e-7
+    assert float((d["optimizer_state"]["state"][i]["exp_avg_sq"] - ref_sd["state"][i]["exp_avg_sq"]).abs().max()) < 1e-9
+    assert int(d["optimizer_state"]["state"][i]["step"]) == 3
+  st2 = S.decode_state(raw, "cpu", backend=EMU)
+  assert st2.model.engine.adam_t == 3 and all(t.equal(st2.model.state_dict()[k], st.model.state_dict()[k]) for k in keys)
