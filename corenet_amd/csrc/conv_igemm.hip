@@ -163,17 +163,21 @@ __global__ void splitk_reduce_kernel(crnView v, const float* scratch, int splits
   }
 }
 
-// process-wide scratch for split-K partial sums (calls on different streams must not overlap)
+// per-device scratch for split-K partial sums (one process drives one GPU; calls that use it on different
+// streams of the same device must not overlap)
 float* splitk_scratch(size_t floats) {
-  static float* buf = nullptr;
-  static size_t cap = 0;
-  if (floats > cap) {
+  constexpr int kMaxDev = 16;
+  static float* buf[kMaxDev] = {};
+  static size_t cap[kMaxDev] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+  if (floats > cap[dev]) {
     if (floats > ((size_t)256 << 20) / 4) return nullptr;       // larger outputs keep the atomic path
-    if (buf) (void)hipFree(buf);
-    cap = std::max(floats, ((size_t)16 << 20) / 4);
-    if (hipMalloc(&buf, cap * 4) != hipSuccess) { buf = nullptr; cap = 0; }
+    if (buf[dev]) (void)hipFree(buf[dev]);
+    cap[dev] = std::max(floats, ((size_t)16 << 20) / 4);
+    if (hipMalloc(&buf[dev], cap[dev] * 4) != hipSuccess) { buf[dev] = nullptr; cap[dev] = 0; }
   }
-  return buf;
+  return buf[dev];
 }
 
 int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
