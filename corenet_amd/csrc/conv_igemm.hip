@@ -44,6 +44,8 @@ struct PwGeom {
   int B, C, N, Npad, S;            // S = positions per sample
   int64_t xsB, ysB;                // batch strides; channel stride = S for both
   int bias_sB, mode;
+  int splits, cps;                 // split-K: blockIdx.z = split*B + b, cps input channels per split (multiple
+                                   // of 32); partial sums go to the dense scratch y (mode 0), split*B + b as batch
 };
 
 __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
@@ -52,7 +54,9 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
   __shared__ __attribute__((aligned(16))) float ldsB[KC * SB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kk = lane >> 4;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, b = blockIdx.z;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int split = blockIdx.z / g.B, b = blockIdx.z - split * g.B;
+  const int cbeg = split * g.cps, cend = min(g.C, cbeg + g.cps);
   const float* xb = g.x + (int64_t)b * g.xsB;
   // staging roles: A: 2 float4 per thread (rows ka0, ka0+16), B: 1 float4 per thread
   const int ka = tid >> 4, ca = (tid & 15) * 4;       // A row / column
@@ -63,12 +67,12 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
   auto issue = [&](int c0) {
     const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int c_a0 = c0 + ka, c_a1 = c0 + ka + 16, c_b = c0 + kb;
-    ra0 = (a_ok && c_a0 < g.C) ? *reinterpret_cast<const f32x4*>(xb + (int64_t)c_a0 * g.S + m0 + ca) : z;
-    ra1 = (a_ok && c_a1 < g.C) ? *reinterpret_cast<const f32x4*>(xb + (int64_t)c_a1 * g.S + m0 + ca) : z;
-    rb = (b_ok && c_b < g.C) ? *reinterpret_cast<const f32x4*>(g.w + (int64_t)c_b * g.Npad + n0 + cb) : z;
+    ra0 = (a_ok && c_a0 < cend) ? *reinterpret_cast<const f32x4*>(xb + (int64_t)c_a0 * g.S + m0 + ca) : z;
+    ra1 = (a_ok && c_a1 < cend) ? *reinterpret_cast<const f32x4*>(xb + (int64_t)c_a1 * g.S + m0 + ca) : z;
+    rb = (b_ok && c_b < cend) ? *reinterpret_cast<const f32x4*>(g.w + (int64_t)c_b * g.Npad + n0 + cb) : z;
   };
   auto xform = [&](f32x4 v, int c) -> f32x4 {
-    if (g.tr.scale && a_ok && c < g.C) {
+    if (g.tr.scale && a_ok && c < cend) {
       const float sc = g.tr.scale[c], sh = g.tr.shift[c];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -82,14 +86,14 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
     return v;
   };
   f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-  issue(0);
-  for (int c0 = 0; c0 < g.C; c0 += KC) {
+  issue(cbeg);
+  for (int c0 = cbeg; c0 < cend; c0 += KC) {
     __syncthreads();
     *reinterpret_cast<f32x4*>(ldsA + ka * SA + ca) = xform(ra0, c0 + ka);
     *reinterpret_cast<f32x4*>(ldsA + (ka + 16) * SA + ca) = xform(ra1, c0 + ka + 16);
     *reinterpret_cast<f32x4*>(ldsB + kb * SB + cb) = rb;
     __syncthreads();
-    if (c0 + KC < g.C) issue(c0 + KC);
+    if (c0 + KC < cend) issue(c0 + KC);
     const float* pa = ldsA + kk * SA + wave * 16 + i16;
     const float* pb = ldsB + kk * SB + i16;
 #pragma unroll
@@ -107,8 +111,8 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
     for (int ns = 0; ns < 2; ++ns) {
       const int n = n0 + ns * 16 + i16;
       if (n < g.N) {
-        const float bsv = g.bias ? g.bias[(int64_t)b * g.bias_sB + n] : 0.f;
-        float* dst = g.y + (int64_t)b * g.ysB + (int64_t)n * g.S + m;
+        const float bsv = (g.bias && split == 0) ? g.bias[(int64_t)b * g.bias_sB + n] : 0.f;
+        float* dst = g.y + (int64_t)(split * g.B + b) * g.ysB + (int64_t)n * g.S + m;
         f32x4 v = acc[ns] + bsv;
         if (g.mode == 1) v += *reinterpret_cast<const f32x4*>(dst);
         *reinterpret_cast<f32x4*>(dst) = v;
@@ -269,9 +273,33 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
     p.tr = tr ? *tr : crnInTransform{nullptr, nullptr, 0, 0};
     p.B = x->B; p.C = x->C; p.N = y->C; p.Npad = Npad; p.S = (int)Sx;
     p.xsB = x->sB; p.ysB = y->sB; p.bias_sB = bias_sB; p.mode = accumulate ? 1 : 0;
-    dim3 grid((unsigned)crn_cdiv(Sx, 64), (unsigned)crn_cdiv(y->C, 32), (unsigned)x->B);
+    p.splits = 1; p.cps = (x->C + 31) & ~31;
+    // long reductions over few positions (stage4/5 of the encoder: K = 1024..2048, 64..256 positions per sample):
+    // split the channels over blocks, partial sums to the split-K scratch, one reduction launch
+    const int64_t blocks = crn_cdiv(Sx, 64) * crn_cdiv(y->C, 32) * (int64_t)x->B;
+    const int64_t ytot = (int64_t)y->B * y->C * Sx;
+    static const bool pw_nosplit = getenv("CRN_PW_NOSPLIT") != nullptr;
+    float* scratch = nullptr;
+    if (splits < 1 && !pw_nosplit && blocks < 256 && x->C >= 256) {
+      int sp = (int)std::min<int64_t>(std::min<int64_t>(x->C / 128, 16), crn_cdiv(512, blocks));
+      if (sp > 1) {
+        p.cps = (crn_cdiv(x->C, sp) + 31) & ~31;
+        sp = crn_cdiv(x->C, p.cps);
+        if (sp > 1 && (scratch = splitk_scratch((size_t)sp * ytot)) != nullptr) {
+          p.splits = sp; p.y = scratch; p.ysB = (int64_t)y->C * Sx; p.mode = 0;
+        } else {
+          p.cps = (x->C + 31) & ~31;
+        }
+      }
+    }
+    dim3 grid((unsigned)crn_cdiv(Sx, 64), (unsigned)crn_cdiv(y->C, 32), (unsigned)(x->B * p.splits));
     hipLaunchKernelGGL(pointwise_fwd_kernel, grid, dim3(256), 0, st, p);
     CRN_CHECK_LAUNCH();
+    if (p.splits > 1) {
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(crn_cdiv(ytot, 256), 4096)), dim3(256), 0, st,
+                         *y, scratch, p.splits, accumulate);
+      CRN_CHECK_LAUNCH();
+    }
     return CRN_OK;
   }
   // Score every (MSUB, NSUB) tile: useful MFMA rows x operand reuse of the tile x how well
