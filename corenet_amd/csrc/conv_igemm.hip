@@ -331,7 +331,7 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
       const double slots = (lead >= 0 ? patch / g_stage_unit / 256 * (g_stage_unit == 4 ? 450.0 : 400.0) : patch / 256 * 350.0) +
                            (double)c.CC * T * NB / 4 / 256 * 300.0;
       const double chunk_work = (double)kM[mi] * kN[ni] * (c.CC / 4) * T * 32.0 * 1.3 + slots;
-      for (int sp = 1; sp <= (splits < 1 ? std::min(nchunks, 16) : 1); sp *= 2) {
+      for (int sp = 1; sp <= (splits < 1 ? std::min(nchunks, 64) : 1); sp *= 2) {
         if (sp > 1 && c.blocks * (sp / 2) >= kSplitFill) break;   // split only to fill the chip
         const int cps = crn_cdiv(nchunks, sp);
         const double bpc = std::max(1.0, std::ceil((double)c.blocks * sp / 256.0));
