@@ -34,14 +34,30 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
 
 
 class GradientSync:
-  """all-reduce(sum) of the flat gradient slab in `chunks` pieces (the division
-  by world_size is folded into the Adam kernel's grad_scale)."""
+  """Gradient exchange of the data-parallel step: all-reduce(sum) over RCCL, the division by world_size is
+  folded into the Adam kernel's grad_scale.
 
-  def __init__(self, world_size: int, chunks: int = 4, group=None):
+  Two ways to drive it.  `sync(grads)` reduces the whole flat slab after backward in `chunks` pieces.
+  With `overlap` (default, env CRN_OVERLAP_ALLREDUCE=0 turns it off) `CoreNet.train_step` passes `push` to
+  `Plan.backward` as the bucket hook: every finished range of the slab (engine.GRAD_BUCKET_LABELS, reverse
+  layer order like DDP's buckets, pipeline.py:199) is reduced on RCCL's own stream while the rest of
+  backward still runs, and `wait` joins them before Adam."""
+
+  def __init__(self, world_size: int, chunks: int = 4, group=None, overlap: Optional[bool] = None,
+               force: bool = False):
     self.world, self.chunks, self.group = world_size, max(1, chunks), group
+    if overlap is None:
+      overlap = os.environ.get("CRN_OVERLAP_ALLREDUCE", "1") != "0"
+    self.overlap = overlap
+    self.force = force          # exchange even at world_size 1 (tests: exercises the stream wiring on one GPU)
+    self._works = []
+    self.pushed = []            # (offset-free) element counts of the buckets of the last step, for tests
+
+  def _active(self) -> bool:
+    return self.world > 1 or (self.force and dist.is_initialized())
 
   def __call__(self, grads: t.Tensor):
-    if self.world <= 1:
+    if not self._active():
       return
     n = grads.numel()
     step = (n + self.chunks - 1) // self.chunks
@@ -51,6 +67,19 @@ class GradientSync:
       works.append(dist.all_reduce(grads[o:o + step], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
     for w in works:
       w.wait()
+
+  def push(self, grads: t.Tensor):
+    """Bucket hook: start the all-reduce of one finished slice of the slab (ordered after the work already
+    queued on the current stream) and return immediately."""
+    self.pushed.append(grads.numel())
+    if self._active():
+      self._works.append(dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+  def wait(self):
+    """The current stream waits for every pushed bucket."""
+    for w in self._works:
+      w.wait()
+    self._works.clear()
 
 
 def broadcast_buffers(store, src: int = 0, group=None):

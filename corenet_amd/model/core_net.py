@@ -218,8 +218,13 @@ class CoreNet(nn.Module):
     plan.gt.copy_(grid)
     eng.be.loss_fwd_bwd(LOSS_KINDS[loss], plan.logits, plan.gt, B, C, 128 ** 3, plan.loss,
                         plan.glogits, 1.0)
-    plan.backward(plan.glogits)
-    if all_reduce is not None:
-      all_reduce(eng.store.grads)
+    if all_reduce is not None and getattr(all_reduce, "overlap", False):
+      all_reduce.pushed.clear()
+      plan.backward(plan.glogits, grad_hook=all_reduce.push)   # buckets are reduced while backward runs
+      all_reduce.wait()
+    else:
+      plan.backward(plan.glogits)
+      if all_reduce is not None:
+        all_reduce(eng.store.grads)
     eng.adam_step(lr, adam_eps, grad_scale=1.0 / world_size)
     return plan.loss

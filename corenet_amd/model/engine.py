@@ -38,6 +38,11 @@ BN_MOMENTUM = 0.01   # batch_renorm.py:19
 
 ENC_STAGES = (("stage2", "abc", (64, 64, 256), 1), ("stage3", "abcd", (128, 128, 512), 2),
               ("stage4", "abcdef", (256, 256, 1024), 2), ("stage5", "abc", (512, 512, 2048), 2))
+# Gradient buckets of the overlapped exchange, in the order backward finishes them; a label is the prefix of
+# the first (lowest-offset) parameter of the bucket, the last bucket runs down to offset 0.  pipeline.py:199
+# gets the same effect from DDP's reverse-order 25 MB buckets.
+GRAD_BUCKET_LABELS = ("decoder.stage_3.", "decoder.stage_0.", "encoder.stage5.c.", "encoder.stage5.b.",
+                      "encoder.stage5.a.", "encoder.stage4.a.", "")
 LOSS_KINDS = {"iou_fgbg": 0, "xent_times_iou_agnostic": 1, "iou_agnostic": 2, "xent": 3,
               "xent_times_iou_fgbg": 4}
 
@@ -259,6 +264,20 @@ class Engine:
                       t.as_tensor(tl[2] if tl[2].size else np.zeros(1, np.int32), device=self.device))
     self.pack_tiles = dev(G.tile_index(pack_parts))
     self.unpack_tiles = dev(G.tile_index(unpack_parts))
+    # gradient buckets for the overlapped exchange (corenet_amd/distributed.py): contiguous ranges of the
+    # grad slab in the order backward completes them, each with the tile descriptors of its own convs
+    los = [min(o for k, (o, _) in s.off.items() if s.kind[k] == "param" and k.startswith(lb))
+           for lb in GRAD_BUCKET_LABELS[:-1]] + [0]
+    self.grad_buckets: List[Tuple[str, int, int]] = []
+    self._bucket_tiles = []
+    hi = s.params.numel()
+    for lb, lo in zip(GRAD_BUCKET_LABELS, los):
+      assert lo < hi
+      self.grad_buckets.append((lb, lo, hi))
+      sel = [up for (name, *_), up in zip(reg, unpack_parts) if lo <= s.offset(name + "weight") < hi]
+      self._bucket_tiles.append(sel)
+      hi = lo
+    self._bucket_dev = None
     po, go = 0, 0
     for (name, fwd, dgrad, repeat, nref), parts in zip(reg, idx_parts):
       nwf, nb = len(parts[0]), len(parts[1])
@@ -270,6 +289,13 @@ class Engine:
       gwf = self.gpacked[go:go + nwf]; go += nwf
       self.convs[name] = Conv(name, fwd, dgrad, wf, wd, bias, gwf,
                               s.view(name + "bias", grad=True), nref)
+
+  def bucket_unpack_tiles(self, i: int):
+    if self._bucket_dev is None:
+      dev = lambda tl: (t.as_tensor(tl[0], device=self.device), t.as_tensor(tl[1].view(np.int64), device=self.device),
+                        t.as_tensor(tl[2] if tl[2].size else np.zeros(1, np.int32), device=self.device))
+      self._bucket_dev = [dev(G.tile_index(sel)) for sel in self._bucket_tiles]
+    return self._bucket_dev[i]
 
   def pack_weights(self):
     """flat parameter slab -> packed kernel layouts (1 launch)."""
@@ -367,6 +393,7 @@ class Plan:
     self.side = t.cuda.Stream(device=dev) if use_side else None
     self._side_ev, self._side_i = [], 0
     self._side_done = t.cuda.Event() if use_side else None
+    self._bucket_ev = [t.cuda.Event() for _ in GRAD_BUCKET_LABELS] if use_side else None
 
   # ------------------------------------------------------------------ cached views
   def _cached(self, key, fn):
@@ -559,8 +586,30 @@ class Plan:
     return blk["out"]
 
   # ------------------------------------------------------------------ backward
-  def backward(self, glogits: t.Tensor):
-    """Fills eng.store.grads with d loss / d params given d loss / d logits."""
+  def _grads_ready(self, label: str, hook):
+    """Bucket `label` of the grad slab is complete once everything issued so far has run: unpack its conv
+    weight gradients and hand the slice to `hook` (an async all-reduce).  Both go to the side stream behind
+    the bucket's weight gradients, so the data-gradient chain on the main stream never waits for them."""
+    if hook is None:
+      return
+    eng = self.eng
+    i = [b[0] for b in eng.grad_buckets].index(label)
+    _, lo, hi = eng.grad_buckets[i]
+    tiles = eng.bucket_unpack_tiles(i)
+    def run():
+      if tiles[0].numel():
+        self.be.copy_tiles(eng.gpacked, eng.store.grads, tiles, reverse=True)
+      hook(eng.store.grads[lo:hi])
+    if self.side is None or self.trace is not None:
+      return run()
+    self._bucket_ev[i].record()                  # bias / norm gradients of the bucket are written on the main stream
+    with t.cuda.stream(self.side):
+      self.side.wait_event(self._bucket_ev[i])
+      run()
+
+  def backward(self, glogits: t.Tensor, grad_hook=None):
+    """Fills eng.store.grads with d loss / d params given d loss / d logits.  With `grad_hook`, finished
+    ranges of the slab are handed over while the rest of backward still runs (GRAD_BUCKET_LABELS)."""
     eng, be, B = self.eng, self.be, self.B
     cv, bn = eng.convs, eng.bns
     assert self.training, "backward needs a training-mode forward"
@@ -606,6 +655,8 @@ class Plan:
                 b1_.gamma, b1_.scale, b1_.shift, b1_.saved, d["gu"], d["cin"] * S, b1_.dgamma, b1_.dbeta,
                 dsum=cprev.dbias, ndsum=cprev.n_ref)
       g_out = d["gu"]
+      if k == 3:
+        self._grads_ready("decoder.stage_3.", grad_hook)
     # stage_1 / stage_0
     c1 = cv["decoder.stage_1.t1."]
     b = bn["decoder.stage_1.b1."]
@@ -618,6 +669,7 @@ class Plan:
     s = eng.store
     be.linear_bwd(self.avg, s.view("decoder.stage_0.weight"), self.gz0, L + 3, B, 2048, L, self.gavg,
                   s.view("decoder.stage_0.weight", grad=True), s.view("decoder.stage_0.bias", grad=True))
+    self._grads_ready("decoder.stage_0.", grad_hook)
     # encoder
     f5, g5 = self.feat["stage5"], self.gfeat["stage5"]
     last = self.blocks[-1]
@@ -627,6 +679,8 @@ class Plan:
     g_in = None          # gradient wrt the block's output (post-ReLU), None for the last block
     for blk in reversed(self.blocks):
       g_in = self._block_bwd(blk, g_in)
+      if blk["prefix"] in GRAD_BUCKET_LABELS:
+        self._grads_ready(blk["prefix"], grad_hook)
     # stem: g_in = d p1
     b1 = bn["encoder.stage1_part2.bn."]
     be.maxpool_bwd(g_in, self.p1_arg, B, 64, 128, 128, self.gy1)
@@ -636,6 +690,10 @@ class Plan:
               b1.saved, self.gy1b, 64 * S1, b1.dgamma, b1.dbeta, dsum=cs.dbias, ndsum=cs.n_ref)
     self._wgrad(cs, self.s2d(self.img, 3, (1, 2, 2)), None, self.vw(self.gy1b))
     # packed weight grads -> reference layout inside the flat grad slab (1 launch)
+    if grad_hook is not None:
+      self._grads_ready("", grad_hook)
+      self._join_side()
+      return
     self._join_side()
     be.copy_tiles(eng.gpacked, eng.store.grads, eng.unpack_tiles, reverse=True)
 

@@ -30,6 +30,15 @@ def _worker(rank, world, port, out):
   assert float(store.buffers[0]) == 1.0 and int(store.nbt[0]) == 5
   store.grads.copy_(t.arange(store.grads.numel(), dtype=t.float32) * (rank + 1))
   D.GradientSync(world, chunks=3)(store.grads)
+  # the overlapped form: buckets pushed from the top of the slab down, joined by wait()
+  g2 = t.arange(store.grads.numel(), dtype=t.float32) * (rank + 1)
+  sync = D.GradientSync(world)
+  assert sync.overlap
+  n = g2.numel()
+  for lo, hi in ((n - 40, n), (16, n - 40), (0, 16)):
+    sync.push(g2[lo:hi])
+  sync.wait()
+  assert t.equal(g2, store.grads) and sync.pushed == [40, n - 56, 16]
   be = EmuBackend()
   m, v = t.zeros_like(store.params), t.zeros_like(store.params)
   be.adam_step(store.params, store.grads, m, v, store.params.numel(), 4e-4, 0.9, 0.999, 1e-4, 1.0 / world, 1)

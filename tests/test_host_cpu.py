@@ -130,6 +130,19 @@ def test_engine_plan_matches_oracle_fp64():
   for k in ("decoder.stage_6.b1.running_mean", "encoder.stage5.c.op_c.bn.running_var"):
     assert float((eng.store.view(k) - s[k]).abs().max()) < 1e-8
   assert int(eng.store.view("decoder.stage_1.b1.num_batches_tracked")) == 30001
+  # bucketed backward (overlapped gradient exchange): every bucket handed to the hook is already final when
+  # the hook runs, the buckets tile the slab from the top down, and the slab ends up identical
+  ref = eng.store.grads.clone()
+  eng.store.grads.fill_(float("nan"))
+  seen = []
+  plan.backward(plan.glogits, grad_hook=lambda g: seen.append((g.storage_offset(), g.clone())))
+  assert t.equal(eng.store.grads.nan_to_num(0.0), ref.nan_to_num(0.0))
+  hi = ref.numel()
+  assert len(seen) == len(eng.grad_buckets) >= 6
+  for off, g in seen:
+    assert off + g.numel() == hi and t.equal(g.nan_to_num(0.0), ref[off:hi].nan_to_num(0.0))
+    hi = off
+  assert hi == 0
 
 
 def test_c_abi_surface():

@@ -129,6 +129,34 @@ def test_train_step_reduces_loss_and_matches_autograd_path():
   assert np.isfinite(l) and l < l0
 
 
+def test_overlapped_gradient_exchange_single_rank_rccl():
+  """The bucketed backward + RCCL all-reduce on its own stream (distributed.GradientSync.push/wait,
+  engine.GRAD_BUCKET_LABELS) against the plain one-slab backward: with one rank the all-reduce is the
+  identity, so gradients and parameters must agree up to the atomics' summation order."""
+  import torch.distributed as dist
+  from corenet_amd import distributed as D
+  dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29650 + os.getpid() % 200}", rank=0, world_size=1)
+  try:
+    sd = O.make_state(0, 2, nbt=0)
+    image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(2, 0, 2)]
+    ma, mb = _model(2, sd).train(), _model(2, sd).train()
+    sync = D.GradientSync(1, force=True)
+    assert sync.overlap
+    for i in range(3):
+      la = ma.train_step(image, v2s, off, grid, "iou_fgbg", lr=4e-4)
+      lb = mb.train_step(image, v2s, off, grid, "iou_fgbg", lr=4e-4, all_reduce=sync)
+      if i == 0:
+        ga, gb = ma.engine.store.grads, mb.engine.store.grads
+        assert sum(sync.pushed) == ga.numel() and len(sync.pushed) == len(mb.engine.grad_buckets)
+        for _, lo, hi in mb.engine.grad_buckets:
+          assert relerr(gb[lo:hi], ga[lo:hi]) < 1e-4, (lo, hi)
+    t.cuda.synchronize()
+    assert abs(float(la) - float(lb)) < 1e-4
+    assert relerr(mb.engine.store.params, ma.engine.store.params) < 1e-3
+  finally:
+    dist.destroy_process_group()
+
+
 def test_super_resolution_x2_golden_and_encoder_reuse():
   """N1: x2 super-resolution through the drop-in of corenet.super_resolution.
   (i) golden pmf generated by the reference's SuperResolutionInference (oracle/gen_golden.py);
