@@ -213,6 +213,10 @@ class HipBackend:
                                sub_side, float(mult), int(conservative), depth_mult, ptr(grid),
                                _lib.stream())
 
+  def transform_meshes(self, triangles, tri_mesh, mesh_matrix, out):
+    self.lib.crn_transform_meshes(ptr(triangles), ptr(tri_mesh), triangles.shape[0], ptr(mesh_matrix),
+                                  mesh_matrix.shape[0], ptr(out), _lib.stream())
+
   def merge_labels(self, meshes_grid, scene_start, labels, B, D, H, W, sub_grid, out):
     self.lib.crn_merge_labels(ptr(meshes_grid), ptr(scene_start), ptr(labels), B, D, H, W,
                               int(sub_grid), ptr(out), _lib.stream())

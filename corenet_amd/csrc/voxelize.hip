@@ -144,7 +144,33 @@ __global__ void merge_labels_kernel(const float* mg, const int32_t* scene_start,
   out[(int64_t)b * S + v] = scene_start[b + 1] > scene_start[b] ? (int32_t)best : 0;
 }
 
+// batched_example.batch (batched_example.py:73-81) -> transformations.transform_mesh (:139-169): every vertex of
+// mesh m is multiplied by its object->view matrix as a point (w = 1) and divided by the resulting w.
+__global__ void transform_meshes_kernel(const float* __restrict__ tri, const int32_t* __restrict__ tri_mesh,
+                                        const float* __restrict__ mats, int64_t nvert, float* __restrict__ out) {
+  const int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (v >= nvert) return;
+  const float* M = mats + (int64_t)tri_mesh[v / 3] * 16;
+  const float x = tri[v * 3], y = tri[v * 3 + 1], z = tri[v * 3 + 2];
+  float r[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) r[n] = fmaf(M[n * 4 + 2], z, fmaf(M[n * 4 + 1], y, fmaf(M[n * 4], x, M[n * 4 + 3])));
+  out[v * 3] = r[0] / r[3]; out[v * 3 + 1] = r[1] / r[3]; out[v * 3 + 2] = r[2] / r[3];
+}
+
 }  // namespace
+
+extern "C" int crn_transform_meshes(const float* triangles, const int32_t* tri_mesh, int T, const float* mesh_matrix,
+                                    int M, float* out, crnStream stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (T < 0 || M < 0 || (T > 0 && (!triangles || !tri_mesh || !mesh_matrix || !out))) return CRN_EINVAL;
+  if (T == 0) return CRN_OK;
+  const int64_t nvert = (int64_t)T * 3;
+  hipLaunchKernelGGL(transform_meshes_kernel, dim3((unsigned)crn_cdiv(nvert, 256)), dim3(256), 0, st, triangles,
+                     tri_mesh, mesh_matrix, nvert, out);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
 
 extern "C" int crn_voxelize_mesh(const float* triangles, const int32_t* tri_mesh, int T, const float* view2voxel,
                                  int M, int D, int H, int W, int sub_grid_side, float image_resolution_multiplier,

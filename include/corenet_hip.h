@@ -241,6 +241,12 @@ int crn_voxelize_mesh(const float* triangles, const int32_t* tri_mesh, int T,
                       const float* view2voxel, int M, int D, int H, int W,
                       int sub_grid_side, float image_resolution_multiplier,
                       int conservative, int depth_multiplier, float* grid, crnStream s);
+/* batch() geometry (data/batched_example.py:73-81 -> geometry/transformations.py:139-169 transform_mesh):
+ * out[t][k] = (mesh_matrix[tri_mesh[t]] . (triangles[t][k], 1)).xyz / .w for the object-space triangles
+ * [T][3][3] of all meshes of a batch, mesh_matrix [M][16] = view_transform . object_to_world per mesh.
+ * out may alias triangles.                                                                       */
+int crn_transform_meshes(const float* triangles, const int32_t* tri_mesh, int T,
+                         const float* mesh_matrix, int M, float* out, crnStream s);
 /* per-scene label merge (batched_example.py:186-196): out[b] = max_m label_m*grid_m
  * over the meshes [scene_mesh_start[b], scene_mesh_start[b+1]) of scene b, int32.
  * sub_grid!=0: meshes_grid is the (2D+1)(2H+1)(2W+1) grid and the sub-grid

@@ -565,6 +565,29 @@ def merge_labels(meshes_grid: np.ndarray, num_meshes: Sequence[int],
   return np.stack(out, 0)
 
 
+def transform_mesh(mesh: Tensor, matrix: Tensor) -> Tensor:
+  """transformations.py:139-169 with vertices_are_points=True: pad w=1, `einsum("bnm,bvm->bvn")`
+  (transform_points_homogeneous :108-136), divide by w."""
+  shape = mesh.shape
+  pts = t.constant_pad_nd(mesh.reshape(1, -1, 3).to(t.float32), [0, 1], value=1.0)
+  res = t.einsum("bnm,bvm->bvn", matrix.reshape(1, 4, 4).to(t.float32), pts)
+  return (res[..., :3] / res[..., 3:4]).reshape(shape)
+
+
+def batch_vertices(examples) -> Tensor:
+  """The geometry of batched_example.batch (batched_example.py:68-95): examples = [(mesh_vertices [T,3,3],
+  mesh_num_tri [M], view_transform [4,4], o2w_transforms [M,4,4])]; every mesh goes to view space through
+  o2v = w2v . o2w; all meshes of all scenes are concatenated."""
+  out = []
+  for verts, num_tri, w2v, o2ws in examples:
+    off = 0
+    for nt, o2w in zip(num_tri, o2ws):
+      nt = int(nt)
+      out.append(transform_mesh(verts[off:off + nt], t.matmul(w2v, o2w)))
+      off += nt
+  return t.cat(out, 0)
+
+
 def view2voxel_matrices(offset: Tensor, resolution) -> Tensor:
   """batched_example.py:153-163: translate(off-0.5) @ scale(m,m,m), m=max(D,H,W) (Q9)."""
   m = float(max(resolution))

@@ -233,9 +233,131 @@ def gen_super_resolution():
   print("[super_resolution] ok")
 
 
+def write_data_fixture(root):
+  """A tiny synthetic dataset in the reference's on-disk format (doc/data_format_and_coordinate_systems.md:9-31,
+  dataset.py:48-51): two scenes of 3 + 2 objects over three classes, meshes of 8-40 triangles, 24x32 images
+  (lossless WebP for the high-realism image, PNG for the low-realism one).  Written by this script, not taken
+  from the reference's data."""
+  import io
+  import json
+  import PIL.Image
+  rng = np.random.RandomState(7)
+  classes = [("03001627", "chair"), ("02958343", "car"), ("04256520", "sofa")]
+  meshes = {("03001627", "aa11"): 8, ("02958343", "bb22"): 40, ("04256520", "cc33"): 13, ("02958343", "dd44"): 21}
+  for (lab, name), nt in meshes.items():
+    os.makedirs(os.path.join(root, "meshes", lab), exist_ok=True)
+    pngs = np.empty((), dtype=object); pngs[()] = [b"", b"\x89PNG-not-decoded"]     # read with .scalar() (scene.py:149)
+    np.savez(os.path.join(root, "meshes", lab, name + ".npz"),
+             vertices=(rng.rand(nt, 3, 3).astype(np.float32) - 0.5),
+             normals=rng.randn(nt, 3, 3).astype(np.float32), material_ids=rng.randint(0, 2, nt).astype(np.int32),
+             texcoords=rng.rand(nt, 3, 2).astype(np.float32), diffuse_colors=rng.rand(2, 3).astype(np.float32),
+             diffuse_texture_pngs=pngs)
+
+  def encode(img, fmt, **kw):
+    b = io.BytesIO(); PIL.Image.fromarray(img).save(b, fmt, **kw); return np.array(b.getvalue())
+
+  def rigid(scale, angle, tr):
+    c, s_ = np.cos(angle), np.sin(angle)
+    m = np.eye(4, dtype=np.float32)
+    m[:3, :3] = scale * np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]], np.float32)
+    m[:3, 3] = tr
+    return m
+
+  camera = O.canonical_camera().numpy().astype(np.float32)
+  scenes = {"s0": [("03001627", "aa11"), ("02958343", "bb22"), ("04256520", "cc33")],
+            "s1": [("02958343", "dd44"), ("03001627", "aa11")]}
+  os.makedirs(os.path.join(root, "scenes"), exist_ok=True)
+  for i, (sid, objs) in enumerate(scenes.items()):
+    o2w = np.stack([rigid(0.25 + 0.1 * k, 0.7 * k + i, [0.3 + 0.2 * k, 0.1 * i, 0.4 - 0.15 * k]) for k in range(len(objs))])
+    view = rigid(1.0, 0.3 + i, [0.5, 0.45, 0.55]).astype(np.float32)
+    np.savez(os.path.join(root, "scenes", sid + ".npz"),
+             scene_filename=np.array(sid.encode()), mesh_labels=np.array([o[0] for o in objs]),
+             mesh_filenames=np.array([o[1] for o in objs]),
+             mesh_visible_fractions=rng.rand(len(objs)).astype(np.float32),
+             mesh_object_to_world_transforms=o2w.astype(np.float32), view_transform=view, camera_transform=camera,
+             opengl_image=encode(rng.randint(0, 256, (24, 32, 3)).astype(np.uint8), "PNG"),
+             pbrt_image=encode(rng.randint(0, 256, (24, 32, 3)).astype(np.uint8), "WEBP", lossless=True))
+  with open(os.path.join(root, "dataset.json"), "w") as fl:
+    json.dump({"classes": [{"id": c, "human_readable": h} for c, h in classes],
+               "files": ["scenes/s0.npz", "scenes/s1.npz"]}, fl, indent=1)
+
+
+def gen_data_path():
+  """N2: the reference's own scene reader, dataset and collate (scene.py:106-151, dataset.py:89-196,
+  batched_example.py:68-95) run on the fixture dataset -> tests/golden/data_path.npz.  Import shims, none of
+  which computes anything that is pinned: empty `google.*` modules (file_system.py:22,25 - only gs:// paths use
+  them), empty `corenet.cc.fill_voxels` / `corenet.geometry.voxelization` (GL, not used by `batch`), and a
+  JsonSchemaMixin.from_dict that builds the two config dataclasses from the JSON dict."""
+  import dataclasses
+  import typing
+  for name in ("google", "google.api_core", "google.api_core.exceptions", "google.cloud", "google.cloud.storage"):
+    sys.modules.setdefault(name, types.ModuleType(name))
+  sys.modules["google"].api_core = sys.modules["google.api_core"]
+  sys.modules["google.api_core"].exceptions = sys.modules["google.api_core.exceptions"]
+  sys.modules["google"].cloud = sys.modules["google.cloud"]
+  sys.modules["google.cloud"].storage = sys.modules["google.cloud.storage"]
+
+  def from_dict(cls, v):
+    kw = {}
+    for f in dataclasses.fields(cls):
+      ft = typing.get_type_hints(cls)[f.name]
+      args = typing.get_args(ft)
+      if args and dataclasses.is_dataclass(args[0]):
+        kw[f.name] = [from_dict(args[0], e) for e in v[f.name]]
+      else:
+        kw[f.name] = v[f.name]
+    return cls(**kw)
+  _m.JsonSchemaMixin.from_dict = classmethod(from_dict)
+  import corenet as _c
+  for name in ("corenet.cc.fill_voxels", "corenet.geometry.voxelization"):
+    sys.modules[name] = types.ModuleType(name)
+  import corenet.cc as _cc
+  import corenet.geometry as _cg
+  _cc.fill_voxels = sys.modules["corenet.cc.fill_voxels"]
+  _cg.voxelization = sys.modules["corenet.geometry.voxelization"]
+  from corenet.data import dataset as RD
+  from corenet.data import batched_example as RB
+  from corenet.data import scene as RS
+
+  root = os.path.join(OUT, "n2_dataset")
+  write_data_fixture(root)
+  out = {}
+  for hr in (True, False):
+    ds = RD.CoReNetDatasetImpl(os.path.join(root, "dataset.json"), os.path.join(root, "meshes"), high_realism=hr)
+    els = [ds[i] for i in range(len(ds))]
+    b = RB.batch(els)
+    tag = "hr" if hr else "lr"
+    out[tag + "_input_image"] = b.input_image.numpy()
+    if hr:
+      out["classes"] = np.array(list(ds.classes))
+      out["vertices"] = b.vertices.numpy()
+      out["view_transform"] = b.view_transform.numpy(); out["camera_transform"] = b.camera_transform.numpy()
+      out["mesh_num_tri"] = t.cat(b.mesh_num_tri).numpy(); out["num_meshes"] = np.array([len(v) for v in b.mesh_num_tri])
+      out["mesh_labels"] = t.cat(b.mesh_labels).numpy(); out["scene_id"] = np.array(b.scene_id)
+      out["grid_sampling_offset"] = b.grid_sampling_offset.numpy()
+      out["raw_vertices"] = t.cat([e.mesh_vertices for e in els]).numpy()
+      out["o2w"] = t.cat([e.o2w_transforms for e in els]).numpy()
+      # oracle restatement of the collate geometry against the reference
+      vo = O.batch_vertices([(e.mesh_vertices, e.mesh_num_tri, e.view_transform, e.o2w_transforms) for e in els])
+      assert t.equal(vo, b.vertices), float((vo - b.vertices).abs().max())
+      vds = RD.CoReNetDataset(ds, ds.classes)
+      big = RD.CoReNetDataset(t.utils.data.ConcatDataset([vds] * 5), ds.classes)      # 10 virtual elements
+      out["shuffle_1234"] = big.shuffle(1234).indices.numpy()
+      out["fraction_02_07"] = big.take_fraction(0.2, 0.7).indices.numpy()
+      out["slice_of_shuffle"] = big.shuffle(7)[3:8].indices.numpy()
+  sc = RS.load_from_npz(os.path.join(root, "scenes", "s0.npz"), os.path.join(root, "meshes"), load_extra_fields=True)
+  out["s0_normals_1"] = sc.normals[1].numpy(); out["s0_material_ids_2"] = sc.material_ids[2].numpy()
+  out["s0_visible"] = sc.mesh_visible_fractions.numpy()
+  np.savez_compressed(os.path.join(OUT, "data_path.npz"), **out)
+  print("[data_path] ok:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
   if "--only-super-resolution" in sys.argv:
     gen_super_resolution()
+    sys.exit(0)
+  if "--only-data-path" in sys.argv:
+    gen_data_path()
     sys.exit(0)
   gen_batch_renorm()
   gen_sample_grid2d()
@@ -245,4 +367,5 @@ if __name__ == "__main__":
   gen_model("h7_eval_b1", 2, 100, 1, "iou_fgbg", training=False)
   gen_model("m9_train_b1", 14, 0, 1, "xent_times_iou_agnostic")
   gen_super_resolution()
+  gen_data_path()
   print("golden fixtures written to", OUT)

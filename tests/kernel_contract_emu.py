@@ -287,6 +287,12 @@ class EmuBackend:
     bc1 = 1 - b1 ** step; bc2 = 1 - b2 ** step
     p.sub_((lr / bc1) * (m / (v.sqrt() / np.sqrt(bc2) + eps)))
 
+  def transform_meshes(self, triangles, tri_mesh, mesh_matrix, out):
+    m = mesh_matrix[tri_mesh.long()]                                  # [T,4,4]
+    pts = t.cat([triangles, t.ones_like(triangles[..., :1])], -1)     # [T,3,4]
+    r = t.einsum("tnm,tvm->tvn", m, pts)
+    out.copy_(r[..., :3] / r[..., 3:4])
+
   def add_i64(self, p, n, v):
     p += v
 

@@ -532,7 +532,7 @@ def test_voxelizer_sphere_vs_oracle_and_labels(be):
   g = voxelization.voxelize_mesh(t.tensor(tris), nt, (R, R, R), v2v[0], image_resolution_multiplier=8).cpu().numpy()
   ref = O.voxelize_mesh(tris, nt, (R, R, R), v2v[0].numpy(), image_resolution_multiplier=8)
   assert (g != ref).mean() <= 5e-4
-  labels = batched_example.voxelize(t.tensor(tris), [t.tensor(nt, dtype=t.int32)], [[3, 5]], off, (R, R, R),
+  labels = batched_example.voxelize_labels(t.tensor(tris), [t.tensor(nt, dtype=t.int32)], [[3, 5]], off, (R, R, R),
                                     image_resolution_multiplier=8).cpu().numpy()
   filled = O.fill_inside_voxels(ref)
   want = O.merge_labels(filled, [2], [[3, 5]])
@@ -540,6 +540,43 @@ def test_voxelizer_sphere_vs_oracle_and_labels(be):
   zz, yy, xx = np.meshgrid(*[np.arange(R) + 0.5] * 3, indexing="ij")
   inside2 = ((xx / R - 0.6) ** 2 + (yy / R - 0.5) ** 2 + (zz / R - 0.5) ** 2) < 0.17 ** 2
   assert (labels[0][inside2] == 5).all()
+
+
+def test_data_path_batch_and_voxelize(be):
+  """N2: fixture dataset -> reader -> `batch` (crn_transform_meshes) -> `voxelize` on the GPU.  View-space vertices
+  against the reference's own collate output (tests/golden/data_path.npz; fp32, summation order of a 4-term dot
+  product: <= 2e-6 relative), label grid against the oracle pipeline run on the golden vertices."""
+  from corenet_amd.data import batched_example as B, dataset as D
+  G_ = os.path.join(os.path.dirname(__file__), "golden")
+  root = os.path.join(G_, "n2_dataset")
+  z = np.load(os.path.join(G_, "data_path.npz"))
+  ds = D.CoReNetDatasetImpl(os.path.join(root, "dataset.json"), os.path.join(root, "meshes"))
+  ex = B.batch([ds[0], ds[1]])
+  assert ex.vertices.is_cuda and ex.input_image.is_cuda and ex.vertices.shape == (90, 3, 3)
+  got, want = ex.vertices.cpu().numpy(), z["vertices"]
+  assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+  assert t.equal(ex.input_image.cpu(), t.as_tensor(z["hr_input_image"]))
+  assert t.equal(ex.view_transform.cpu(), t.as_tensor(z["view_transform"]))
+  # in place over the input is allowed by the ABI
+  raw = t.as_tensor(z["raw_vertices"]).to(DEV)
+  from corenet_amd.geometry import voxelization
+  tm = voxelization.dynamic_tile(t.as_tensor(z["mesh_num_tri"])).to(DEV)
+  mats = t.cat([t.matmul(e.view_transform[None], e.o2w_transforms) for e in (ds[0], ds[1])]).to(DEV)
+  be.transform_meshes(raw, tm, mats, raw)
+  assert t.equal(raw, ex.vertices)
+  R = 32
+  out = B.voxelize(ex, (R, R, R), B.VoxelContentSemanticLabel(ex.mesh_labels), image_resolution_multiplier=8)
+  assert out.grid.shape == (2, R, R, R) and out.grid.dtype == t.int32 and out.grid.is_cuda
+  assert t.equal(out.v2x_transform.cpu(), t.diag(t.tensor([32.0, 32, 32, 1])).expand(2, 4, 4))
+  v2v = O.view2voxel_matrices(t.full((2, 3), 0.5), (R, R, R)).numpy()
+  nm = list(z["num_meshes"])
+  mesh_v2v = np.concatenate([np.repeat(v2v[b:b + 1], n, 0) for b, n in enumerate(nm)])
+  ref = O.voxelize_mesh(want, list(z["mesh_num_tri"]), (R, R, R), mesh_v2v, image_resolution_multiplier=8)
+  labels = np.split(z["mesh_labels"], np.cumsum(nm)[:-1])
+  wantg = O.merge_labels(O.fill_inside_voxels(ref), nm, labels)
+  assert wantg.max() >= 2 and (out.grid.cpu().numpy() != wantg).mean() <= 1e-3
+  plain = B.voxelize(ex, (R, R, R), image_resolution_multiplier=8).grid.cpu().numpy()
+  assert set(np.unique(plain)) <= {0, 1, 2, 3} and ((plain > 0) == (wantg > 0)).mean() >= 1 - 1e-3
 
 
 def test_copy_tiles_pack_unpack(be):

@@ -206,3 +206,48 @@ def test_super_resolution_golden_and_host_logic():
   for n in range(8):
     iz, iy, ix = n // 4, (n // 2) % 2, n % 2
     assert float((out[0, 0, iz::2, iy::2, ix::2] - (n + t.arange(4.0) / 10)).abs().max()) == 0.0
+
+
+def test_data_path_golden_and_host_logic():
+  """N2: the scene/mesh NPZ reader, dataset and collate against the outputs of the reference's own
+  `CoReNetDatasetImpl` + `batched_example.batch` on the fixture dataset (oracle/gen_golden.py:gen_data_path).
+  Loader outputs are bit-exact; the collate geometry is checked for the oracle restatement and, through the
+  CPU contract emulator, for the product's host wiring (the HIP kernel itself: tests/test_kernels_gpu.py)."""
+  from corenet_amd.data import batched_example as B, dataset as D, scene as S
+  from kernel_contract_emu import EmuBackend
+  root = os.path.join(G, "n2_dataset")
+  z = np.load(os.path.join(G, "data_path.npz"))
+  ds = D.CoReNetDatasetImpl(os.path.join(root, "dataset.json"), os.path.join(root, "meshes"), high_realism=True)
+  assert list(ds.classes) == list(z["classes"]) == ["__void__", "car", "chair", "sofa"] and len(ds) == 2
+  els = [ds[i] for i in range(len(ds))]
+  assert [e.scene_id for e in els] == list(z["scene_id"]) == ["scenes/s0", "scenes/s1"]
+  eq = lambda a, b: a.dtype == t.as_tensor(b).dtype and t.equal(a, t.as_tensor(b))
+  assert eq(t.cat([e.mesh_vertices for e in els]), z["raw_vertices"])
+  assert eq(t.cat([e.o2w_transforms for e in els]), z["o2w"])
+  assert eq(t.cat([e.mesh_num_tri for e in els]), z["mesh_num_tri"])
+  assert eq(t.cat([e.mesh_labels for e in els]), z["mesh_labels"]) and els[0].mesh_labels.tolist() == [2, 1, 3]
+  assert eq(t.stack([e.input_image for e in els]), z["hr_input_image"])
+  lr = D.CoReNetDatasetImpl(os.path.join(root, "dataset.json"), os.path.join(root, "meshes"), high_realism=False)
+  assert eq(t.stack([lr[i].input_image for i in range(2)]), z["lr_input_image"])
+  sc = S.load_from_npz(os.path.join(root, "scenes", "s0.npz"), os.path.join(root, "meshes"), load_extra_fields=True)
+  assert eq(sc.normals[1], z["s0_normals_1"]) and eq(sc.material_ids[2], z["s0_material_ids_2"])
+  assert eq(sc.mesh_visible_fractions, z["s0_visible"]) and sc.diffuse_texture_pngs[0].item()[0] == b""
+  # virtual dataset semantics (dataset.py:199-252)
+  vds = D.CoReNetDataset(ds, ds.classes)
+  big = D.CoReNetDataset(t.utils.data.ConcatDataset([vds] * 5), ds.classes)
+  assert eq(big.shuffle(1234).indices, z["shuffle_1234"]) and eq(big.take_fraction(0.2, 0.7).indices, z["fraction_02_07"])
+  assert eq(big.shuffle(7)[3:8].indices, z["slice_of_shuffle"]) and len(vds + vds) == 4
+  assert big.shuffle(7)[4].scene_id in ("scenes/s0", "scenes/s1")
+  with pytest.raises(ValueError):
+    S._to_tensor(np.zeros(3, np.float64), t.float32)
+  # collate geometry: oracle restatement, then the product's host wiring over the contract emulator
+  vo = O.batch_vertices([(e.mesh_vertices, e.mesh_num_tri, e.view_transform, e.o2w_transforms) for e in els])
+  np.testing.assert_allclose(vo.numpy(), z["vertices"], rtol=1e-6, atol=1e-7)
+  ex = B.batch(els, device="cpu", backend=EmuBackend())
+  np.testing.assert_allclose(ex.vertices.numpy(), z["vertices"], rtol=1e-5, atol=1e-6)
+  assert eq(ex.view_transform, z["view_transform"]) and eq(ex.camera_transform, z["camera_transform"])
+  assert eq(ex.input_image, z["hr_input_image"]) and eq(ex.grid_sampling_offset, z["grid_sampling_offset"])
+  assert [len(v) for v in ex.mesh_num_tri] == list(z["num_meshes"]) and ex.scene_id == list(z["scene_id"])
+  assert B.voxel_content_mesh_index(1, 2) == 3 and B.voxel_content_1(1, 2) == 1
+  assert int(B.VoxelContentSemanticLabel(ex.mesh_labels)(1, 0)) == 1
+
