@@ -156,6 +156,19 @@ def main():
   fill_s = e0.elapsed_time(e1) / 5 * 1e-3
   assert bool((filled == t.stack([(dist3 <= r).float() for r in (10, 30, 50)] * B)).all())
   fill_bytes = 8.0 * shells.numel()
+  # ray-sample gather at 64^3 again as a burst of 20 launches on the step's own buffers: one HIP-event pair
+  # around a single ~13 us launch (the in-step probe) also times ~3-4 us of marker / kernel-boundary latency
+  k5 = model.engine.skip_ch[5]
+  u6 = plan.dec[6]["u"]
+  ray_args = (plan.smap[5], plan.smap[5].stride(0), B, k5, 64, 64, plan.layer_mats[3], plan.offset,
+              u6[:, u6.shape[1] - k5:], u6.stride(0), 64, 64, 64)
+  for _ in range(3):
+    be.ray_sample_fwd(*ray_args, map_sC=1, map_sP=k5)
+  e0.record()
+  for _ in range(20):
+    be.ray_sample_fwd(*ray_args, map_sC=1, map_sP=k5)
+  e1.record(); t.cuda.synchronize()
+  ray_burst_s = e0.elapsed_time(e1) / 20 * 1e-3
   # forward-only (eval mode, running BatchRenorm statistics): SURVEY 8(d) asks for it next to the train step
   model.eval()
   with t.no_grad():
@@ -182,10 +195,13 @@ def main():
                    "bound": "mfma", "achieved": CONV6_FLOP * B / conv_s / 1e12, "peak": PEAK_F32_MFMA / 1e12,
                    "unit": "TFLOP/s", "frac": CONV6_FLOP * B / conv_s / PEAK_F32_MFMA, "traffic": traffic.get("conv"),
                    "avg_launch_ms": conv_s * 1e3},
-      "roofline_ray_sample": {"kernel": "ray_sample_fwd_kernel<4> (64^3 x 12 ch)", "bound": "hbm",
-                              "achieved": RAY64_BYTES * B / ray_s / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                              "frac": RAY64_BYTES * B / ray_s / PEAK_HBM, "traffic": traffic.get("ray"),
-                              "avg_launch_ms": ray_s * 1e3},
+      # duration = burst of 20 launches on the step's own buffers (12.2 us; rocprofv3 kernel-trace of the in-step
+      # launches: 12.6-13.4 us).  The in-step probe brackets ONE launch with a HIP-event pair, which also times
+      # ~5 us of marker latency (rocprof shows a 7 us gap in front of the probed launches) -- reported beside it.
+      "roofline_ray_sample": {"kernel": "ray_sample_fwd_kernel<4,channel-last map> (64^3 x 12 ch)", "bound": "hbm",
+                              "achieved": RAY64_BYTES * B / ray_burst_s / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                              "frac": RAY64_BYTES * B / ray_burst_s / PEAK_HBM, "traffic": traffic.get("ray"),
+                              "avg_launch_ms": ray_burst_s * 1e3, "in_step_event_pair_ms": ray_s * 1e3},
       "roofline_fill_voxels": {"kernel": f"fill_fused_kernel<float,2> ({3 * B} x 128^3 shells, whole call)", "bound": "hbm",
                                "achieved": fill_bytes / fill_s / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                                "frac": fill_bytes / fill_s / PEAK_HBM, "traffic": traffic.get("fill"),

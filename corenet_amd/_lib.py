@@ -68,7 +68,7 @@ _SIGS = {
     "crn_linear_fwd": [vp, vp, vp, i32, i32, i32, vp, i32, vp],
     "crn_linear_bwd": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp],
     "crn_fill_offset_channels": [vp, i32, i64, i64, i32, vp, vp],
-    "crn_ray_sample_fwd": [vp, i64, i32, i32, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp],
+    "crn_ray_sample_fwd": [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp],
     "crn_ray_sample_bwd": [vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp],
     "crn_loss_fwd_bwd": [i32, vp, vp, i32, i32, i64, vp, vp, f32, vp, sz, vp],
     "crn_argmax_confusion": [vp, vp, i32, i32, i64, vp, vp, vp],

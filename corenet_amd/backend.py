@@ -167,9 +167,11 @@ class HipBackend:
     self.lib.crn_fill_offset_channels(ptr(x), B, sB, S, c0, ptr(offset), _lib.stream())
 
   # -- ray-traced skip ------------------------------------------------------------------
-  def ray_sample_fwd(self, fmap, map_sB, B, Cn, h, w, matrix, offset, out, out_sB, D, H, W):
-    self.lib.crn_ray_sample_fwd(ptr(fmap), map_sB, B, Cn, h, w, ptr(matrix), ptr(offset),
-                                ptr(out), out_sB, D, H, W, _lib.stream())
+  def ray_sample_fwd(self, fmap, map_sB, B, Cn, h, w, matrix, offset, out, out_sB, D, H, W,
+                     map_sC=None, map_sP=1):
+    """map element (b, c, iy, ix) at b*map_sB + c*map_sC + (iy*w+ix)*map_sP; default [B][C][h][w]."""
+    self.lib.crn_ray_sample_fwd(ptr(fmap), map_sB, h * w if map_sC is None else map_sC, map_sP, B, Cn, h, w,
+                                ptr(matrix), ptr(offset), ptr(out), out_sB, D, H, W, _lib.stream())
 
   def ray_sample_bwd(self, dout, dout_sB, B, Cn, D, H, W, matrix, offset, dmap, dmap_sB, h, w,
                      zero_first=True):

@@ -42,7 +42,8 @@ struct PwGeom {
   const float* x; float* y; const float* w; const float* bias;
   crnInTransform tr;
   int B, C, N, Npad, S;            // S = positions per sample
-  int64_t xsB, ysB;                // batch strides; channel stride = S for both
+  int64_t xsB, ysB;                // batch strides; x channel stride = S
+  int64_t ysC, ysP;                // y channel / position strides: (S, 1) plain, (1, row pitch) channel-last
   int bias_sB, mode;
   int splits, cps;                 // split-K: blockIdx.z = split*B + b, cps input channels per split (multiple
                                    // of 32); partial sums go to the dense scratch y (mode 0), split*B + b as batch
@@ -112,10 +113,15 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
       const int n = n0 + ns * 16 + i16;
       if (n < g.N) {
         const float bsv = (g.bias && split == 0) ? g.bias[(int64_t)b * g.bias_sB + n] : 0.f;
-        float* dst = g.y + (int64_t)(split * g.B + b) * g.ysB + (int64_t)n * g.S + m;
+        float* dst = g.y + (int64_t)(split * g.B + b) * g.ysB + (int64_t)n * g.ysC + (int64_t)m * g.ysP;
         f32x4 v = acc[ns] + bsv;
-        if (g.mode == 1) v += *reinterpret_cast<const f32x4*>(dst);
-        *reinterpret_cast<f32x4*>(dst) = v;
+        if (g.ysP == 1) {
+          if (g.mode == 1) v += *reinterpret_cast<const f32x4*>(dst);
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {          // channel-last output: the 16 lanes of a row group write 16 consecutive channels
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dst[i * g.ysP] = g.mode == 1 ? dst[i * g.ysP] + v[i] : v[i];
+        }
       }
     }
   }
@@ -131,6 +137,14 @@ int vec_lead(int pw) { return ((-pw) % 4 + 4) % 4; }   // (w0 - pw - lead) % 4 =
 bool plain_view(const crnView& v) {
   return v.chan_off == nullptr && v.sW == 1 && v.sH == v.W && (v.D == 1 || v.sD == v.H * v.W) &&
          v.sC == (int64_t)v.D * v.H * v.W && (((uintptr_t)v.base) & 15) == 0 && (v.sB & 3) == 0;
+}
+
+// y of a pointwise conv: positions flatten to one index with a single stride (plain: 1; channel-last
+// [B][pos][C]: the pixel pitch), channels have their own stride
+bool flat_out_view(const crnView& v) {
+  if (plain_view(v)) return true;
+  return v.chan_off == nullptr && v.sH == (int64_t)v.W * v.sW && (v.D == 1 || v.sD == (int64_t)v.H * v.W * v.sW) &&
+         v.sC >= 1 && v.sW >= 1;
 }
 
 __global__ void zero_view_kernel(crnView v) {
@@ -266,13 +280,14 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   if (y->C > Npad) return CRN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int64_t Sx = (int64_t)x->D * x->H * x->W;
-  if (kd * kh * kw == 1 && pd == 0 && ph == 0 && pw == 0 && splits <= 1 && plain_view(*x) && plain_view(*y) &&
+  if (kd * kh * kw == 1 && pd == 0 && ph == 0 && pw == 0 && splits <= 1 && plain_view(*x) && flat_out_view(*y) &&
       Sx == (int64_t)y->D * y->H * y->W && (Sx & 3) == 0 && (((uintptr_t)w) & 15) == 0) {
     PwGeom p{};
     p.x = x->base; p.y = y->base; p.w = w; p.bias = bias;
     p.tr = tr ? *tr : crnInTransform{nullptr, nullptr, 0, 0};
     p.B = x->B; p.C = x->C; p.N = y->C; p.Npad = Npad; p.S = (int)Sx;
     p.xsB = x->sB; p.ysB = y->sB; p.bias_sB = bias_sB; p.mode = accumulate ? 1 : 0;
+    p.ysC = y->sC; p.ysP = y->sW;
     p.splits = 1; p.cps = (x->C + 31) & ~31;
     // long reductions over few positions (stage4/5 of the encoder: K = 1024..2048, 64..256 positions per sample):
     // split the channels over blocks, partial sums to the split-K scratch, one reduction launch
@@ -286,7 +301,7 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
         p.cps = (crn_cdiv(x->C, sp) + 31) & ~31;
         sp = crn_cdiv(x->C, p.cps);
         if (sp > 1 && (scratch = splitk_scratch((size_t)sp * ytot)) != nullptr) {
-          p.splits = sp; p.y = scratch; p.ysB = (int64_t)y->C * Sx; p.mode = 0;
+          p.splits = sp; p.y = scratch; p.ysB = (int64_t)y->C * Sx; p.ysC = Sx; p.ysP = 1; p.mode = 0;
         } else {
           p.cps = (x->C + 31) & ~31;
         }

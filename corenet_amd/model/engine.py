@@ -381,8 +381,10 @@ class Plan:
     self.glogits = f(B, C, 128, 128, 128)
     self.skip_src = {2: "stage5", 3: "stage4", 4: "stage3", 5: "stage2"}
     self.skip_hw = {2: 8, 3: 16, 4: 32, 5: 64}
-    self.smap = {k: f(B, sk[k], self.skip_hw[k], self.skip_hw[k]) for k in sk}
-    self.gsmap = {k: t.zeros_like(v) for k, v in self.smap.items()}
+    # compressed skip maps are channel-last [B][h][w][C]: the ray-sample gather then fetches four channels of a
+    # pixel per load (crn_ray_sample_fwd); their gradients stay channel-major (scatter-add per channel plane)
+    self.smap = {k: f(B, self.skip_hw[k], self.skip_hw[k], sk[k]) for k in sk}
+    self.gsmap = {k: f(B, sk[k], self.skip_hw[k], self.skip_hw[k]) for k in sk}
     self.layer_mats = f(4, B, 16)
     self.layer_scales = t.tensor([[128.0 / (2 * self.dec[k]["r"])] * 3 + [1.0] for k in (2, 3, 4, 5)],
                                  dtype=eng.dtype, device=dev).reshape(4, 1, 1, 4)
@@ -544,11 +546,11 @@ class Plan:
         ft = self.feat[self.skip_src[k]]
         hw = self.skip_hw[k]
         self._conv(cv[f"decoder.rt_skip_{k}.compress_channels."], self.vw(ft), None,
-                   self.vw(self.smap[k]))
+                   self.vw(self.smap[k].permute(0, 3, 1, 2)))
         ro = 2 * r
         self._probe(f"ray_sample_fwd_{ro}", lambda: be.ray_sample_fwd(
             self.smap[k], self.smap[k].stride(0), B, eng.skip_ch[k], hw, hw, self.layer_mats[k - 2],
-            self.offset, out[:, d["cout"]:], out.stride(0), ro, ro, ro))
+            self.offset, out[:, d["cout"]:], out.stride(0), ro, ro, ro, map_sC=1, map_sP=eng.skip_ch[k]))
     if training:
       be.add_i64(eng.store.nbt, eng.store.nbt.numel(), 1)     # batch_renorm.py:57
     return self.logits

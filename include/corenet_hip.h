@@ -181,11 +181,13 @@ int crn_fill_offset_channels(float* x, int B, int64_t sB, int64_t S, int c0,
  * Gather part of SampleGrid2d.forward (ray_traced_skip_connection.py:91-144):
  * per voxel centre (x,y,z)+off: p = M*(.,1); u=(px/pw)/2+.5; ix=(int)(u*W);
  * iy likewise (C truncation); +1 and clamp into the 1-px zero pad;
- * zero when p.z < 0 (Q7).  map: [B][C][h][w] (batch stride map_sB);
+ * zero when p.z < 0 (Q7).  map: element (b, c, iy, ix) at b*map_sB + c*map_sC +
+ * (iy*w+ix)*map_sP: (h*w, 1) is [B][C][h][w]; (1, C) is the channel-last [B][h][w][C]
+ * that the compress conv can write and that is gathered four channels per load.
  * out: channels [0,C) of a view with batch stride out_sB, spatial D*H*W.
  * matrix: [B][16] row-major layer matrix, offset: [B][3].                     */
-int crn_ray_sample_fwd(const float* map, int64_t map_sB, int B, int C, int h, int w,
-                       const float* matrix, const float* offset,
+int crn_ray_sample_fwd(const float* map, int64_t map_sB, int64_t map_sC, int64_t map_sP,
+                       int B, int C, int h, int w, const float* matrix, const float* offset,
                        float* out, int64_t out_sB, int D, int H, int W, crnStream s);
 /* Backward (reference: autograd index_put_(accumulate=True)): dmap must be
  * zeroed by the caller unless zero_first.                                     */

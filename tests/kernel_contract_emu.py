@@ -237,8 +237,10 @@ class EmuBackend:
         offset.view(B, 3, 1).expand(B, 3, S))
 
   # -- ray-traced skip ------------------------------------------------------------------
-  def ray_sample_fwd(self, fmap, map_sB, B, Cn, h, w, matrix, offset, out, out_sB, D, H, W):
-    m = t.as_strided(fmap, (B, Cn, h, w), (map_sB, h * w, w, 1), fmap.storage_offset())
+  def ray_sample_fwd(self, fmap, map_sB, B, Cn, h, w, matrix, offset, out, out_sB, D, H, W,
+                     map_sC=None, map_sP=1):
+    sC = h * w if map_sC is None else map_sC
+    m = t.as_strided(fmap, (B, Cn, h, w), (map_sB, sC, w * map_sP, map_sP), fmap.storage_offset())
     res = O.ray_sample(m, matrix.view(B, 4, 4).float(), offset.view(B, 3).float(), (D, H, W))
     t.as_strided(out, (B, Cn, D, H, W), (out_sB, D * H * W, H * W, W, 1), out.storage_offset()).copy_(res)
 

@@ -315,6 +315,11 @@ def test_ray_sample_golden_and_edge(be, golden_dir):
                     out[:, 2:], (C + 2) * 4096, 16, 16, 16)
   assert int((out[:, 2:].cpu() != t.tensor(z["y"])).sum()) == 0        # bit-exact incl. edge-case camera
   assert float((out[:, :2] - 7.0).abs().max()) == 0
+  if C % 4 == 0:   # channel-last map [B][h][w][C] (dwordx4 gathers), same result bit for bit
+    out2 = t.full((B, C + 2, 16, 16, 16), 7.0, device=DEV)
+    be.ray_sample_fwd(cmap.permute(0, 2, 3, 1).contiguous().to(DEV), C * 256, B, C, 16, 16, mats.reshape(B, 16).to(DEV),
+                      off.to(DEV), out2[:, 2:], (C + 2) * 4096, 16, 16, 16, map_sC=1, map_sP=C)
+    assert t.equal(out2, out)
   gy = t.tensor(z["gy"])
   dmap = t.zeros(B, C, 16, 16, device=DEV)
   be.ray_sample_bwd(gy.to(DEV), C * 4096, B, C, 16, 16, 16, mats.reshape(B, 16).to(DEV), off.to(DEV), dmap, C * 256,
@@ -337,6 +342,34 @@ def test_ray_sample_decoder_scales(be, res, C):
                     C * res ** 3, res, res, res)
   ref = O.ray_sample(cmap, m, off, (res,) * 3)
   assert int((out.cpu() != ref).sum()) == 0
+  # the layout the model uses: channel-last map written by the 1x1 compress conv
+  out2 = t.zeros(B, C, res, res, res, device=DEV)
+  be.ray_sample_fwd(cmap.permute(0, 2, 3, 1).contiguous().to(DEV), C * res * res, B, C, res, res,
+                    m.reshape(B, 16).to(DEV), off.to(DEV), out2, C * res ** 3, res, res, res, map_sC=1, map_sP=C)
+  assert int((out2.cpu() != ref).sum()) == 0
+
+
+@pytest.mark.parametrize("Cin,N,hw", [(2048, 96, 8), (256, 12, 64), (96, 20, 16)])
+def test_pointwise_conv_channel_last_output(be, Cin, N, hw):
+  """1x1 conv writing a channel-last view (compress_channels -> skip map), with and without split-K, against
+  the same conv into a plain view."""
+  from corenet_amd.model import conv_geometry as G
+  from corenet_amd import views as V
+  g = t.Generator().manual_seed(Cin)
+  B = 2
+  x = t.randn(B, Cin, hw, hw, generator=g).to(DEV)
+  w = t.randn(N, Cin, 1, 1, generator=g) / np.sqrt(Cin)
+  geo = G.conv_fwd(tuple(w.shape), 0)
+  wp = EMU_pack(w, geo)
+  b_ref = t.randn(N, generator=g)
+  bias = EMU_pack(b_ref, None, G.bias_index(N, 1, geo.npad, parity_major=False))
+  y0 = t.zeros(B, N, hw, hw, device=DEV); y1 = t.full((B, hw, hw, N), 3.0, device=DEV)
+  for y in (V.view_of(y0), V.view_of(y1.permute(0, 3, 1, 2))):
+    be.conv_fwd(V.view_of(x), None, wp.to(DEV), geo.npad, bias.to(DEV), 0, y, geo.window, geo.pad_lo, 0, False,
+                boxes=(geo.n_boxes, geo.c_boxes))
+  ref = t.nn.functional.conv2d(x.cpu(), w, b_ref)
+  close(y0, ref, 2e-5, "pointwise plain")
+  assert t.equal(y1.permute(0, 3, 1, 2), y0)
 
 
 # ------------------------------------------------------------------ losses / metrics / adam

@@ -15,10 +15,11 @@ def timeit(fn, n=20):
   b.record(); t.cuda.synchronize(); return a.elapsed_time(b) / n * 1e-3
 for res, C in ((64, 12), (32, 24), (16, 48), (8, 96)):
   cmap = t.randn(B, C, res, res).cuda()
+  cmap_cl = cmap.permute(0, 2, 3, 1).contiguous()      # the model's layout: channel-last skip map
   m = (O.canonical_camera() @ O.scale([1.0 / 128] * 3) @ O.scale([128.0 / res] * 3))[None].expand(B, 4, 4).reshape(B, 16).contiguous().cuda()
   off = t.full((B, 3), 0.5).cuda()
   out = t.zeros(B, C, res, res, res).cuda(); g = t.randn(B, C, res, res, res).cuda(); dmap = t.zeros_like(cmap)
-  s = timeit(lambda: be.ray_sample_fwd(cmap, C * res * res, B, C, res, res, m, off, out, C * res ** 3, res, res, res))
+  s = timeit(lambda: be.ray_sample_fwd(cmap_cl, C * res * res, B, C, res, res, m, off, out, C * res ** 3, res, res, res, map_sC=1, map_sP=C))
   by = 4.0 * B * C * (res ** 3 + res * res)
   print(f"ray_sample_fwd {res}^3 x{C}: {s*1e6:.1f} us  {by/s/1e9:.0f} GB/s ({by/s/8e12*100:.0f}% of 8 TB/s)")
   s = timeit(lambda: be.ray_sample_bwd(g, C * res ** 3, B, C, res, res, res, m, off, dmap, C * res * res, res, res, True))
