@@ -211,18 +211,40 @@ __global__ __launch_bounds__(kTMax * kTMax) void ray_sample_bwd_kernel(
 #pragma unroll
       for (int k = 0; k < CN; ++k) acc[k] = 0.f;
     };
-    for (int z = z0; z < z1; ++z) {
-      // the CN loads of this step do not depend on the projection: issue them first
-      float gv[CN];
+    // The z loop is a chain of (load, project, compare, maybe flush) steps whose branches keep the compiler from
+    // hoisting the next loads: with one wave per SIMD (256 workgroups at 64^3) every step paid a full HBM latency
+    // (49 us for 50 MB).  Loads are therefore issued kZC planes at a time into two register buffers, the next
+    // chunk in flight while the current one is consumed; addresses are clamped so that no load sits under a branch.
+    constexpr int kZC = 4;
+    float ga[kZC][CN], gb2[kZC][CN];
+    auto load_chunk = [&](float (&g)[kZC][CN], int zc) {
 #pragma unroll
-      for (int k = 0; k < CN; ++k)
-        gv[k] = (cbase + k < C) ? __builtin_nontemporal_load(gb + k * S + (int64_t)z * H * W) : 0.f;
-      const int po = project(cam, x, y, z, w, h);
-      if (po != cur) { flush(); cur = po; }
-      if (po >= 0) {
+      for (int j = 0; j < kZC; ++j) {
+        const int64_t zo = (int64_t)min(zc + j, z1 - 1) * H * W;
 #pragma unroll
-        for (int k = 0; k < CN; ++k) acc[k] += gv[k];
+        for (int k = 0; k < CN; ++k) g[j][k] = __builtin_nontemporal_load(gb + (cbase + k < C ? k : 0) * S + zo);
       }
+    };
+    auto consume = [&](float (&g)[kZC][CN], int zc) {
+#pragma unroll
+      for (int j = 0; j < kZC; ++j) {
+        const int z = zc + j;
+        if (z < z1) {
+          const int po = project(cam, x, y, z, w, h);
+          if (po != cur) { flush(); cur = po; }
+          if (po >= 0) {
+#pragma unroll
+            for (int k = 0; k < CN; ++k) acc[k] += g[j][k];
+          }
+        }
+      }
+    };
+    load_chunk(ga, z0);
+    for (int zc = z0; zc < z1; zc += 2 * kZC) {
+      load_chunk(gb2, zc + kZC);
+      consume(ga, zc);
+      load_chunk(ga, zc + 2 * kZC);
+      consume(gb2, zc + kZC);
     }
     flush();
   }
@@ -274,7 +296,8 @@ extern "C" int crn_ray_sample_bwd(const float* dout, int64_t dout_sB, int B, int
       for (int b = 0; b < B; ++b) CRN_HIP(hipMemsetAsync(dmap + b * dmap_sB, 0, (size_t)C * h * w * 4, st));
     }
   }
-  const int zseg = D >= 32 ? 16 : (D >= 16 ? 8 : D);
+  static const int zseg_env = getenv("CRN_RAY_ZSEG") ? atoi(getenv("CRN_RAY_ZSEG")) : 0;
+  const int zseg = zseg_env > 0 ? std::min(zseg_env, D) : (D >= 32 ? 16 : (D >= 16 ? 8 : D));
   const int nseg = (D + zseg - 1) / zseg;
   const bool big = W >= 64 && H >= 64;
   const int kTX = big ? 32 : 8, kTY = 8;
