@@ -15,6 +15,7 @@ from typing import Optional
 
 import torch as t
 import torch.distributed as dist
+import torch.utils.data
 
 
 def init_from_env(backend: Optional[str] = None) -> tuple:
@@ -94,3 +95,26 @@ def reduce_confusion_matrix(cm: t.Tensor, dst: int = 0, group=None):
   if dist.is_initialized() and dist.get_world_size(group) > 1:
     dist.reduce(cm, dst, op=dist.ReduceOp.SUM, group=group)
   return cm
+
+
+class DistributedSampler(t.utils.data.Sampler):
+  """Rank's share of a dataset (reference distributed.py:203-230): a fixed-seed (0x1234) permutation of the
+  dataset, zero-padded to a multiple of the world size when `pad_data`, cut into contiguous per-rank slices."""
+
+  def __init__(self, dataset, global_rank: int, global_world_size: int, pad_data: bool):
+    n = len(dataset)
+    total_size = (n + global_world_size - 1) // global_world_size * global_world_size if pad_data else n
+    g = t.Generator()
+    g.manual_seed(0x1234)
+    indices = t.randperm(n, generator=g)
+    indices = t.constant_pad_nd(indices, [0, total_size - indices.shape[0]])
+    start = global_rank * total_size // global_world_size
+    end = (global_rank + 1) * total_size // global_world_size
+    self.indices = indices[start:end]
+
+  def __iter__(self):
+    return iter(self.indices)
+
+  def __len__(self):
+    return self.indices.shape[0]
+

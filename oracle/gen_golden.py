@@ -345,6 +345,13 @@ def gen_data_path():
       out["shuffle_1234"] = big.shuffle(1234).indices.numpy()
       out["fraction_02_07"] = big.take_fraction(0.2, 0.7).indices.numpy()
       out["slice_of_shuffle"] = big.shuffle(7)[3:8].indices.numpy()
+  from corenet import distributed as RDist                      # rank's share of a dataset (distributed.py:203-230)
+  # torch 2.10's Sampler.__init__ no longer takes the data source the reference passes up (torch 1.7 API)
+  t.utils.data.Sampler.__init__ = lambda self, *a, **k: None
+  for pad in (True, False):
+    out[f"sampler_pad{int(pad)}"] = np.stack([np.pad(
+        RDist.DistributedSampler(list(range(10)), r, 4, pad).indices.numpy(), (0, 1), constant_values=-1)[:3]
+        for r in range(4)])
   sc = RS.load_from_npz(os.path.join(root, "scenes", "s0.npz"), os.path.join(root, "meshes"), load_extra_fields=True)
   out["s0_normals_1"] = sc.normals[1].numpy(); out["s0_material_ids_2"] = sc.material_ids[2].numpy()
   out["s0_visible"] = sc.mesh_visible_fractions.numpy()

@@ -159,6 +159,35 @@ def test_overlapped_gradient_exchange_single_rank_rccl():
     dist.destroy_process_group()
 
 
+def test_pipeline_process_batch_from_dataset():
+  """dataset elements -> batch (GPU) -> ground-truth voxelization -> v2s -> train step (pipeline.process_batch,
+  reference TrainPipeline._process_batch pipeline.py:215-242): runs end to end on the fixture dataset (images
+  replaced by 256x256 ones through the dataset's data_transforms hook), the loss is finite and equals the loss of
+  the same step driven by hand from the batch's tensors."""
+  import dataclasses
+  from corenet_amd import pipeline
+  from corenet_amd.data import batched_example as B, dataset as D
+  root = os.path.join(G, "n2_dataset")
+  g = t.Generator().manual_seed(5)
+  def big_image(scene, el):
+    return dataclasses.replace(el, input_image=t.randint(0, 256, (3, 256, 256), generator=g, dtype=t.uint8))
+  ds = D.CoReNetDatasetImpl(os.path.join(root, "dataset.json"), os.path.join(root, "meshes"), data_transforms=[big_image])
+  els = [ds[0], ds[1]]
+  sd = O.make_state(0, 4, nbt=0)
+  for task, nc in (("semantic", 4), ("fg_bg", 2)):
+    sd = O.make_state(0, nc, nbt=0)
+    ma, mb = _model(nc, sd).train(), _model(nc, sd).train()
+    la = pipeline.process_batch(ma, els, task)
+    ex = pipeline.voxelize_batch(B.batch(els), task)
+    assert ex.grid.shape == (2, 128, 128, 128) and int(ex.grid.max()) == (3 if task == "semantic" else 1)
+    v2s = ex.camera_transform @ t.diag(t.tensor([1 / 128.0] * 3 + [1.0])).cuda()
+    lb = mb.train_step(ex.input_image, v2s, ex.grid_sampling_offset, ex.grid, pipeline.LOSS_OF_TASK[task])
+    assert np.isfinite(float(la)) and abs(float(la) - float(lb)) < 1e-4
+    pmf, ex2 = pipeline.evaluate_batch(lambda im, cam, v2x, off, res: ma(im, cam @ v2x.cpu().inverse().cuda(), off).softmax(1),
+                                       els, task)
+    assert pmf.shape == (2, nc, 128, 128, 128) and t.equal(ex2.grid, ex.grid)
+
+
 def test_super_resolution_x2_golden_and_encoder_reuse():
   """N1: x2 super-resolution through the drop-in of corenet.super_resolution.
   (i) golden pmf generated by the reference's SuperResolutionInference (oracle/gen_golden.py);

@@ -240,6 +240,17 @@ def test_data_path_golden_and_host_logic():
   assert big.shuffle(7)[4].scene_id in ("scenes/s0", "scenes/s1")
   with pytest.raises(ValueError):
     S._to_tensor(np.zeros(3, np.float64), t.float32)
+  # rank's share of a dataset (reference distributed.py:203-230), 10 elements over 4 ranks
+  from corenet_amd.distributed import DistributedSampler
+  from corenet_amd import pipeline
+  for pad in (True, False):
+    for r in range(4):
+      got = DistributedSampler(list(range(10)), r, 4, pad).indices
+      want = z[f"sampler_pad{int(pad)}"][r]
+      assert got.tolist() == [int(v) for v in want if v >= 0][:len(got)] and len(got) == int((want >= 0).sum())
+  loader = pipeline.create_distributed_loader(big, batch_size=2, global_rank=1, global_world_size=4, pad_data=True)
+  batches = list(loader)
+  assert [len(b) for b in batches] == [2, 1] and isinstance(batches[0][0], D.DatasetElement)
   # collate geometry: oracle restatement, then the product's host wiring over the contract emulator
   vo = O.batch_vertices([(e.mesh_vertices, e.mesh_num_tri, e.view_transform, e.o2w_transforms) for e in els])
   np.testing.assert_allclose(vo.numpy(), z["vertices"], rtol=1e-6, atol=1e-7)
