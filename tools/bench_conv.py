@@ -13,6 +13,7 @@ LAYERS = {  # name: (kind, wshape, pad, in dims)
     "s5c1": ("conv", (32, 56, 5, 5, 5), 2, (32, 32, 32)),
     "s6t1": ("convT", (16, 2, 7, 7, 7), 3, (64, 64, 64)),
     "s5t1": ("convT", (32, 16, 7, 7, 7), 3, (32, 32, 32)),
+    "s6t1c14": ("convT", (16, 14, 7, 7, 7), 3, (64, 64, 64)),     # m7/m9: 14 classes
     "e2c": ("conv", (256, 64, 1, 1), 0, (1, 64, 64)),
     "e3b": ("conv", (128, 128, 3, 3), 1, (1, 32, 32)),
     "e2b": ("conv", (64, 64, 3, 3), 1, (1, 64, 64)),
