@@ -152,9 +152,11 @@ def test_overlapped_gradient_exchange_single_rank_rccl():
           # two runs of the same step differ by the summation order of the weight-gradient atomics
           assert relerr(gb[lo:hi], ga[lo:hi]) < 2e-3, (lo, hi)
     t.cuda.synchronize()
-    assert abs(float(la) - float(lb)) < 1e-3
+    assert abs(float(la) - float(lb)) < 3e-3                                       # measured: 0.7-3e-4
     d = (mb.engine.store.params - ma.engine.store.params).abs()
-    assert float(d.max()) <= 5e-3 and float((d > 1e-4).float().mean()) < 0.05
+    # Adam normalises every gradient to +-lr, so run-to-run noise on near-zero gradients moves those parameters
+    # by up to 2*lr per step: bound the distance, do not count how many moved
+    assert float(d.max()) <= 3 * 2 * 4e-4 * 1.05 and float(d.mean()) < 3e-4        # measured: mean 2-3e-5
   finally:
     dist.destroy_process_group()
 
