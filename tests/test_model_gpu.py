@@ -144,6 +144,32 @@ def test_training_trajectory_matches_oracle():
   assert relerr(m.state_dict()["decoder.stage_6.b1.running_mean"], so["decoder.stage_6.b1.running_mean"].detach()) < 2e-2
 
 
+def test_mean_iou_parity_on_trained_weights():
+  """Mean-IoU parity (BASELINE metric) on weights that were actually trained: 80 HIP training steps on a fixed
+  synthetic batch, then the eval-mode forward of the HIP path and of the oracle on those weights -- logits within the
+  north_star tolerance, confusion matrices (fused argmax + histogram vs the oracle's) and mean IoU equal."""
+  from corenet_amd import voxel_metrics as VM
+  sd = O.make_state(0, 2, nbt=0)
+  m = _model(2, sd).train()
+  image, v2s, off, grid = O.synthetic_batch(2, 0, 2)
+  gi, gg = [x.cuda() for x in (image, v2s, off)], grid.cuda().to(t.int32)
+  for _ in range(80):
+    m.train_step(gi[0], gi[1], gi[2], gg, "iou_fgbg", lr=4e-4, adam_eps=1e-4)
+  m.eval()
+  with t.no_grad():
+    lh = m(*gi)
+    so = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    lo = O.corenet_forward(so, image, v2s, off, training=False)
+  assert relerr(lh, lo) < 1e-3
+  _, cm = VM.argmax_confusion(lh, gg, 2)
+  cmo = O.confusion_matrix(grid, O.extract_labels(lo), 2)
+  iou_h, iou_o = VM.mean_iou(cm), O.mean_iou(cmo)
+  assert int((cm.cpu() - cmo).abs().sum()) <= 8                                      # ties in the argmax at most
+  # (80 steps at momentum 0.01 leave the running statistics far from the batch statistics, so the eval-mode IoU
+  # itself is still low; the point is that both paths agree on it)
+  assert abs(iou_h - iou_o) < 1e-4, (iou_h, iou_o)
+
+
 def test_train_step_reduces_loss_and_matches_autograd_path():
   sd = O.make_state(0, 2, nbt=0)
   m = _model(2, sd).train()
