@@ -194,6 +194,7 @@ class Engine:
     self.adam_m: Optional[t.Tensor] = None
     self.adam_v: Optional[t.Tensor] = None
     self.adam_t = 0
+    self.dgrad_dirty = True
     self.weights_dirty = True
 
   # ------------------------------------------------------------------ layers
@@ -252,17 +253,21 @@ class Engine:
     # 8x8-tile descriptors of the pack (reference -> packed) and un-pack (packed grad -> reference grad)
     # copies: crn_copy_tiles_f32 moves both sides in full 32-byte sectors and reads ~0.5 B of index per element
     # instead of 4 (conv_geometry.tile_index)
-    pack_parts, unpack_parts = [], []
+    pack_parts, pack_is_bwd, unpack_parts = [], [], []
     po, go = 0, 0
     for (name, fwd, dgrad, repeat, nref), parts in zip(reg, idx_parts):
-      pack_parts.append((po, parts[0], fwd.npad, 0)); po += len(parts[0])
-      pack_parts.append((po, parts[1], len(parts[1]), 0)); po += len(parts[1])
+      pack_parts.append((po, parts[0], fwd.npad, 0)); po += len(parts[0]); pack_is_bwd.append(False)
+      pack_parts.append((po, parts[1], len(parts[1]), 0)); po += len(parts[1]); pack_is_bwd.append(False)
       if dgrad is not None:
         pack_parts.append((po, parts[2], dgrad.npad, dgrad.taps if dgrad.taps > 1 else 0)); po += len(parts[2])
+        pack_is_bwd.append(True)
       unpack_parts.append((go, parts[0], fwd.npad, 0)); go += len(parts[0])
     dev = lambda tl: (t.as_tensor(tl[0], device=self.device), t.as_tensor(tl[1].view(np.int64), device=self.device),
                       t.as_tensor(tl[2] if tl[2].size else np.zeros(1, np.int32), device=self.device))
-    self.pack_tiles = dev(G.tile_index(pack_parts))
+    # two packs: what forward reads (forward weights + biases) and what only backward reads (data-gradient
+    # weights) -- the second one runs on the side stream under the forward pass, and never in eval mode
+    self.pack_tiles = dev(G.tile_index([pp for pp, bwd in zip(pack_parts, pack_is_bwd) if not bwd]))
+    self.pack_tiles_bwd = dev(G.tile_index([pp for pp, bwd in zip(pack_parts, pack_is_bwd) if bwd]))
     self.unpack_tiles = dev(G.tile_index(unpack_parts))
     # gradient buckets for the overlapped exchange (corenet_amd/distributed.py): contiguous ranges of the
     # grad slab in the order backward completes them, each with the tile descriptors of its own convs
@@ -297,10 +302,25 @@ class Engine:
       self._bucket_dev = [dev(G.tile_index(sel)) for sel in self._bucket_tiles]
     return self._bucket_dev[i]
 
+  @property
+  def weights_dirty(self) -> bool:
+    return self._weights_dirty
+
+  @weights_dirty.setter
+  def weights_dirty(self, v: bool):
+    self._weights_dirty = v
+    if v:
+      self.dgrad_dirty = True
+
   def pack_weights(self):
-    """flat parameter slab -> packed kernel layouts (1 launch)."""
+    """flat parameter slab -> packed forward weights and biases (1 launch)."""
     self.be.copy_tiles(self.store.params, self.packed, self.pack_tiles)
-    self.weights_dirty = False
+    self._weights_dirty = False
+
+  def pack_dgrad_weights(self):
+    """flat parameter slab -> packed data-gradient weights (1 launch; backward only)."""
+    self.be.copy_tiles(self.store.params, self.packed, self.pack_tiles_bwd)
+    self.dgrad_dirty = False
 
   # -------------------------------------------------------------------- plans
   def plan(self, batch: int) -> "Plan":
@@ -396,6 +416,9 @@ class Plan:
     self._side_ev, self._side_i = [], 0
     self._side_done = t.cuda.Event() if use_side else None
     self._bucket_ev = [t.cuda.Event() for _ in GRAD_BUCKET_LABELS] if use_side else None
+    self._pack_ev = t.cuda.Event() if use_side else None
+    self._dgrad_packed = t.cuda.Event() if use_side else None
+    self._dgrad_pack_pending = False
 
   # ------------------------------------------------------------------ cached views
   def _cached(self, key, fn):
@@ -492,6 +515,15 @@ class Plan:
     eng, be, B = self.eng, self.be, self.B
     if eng.weights_dirty:
       eng.pack_weights()
+    self._dgrad_pack_pending = False
+    if training and eng.dgrad_dirty and self.side is not None:
+      # the data-gradient weights are not needed before backward: pack them beside the forward pass
+      self._pack_ev.record()                      # the parameters are final on the main stream
+      with t.cuda.stream(self.side):
+        self.side.wait_event(self._pack_ev)
+        eng.pack_dgrad_weights()
+        self._dgrad_packed.record(self.side)
+      self._dgrad_pack_pending = True
     cv, bn = eng.convs, eng.bns
     self.training = training
     be.preprocess(image_u8, self.img)
@@ -615,6 +647,11 @@ class Plan:
     eng, be, B = self.eng, self.be, self.B
     cv, bn = eng.convs, eng.bns
     assert self.training, "backward needs a training-mode forward"
+    if self._dgrad_pack_pending:
+      t.cuda.current_stream().wait_event(self._dgrad_packed)
+      self._dgrad_pack_pending = False
+    elif eng.dgrad_dirty:
+      eng.pack_dgrad_weights()
     be.zero(eng.gpacked)
     L = eng.latent
     g_out = glogits
