@@ -46,7 +46,8 @@ def batch(examples: List[dataset.DatasetElement], device=None, backend=None) -> 
       mats.append(t.matmul(ex.view_transform[None], ex.o2w_transforms))      # o2v = w2v . o2w  (:78)
     mats = t.cat(mats, 0).to(t.float32).contiguous()
     raw = t.cat([ex.mesh_vertices for ex in examples], 0).to(dev).contiguous()
-    tri_mesh = voxelization.dynamic_tile(t.cat(num_tri, 0)).to(dev)
+    tri_mesh = (voxelization.dynamic_tile(t.cat(num_tri, 0), dev, total=int(raw.shape[0])) if dev.type == "cuda"
+                else voxelization.dynamic_tile(t.cat(num_tri, 0)))
     assert tri_mesh.shape[0] == raw.shape[0] and raw.shape[1:] == (3, 3) and raw.dtype == t.float32
     all_vertices = t.empty_like(raw)
     be.transform_meshes(raw, tri_mesh, mats.to(dev), all_vertices)

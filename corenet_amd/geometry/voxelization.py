@@ -10,10 +10,14 @@ import torch as t
 from corenet_amd.backend import default_backend
 
 
-def dynamic_tile(partition_lengths: t.Tensor) -> t.Tensor:
-  """misc_util.py:32-48: [n0 zeros, n1 ones, ...] int32."""
-  return t.repeat_interleave(t.arange(len(partition_lengths), dtype=t.int32),
-                             partition_lengths.to(t.int64).cpu())
+def dynamic_tile(partition_lengths: t.Tensor, device=None, total: int = None) -> t.Tensor:
+  """misc_util.py:32-48: [n0 zeros, n1 ones, ...] int32.  With `device` the table is expanded there (only the
+  few partition lengths cross the bus; `total` = sum of the lengths avoids a device->host read-back)."""
+  if device is None:
+    return t.repeat_interleave(t.arange(len(partition_lengths), dtype=t.int32),
+                               partition_lengths.to(t.int64).cpu())
+  n = partition_lengths.to(device=device, dtype=t.int64, non_blocking=True)
+  return t.repeat_interleave(t.arange(len(partition_lengths), dtype=t.int32, device=device), n, output_size=total)
 
 
 def voxelize_mesh(triangles, mesh_num_tri, resolution: Tuple[int, int, int], view2voxel,
@@ -39,7 +43,9 @@ def voxelize_mesh(triangles, mesh_num_tri, resolution: Tuple[int, int, int], vie
     raise ValueError("projection_depth_multiplier must be 1 if sub_grid_sampling is True")
   D, H, W = resolution
   tri = triangles.to(dev).contiguous()
-  tri_mesh = dynamic_tile(mesh_num_tri).to(dev)
+  if not mesh_num_tri.is_cuda:
+    assert int(mesh_num_tri.sum()) == triangles.shape[0], "mesh_num_tri must add up to the number of triangles"
+  tri_mesh = dynamic_tile(mesh_num_tri, dev, total=int(triangles.shape[0]))
   v2v = view2voxel.to(dev).contiguous()
   shape = (M, 2 * D + 1, 2 * H + 1, 2 * W + 1) if sub_grid_sampling else (M, D, H, W)
   grid = t.empty(shape, dtype=t.float32, device=dev)
