@@ -203,7 +203,10 @@ def test_conv_1to4(be):
 # ------------------------------------------------------------------ BatchRenorm & elementwise
 @pytest.mark.parametrize("B,C,S,pre,post,nbt", [(3, 5, 24, False, False, 0), (2, 28, 4096, True, False, 30000),
                                                (4, 64, 1024, False, True, 12000), (4, 67, 1, True, False, 0),
-                                               (2, 7, 33, True, False, 7000)])
+                                               (2, 7, 33, True, False, 7000),
+                                               # channel-owner kernels (C >= 64, B*S <= 65536)
+                                               (4, 128, 1024, False, True, 12000), (4, 256, 64, True, False, 30000),
+                                               (2, 130, 37, False, False, 0), (4, 512, 256, False, True, 6000)])
 def test_batch_renorm(be, B, C, S, pre, post, nbt):
   g = t.Generator().manual_seed(B * 100 + C)
   Ct = C + 2
