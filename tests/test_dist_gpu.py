@@ -1,0 +1,48 @@
+"""Two data-parallel ranks on ONE GPU (gloo over CUDA tensors: a single-GPU box cannot host two RCCL ranks):
+the real HIP train step with the bucketed backward, the side stream and asynchronous all-reduces of the slab
+slices, world size 2.  RCCL itself is exercised by tests/test_model_gpu.py (one rank) and by bench.py on a node."""
+import os
+import sys
+
+import pytest
+import torch as t
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out):
+  sys.path.insert(0, ROOT)
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                    LOCAL_RANK="0")
+  from corenet_amd import distributed as D
+  from corenet_amd.model.core_net import CoreNet, CoreNetConfig, DecoderConfig
+  from oracle import corenet_oracle as O
+  t.cuda.set_device(0)
+  D.init_from_env("gloo")
+  model = CoreNet(CoreNetConfig(DecoderConfig((128, 128, 128), 2, 2, 64, 0.75)), device="cuda:0")
+  model.load_state_dict(O.make_state(0, 2, nbt=0)); model.train()
+  image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(1, seed=rank, num_classes=2)]
+  grid = grid.to(t.int32)
+  sync = D.GradientSync(world)
+  assert sync.overlap and model.engine.plan(1).side is not None
+  losses = []
+  for _ in range(3):
+    D.broadcast_buffers(model.engine.store)
+    losses.append(float(model.train_step(image, v2s, off, grid, "iou_fgbg", world_size=world, all_reduce=sync)))
+  t.cuda.synchronize()
+  t.save({"p": model.engine.store.params.cpu(), "g": model.engine.store.grads.cpu(), "losses": losses,
+          "pushed": list(sync.pushed), "n": model.engine.store.grads.numel()}, os.path.join(out, f"g{rank}.pt"))
+  dist.barrier(); dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_overlapped_train_steps(tmp_path):
+  world, port = 2, 29333 + os.getpid() % 200
+  mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+  a, b = t.load(tmp_path / "g0.pt"), t.load(tmp_path / "g1.pt")
+  assert t.equal(a["g"], b["g"]) and t.equal(a["p"], b["p"])          # same summed gradients, same parameters
+  assert sum(a["pushed"]) == a["n"] and len(a["pushed"]) == 7
+  assert a["losses"][0] != b["losses"][0]                              # different samples per rank
+  assert a["losses"][-1] < a["losses"][0] and b["losses"][-1] < b["losses"][0]
