@@ -80,6 +80,8 @@ def main():
 
   rank, local, world = D.init_from_env()
   assert world == args.gpus or world == 1, (world, args.gpus)
+  if os.environ.get("CRN_DIST_BACKEND") == "gloo":      # dry run of the N > 1 path on fewer GPUs than ranks
+    local = local % t.cuda.device_count()
   t.cuda.set_device(local)
   dev = f"cuda:{local}"
   C, B = args.classes, args.batch

@@ -27,7 +27,8 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if backend is None:
-      backend = "nccl" if t.cuda.is_available() else "gloo"
+      # CRN_DIST_BACKEND=gloo: dry runs of the multi-rank path on a box with fewer GPUs than ranks
+      backend = os.environ.get("CRN_DIST_BACKEND") or ("nccl" if t.cuda.is_available() else "gloo")
     if backend == "nccl":
       t.cuda.set_device(local)
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
