@@ -76,6 +76,7 @@ _SIGS = {
     "crn_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp],
     "crn_fill_voxels": [vp, vp, i32, i32, i32, i32, i32, vp, sz, vp],
     "crn_voxelize_mesh": [vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp],
+    "crn_batch_renorm_eval_affine": [vp, vp, vp, i32, f32, vp, vp, vp],
     "crn_transform_meshes": [vp, vp, i32, vp, i32, vp, vp],
     "crn_merge_labels": [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp],
     "crn_zero_f32": [vp, i64, vp],

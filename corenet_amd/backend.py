@@ -127,6 +127,10 @@ class HipBackend:
                                   ptr(dx), sB_dx, ptr(dgamma), ptr(dbeta), int(accumulate),
                                   ptr(dsum), int(ndsum), ptr(ws), n, _lib.stream())
 
+  def bn_eval_affine(self, params, buffers, table, eps, scale, shift):
+    self.lib.crn_batch_renorm_eval_affine(ptr(params), ptr(buffers), ptr(table), table.shape[0], eps,
+                                          ptr(scale), ptr(shift), _lib.stream())
+
   def affine_add_relu(self, x, scale, shift, r, rscale, rshift, B, Cn, S, sB_x, sB_r,
                       y_pre, sB_pre, y, sB_y, relu):
     self.lib.crn_affine_add_relu(ptr(x), ptr(scale), ptr(shift), ptr(r), ptr(rscale), ptr(rshift),

@@ -106,6 +106,21 @@ __global__ void bn_finalize_kernel(const double* ws, int nparts, int C, double c
                       saved);
 }
 
+// Eval mode: scale/shift of EVERY BatchRenorm of the model from the running statistics in one launch
+// (batch_renorm.py:59); table rows = (gamma, beta offsets in the parameter slab; running_mean, running_var
+// offsets in the buffer slab; output offset in the scale/shift slabs).  Same arithmetic as the eval branch of
+// bn_finalize_kernel.
+__global__ void bn_eval_affine_kernel(const float* params, const float* buffers, const int32_t* table, int n,
+                                      float eps, float* scale, float* shift) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int32_t* r = table + (int64_t)j * 5;
+  const float g = params[r[0]], bt = params[r[1]];
+  const float rstd = 1.0f / sqrtf(buffers[r[3]] + eps);
+  scale[r[4]] = g * rstd;
+  shift[r[4]] = bt - g * buffers[r[2]] * rstd;
+}
+
 // Channel-owner form for many small channels (the encoder from stage 3 on, the coarse decoder stages): one
 // workgroup reduces all of (B, S) of its channel and finalizes it -- one launch instead of two, no workspace.
 template <bool VEC>
@@ -436,6 +451,16 @@ extern "C" int crn_batch_renorm_stats(const float* x, int B, int C, int64_t S, i
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(crn_cdiv(C, 128)), dim3(128), 0, st, ws, nparts, C,
                      (double)B * (double)S, gamma, beta, running_mean, running_var, nbt, eps, momentum,
                      training, scale, shift, saved);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_batch_renorm_eval_affine(const float* params, const float* buffers, const int32_t* table,
+                                            int n, float eps, float* scale, float* shift, crnStream stream) {
+  if (n < 0 || (n > 0 && (!params || !buffers || !table || !scale || !shift))) return CRN_EINVAL;
+  if (n == 0) return CRN_OK;
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(crn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, params,
+                     buffers, table, n, eps, scale, shift);
   CRN_CHECK_LAUNCH();
   return CRN_OK;
 }

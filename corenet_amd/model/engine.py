@@ -202,16 +202,43 @@ class Engine:
     s = self.store
     c = s.off[prefix + "weight"][1][0]
     dev = self.device
+    # scale / shift live in two slabs shared by all instances: eval mode fills them in one launch (_bn_slabs)
+    o = self._bn_slab_off[prefix]
     return BN(c, s.view(prefix + "weight"), s.view(prefix + "bias"), s.view(prefix + "running_mean"),
               s.view(prefix + "running_var"), s.view(prefix + "num_batches_tracked"),
               s.view(prefix + "weight", grad=True), s.view(prefix + "bias", grad=True),
-              t.zeros(c, device=dev, dtype=self.dtype), t.zeros(c, device=dev, dtype=self.dtype),
+              self.bn_scale[o:o + c], self.bn_shift[o:o + c],
               t.zeros(4 * c, device=dev, dtype=self.dtype))
+
+  def _bn_slabs(self):
+    """Offsets of every BatchRenorm instance in the shared scale / shift slabs (16-byte aligned) and the table of
+    crn_batch_renorm_eval_affine: one row per channel."""
+    s = self.store
+    self._bn_slab_off, rows, n = {}, [], 0
+    for key, shape, kind in self.specs:
+      if not key.endswith("running_mean"):
+        continue
+      p = key[:-len("running_mean")]
+      c = shape[0]
+      self._bn_slab_off[p] = n
+      ch = np.arange(c)
+      rows.append(np.stack([s.offset(p + "weight") + ch, s.offset(p + "bias") + ch, s.offset(p + "running_mean") + ch,
+                            s.offset(p + "running_var") + ch, n + ch], 1))
+      n += (c + 3) // 4 * 4
+    self.bn_scale = t.zeros(n, device=self.device, dtype=self.dtype)
+    self.bn_shift = t.zeros(n, device=self.device, dtype=self.dtype)
+    self.bn_eval_table = t.as_tensor(np.concatenate(rows).astype(np.int32), device=self.device)
+
+  def bn_eval_affine(self):
+    """Eval-mode scale / shift of every BatchRenorm from the running statistics (batch_renorm.py:59): 1 launch."""
+    self.be.bn_eval_affine(self.store.params, self.store.buffers, self.bn_eval_table, BN_EPS, self.bn_scale,
+                           self.bn_shift)
 
   def _build_layers(self):
     s = self.store
     self.convs: Dict[str, Conv] = {}
     self.bns: Dict[str, BN] = {}
+    self._bn_slabs()
     reg: List[Tuple[str, G.Geom, Optional[G.Geom], int, int]] = []   # name, fwd, dgrad, repeat, nref
 
     def add(name, fwd, dgrad, repeat=1):
@@ -455,6 +482,8 @@ class Plan:
     self.probes[name].append((a, b))
 
   def _stats(self, bn: BN, x: t.Tensor, S: int, sB: int, pre_relu: bool, training: bool):
+    if not training:
+      return            # eval mode: forward_encoder filled every scale / shift already (Engine.bn_eval_affine)
     self.be.bn_stats(x, self.B, bn.C, S, sB, pre_relu, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.nbt,
                      BN_EPS, BN_MOMENTUM, training, bn.scale, bn.shift, bn.saved)
 
@@ -526,6 +555,8 @@ class Plan:
       self._dgrad_pack_pending = True
     cv, bn = eng.convs, eng.bns
     self.training = training
+    if not training:
+      eng.bn_eval_affine()
     be.preprocess(image_u8, self.img)
     # stem (resnet50.py:122-131)
     c1 = cv["encoder.stage1.conv."]

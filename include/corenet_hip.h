@@ -119,6 +119,12 @@ int crn_batch_renorm_stats(const float* x, int B, int C, int64_t S, int64_t sB, 
                            double* workspace, size_t workspace_bytes, crnStream s);
 size_t crn_batch_renorm_workspace_bytes(int C);
 
+/* Eval mode (batch_renorm.py:59: (x - running_mean) / sqrt(running_var + eps) * weight + bias) for all
+ * BatchRenorm instances of a model at once: n channels, table [n][5] = offsets of (weight, bias) in `params`,
+ * of (running_mean, running_var) in `buffers`, and of the channel in the `scale` / `shift` output slabs.  */
+int crn_batch_renorm_eval_affine(const float* params, const float* buffers, const int32_t* table,
+                                 int n, float eps, float* scale, float* shift, crnStream s);
+
 /* Backward.  With x' = pre_relu ? max(x,0) : x, xn = (x'-mu)*rstd,
  * out = x'*scale+shift, g = dy * (post_relu ? out>0 : 1):
  *   dbeta = sum g ; dgamma = sum g*(r*xn+d)

@@ -171,6 +171,13 @@ class EmuBackend:
     if dsum is not None:
       dsum[:ndsum].copy_(o[:, :ndsum].double().sum((0, 2)).to(x.dtype))
 
+  def bn_eval_affine(self, params, buffers, table, eps, scale, shift):
+    tb = table.long()
+    g, bt, rm, rv = params[tb[:, 0]], params[tb[:, 1]], buffers[tb[:, 2]], buffers[tb[:, 3]]
+    rstd = 1.0 / (rv + eps).sqrt()
+    scale[tb[:, 4]] = g * rstd
+    shift[tb[:, 4]] = bt - g * rm * rstd
+
   def affine_add_relu(self, x, scale, shift, r, rscale, rshift, B, Cn, S, sB_x, sB_r, y_pre, sB_pre,
                       y, sB_y, relu):
     v = t.as_strided(x, (B, Cn, S), (sB_x, S, 1), x.storage_offset())
