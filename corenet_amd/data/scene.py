@@ -51,15 +51,26 @@ class TensorContainerMixin:
 
 @d.dataclass(frozen=True)
 class Scene(TensorContainerMixin):
-  """A rendered synthetic scene (scene.py:32-76)."""
-  mesh_vertices: List[t.Tensor]          # List[float32[num_triangles, 3, 3]], object space
-  view_transform: t.Tensor               # float32[4, 4] world -> view
-  o2w_transforms: t.Tensor               # float32[num_meshes, 4, 4]
-  camera_transform: t.Tensor             # float32[4, 4]
+  """One rendered synthetic scene (scene.py:32-76).  Field order is the reference's (positional construction).
+
+  mesh_vertices           per mesh float32[num_triangles, 3, 3], object space
+  view_transform          float32[4, 4]               world -> view
+  o2w_transforms          float32[num_meshes, 4, 4]   object -> world
+  camera_transform        float32[4, 4]               projection
+  mesh_labels             per mesh class id (str)
+  mesh_visible_fractions  float32[num_meshes]
+  opengl_image            uint8[height, width, 3]     low-realism rendering
+  pbrt_image              uint8[height, width, 3]     high-realism rendering
+  normals, texcoords, material_ids, diffuse_colors, diffuse_texture_pngs
+                          per mesh extras, filled only by load_from_npz(load_extra_fields=True)"""
+  mesh_vertices: List[t.Tensor]
+  view_transform: t.Tensor
+  o2w_transforms: t.Tensor
+  camera_transform: t.Tensor
   mesh_labels: List[Text]
-  mesh_visible_fractions: t.Tensor       # float32[num_meshes]
-  opengl_image: t.Tensor                 # uint8[height, width, 3]
-  pbrt_image: t.Tensor                   # uint8[height, width, 3]
+  mesh_visible_fractions: t.Tensor
+  opengl_image: t.Tensor
+  pbrt_image: t.Tensor
   normals: List[t.Tensor] = d.field(default_factory=list)
   texcoords: List[t.Tensor] = d.field(default_factory=list)
   material_ids: List[t.Tensor] = d.field(default_factory=list)
@@ -67,55 +78,61 @@ class Scene(TensorContainerMixin):
   diffuse_texture_pngs: List[List[bytes]] = d.field(default_factory=list)
 
 
-def _load_image(i) -> t.Tensor:
+def _decode_image(encoded) -> t.Tensor:
+  """Image bytes (WebP / PNG / ... whatever PIL reads) -> uint8[height, width, 3]."""
   import PIL.Image
-  return _to_tensor(np.array(PIL.Image.open(io.BytesIO(i))), t.uint8)
+  with PIL.Image.open(io.BytesIO(encoded)) as im:
+    return _to_tensor(np.array(im), t.uint8)
 
 
 class NpzReader:
-  """scene.py:83-103."""
+  """Typed access to the arrays of one NPZ file (scene.py:83-103)."""
 
   def __init__(self, path: str):
     with open(path, "rb") as fl:
       self.npz = np.load(io.BytesIO(fl.read()), allow_pickle=True)
 
   def tensor(self, item: str, dtype: Optional[t.dtype] = None) -> t.Tensor:
-    result = self.npz[item]
-    return _to_tensor(result, dtype) if dtype else t.as_tensor(result)
+    """The array as a tensor; with `dtype` its type is checked, not converted."""
+    arr = self.npz[item]
+    return t.as_tensor(arr) if dtype is None else _to_tensor(arr, dtype)
 
   def list(self, item: str) -> List[Any]:
-    result = self.npz[item]
-    assert len(result.shape) == 1
-    return list(result)
+    arr = self.npz[item]
+    assert arr.ndim == 1
+    return [v for v in arr]
 
   def scalar(self, item: str) -> Any:
-    result = self.npz[item]
-    assert len(result.shape) == 0
-    return result
+    arr = self.npz[item]
+    assert arr.ndim == 0
+    return arr
+
+
+# extra per-mesh fields of a mesh NPZ: (Scene field, NPZ key, dtype or None for a 0-d object array)
+_EXTRA_FIELDS = (("normals", "normals", t.float32), ("material_ids", "material_ids", t.int32),
+                 ("texcoords", "texcoords", t.float32), ("diffuse_colors", "diffuse_colors", t.float32),
+                 ("diffuse_texture_pngs", "diffuse_texture_pngs", None))
 
 
 def load_from_npz(path: Text, meshes_dir: Text, load_extra_fields=False) -> Scene:
-  """Loads one scene and the ShapeNet meshes it points to (scene.py:106-151): the mesh of object i is
-  `<meshes_dir>/<mesh_labels[i]>/<mesh_filenames[i]>.npz`."""
-  scene_npz = NpzReader(path)
-  mesh_paths = [os.path.join(meshes_dir, *v) + ".npz"
-                for v in zip(scene_npz.list("mesh_labels"), scene_npz.list("mesh_filenames"))]
-  result = Scene(
-      mesh_vertices=[],
-      view_transform=scene_npz.tensor("view_transform", t.float32),
-      o2w_transforms=scene_npz.tensor("mesh_object_to_world_transforms", t.float32),
-      camera_transform=scene_npz.tensor("camera_transform", t.float32),
-      mesh_labels=[v for v in scene_npz.list("mesh_labels")],
-      opengl_image=_load_image(scene_npz.scalar("opengl_image")),
-      pbrt_image=_load_image(scene_npz.scalar("pbrt_image")),
-      mesh_visible_fractions=scene_npz.tensor("mesh_visible_fractions", t.float32))
-  for mesh_path in mesh_paths:
-    mesh_npz = NpzReader(mesh_path)
-    result.mesh_vertices.append(mesh_npz.tensor("vertices", t.float32))
+  """Reads a scene NPZ and the meshes it names (scene.py:106-151): object i is
+  `<meshes_dir>/<mesh_labels[i]>/<mesh_filenames[i]>.npz`; its `vertices` always, the fields of _EXTRA_FIELDS
+  (not needed by the training pipeline) only on request."""
+  rd = NpzReader(path)
+  labels = [str(v) for v in rd.list("mesh_labels")]
+  names = [str(v) for v in rd.list("mesh_filenames")]
+  sc = Scene(mesh_vertices=[],
+             view_transform=rd.tensor("view_transform", t.float32),
+             o2w_transforms=rd.tensor("mesh_object_to_world_transforms", t.float32),
+             camera_transform=rd.tensor("camera_transform", t.float32),
+             mesh_labels=labels,
+             mesh_visible_fractions=rd.tensor("mesh_visible_fractions", t.float32),
+             opengl_image=_decode_image(rd.scalar("opengl_image")),
+             pbrt_image=_decode_image(rd.scalar("pbrt_image")))
+  for label, name in zip(labels, names):
+    mesh = NpzReader(os.path.join(meshes_dir, label, name) + ".npz")
+    sc.mesh_vertices.append(mesh.tensor("vertices", t.float32))
     if load_extra_fields:
-      result.normals.append(mesh_npz.tensor("normals", t.float32))
-      result.material_ids.append(mesh_npz.tensor("material_ids", t.int32))
-      result.texcoords.append(mesh_npz.tensor("texcoords", t.float32))
-      result.diffuse_colors.append(mesh_npz.tensor("diffuse_colors", t.float32))
-      result.diffuse_texture_pngs.append(mesh_npz.scalar("diffuse_texture_pngs"))
-  return result
+      for field, key, dtype in _EXTRA_FIELDS:
+        getattr(sc, field).append(mesh.scalar(key) if dtype is None else mesh.tensor(key, dtype))
+  return sc

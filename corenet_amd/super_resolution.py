@@ -24,48 +24,56 @@ class MultiOffsetInferenceFn:
 
 
 class SuperResolutionInference:
-  """super_resolution.py:46-112."""
+  """Inference at m times the native grid resolution from m^3 native passes at shifted sampling offsets
+  (super_resolution.py:46-112)."""
 
   def __init__(self, inference_fn: MultiOffsetInferenceFn, resolution: Tuple[int, int, int]):
-    self.resolution = resolution
     self.inference_fn = inference_fn
-    self.offset_cache = {}
+    self.resolution = resolution
+    self.offset_cache = {}          # output resolution -> unit-cube offsets f32[m^3, 3]
 
   def get_resolution_multiplier(self, output_resolution: Tuple[int, int, int]) -> int:
-    """Multiplier between the native and the output resolution (super_resolution.py:53-64)."""
-    rm = (t.as_tensor(output_resolution, dtype=t.float32) / t.as_tensor(self.resolution, dtype=t.float32))
-    if (rm.floor() != rm.ceil()).any() or (rm < 1).any() or rm.min() != rm.max():
+    """m = output / native resolution: one integer >= 1 for all three axes, else ValueError
+    (super_resolution.py:53-64)."""
+    ratio = t.tensor(output_resolution, dtype=t.float32) / t.tensor(self.resolution, dtype=t.float32)
+    whole = bool((ratio == ratio.round()).all())
+    if not whole or float(ratio.min()) < 1 or float(ratio.min()) != float(ratio.max()):
       raise ValueError("The output resolution should be divisible by the native resolution")
-    return int(rm[0])
+    return int(ratio[0])
+
+  def _unit_offsets(self, output_resolution: Tuple[int, int, int], m: int) -> t.Tensor:
+    """(ix, iy, iz) / m for offset index n = (iz * m + iy) * m + ix, cached per output resolution."""
+    hit = self.offset_cache.get(output_resolution)
+    if hit is None:
+      n = t.arange(m ** 3)
+      hit = t.stack([n % m, (n // m) % m, n // (m * m)], 1).to(t.float32) / m
+      self.offset_cache[output_resolution] = hit
+    return hit
 
   def get_native_offsets(self, output_resolution: Tuple[int, int, int], grid_offsets: t.Tensor) -> t.Tensor:
-    """Sampling offsets in the native grid, f32[m^3, B, 3] (super_resolution.py:66-90): offset index
-    n = (iz*m + iy)*m + ix  <->  ((ix, iy, iz) + grid_offset) / m."""
+    """Sampling offsets of the m^3 native passes, f32[m^3, B, 3]: ((ix, iy, iz) + grid_offset) / m
+    (super_resolution.py:66-90)."""
     output_resolution = tuple(output_resolution)
     assert len(output_resolution) == 3
     m = self.get_resolution_multiplier(output_resolution)
-    if output_resolution not in self.offset_cache:
-      zz, yy, xx = t.meshgrid([t.arange(m, device="cpu")] * 3, indexing="ij")
-      offsets = t.stack([xx, yy, zz], -1) / m
-      self.offset_cache[output_resolution] = offsets.reshape([-1, 3])
-    offsets = self.offset_cache[output_resolution].to(grid_offsets.device)
-    return offsets[:, None] + grid_offsets[None, :] / m
+    unit = self._unit_offsets(output_resolution, m).to(grid_offsets.device)
+    return unit.unsqueeze(1) + grid_offsets.unsqueeze(0) / m
 
   def __call__(self, input_image: t.Tensor, camera_transform: t.Tensor, view_to_voxel_transform: t.Tensor,
                grid_offsets: t.Tensor, output_resolution: Tuple[int, int, int]) -> t.Tensor:
-    native_offsets = self.get_native_offsets(output_resolution, grid_offsets)
+    """pmf f32[B, C, m*D, m*H, m*W] (super_resolution.py:92-112)."""
     m = self.get_resolution_multiplier(output_resolution)
-    batch_size = input_image.shape[0]
-    scale = transformations.scale([1 / m, 1 / m, 1 / m])
-    view_to_voxel_transform = view_to_voxel_transform @ scale.to(view_to_voxel_transform.device)
+    offsets = self.get_native_offsets(output_resolution, grid_offsets)
+    # the native grid spans the same volume with m times fewer voxels per axis
+    v2x_native = view_to_voxel_transform @ transformations.scale([1.0 / m] * 3).to(view_to_voxel_transform.device)
     fused = getattr(self.inference_fn, "interleaved", None)
-    if fused is not None:       # HIP path: returns [B, C, mD, mH, mW] directly
-      return fused(input_image, camera_transform, view_to_voxel_transform, native_offsets, m)
-    pmfs = self.inference_fn(input_image, camera_transform, view_to_voxel_transform, native_offsets)
-    _, _, num_channels, d, h, w = pmfs.shape
-    pmfs = pmfs.reshape([m, m, m, batch_size, num_channels, d, h, w])
-    pmfs = pmfs.permute([3, 4, 5, 0, 6, 1, 7, 2])
-    return pmfs.reshape([batch_size, num_channels, m * d, m * h, m * w])
+    if fused is not None:       # HIP path: softmax + interleave in one kernel, [B, C, mD, mH, mW] directly
+      return fused(input_image, camera_transform, v2x_native, offsets, m)
+    pmfs = self.inference_fn(input_image, camera_transform, v2x_native, offsets)      # [m^3, B, C, D, H, W]
+    B, C, D, H, W = pmfs.shape[1:]
+    # [iz, iy, ix, B, C, D, H, W] -> [B, C, D, iz, H, iy, W, ix] -> fine voxel = coarse voxel * m + sub-position
+    fine = pmfs.reshape(m, m, m, B, C, D, H, W).permute(3, 4, 5, 0, 6, 1, 7, 2)
+    return fine.reshape(B, C, m * D, m * H, m * W)
 
 
 class CoreNetMultiOffset(MultiOffsetInferenceFn):
