@@ -477,7 +477,10 @@ __global__ __launch_bounds__(1024) void fill_fused_kernel(const T* grid, T* out,
     pend = __syncthreads_or(pnd);
   }
   // on failure nothing is written: the caller re-runs the multi-launch path on the untouched input
-  if (!ok) { if (threadIdx.x == 0) atomicOr(status, 1); return; }
+  if (!ok) {       // status lives in host-mapped memory: a plain system-scope store, read after the stream sync
+    if (threadIdx.x == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   store_slab();
 }
 
@@ -522,7 +525,17 @@ int run_fill_fused(const T* grid, T* out, int N, int D, int H, int W, int WX, vo
   const int64_t nwords = (int64_t)N * D * H * WX;
   char* base = reinterpret_cast<char*>(ws) + fused_offset(nwords);
   FusedCtl* ctl = reinterpret_cast<FusedCtl*>(base);
-  int* status = reinterpret_cast<int*>(base + align256((size_t)N * sizeof(FusedCtl)));
+  // failure flag in pinned host memory the kernel writes directly: no device->host copy on the way out
+  static thread_local int* h_status = nullptr;
+  static thread_local int* status = nullptr;
+  if (!h_status) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&h_status), 64, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(reinterpret_cast<void**>(&status), h_status, 0) != hipSuccess) {
+      h_status = nullptr;
+      return CRN_EAGAIN;
+    }
+  }
+  *h_status = 0;
   u64* halo = reinterpret_cast<u64*>(base + align256((size_t)N * sizeof(FusedCtl)) + 256);
   CRN_HIP(hipMemsetAsync(base, 0, align256((size_t)N * sizeof(FusedCtl)) + 256, st));
   const int64_t gstride = (int64_t)D * H * W;
@@ -536,14 +549,9 @@ int run_fill_fused(const T* grid, T* out, int N, int D, int H, int W, int WX, vo
 #undef CRN_FUSED
     if (rc != CRN_OK) return rc;
   }
-  // in-place calls cannot be repeated on failure, so the status is checked only when a retry is possible
-  if ((const void*)grid == (const void*)out) {
-    // the fused kernel leaves the slab untouched on failure: safe to check and fall back
-  }
-  int h_status = 0;
-  CRN_HIP(hipMemcpyAsync(&h_status, status, sizeof(int), hipMemcpyDeviceToHost, st));
+  // a failing kernel leaves its output untouched (also in place), so the caller can re-run the multi-launch path
   CRN_HIP(hipStreamSynchronize(st));
-  return h_status ? CRN_EAGAIN : CRN_OK;
+  return *reinterpret_cast<volatile int*>(h_status) ? CRN_EAGAIN : CRN_OK;
 }
 
 template <typename T>
