@@ -70,11 +70,12 @@ _SIGS = {
     "crn_fill_offset_channels": [vp, i32, i64, i64, i32, vp, vp],
     "crn_ray_sample_fwd": [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp],
     "crn_ray_sample_bwd": [vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp],
-    "crn_loss_fwd_bwd": [i32, vp, vp, i32, i32, i64, vp, vp, f32, vp, sz, vp],
+    "crn_loss_fwd_bwd": [i32, vp, vp, vp, i32, i32, i64, vp, vp, f32, vp, sz, vp],
     "crn_argmax_confusion": [vp, vp, i32, i32, i64, vp, vp, vp],
     "crn_softmax_superres": [vp, i32, i32, i32, i32, i32, i32, vp, vp],
     "crn_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp],
     "crn_fill_voxels": [vp, vp, i32, i32, i32, i32, i32, vp, sz, vp],
+    "crn_fill_voxels_cpu": [vp, vp, i32, i32, i32, i32, i32, i32],
     "crn_voxelize_mesh": [vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp],
     "crn_batch_renorm_eval_affine": [vp, vp, vp, i32, f32, vp, vp, vp],
     "crn_transform_meshes": [vp, vp, i32, vp, i32, vp, vp],
@@ -87,7 +88,10 @@ _SIZE_FNS = {
     "crn_loss_workspace_bytes": [i32, i32],
     "crn_fill_voxels_workspace_bytes": [i32, i32, i32, i32],
 }
-ALL_SYMBOLS = list(_SIGS) + list(_SIZE_FNS) + ["crn_version"]
+_PTR_FNS = {
+    "crn_loss_status_ptr": [vp, i32],
+}
+ALL_SYMBOLS = list(_SIGS) + list(_SIZE_FNS) + list(_PTR_FNS) + ["crn_version"]
 
 
 class _Lib:
@@ -107,6 +111,11 @@ class _Lib:
       fn = getattr(self.cdll, name)
       fn.argtypes = sig
       fn.restype = C.c_size_t
+      setattr(self, name, fn)
+    for name, sig in _PTR_FNS.items():
+      fn = getattr(self.cdll, name)
+      fn.argtypes = sig
+      fn.restype = C.c_void_p
       setattr(self, name, fn)
     self.cdll.crn_version.restype = C.c_char_p
 

@@ -183,11 +183,18 @@ class HipBackend:
                                 ptr(dmap), dmap_sB, h, w, int(zero_first), _lib.stream())
 
   # -- losses / metrics / optimizer ---------------------------------------------------------
-  def loss_fwd_bwd(self, kind, logits, gt_i32, B, Cn, S, loss, dlogits, grad_scale=1.0):
+  def loss_fwd_bwd(self, kind, logits, gt_i32, B, Cn, S, loss, dlogits, grad_scale=1.0, weights=None):
     n = self.lib.crn_loss_workspace_bytes(B, Cn)
     ws = self.workspace("loss", n, logits.device)
-    self.lib.crn_loss_fwd_bwd(kind, ptr(logits), ptr(gt_i32), B, Cn, S, ptr(loss), ptr(dlogits),
+    self.lib.crn_loss_fwd_bwd(kind, ptr(logits), ptr(gt_i32), ptr(weights), B, Cn, S, ptr(loss), ptr(dlogits),
                               grad_scale, ptr(ws), n, _lib.stream())
+
+  def loss_labels_in_range(self, B, Cn, device) -> bool:
+    """True unless the last loss_fwd_bwd on `device` saw a label outside [0, C) (synchronises)."""
+    n = self.lib.crn_loss_workspace_bytes(B, Cn)
+    ws = self.workspace("loss", n, device)
+    off = self.lib.crn_loss_status_ptr(ptr(ws), B) - ws.data_ptr()
+    return int(ws[off:off + 4].view(t.int32)) == 0
 
   def softmax_superres(self, logits, m, B, Cn, D, H, W, out):
     self.lib.crn_softmax_superres(ptr(logits), m, B, Cn, D, H, W, ptr(out), _lib.stream())

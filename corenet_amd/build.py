@@ -12,11 +12,14 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcorenet_hip.so")
 SOURCES = ["conv_igemm.hip", "batch_renorm.hip", "ray_sample.hip", "misc_ops.hip", "losses.hip", "fill_voxels.hip",
-           "voxelize.hip"]
+           "voxelize.hip", "fill_voxels_cpu.cpp"]
 # conv engine tile configurations (conv_kernels.h CRN_FWD_CONFIGS / CRN_WG_CONFIGS): one object each
 CONV_CONFIGS = [(8, 1), (4, 2), (4, 1), (2, 4), (2, 2), (2, 1), (1, 4), (1, 2), (1, 1)]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-ffp-contract=off", "-Wno-unused-result"]
+
+
+HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-pthread"]
 
 
 def _stale(obj, src):
@@ -34,10 +37,11 @@ def build(verbose=True, force=False):
   objs, jobs = [], []
   for s in SOURCES:
     src = os.path.join(CSRC, s)
-    obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+    obj = os.path.join(LIBDIR, os.path.splitext(s)[0] + ".o")
     objs.append(obj)
     if force or _stale(obj, src):
-      jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+      flags = FLAGS if s.endswith(".hip") else HOST_FLAGS           # .cpp: host-only code of the library
+      jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
   inst = os.path.join(CSRC, "conv_inst.hip")
   for kind, macro in (("wgrad", "CRN_INST_WGRAD"), ("fwd", "CRN_INST_FWD")):   # the slow ones first
     for m, n in CONV_CONFIGS:

@@ -180,6 +180,76 @@ __global__ __launch_bounds__(512) void fill_sweep_kernel(const u64* E, u64* R, i
   }
 }
 
+// ---- device-side rescue path ---------------------------------------------------------------------
+// Enqueued behind the single-launch kernel on every call; returns at once unless that kernel raised its
+// status word (a partner workgroup was not resident, or more slab exchanges were needed than kFusedIters).
+// One workgroup per grid: pack -> sweep the slabs of the grid through LDS until a whole pass changes
+// nothing -> unpack.  No inter-workgroup dependency, so it always terminates; the host never has to look
+// at the status, i.e. crn_fill_voxels stays asynchronous (the reference op is: fill_voxels_gpu.cu:158-165).
+// Reads `grid` again: a failed single-launch kernel leaves each grid either untouched or (in place, some
+// slabs) already at the final answer, and the fill is idempotent on such a mix (empties only shrink to
+// the reached set), so the result is the same fixed point.
+template <typename T, int WX>
+__global__ __launch_bounds__(512) void fill_rescue_kernel(const T* grid, T* out, u64* E, u64* R, int D, int H, int W,
+                                                          int zs, int nslabs, const int* status, int force) {
+  extern __shared__ __attribute__((aligned(16))) u64 sm[];
+  if (!force && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+  const int n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int rowsz = H * WX;
+  const int64_t gwords = (int64_t)D * rowsz;
+  u64* Eg = E + n * gwords;
+  u64* Rg = R + n * gwords;
+  const T* gsrc = grid + (int64_t)n * D * H * W;
+  T* gdst = out + (int64_t)n * D * H * W;
+  for (int64_t wi = wave; wi < gwords; wi += nwaves) {          // fill_pack_kernel for this grid
+    const int k = (int)(wi % WX);
+    const int64_t row = wi / WX;                                // z*H + y
+    const int y = (int)(row % H), z = (int)(row / H);
+    const int x = k * 64 + lane;
+    bool empty = false;
+    if (x < W) empty = !(gsrc[row * W + x] > (T)0);
+    const u64 e = __ballot(empty);
+    if (lane == 0) {
+      Eg[wi] = e;
+      Rg[wi] = (y == 0 || z == 0) ? e : (k == 0 ? (e & 1ull) : 0ull);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  u64* El = sm;                          // [zs][H][WX]
+  u64* Rl = sm + (size_t)zs * rowsz;     // [zs+2][H][WX]
+  for (int round = 0; round < (1 << 20); ++round) {
+    int pass_changed = 0;
+    for (int slab = 0; slab < nslabs; ++slab) {
+      const int z0 = slab * zs, nz = min(zs, D - z0);
+      const u64* Es = Eg + (int64_t)z0 * rowsz;
+      u64* Rs = Rg + (int64_t)z0 * rowsz;
+      for (int i = threadIdx.x; i < nz * rowsz; i += blockDim.x) { El[i] = Es[i]; Rl[rowsz + i] = Rs[i]; }
+      for (int i = threadIdx.x; i < rowsz; i += blockDim.x) {
+        Rl[i] = z0 > 0 ? Rs[i - rowsz] : 0ull;
+        Rl[(nz + 1) * rowsz + i] = (z0 + nz < D) ? Rs[nz * rowsz + i] : 0ull;
+      }
+      __syncthreads();
+      const int any = relax_slab<WX>(El, Rl, nz, H);
+      if (any) {
+        for (int i = threadIdx.x; i < nz * rowsz; i += blockDim.x) Rs[i] = Rl[rowsz + i];
+        pass_changed = 1;
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    if (!pass_changed || nslabs == 1) break;
+  }
+  for (int64_t wi = wave; wi < gwords; wi += nwaves) {          // fill_unpack_kernel for this grid
+    const int k = (int)(wi % WX);
+    const int64_t row = wi / WX;
+    const int x = k * 64 + lane;
+    const u64 outside = Eg[wi] & Rg[wi];
+    if (x < W) gdst[row * W + x] = ((outside >> lane) & 1ull) ? (T)0 : (T)1;
+  }
+}
+
 // ---- wave-level plane closure (single-launch path) --------------------------------------------
 // One wavefront owns a z-plane: lane = row y (64 rows per group).  Along x the closure is the carry
 // trick per row; along y it is a segmented OR-scan over the lanes (Kogge-Stone on (reach, empty)
@@ -476,9 +546,10 @@ __global__ __launch_bounds__(1024) void fill_fused_kernel(const T* grid, T* out,
     }
     pend = __syncthreads_or(pnd);
   }
-  // on failure nothing is written: the caller re-runs the multi-launch path on the untouched input
-  if (!ok) {       // status lives in host-mapped memory: a plain system-scope store, read after the stream sync
-    if (threadIdx.x == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // on failure this workgroup writes nothing and raises the status word: the rescue kernel enqueued behind this
+  // launch (fill_rescue_kernel) redoes the call
+  if (!ok) {
+    if (threadIdx.x == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   store_slab();
@@ -501,9 +572,28 @@ int launch_fused(const T* grid, T* out, int G, int D, int H, int W, int zs, int 
   return CRN_OK;
 }
 
+template <typename T, int WX>
+int launch_rescue(const T* grid, T* out, u64* E, u64* R, int N, int D, int H, int W, const int* status, int force,
+                  hipStream_t st) {
+  const size_t plane = (size_t)H * WX * 8;
+  int zs = (int)std::min<size_t>((size_t)D, (kSweepLds / plane - 2) / 2);
+  if (zs < 1) return CRN_EINVAL;
+  const int nslabs = (D + zs - 1) / zs;
+  zs = (D + nslabs - 1) / nslabs;
+  const size_t lds = (size_t)(2 * zs + 2) * plane;
+  auto k = fill_rescue_kernel<T, WX>;
+  if (lds > 65536) CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, dim3(N), dim3(512), lds, st, grid, out, E, R, D, H, W, zs, nslabs, status, force);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+// Single-launch kernel + the rescue kernel behind it: nothing here waits for the GPU.
+// CRN_FILL_RESCUE=1 (tests): skip the single-launch kernel and run the rescue path alone.
 template <typename T>
 int run_fill_fused(const T* grid, T* out, int N, int D, int H, int W, int WX, void* ws, hipStream_t st) {
   static const bool off = getenv("CRN_FILL_MULTI") != nullptr;
+  static const bool rescue_only = getenv("CRN_FILL_RESCUE") != nullptr;
   if (off) return CRN_EAGAIN;
   const size_t plane = (size_t)H * WX * 8;
   const int zs_max = (int)std::min<size_t>((size_t)D, (kSweepLds / plane - 2) / 2);
@@ -523,24 +613,18 @@ int run_fill_fused(const T* grid, T* out, int N, int D, int H, int W, int WX, vo
   nslabs = (D + zs - 1) / zs;
   const size_t lds = (size_t)(2 * zs + 2) * plane;
   const int64_t nwords = (int64_t)N * D * H * WX;
+  u64* E = reinterpret_cast<u64*>(ws);
+  u64* R = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + align256((size_t)nwords * 8));
   char* base = reinterpret_cast<char*>(ws) + fused_offset(nwords);
   FusedCtl* ctl = reinterpret_cast<FusedCtl*>(base);
-  // failure flag in pinned host memory the kernel writes directly: no device->host copy on the way out
-  static thread_local int* h_status = nullptr;
-  static thread_local int* status = nullptr;
-  if (!h_status) {
-    if (hipHostMalloc(reinterpret_cast<void**>(&h_status), 64, hipHostMallocMapped) != hipSuccess ||
-        hipHostGetDevicePointer(reinterpret_cast<void**>(&status), h_status, 0) != hipSuccess) {
-      h_status = nullptr;
-      return CRN_EAGAIN;
-    }
-  }
-  *h_status = 0;
+  // status word in device memory right behind the control blocks (cleared by the same memset); only the rescue
+  // kernel reads it
+  int* status = reinterpret_cast<int*>(base + align256((size_t)N * sizeof(FusedCtl)));
   u64* halo = reinterpret_cast<u64*>(base + align256((size_t)N * sizeof(FusedCtl)) + 256);
   CRN_HIP(hipMemsetAsync(base, 0, align256((size_t)N * sizeof(FusedCtl)) + 256, st));
   const int64_t gstride = (int64_t)D * H * W;
   const int64_t hstride = (int64_t)nslabs * 2 * 2 * H * WX;
-  for (int g0 = 0; g0 < N; g0 += G) {
+  for (int g0 = 0; g0 < N && !rescue_only; g0 += G) {
     const int Gn = std::min(G, N - g0);
     int rc = CRN_EINVAL;
 #define CRN_FUSED(K) case K: rc = launch_fused<T, K>(grid + g0 * gstride, out + g0 * gstride, Gn, D, H, W, zs, nslabs, lds, \
@@ -549,9 +633,11 @@ int run_fill_fused(const T* grid, T* out, int N, int D, int H, int W, int WX, vo
 #undef CRN_FUSED
     if (rc != CRN_OK) return rc;
   }
-  // a failing kernel leaves its output untouched (also in place), so the caller can re-run the multi-launch path
-  CRN_HIP(hipStreamSynchronize(st));
-  return *reinterpret_cast<volatile int*>(h_status) ? CRN_EAGAIN : CRN_OK;
+  int rc = CRN_EINVAL;
+#define CRN_RESCUE(K) case K: rc = launch_rescue<T, K>(grid, out, E, R, N, D, H, W, status, rescue_only ? 1 : 0, st); break;
+  switch (WX) { CRN_RESCUE(1) CRN_RESCUE(2) CRN_RESCUE(3) CRN_RESCUE(4) CRN_RESCUE(5) CRN_RESCUE(6) CRN_RESCUE(7) CRN_RESCUE(8) }
+#undef CRN_RESCUE
+  return rc;
 }
 
 template <typename T>

@@ -35,32 +35,36 @@ struct Soft {
 
 template <int CT>
 __global__ __launch_bounds__(kThreads) void loss_pass1_kernel(const float* logits, const int32_t* gt,
-                                                              int C, int64_t S, double* part) {
+                                                              const float* weights, int C, int64_t S, double* part,
+                                                              int* bad_label) {
   __shared__ double red[kThreads / 64];
   const int b = blockIdx.y;
   const float* lb = logits + (int64_t)b * C * S;
   const int32_t* gb = gt + (int64_t)b * S;
+  const float* wb = weights ? weights + (int64_t)b * S : nullptr;
   double q[kNQ] = {0, 0, 0, 0, 0};
   for (int64_t v = blockIdx.x * (int64_t)kThreads + threadIdx.x; v < S; v += (int64_t)gridDim.x * kThreads) {
     Soft<CT> sm;
     sm.compute(lb + v, S, C);
-    const int g = gb[v];
+    int g = gb[v];
+    if (g < 0 || g >= C) { *bad_label = 1; g = 0; }     // F.one_hot / cross_entropy raise (losses.py:36,131); no OOB read here
+    const float w = wb ? wb[v] : 1.f;                   // per-voxel loss weights (losses.py:47-49,99-102,134-136)
     float pfg = 0.f;
 #pragma unroll
     for (int c = 1; c < CT; ++c) pfg += sm.s[c];
     const float gf = g >= 1 ? 1.f : 0.f;
-    q[0] += (double)fminf(gf, pfg);
-    q[1] += (double)fmaxf(gf, pfg);
+    q[0] += (double)(fminf(gf, pfg) * w);
+    q[1] += (double)(fmaxf(gf, pfg) * w);
     float ia = 0.f, ua = 0.f;
 #pragma unroll
     for (int c = 1; c < CT; ++c) {
       if (c < C) {
-        if (c == g) { ia += sm.s[c] * (float)(C - 1); ua += (float)(C - 1); }   // min(1,p)=p, max(1,p)=1
-        else ua += sm.s[c];
+        if (c == g) { ia += sm.s[c] * ((float)(C - 1) * w); ua += (float)(C - 1) * w; }   // min(1,p)=p, max(1,p)=1
+        else ua += sm.s[c] * w;
       }
     }
     q[2] += (double)ia; q[3] += (double)ua;
-    q[4] += (double)(sm.logz - lb[v + (int64_t)g * S]);
+    q[4] += (double)((sm.logz - lb[v + (int64_t)g * S]) * w);
   }
   for (int k = 0; k < kNQ; ++k) {
     const double t = crn_block_sum(q[k], red);
@@ -109,23 +113,27 @@ __global__ void loss_finalize_kernel(const double* part, int nblk, int B, int64_
 
 template <int CT>
 __global__ __launch_bounds__(kThreads) void loss_pass2_kernel(const float* logits, const int32_t* gt,
-                                                              int C, int64_t S, const float* coef,
-                                                              float* dlogits) {
+                                                              const float* weights, int C, int64_t S,
+                                                              const float* coef, float* dlogits) {
   const int b = blockIdx.y;
   const float* lb = logits + (int64_t)b * C * S;
   const int32_t* gb = gt + (int64_t)b * S;
+  const float* wb = weights ? weights + (int64_t)b * S : nullptr;
   float* db = dlogits + (int64_t)b * C * S;
-  const float kfg = coef[1], kag = coef[2], kx = coef[3];
+  const float kfg0 = coef[1], kag0 = coef[2], kx0 = coef[3];
   const float ifg = coef[4 + b * 4 + 0], ufg = coef[4 + b * 4 + 1];
   const float iag = coef[4 + b * 4 + 2], uag = coef[4 + b * 4 + 3];
   for (int64_t v = blockIdx.x * (int64_t)kThreads + threadIdx.x; v < S; v += (int64_t)gridDim.x * kThreads) {
     Soft<CT> sm;
     sm.compute(lb + v, S, C);
-    const int g = gb[v];
+    int g = gb[v];
+    if (g < 0 || g >= C) g = 0;
+    const float w = wb ? wb[v] : 1.f;                   // every per-voxel term of the three sums carries w
+    const float kfg = kfg0 * w, kag = kag0 * w, kx = kx0 * w;
     float d[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) d[c] = 0.f;
-    if (kfg != 0.f) {
+    if (kfg0 != 0.f) {
       float pfg = 0.f;
 #pragma unroll
       for (int c = 1; c < CT; ++c) pfg += sm.s[c];
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(kThreads) void loss_pass2_kernel(const float* logit
 #pragma unroll
       for (int c = 0; c < CT; ++c) d[c] += dp * sm.s[c] * ((c >= 1 ? 1.f : 0.f) - pfg);
     }
-    if (kag != 0.f) {
+    if (kag0 != 0.f) {
       float qv[CT];
       float dot = 0.f;
 #pragma unroll
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(kThreads) void loss_pass2_kernel(const float* logit
 #pragma unroll
       for (int c = 0; c < CT; ++c) d[c] += sm.s[c] * (qv[c] - dot);
     }
-    if (kx != 0.f) {
+    if (kx0 != 0.f) {
 #pragma unroll
       for (int c = 0; c < CT; ++c) d[c] += kx * (sm.s[c] - (c == g ? 1.f : 0.f));
     }
@@ -189,11 +197,11 @@ inline int loss_nblk(int64_t S) { return (int)std::min<int64_t>(std::max<int64_t
 
 extern "C" size_t crn_loss_workspace_bytes(int B, int C) {
   (void)C;
-  return (size_t)B * 512 * kNQ * sizeof(double) + (size_t)(4 + 4 * B) * sizeof(float) + 64;
+  return (size_t)B * 512 * kNQ * sizeof(double) + (size_t)(4 + 4 * B) * sizeof(float) + 64;   // last 64 B: status word
 }
 
-extern "C" int crn_loss_fwd_bwd(int kind, const float* logits, const int32_t* gt, int B, int C, int64_t S,
-                                float* loss, float* dlogits, float grad_scale, void* workspace,
+extern "C" int crn_loss_fwd_bwd(int kind, const float* logits, const int32_t* gt, const float* weights, int B, int C,
+                                int64_t S, float* loss, float* dlogits, float grad_scale, void* workspace,
                                 size_t workspace_bytes, crnStream stream) {
   hipStream_t st = (hipStream_t)stream;
   if (kind < 0 || kind > 4 || B < 1 || C < 2 || C > 32 || S < 1 || !logits || !gt || !loss) return CRN_EINVAL;
@@ -201,8 +209,10 @@ extern "C" int crn_loss_fwd_bwd(int kind, const float* logits, const int32_t* gt
   const int nblk = loss_nblk(S);
   double* part = reinterpret_cast<double*>(workspace);
   float* coef = reinterpret_cast<float*>(part + (size_t)B * 512 * kNQ);
+  int* bad_label = reinterpret_cast<int*>(coef + 4 + 4 * B + (16 - (4 + 4 * B) % 16) % 16);   // crn_loss_status reads it
+  CRN_HIP(hipMemsetAsync(bad_label, 0, sizeof(int), st));
   dim3 grid(nblk, B);
-#define CRN_LOSS_P1(CT) hipLaunchKernelGGL(loss_pass1_kernel<CT>, grid, dim3(kThreads), 0, st, logits, gt, C, S, part)
+#define CRN_LOSS_P1(CT) hipLaunchKernelGGL(loss_pass1_kernel<CT>, grid, dim3(kThreads), 0, st, logits, gt, weights, C, S, part, bad_label)
   if (C <= 2) CRN_LOSS_P1(2); else if (C <= 4) CRN_LOSS_P1(4); else if (C <= 8) CRN_LOSS_P1(8);
   else if (C <= 16) CRN_LOSS_P1(16); else CRN_LOSS_P1(32);
 #undef CRN_LOSS_P1
@@ -210,13 +220,21 @@ extern "C" int crn_loss_fwd_bwd(int kind, const float* logits, const int32_t* gt
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, part, nblk, B, S, kind, grad_scale, loss, coef);
   CRN_CHECK_LAUNCH();
   if (dlogits) {
-#define CRN_LOSS_P2(CT) hipLaunchKernelGGL(loss_pass2_kernel<CT>, grid, dim3(kThreads), 0, st, logits, gt, C, S, coef, dlogits)
+#define CRN_LOSS_P2(CT) hipLaunchKernelGGL(loss_pass2_kernel<CT>, grid, dim3(kThreads), 0, st, logits, gt, weights, C, S, coef, dlogits)
     if (C <= 2) CRN_LOSS_P2(2); else if (C <= 4) CRN_LOSS_P2(4); else if (C <= 8) CRN_LOSS_P2(8);
     else if (C <= 16) CRN_LOSS_P2(16); else CRN_LOSS_P2(32);
 #undef CRN_LOSS_P2
     CRN_CHECK_LAUNCH();
   }
   return CRN_OK;
+}
+
+// Device address of the status word of the last crn_loss_fwd_bwd on this workspace: != 0 when a label was
+// outside [0, C) (such a label is computed as class 0; the reference raises inside F.one_hot).
+extern "C" const int* crn_loss_status_ptr(void* workspace, int B) {
+  double* part = reinterpret_cast<double*>(workspace);
+  float* coef = reinterpret_cast<float*>(part + (size_t)B * 512 * kNQ);
+  return reinterpret_cast<int*>(coef + 4 + 4 * B + (16 - (4 + 4 * B) % 16) % 16);
 }
 
 extern "C" int crn_argmax_confusion(const float* logits, const int32_t* gt, int B, int C, int64_t S,

@@ -68,15 +68,26 @@ class _CoreNetFn(t.autograd.Function):
   def forward(ctx, model, image, v2s, offset, *params):
     plan = model.engine.plan(image.shape[0])
     logits = plan.forward(image, v2s, offset, training=model.training)
-    ctx.model, ctx.plan = model, plan
+    ctx.model, ctx.plan, ctx.generation = model, plan, plan.generation
     return logits.clone()      # the plan's buffer is reused by the next forward
 
   @staticmethod
   def backward(ctx, glogits):
     model, plan = ctx.model, ctx.plan
-    plan.backward(glogits.contiguous())
-    grads = tuple(model.engine.store.view(k, grad=True) for k in model._param_keys)
-    return (None, None, None, None) + grads
+    if plan.generation != ctx.generation:
+      # the saved activations and BatchRenorm statistics of a forward live in the (per batch size) plan: a later
+      # forward with the same batch size has overwritten them.  The reference's autograd keeps one set per graph;
+      # raising beats returning gradients of the wrong activations.
+      raise RuntimeError("corenet_amd.CoreNet: backward() of a forward pass whose saved activations were "
+                         "overwritten by a later forward with the same batch size; run backward before the "
+                         "next forward (gradient accumulation: forward, backward, forward, backward)")
+    plan.glogits.copy_(glogits)          # plan-owned buffer: no per-step view cache entries, no pinned tensors
+    plan.backward(plan.glogits)
+    # autograd keeps (or accumulates into) what is returned here, so it must not alias the engine's gradient slab,
+    # which the next backward overwrites: ONE copy of the slab, handed out as per-parameter views
+    store = model.engine.store
+    grads = store.grads.clone()
+    return (None, None, None, None) + tuple(store.view_of(grads, k) for k in model._param_keys)
 
 
 class CoreNet(nn.Module):
@@ -151,7 +162,7 @@ class CoreNet(nn.Module):
     B = image.shape[0]
     assert voxel_projection_matrix.shape == (B, 4, 4)
     assert voxel_sample_locations.shape == (B, 3)
-    if not image.is_cuda:
+    if not image.is_cuda and getattr(self.engine.be, "name", "") != "emu":   # "emu": tests' contract emulator
       raise ValueError("Only CUDA(HIP) tensors are supported by corenet_amd.CoreNet")
     self.engine.weights_dirty = True     # parameters may have been stepped by an external optimizer
     image = image.contiguous()

@@ -132,6 +132,12 @@ class ParamStore:
   def offset(self, key) -> int:
     return self.off[key][0]
 
+  def view_of(self, slab: t.Tensor, key) -> t.Tensor:
+    """The parameter `key`'s slice of any tensor laid out like the parameter slab."""
+    o, shape = self.off[key]
+    n = int(np.prod(shape)) if len(shape) else 1
+    return slab[o:o + n].view(shape)
+
 
 @dataclasses.dataclass
 class BN:
@@ -375,6 +381,7 @@ class Plan:
   def __init__(self, eng: Engine, B: int):
     self.eng, self.B = eng, B
     self.be = eng.be
+    self.generation = 0            # bumped by every forward: CoreNet's autograd node checks it in backward
     self._views = {}
     dev = eng.device
     self.dev = dev
@@ -542,6 +549,7 @@ class Plan:
     """ResNet-50 features + global average (resnet50.py:176-186).  In eval mode the result does not depend
     on the sampling offset, so multi-offset inference (super_resolution.py:123-125) runs it once."""
     eng, be, B = self.eng, self.be, self.B
+    self.generation += 1
     if eng.weights_dirty:
       eng.pack_weights()
     self._dgrad_pack_pending = False
@@ -574,6 +582,7 @@ class Plan:
     """Offset channels, skip compression + ray sampling, 3D decoder (reconstruction_decoder.py:97-151)."""
     eng, be, B = self.eng, self.be, self.B
     cv, bn = eng.convs, eng.bns
+    self.generation += 1
     self.offset.copy_(offset)
     # layer matrices v2s @ scale(128 / r) for the four skip grids (reconstruction_decoder.py:111-116)
     v = v2s.to(self.layer_mats.dtype).reshape(1, B, 4, 4)

@@ -27,10 +27,48 @@ class FusedAdam:
 
   # -- torch.optim.Optimizer surface used by the reference's train loop (pipeline.py:224-230) --
   def zero_grad(self, set_to_none: bool = False):
+    """torch 1.7 semantics by default (zero in place, pipeline.py:225); like torch.optim, the gradients are the
+    parameters' `.grad` tensors -- the engine's slab is only the staging area of step()."""
+    for p in self.model.parameters():
+      if p.grad is not None:
+        if set_to_none:
+          p.grad = None
+        else:
+          p.grad.detach_()
+          p.grad.requires_grad_(False)
+          p.grad.zero_()
     self.model.engine.store.grads.zero_()
+
+  def _gather_grads(self):
+    """`.grad` of the model's parameters -> the engine's flat gradient slab.  After loss.backward() the
+    gradients are views of one slab-shaped tensor (core_net._CoreNetFn.backward): one copy; anything else
+    (gradients replaced by the user, DistributedDataParallel buckets with gradient_as_bucket_view, ...) is
+    copied per parameter.  Parameters without a gradient are skipped by torch.optim.Adam; the fused kernel
+    steps the whole slab, so they get a zero gradient (their moments decay like Adam's would not -- the
+    reference never trains with frozen parameters)."""
+    store = self.model.engine.store
+    slab = store.grads
+    params = [self.model.get_parameter(k) for k in self.model._param_keys]
+    if all(p.grad is None for p in params):
+      return                                        # the fused path (CoreNet.train_step) wrote the slab itself
+    base = params[0].grad._base if params[0].grad is not None else None
+    if base is not None and base.shape == slab.shape and base.dtype == slab.dtype and all(
+        p.grad is not None and p.grad._base is base and p.grad.is_contiguous()
+        and p.grad.storage_offset() - base.storage_offset() == store.offset(k)
+        for p, k in zip(params, self.model._param_keys)):
+      if base.data_ptr() != slab.data_ptr():
+        slab.copy_(base)
+      return
+    for p, k in zip(params, self.model._param_keys):
+      v = store.view(k, grad=True)
+      if p.grad is None:
+        v.zero_()
+      elif p.grad.data_ptr() != v.data_ptr():
+        v.copy_(p.grad)
 
   def step(self, grad_scale: float = 1.0):
     g = self.param_groups[0]
+    self._gather_grads()
     self.model.engine.adam_step(g["lr"], g["eps"], betas=g["betas"], grad_scale=grad_scale)
 
   def _moments(self):

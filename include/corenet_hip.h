@@ -204,13 +204,17 @@ int crn_ray_sample_bwd(const float* dout, int64_t dout_sB, int B, int C, int D, 
 /* ---------------- losses (losses.py) ---------------------------------------
  * kind: 0 iou_fgbg (:64-114), 1 xent_times_iou_agnostic (:144-160),
  *       2 iou_agnostic (:19-61), 3 xent (:117-141), 4 xent_times_iou_fgbg.
- * logits [B][C][S] fp32, gt [B][S] int32 labels.  Writes loss[0] and, when
- * dlogits != NULL, d loss / d logits * grad_scale.
- * workspace: crn_loss_workspace_bytes(B,C).                                   */
-int crn_loss_fwd_bwd(int kind, const float* logits, const int32_t* gt, int B, int C, int64_t S,
-                     float* loss, float* dlogits, float grad_scale,
+ * logits [B][C][S] fp32, gt [B][S] int32 labels, weights [B][S] fp32 per-voxel
+ * loss weights or NULL (losses.py:47-49,99-102,134-136).  Writes loss[0] and,
+ * when dlogits != NULL, d loss / d logits * grad_scale.
+ * workspace: crn_loss_workspace_bytes(B,C).  A label outside [0,C) (the
+ * reference raises inside F.one_hot / cross_entropy) is computed as class 0 and
+ * sets the int at crn_loss_status_ptr(workspace, B) (device memory) to 1.      */
+int crn_loss_fwd_bwd(int kind, const float* logits, const int32_t* gt, const float* weights,
+                     int B, int C, int64_t S, float* loss, float* dlogits, float grad_scale,
                      void* workspace, size_t workspace_bytes, crnStream s);
 size_t crn_loss_workspace_bytes(int B, int C);
+const int* crn_loss_status_ptr(void* workspace, int B);
 
 /* ---------------- eval epilogue ---------------------------------------------
  * argmax over classes + confusion matrix (evaluation_results.py:40-51,
@@ -240,6 +244,18 @@ int crn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int crn_fill_voxels(const void* grid, void* out, int dtype, int N, int D, int H, int W,
                     void* workspace, size_t workspace_bytes, crnStream s);
 size_t crn_fill_voxels_workspace_bytes(int N, int D, int H, int W);
+/* crn_fill_voxels never waits for the GPU (the reference op is asynchronous too,
+ * fill_voxels_gpu.cu:158-165): a single-launch kernel plus a rescue kernel that
+ * only does work when the first one raised its device-side status word.        */
+
+/* fill_inside_voxels_cpu (cc/module.cc:24-29, cc/fill_voxels_cpu.cc:158-183):
+ * HOST memory in and out (out may alias grid), same dtype codes.  Reference CPU
+ * semantics (fill_voxels_cpu.cc:150-154): voxels outside the empty
+ * region connected to the x==0 / y==0 / z==0 faces become 1, every other voxel
+ * keeps its input value (the GPU op writes strict {0,1}).  Grids are processed
+ * by num_threads host threads (<= 0: all hardware threads).                    */
+int crn_fill_voxels_cpu(const void* grid, void* out, int dtype, int N, int D, int H, int W,
+                        int num_threads);
 
 /* voxelize_mesh (geometry/voxelization.py:32-164 + shaders/voxelize.{geom,frag}):
  * triangles [T][3][3] (view space), tri_mesh [T] mesh index per triangle

@@ -374,14 +374,18 @@ def confusion_matrix(gt: Tensor, pred: Tensor, num_classes: int) -> Tensor:
 
 
 def mean_iou(cm: Tensor, void_class: int = 0) -> float:
-  """voxel_metrics.py:123-138 + evaluation_results.py:262-266."""
+  """voxel_metrics.py:118-138 (`nan_tp_div`: IoU is NaN for a class with tp == 0) +
+  evaluation_results.py:262-266 (`mm.iloc[:, 1:-1].T.mean().iou`: pandas mean over the
+  non-void classes, NaNs skipped; NaN if every class is NaN)."""
   cm = cm.to(t.float64)
   tp = cm.diag()
   fp = cm.sum(0) - tp
   fn = cm.sum(1) - tp
-  iou = tp / (tp + fp + fn).clamp(min=1)
-  keep = [i for i in range(cm.shape[0]) if i != void_class]
-  return float(iou[keep].mean())
+  iou = t.where(tp == 0, t.full_like(tp, math.nan), tp / (tp + fp + fn))
+  keep = t.tensor([i for i in range(cm.shape[0]) if i != void_class], dtype=t.int64)
+  vals = iou[keep]
+  vals = vals[~vals.isnan()]
+  return float(vals.mean()) if vals.numel() else math.nan
 
 
 # ----------------------------------------------------------------------------
@@ -434,7 +438,7 @@ def fill_inside_voxels(grid: np.ndarray) -> np.ndarray:
 def voxelize_mesh(triangles: np.ndarray, mesh_num_tri: Sequence[int], resolution,
                   view2voxel: np.ndarray, sub_grid_sampling=False,
                   image_resolution_multiplier=4, conservative_rasterization=False,
-                  projection_depth_multiplier=1) -> np.ndarray:
+                  projection_depth_multiplier=1, chunk_pixels: int = 1 << 22) -> np.ndarray:
   """Restatement of voxelization.py:98-164 with the rasterizer written out.
 
   Rules (PARITY UNPINNED beyond voxelization_test.py:53-147 -- the reference
@@ -451,14 +455,21 @@ def voxelize_mesh(triangles: np.ndarray, mesh_num_tri: Sequence[int], resolution
       pixel centre, extrapolated)
     * fragment stage: bounds test, floor, flat index / sub-grid index
       (voxelize.frag:36-56)
-  All arithmetic in float64 on fp32-rounded inputs (the HIP kernel follows the
-  same formulae in fp32; tests use geometry where this cannot flip a voxel).
+
+  BIT-DEFINED: every operation is an IEEE fp32 add / sub / mul / div / sqrt in a
+  fixed order without FMA contraction (numpy float32 arrays never fuse); the HIP
+  rasterizer (csrc/voxelize.hip, built with -ffp-contract=off) performs the same
+  operations in the same order, so the two must agree on EVERY voxel, like
+  ray_sample_indices.  Vectorised over triangles and over the pixels of their
+  bounding boxes (chunked) so that the 128^3 / multiplier 8 / 40 k triangle
+  workload finishes in seconds.
   """
-  tri = np.asarray(triangles, np.float32).astype(np.float64)
+  f = np.float32
+  tri = np.ascontiguousarray(np.asarray(triangles, f).reshape(-1, 3, 3))
   mnt = np.asarray(mesh_num_tri, np.int64)
   M = len(mnt)
-  D, H, W = resolution
-  v2v = np.asarray(view2voxel, np.float32).astype(np.float64)
+  D, H, W = (int(r) for r in resolution)
+  v2v = np.asarray(view2voxel, f)
   if v2v.ndim == 2:
     v2v = np.broadcast_to(v2v, (M, 4, 4))
   if sub_grid_sampling and image_resolution_multiplier % 2 == 0:
@@ -469,79 +480,108 @@ def voxelize_mesh(triangles: np.ndarray, mesh_num_tri: Sequence[int], resolution
   R = int(round(max(W, H, depth_ext) * image_resolution_multiplier))
   vs = int(image_resolution_multiplier) if sub_grid_sampling else -1
   if sub_grid_sampling:
-    out = np.zeros((M, 2 * D + 1, 2 * H + 1, 2 * W + 1), np.float32)
+    Dg, Hg, Wg = 2 * D + 1, 2 * H + 1, 2 * W + 1
   else:
-    out = np.zeros((M, D, H, W), np.float32)
-  ext = np.array([W, H, depth_ext], np.float64)
+    Dg, Hg, Wg = D, H, W
+  out = np.zeros((M, Dg, Hg, Wg), np.float32)
+  if tri.shape[0] == 0:
+    return out
+  one, two, half = f(1), f(2), f(0.5)
+  Wf, Hf, Df, Def, Rf = f(W), f(H), f(D), f(depth_ext), f(R)
 
-  for ti in range(tri.shape[0]):
-    m = shape_index[ti]
-    v = tri[ti] @ v2v[m][:3, :3].T + v2v[m][:3, 3]          # [3 verts, xyz]
-    e1, e2 = v[1] - v[0], v[2] - v[0]
-    n1 = np.linalg.norm(e1); n2 = np.linalg.norm(e2)
-    if n1 == 0 or n2 == 0:
-      continue
-    nrm = np.cross(e1 / n1, e2 / n2)
-    a = np.abs(nrm)
-    if a[0] > a[1] and a[0] > a[2]:
-      ax = (1, 2, 0)       # screen x<-y, screen y<-z, depth<-x   (yzxw)
-    elif a[1] > a[0] and a[1] > a[2]:
-      ax = (2, 0, 1)       # screen x<-z, screen y<-x, depth<-y   (zxyw)
-    else:
-      ax = (0, 1, 2)
-    # NDC of each vertex BEFORE swizzle: x: 2x/W-1, y: 1-2y/H, z: 2z/De-1
-    ndc = np.stack([2 * v[:, 0] / ext[0] - 1, 1 - 2 * v[:, 1] / ext[1],
-                    2 * v[:, 2] / ext[2] - 1], 1)
-    sx = (ndc[:, ax[0]] + 1) * 0.5 * R
-    sy = (ndc[:, ax[1]] + 1) * 0.5 * R
-    area = (sx[1] - sx[0]) * (sy[2] - sy[0]) - (sx[2] - sx[0]) * (sy[1] - sy[0])
-    if area == 0:
-      continue
-    x0 = max(int(math.floor(sx.min())) - 1, 0); x1 = min(int(math.ceil(sx.max())) + 1, R)
-    y0 = max(int(math.floor(sy.min())) - 1, 0); y1 = min(int(math.ceil(sy.max())) + 1, R)
-    if x1 <= x0 or y1 <= y0:
-      continue
-    px = np.arange(x0, x1) + 0.5
-    py = np.arange(y0, y1) + 0.5
-    PX, PY = np.meshgrid(px, py)
-    sgn = 1.0 if area > 0 else -1.0
-    ws = []
-    inside = np.ones(PX.shape, bool)
+  with np.errstate(all="ignore"):
+    A = v2v[shape_index]                                     # [T,4,4]
+    x, y, z = tri[:, :, 0], tri[:, :, 1], tri[:, :, 2]       # [T,3 verts]
+    # v[t, vert, r] = ((A[r,0]*x + A[r,1]*y) + A[r,2]*z) + A[r,3]
+    v = np.stack([((A[:, r, 0, None] * x + A[:, r, 1, None] * y) + A[:, r, 2, None] * z) + A[:, r, 3, None]
+                  for r in range(3)], -1)
+    e1 = v[:, 1] - v[:, 0]
+    e2 = v[:, 2] - v[:, 0]
+    n1 = np.sqrt((e1[:, 0] * e1[:, 0] + e1[:, 1] * e1[:, 1]) + e1[:, 2] * e1[:, 2])
+    n2 = np.sqrt((e2[:, 0] * e2[:, 0] + e2[:, 1] * e2[:, 1]) + e2[:, 2] * e2[:, 2])
+    alive = (n1 != 0) & (n2 != 0)
+    e1 = e1 / n1[:, None]
+    e2 = e2 / n2[:, None]
+    ax_ = np.abs(e1[:, 1] * e2[:, 2] - e1[:, 2] * e2[:, 1])
+    ay_ = np.abs(e1[:, 2] * e2[:, 0] - e1[:, 0] * e2[:, 2])
+    az_ = np.abs(e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0])
+    T = tri.shape[0]
+    # screen x, screen y, depth <- voxel axes (voxelize.geom:53-55: yzxw / zxyw / xyzw)
+    a0 = np.zeros(T, np.int64); a1 = np.ones(T, np.int64); a2 = np.full(T, 2, np.int64)
+    cx_ = (ax_ > ay_) & (ax_ > az_)
+    cy_ = ~cx_ & (ay_ > ax_) & (ay_ > az_)
+    a0[cx_], a1[cx_], a2[cx_] = 1, 2, 0
+    a0[cy_], a1[cy_], a2[cy_] = 2, 0, 1
+    # transformations.ortho_lh(0, W, H, 0, 0, depth_ext): x: 2x/W-1, y: 1-2y/H, z: 2z/De-1
+    ndc = np.stack([two * v[:, :, 0] / Wf - one, one - two * v[:, :, 1] / Hf, two * v[:, :, 2] / Def - one], -1)
+    ar = np.arange(T)[:, None]
+    sx = (ndc[ar, np.arange(3)[None], a0[:, None]] + one) * half * Rf      # [T,3]
+    sy = (ndc[ar, np.arange(3)[None], a1[:, None]] + one) * half * Rf
+    sz = ndc[ar, np.arange(3)[None], a2[:, None]]
+    area = (sx[:, 1] - sx[:, 0]) * (sy[:, 2] - sy[:, 0]) - (sx[:, 2] - sx[:, 0]) * (sy[:, 1] - sy[:, 0])
+    alive &= (area != 0) & ~np.isnan(area)
+    sgn = np.where(area > 0, one, -one).astype(f)
+    def toint(q):                    # (int) of a finite float; triangles with NaN / inf corners are dropped above
+      return np.where(np.isfinite(q), q, 0).astype(np.int64)
+    smin = lambda s: np.minimum(s[:, 0], np.minimum(s[:, 1], s[:, 2]))
+    smax = lambda s: np.maximum(s[:, 0], np.maximum(s[:, 1], s[:, 2]))
+    x0 = np.maximum(toint(np.floor(smin(sx))) - 1, 0); x1 = np.minimum(toint(np.ceil(smax(sx))) + 1, R)
+    y0 = np.maximum(toint(np.floor(smin(sy))) - 1, 0); y1 = np.minimum(toint(np.ceil(smax(sy))) + 1, R)
+    alive &= (x1 > x0) & (y1 > y0)
+    EA, EB, EC = [], [], []
     for i in range(3):
       ja, jb = (i + 1) % 3, (i + 2) % 3
-      A = (sy[ja] - sy[jb]) * sgn
-      Bc = (sx[jb] - sx[ja]) * sgn
-      Cc = (sx[ja] * sy[jb] - sx[jb] * sy[ja]) * sgn
-      E = A * PX + Bc * PY + Cc                 # >0 inside
-      ws.append(E)
-      if conservative_rasterization:
-        # evaluate at the pixel-square corner that is most inside
-        Em = E + 0.5 * (abs(A) + abs(Bc))
-        inside &= Em >= 0
-      else:
-        topleft = (A > 0) or (A == 0 and Bc > 0)
-        inside &= (E > 0) | ((E == 0) & topleft)
-    if not inside.any():
-      continue
-    tot = abs(area)
-    l0, l1, l2 = ws[0] / tot, ws[1] / tot, ws[2] / tot
-    pos = (l0[..., None] * v[0] + l1[..., None] * v[1] + l2[..., None] * v[2])
-    # depth clipping of the projected axis to NDC z in [-1, 1]
-    zndc = l0 * ndc[0, ax[2]] + l1 * ndc[1, ax[2]] + l2 * ndc[2, ax[2]]
-    inside &= (zndc >= -1) & (zndc <= 1)
-    p = pos[inside]
-    ok = ((p[:, 0] >= 0) & (p[:, 1] >= 0) & (p[:, 2] >= 0) &
-          (p[:, 0] < W) & (p[:, 1] < H) & (p[:, 2] < D))
-    p = p[ok]
-    if vs <= 0:
-      c = np.floor(p).astype(np.int64)
-      out[m, c[:, 2], c[:, 1], c[:, 0]] = 1
-    else:
-      vv = np.floor(p * float(vs)).astype(np.int64) + vs // 2
-      c = vv // vs
-      r = (vv % vs) == (vs - 1)
-      c = 2 * c + r.astype(np.int64)
-      out[m, c[:, 2], c[:, 1], c[:, 0]] = 1
+      EA.append((sy[:, ja] - sy[:, jb]) * sgn)
+      EB.append((sx[:, jb] - sx[:, ja]) * sgn)
+      EC.append((sx[:, ja] * sy[:, jb] - sx[:, jb] * sy[:, ja]) * sgn)
+    EA, EB, EC = np.stack(EA, 1), np.stack(EB, 1), np.stack(EC, 1)            # [T,3]
+    tl = (EA > 0) | ((EA == 0) & (EB > 0))
+    cons_margin = half * (np.abs(EA) + np.abs(EB))
+    inv_tot = one / np.abs(area)
+
+    ids = np.nonzero(alive)[0]
+    bw = (x1 - x0)[ids]
+    npix = bw * (y1 - y0)[ids]
+    flat = out.reshape(M, -1)
+    start = 0
+    while start < len(ids):
+      # greedy chunk of triangles with <= chunk_pixels bounding-box pixels (at least one triangle)
+      cs = np.cumsum(npix[start:])
+      n = max(1, int(np.searchsorted(cs, chunk_pixels, side="right")))
+      sel, sbw, snp = ids[start:start + n], bw[start:start + n], npix[start:start + n]
+      start += n
+      tix = np.repeat(np.arange(len(sel)), snp)                       # pixel -> local triangle
+      q = np.arange(int(snp.sum())) - np.repeat(np.cumsum(snp) - snp, snp)
+      tg = sel[tix]
+      PX = (x0[tg] + q % sbw[tix]).astype(f) + half
+      PY = (y0[tg] + q // sbw[tix]).astype(f) + half
+      inside = np.ones(len(tg), bool)
+      l = []
+      for i in range(3):
+        E = (EA[tg, i] * PX + EB[tg, i] * PY) + EC[tg, i]
+        l.append(E * inv_tot[tg])
+        if conservative_rasterization:
+          inside &= (E + cons_margin[tg, i]) >= 0
+        else:
+          inside &= (E > 0) | ((E == 0) & tl[tg, i])
+      zn = (l[0] * sz[tg, 0] + l[1] * sz[tg, 1]) + l[2] * sz[tg, 2]
+      inside &= (zn >= -one) & (zn <= one)
+      tg = tg[inside]
+      l = [li[inside] for li in l]
+      pos = [(l[0] * v[tg, 0, r] + l[1] * v[tg, 1, r]) + l[2] * v[tg, 2, r] for r in range(3)]
+      px, py, pz = pos
+      # voxelize.frag:36-40
+      ok = (px >= 0) & (py >= 0) & (pz >= 0) & (px < Wf) & (py < Hf) & (pz < Df)
+      tg, px, py, pz = tg[ok], px[ok], py[ok], pz[ok]
+      if vs <= 0:                                            # voxelize.frag:42-47
+        cx, cy, cz = (np.floor(c).astype(np.int64) for c in (px, py, pz))
+      else:                                                  # voxelize.frag:48-56
+        def sub(c):
+          vv = np.floor(c * f(vs)).astype(np.int64) + vs // 2
+          return 2 * (vv // vs) + ((vv % vs) == vs - 1).astype(np.int64)
+        cx, cy, cz = sub(px), sub(py), sub(pz)
+      ok = (cx < Wg) & (cy < Hg) & (cz < Dg)
+      flat[shape_index[tg[ok]], ((cz * Hg + cy) * Wg + cx)[ok]] = 1
   return out
 
 

@@ -85,6 +85,7 @@ class EmuBackend:
         out = out + bias[:y.C].view(1, -1, 1, 1, 1)
     write_logical(y, out, accumulate)
 
+  @t.enable_grad()        # uses autograd as a calculator; may be called from inside an autograd Function
   def conv_wgrad(self, x, tr, dy, dw, npad, window, pad_lo, zero_first=True, boxes=None):
     xl = _transform(logical(x), tr)
     xp = _padded(xl, window, pad_lo, (dy.D, dy.H, dy.W))
@@ -270,9 +271,11 @@ class EmuBackend:
   LOSSES = {0: "iou_fgbg", 1: "xent_times_iou_agnostic", 2: "iou_agnostic", 3: "xent",
             4: "xent_times_iou_fgbg"}
 
-  def loss_fwd_bwd(self, kind, logits, gt_i32, B, Cn, S, loss, dlogits, grad_scale=1.0):
+  @t.enable_grad()
+  def loss_fwd_bwd(self, kind, logits, gt_i32, B, Cn, S, loss, dlogits, grad_scale=1.0, weights=None):
     l = logits.detach().clone().requires_grad_(dlogits is not None)
-    v = getattr(O, self.LOSSES[kind])(gt_i32.long().view(l.shape[0], *l.shape[2:]), l)
+    w = None if weights is None else weights.view(l.shape[0], *l.shape[2:])
+    v = getattr(O, self.LOSSES[kind])(gt_i32.long().view(l.shape[0], *l.shape[2:]), l, w)
     loss.fill_(float(v))
     if dlogits is not None:
       v.backward()
@@ -301,6 +304,17 @@ class EmuBackend:
     pts = t.cat([triangles, t.ones_like(triangles[..., :1])], -1)     # [T,3,4]
     r = t.einsum("tnm,tvm->tvn", m, pts)
     out.copy_(r[..., :3] / r[..., 3:4])
+
+  def merge_labels(self, meshes_grid, scene_start, labels, B, D, H, W, sub_grid, out):
+    """batched_example.py:186-196: out[b] = int32(max over the scene's meshes of label_m * grid_m); sub_grid: the
+    grids are (2D+1)(2H+1)(2W+1) and only the odd centres are read (voxelization.py:167-182); no meshes -> 0."""
+    g = meshes_grid[:, 1::2, 1::2, 1::2] if sub_grid else meshes_grid
+    for b in range(B):
+      lo, hi = int(scene_start[b]), int(scene_start[b + 1])
+      if hi == lo:
+        out[b].zero_()
+      else:
+        out[b].copy_((labels[lo:hi].to(g.dtype)[:, None, None, None] * g[lo:hi]).max(0).values.to(t.int32))
 
   def add_i64(self, p, n, v):
     p += v

@@ -145,6 +145,57 @@ def test_engine_plan_matches_oracle_fp64():
   assert hi == 0
 
 
+def test_autograd_path_with_fused_adam_two_steps():
+  """The reference's train loop body (pipeline.py:224-230: zero_grad, forward, loss, backward, step) through the
+  drop-in's autograd node + FusedAdam, over the contract emulator: two steps must land on the parameters of two
+  fused `train_step`s (the gradient slab is reused by every backward, so `.grad` must never alias it: ADVICE r1),
+  gradient accumulation adds up, and a backward whose forward was overwritten raises instead of returning
+  gradients of the wrong activations."""
+  from corenet_amd import state as S
+  from corenet_amd.model.core_net import CoreNet, CoreNetConfig, DecoderConfig
+  t.set_num_threads(min(8, os.cpu_count() or 1))
+  sd = O.make_state(0, 2, nbt=0)
+  cfg = CoreNetConfig(DecoderConfig((128, 128, 128), 2, 2, 64, 0.75))
+  ma, mb = (CoreNet(cfg, device="cpu", backend=EmuBackend()) for _ in range(2))
+  ma.load_state_dict(sd); mb.load_state_dict(sd)
+  ma.train(); mb.train()
+  image, v2s, off, grid = O.synthetic_batch(1, 0, 2)
+  opt = S.FusedAdam(ma, lr=4e-4, eps=1e-4)
+  for step in range(2):
+    opt.zero_grad()
+    loss = O.iou_fgbg(grid, ma(image, v2s, off))
+    loss.backward()
+    opt.step()
+    lb = mb.train_step(image, v2s, off, grid.to(t.int32), "iou_fgbg", lr=4e-4, adam_eps=1e-4)
+    assert abs(float(loss) - float(lb)) < 1e-5 * abs(float(lb)), (step, float(loss), float(lb))
+  pa, pb = ma.engine.store.params, mb.engine.store.params
+  # Adam moves every parameter by <= lr per step; 2x gradients on step 2 would not change m/sqrt(v) by much, so
+  # compare the first moments too (they are linear in the gradient)
+  assert float((pa - pb).abs().max()) < 1e-6
+  assert float((ma.engine.adam_m - mb.engine.adam_m).abs().max()) <= 1e-5 * float(mb.engine.adam_m.abs().max())
+  # .grad does not alias the slab
+  g = ma.get_parameter("decoder.stage_6.t1.weight").grad
+  assert g.data_ptr() != ma.engine.store.view("decoder.stage_6.t1.weight", grad=True).data_ptr()
+  # gradient accumulation (no zero_grad in between): g1 + g2
+  g1 = g.clone()
+  loss = O.iou_fgbg(grid, ma(image, v2s, off)); loss.backward()
+  g12 = ma.get_parameter("decoder.stage_6.t1.weight").grad
+  opt.zero_grad(set_to_none=True)
+  loss = O.iou_fgbg(grid, ma(image, v2s, off)); loss.backward()
+  g2 = ma.get_parameter("decoder.stage_6.t1.weight").grad
+  assert float((g12 - (g1 + g2)).abs().max()) <= 1e-5 * float(g12.abs().max())
+  # no per-step growth of the plan's view cache (ADVICE r1: one pinned glogits tensor per step)
+  n_views = len(ma.engine.plan(1)._views)
+  loss = O.iou_fgbg(grid, ma(image, v2s, off)); loss.backward()
+  assert len(ma.engine.plan(1)._views) == n_views
+  # stale forward
+  l1 = O.iou_fgbg(grid, ma(image, v2s, off))
+  with t.no_grad():
+    ma(image, v2s, off)
+  with pytest.raises(RuntimeError, match="overwritten"):
+    l1.backward()
+
+
 def test_c_abi_surface():
   """The shared library loads (no GPU needed) and exports every symbol of include/corenet_hip.h."""
   import re
@@ -173,6 +224,40 @@ def test_product_has_no_cpu_fallback():
         assert not re.search(r"^\s*(from|import)\s+(oracle|kernel_contract_emu|tests)\b", src, re.M), f
   with pytest.raises(ValueError):
     fv.fill_inside_voxels_gpu(t.zeros(1, 2, 2, 2))
+
+
+def test_fill_inside_voxels_cpu_operator():
+  """The boundary's host operator `fill_inside_voxels_cpu` (cc/module.cc:24-29, fill_voxels_cpu.cc:158-183), the
+  library's own C++ (crn_fill_voxels_cpu): the reference's grid1/grid2 vectors (voxelization_test.py:152-214),
+  bit-exact against the C oracle on random grids of every dispatched dtype, the CPU-only semantics (reached voxels
+  keep their input value: SURVEY Q10 probe `[0.5,-3,0,2] -> [1,-3,0,1]`), clone ownership and the ValueErrors."""
+  import fill_oracle_c
+  from reference_known_answers import fill_grids
+  from corenet_amd.cc import fill_voxels as fv
+  g1, g2, e1, e2 = fill_grids()
+  got = fv.fill_inside_voxels_cpu(t.tensor(np.stack([g1, g2])))
+  np.testing.assert_array_equal(got.numpy(), np.stack([e1, e2]))
+  rng = np.random.RandomState(3)
+  for shape in ((3, 5, 6, 7), (2, 33, 31, 65), (1, 9, 9, 130), (5, 24, 40, 64), (2, 7, 7, 7), (1, 3, 200, 3)):
+    for dens in (0.2, 0.45, 0.7):
+      g = (rng.rand(*shape) < dens).astype(np.float32)
+      g[0].flat[::7] = -3.0                                    # non-positive values count as empty
+      want = np.where(fill_oracle_c.fill(g) == 0, g, 1)        # oracle: GPU {0,1} semantics -> CPU semantics
+      for dt in (t.float32, t.float64, t.int32, t.int64, t.int16, t.int8):
+        x = t.tensor(g).to(dt)
+        keep = x.clone()
+        out = fv.fill_inside_voxels_cpu(x)
+        assert out.dtype == dt and out.data_ptr() != x.data_ptr() and t.equal(x, keep)
+        np.testing.assert_array_equal(out.numpy(), want.astype(out.numpy().dtype))
+      u = t.tensor(np.maximum(g, 0)).to(t.uint8)
+      np.testing.assert_array_equal(fv.fill_inside_voxels_cpu(u).numpy(), fill_oracle_c.fill(g).astype(np.uint8))
+  assert fv.fill_inside_voxels_cpu(t.tensor([0.5, -3, 0, 2]).reshape(1, 1, 1, 4)).flatten().tolist() == [1, -3, 0, 1]
+  nc = t.tensor(g).permute(0, 1, 3, 2)                         # non-contiguous input: cloned contiguous
+  np.testing.assert_array_equal(fv.fill_inside_voxels_cpu(nc).numpy(),
+                                np.where(fill_oracle_c.fill(nc.contiguous().numpy()) == 0, nc.numpy(), 1))
+  with pytest.raises(ValueError):
+    fv.fill_inside_voxels_cpu(t.zeros(2, 2, 2))
+  assert fv.fill_inside_voxels_cpu(t.zeros(0, 4, 4, 4)).shape == (0, 4, 4, 4)
 
 
 def test_tap_boxes_cover_every_real_weight():

@@ -60,7 +60,31 @@ def test_forward_eval_golden():
   assert abs(float(losses.iou_fgbg(grid.cuda(), logits)) - float(z["loss"])) < 1e-5
 
 
+def test_forward_eval_b4_matches_oracle():
+  """The bench batch size (B=4/GPU, h7.json5:42) end to end: eval-mode logits of the HIP path against the oracle on
+  the same four images, 1e-4 relative (eval mode is conditioned at 2e-6), every voxel compared."""
+  sd = O.make_state(0, 2, nbt=100)
+  m = _model(2, sd).eval()
+  image, v2s, off, grid = O.synthetic_batch(4, 0, 2)
+  with t.no_grad():
+    logits = m(image.cuda(), v2s.cuda(), off.cuda())
+    want = O.corenet_forward({k: v.clone() for k, v in sd.items()}, image, v2s, off, training=False)
+  assert logits.shape == (4, 2, 128, 128, 128)
+  for b in range(4):
+    assert relerr(logits[b], want[b]) < 1e-4, b
+  assert float((logits[0] - logits[1]).abs().max()) > 0           # different images, not one sample four times
+
+
+# element-wise bars of the five full gradients the fixtures store (oracle/gen_golden.py:87-90), by depth of the
+# tensor below the loss: last layer / its norm / the 64^3 skip compression (through stage_6) / the latent bias
+# (through the whole decoder; BatchRenorm over B=1 has zero gradient there).  The reference itself moves by
+# 4e-5 ... 5e-2 between fp32 and fp64 on these inputs (DESIGN section 4, "Conditioning").
+FULL_GRAD_TOL = {"decoder.stage_6.t1.weight": 2e-3, "decoder.stage_6.b2.weight": 5e-3,
+                 "decoder.rt_skip_5.compress_channels.weight": 2e-2, "decoder.stage_0.bias": 1e-1}
+
+
 @pytest.mark.parametrize("tag,nc,nbt,B,lossname", [("h7_train_b1", 2, 0, 1, "iou_fgbg"),
+                                                   ("h7_train_b2_nbt30k", 2, 30000, 2, "iou_fgbg"),
                                                    ("m9_train_b1", 14, 0, 1, "xent_times_iou_agnostic")])
 def test_train_forward_backward_golden(tag, nc, nbt, B, lossname):
   from corenet_amd.model import losses
@@ -74,8 +98,20 @@ def test_train_forward_backward_golden(tag, nc, nbt, B, lossname):
   assert abs(float(loss) - float(z["loss"])) < 2e-4 * max(1.0, abs(float(z["loss"])))
   loss.backward()
   params = dict(m.named_parameters())
-  # last layers: well-conditioned -> element-wise
-  assert relerr(params["decoder.stage_6.t1.weight"].grad, z["grad::decoder.stage_6.t1.weight"]) < 2e-3
+  # the five stored full gradients, element-wise
+  for name, tol in FULL_GRAD_TOL.items():
+    want = z["grad::" + name]
+    if float(np.abs(want).max()) < 1e-12:
+      assert float(params[name].grad.abs().max()) < 1e-6, name
+      continue
+    e = relerr(params[name].grad, want)
+    print(f"[{tag}] grad {name}: max-abs-err/max = {e:.2e}")
+    assert e < tol, (name, e)
+  # a conv bias in front of a train-mode BatchRenorm has a true gradient of exactly 0: what both sides hold is
+  # rounding noise, bounded against the scale of the weight gradient of the same conv
+  noise = float(params["encoder.stage1.conv.bias"].grad.abs().max())
+  scale = float(params["encoder.stage1.conv.weight"].grad.abs().max())
+  assert noise <= 1e-2 * scale + 1e-12 and float(np.abs(z["grad::encoder.stage1.conv.bias"]).max()) <= 1e-2 * scale + 1e-12
   names, norms = list(z["grad_names"]), z["grad_norms"]
   bad = []
   for n, want in zip(names, norms):
@@ -171,13 +207,90 @@ def test_mean_iou_parity_on_trained_weights():
 
 
 def test_train_step_reduces_loss_and_matches_autograd_path():
+  """The reference's loop body (pipeline.py:224-230: optimizer.zero_grad(); loss = f(model(...)); loss.backward();
+  optimizer.step()) through the drop-in's autograd node + FusedAdam against the fused `train_step`, THREE steps:
+  same losses, same parameters, same Adam moments (a `.grad` that aliases the engine's gradient slab doubles every
+  gradient from step 2 on: ADVICE r1), no memory growth per step, gradient accumulation adds up, and a backward
+  whose forward was overwritten raises."""
+  from corenet_amd import state as S
+  from corenet_amd.model import losses
   sd = O.make_state(0, 2, nbt=0)
-  m = _model(2, sd).train()
+  m, ma = _model(2, sd).train(), _model(2, sd).train()
   image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(2, 0, 2)]
-  l0 = float(m.train_step(image, v2s, off, grid, "iou_fgbg", lr=4e-4))
-  for _ in range(3):
-    l = float(m.train_step(image, v2s, off, grid, "iou_fgbg", lr=4e-4))
-  assert np.isfinite(l) and l < l0
+  opt = S.FusedAdam(ma, lr=4e-4, eps=1e-4)
+  ls, las = [], []
+  for step in range(3):
+    ls.append(float(m.train_step(image, v2s, off, grid, "iou_fgbg", lr=4e-4, adam_eps=1e-4)))
+    opt.zero_grad()
+    loss = losses.iou_fgbg(grid, ma(image, v2s, off))
+    loss.backward()
+    opt.step()
+    las.append(float(loss))
+    if step == 0:
+      t.cuda.synchronize(); mem0 = t.cuda.memory_allocated()
+  t.cuda.synchronize()
+  assert t.cuda.memory_allocated() <= mem0 + (1 << 20), (mem0, t.cuda.memory_allocated())
+  assert np.isfinite(ls[-1]) and ls[-1] < ls[0]
+  for a, b in zip(las, ls):
+    assert abs(a - b) < 3e-3 * abs(b), (las, ls)            # two runs of the same step differ by atomics order
+  # first moments are linear in the gradients: doubled gradients on steps 2, 3 would show as ~1.9x
+  ra = float(ma.engine.adam_m.norm() / m.engine.adam_m.norm())
+  assert abs(ra - 1.0) < 2e-2, ra
+  g = ma.get_parameter("decoder.stage_6.t1.weight")
+  assert g.grad.data_ptr() != ma.engine.store.view("decoder.stage_6.t1.weight", grad=True).data_ptr()
+  # accumulation: backward twice without zero_grad -> g1 + g2 (the same sample twice: 2 * g up to atomics order)
+  opt.zero_grad(set_to_none=True)
+  losses.iou_fgbg(grid, ma(image, v2s, off)).backward()
+  g1 = g.grad.clone()
+  losses.iou_fgbg(grid, ma(image, v2s, off)).backward()
+  assert relerr(g.grad, 2 * g1) < 2e-3
+  # torch.optim.Adam on the same parameters works too (the parameters are views of the engine's slab)
+  topt = t.optim.Adam(ma.parameters(), lr=4e-4, eps=1e-4)
+  topt.zero_grad()
+  before = ma.engine.store.params.clone()
+  losses.iou_fgbg(grid, ma(image, v2s, off)).backward()
+  topt.step()
+  assert float((ma.engine.store.params - before).abs().max()) > 1e-5
+  l1 = losses.iou_fgbg(grid, ma(image, v2s, off))
+  with t.no_grad():
+    ma(image, v2s, off)
+  with pytest.raises(RuntimeError, match="overwritten"):
+    l1.backward()
+
+
+def test_wrapped_in_distributed_data_parallel():
+  """pipeline.py:199-200,224-230 unmodified: `DistributedDataParallel(model, device_ids=[dev])`, then
+  `loss = f(ddp(...))`, `loss.backward()`, `optimizer.step()` -- world 1 over RCCL.  DDP broadcasts parameters and
+  buffers from rank 0 (in place: they stay views of the engine's slabs), hooks every parameter's gradient
+  accumulator and all-reduces its buckets; with one rank that is the identity, so losses and parameters must follow
+  the fused train_step."""
+  import torch.distributed as dist
+  from torch.nn.parallel import DistributedDataParallel
+  from corenet_amd import state as S
+  from corenet_amd.model import losses
+  dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29850 + os.getpid() % 100}", rank=0, world_size=1)
+  try:
+    sd = O.make_state(0, 2, nbt=0)
+    m, ma = _model(2, sd).train(), _model(2, sd).train()
+    image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(2, 0, 2)]
+    ddp = DistributedDataParallel(ma, device_ids=[t.cuda.current_device()])
+    assert ma.get_parameter("decoder.stage_6.t1.weight").data_ptr() == \
+        ma.engine.store.view("decoder.stage_6.t1.weight").data_ptr()           # still views of the slab
+    opt = S.FusedAdam(ma, lr=4e-4, eps=1e-4)
+    for step in range(3):
+      lf = float(m.train_step(image, v2s, off, grid, "iou_fgbg", lr=4e-4, adam_eps=1e-4))
+      opt.zero_grad()
+      loss = losses.iou_fgbg(grid, ddp(image, v2s, off))
+      loss.backward()
+      opt.step()
+      assert abs(float(loss) - lf) < 3e-3 * abs(lf), (step, float(loss), lf)
+    ra = float(ma.engine.adam_m.norm() / m.engine.adam_m.norm())
+    assert abs(ra - 1.0) < 2e-2, ra
+    d = (ma.engine.store.params - m.engine.store.params).abs()
+    assert float(d.max()) <= 3 * 2 * 4e-4 * 1.05 and float(d.mean()) < 3e-4
+    assert int(ma.state_dict()["decoder.stage_1.b1.num_batches_tracked"]) == 3
+  finally:
+    dist.destroy_process_group()
 
 
 def test_overlapped_gradient_exchange_single_rank_rccl():
