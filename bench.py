@@ -30,38 +30,88 @@ PEAK_F32_MFMA = 157.3e12                           # MI355X_MICROARCH.md: fp32 m
 PEAK_HBM = 8.0e12                                  # HBM3E spec peak
 
 
-def cpu_baseline(num_classes, loss_name, seconds_budget=25.0):
-  """The oracle (torch-CPU restatement of the reference, validated against the imported
-  reference in oracle/gen_golden.py) timed on this host's cores: B=1 fwd+loss+bwd."""
-  from oracle import corenet_oracle as O
-  # oneDNN conv3d oversubscribes badly on many-core hosts (256 threads: 340 s/step measured);
-  # 16 threads is the fastest setting found and is what `cores` reports.
+def canonical_camera():
+  """The dataset's canonical camera (doc/data_format_and_coordinate_systems.md:103-111)."""
+  import math
+  from corenet_amd.geometry import transformations as T
+  return T.perspective_rh(math.radians(60.0), 1.0, 1e-4, 10.0) @ T.look_at_rh(
+      [0.5, 0.5, -0.8666666], [0.5, 0.5, 0.5], [0, -1, 0])
+
+
+def synthetic_batch(batch, seed, num_classes):
+  """SURVEY 8(d) synthetic inputs: seeded uint8 256x256 images, the canonical camera, v2s = camera @ scale(1/128),
+  sampling offset 0.5, ground truth = analytic ball(s)."""
+  g = t.Generator().manual_seed(1000 + seed)
+  image = t.randint(0, 256, (batch, 3, 256, 256), generator=g, dtype=t.uint8)
+  v2s = (canonical_camera() @ t.diag(t.tensor([1 / 128.0] * 3 + [1.0])))[None].expand(batch, 4, 4).contiguous()
+  offset = t.full((batch, 3), 0.5)
+  ax = t.arange(128, dtype=t.float32) + 0.5
+  zz, yy, xx = t.meshgrid(ax, ax, ax, indexing="ij")
+  grid = t.zeros((batch, 128, 128, 128), dtype=t.int64)
+  nballs = 1 if num_classes == 2 else 3
+  for b in range(batch):
+    for k in range(nballs):
+      cx = (0.5 + 0.22 * (k - (nballs - 1) / 2)) * 128
+      r = (0.3 if nballs == 1 else 0.1) * 128
+      grid[b][((xx - cx) ** 2 + (yy - 64) ** 2 + (zz - 64) ** 2) <= r * r] = \
+          1 if num_classes == 2 else (1 + (3 * b + k) % (num_classes - 1))
+  return image, v2s, offset, grid
+
+
+def host_threads():
   try:
     avail = len(os.sched_getaffinity(0))
   except AttributeError:
     avail = os.cpu_count() or 1
+  return avail
+
+
+def cpu_baseline(state, batch, loss_name, seconds_budget=25.0):
+  """The oracle (torch-CPU restatement of the reference, validated against the imported reference in
+  oracle/gen_golden.py) timed on this host's cores on the bench's own weights and inputs: fwd+loss+bwd of the
+  bench batch (B=4) when one step fits the budget, else of its first sample."""
+  from oracle import corenet_oracle as O
+  # oneDNN conv3d oversubscribes badly on many-core hosts (256 threads: 340 s/step measured);
+  # 16 threads is the fastest setting found and is what `cores` reports.
+  avail = host_threads()
   nthreads = max(1, min(avail, 16))
   t.set_num_threads(nthreads)
-  sd = O.make_state(0, num_classes, nbt=0)
+  sd = {k: v.detach().cpu().clone() for k, v in state.items()}
   for k in sd:
     if sd[k].dtype == t.float32 and "running" not in k:
       sd[k].requires_grad_(True)
-  image, v2s, off, grid = O.synthetic_batch(1, 0, num_classes)
-  def step():
+  image, v2s, off, grid = [x.cpu() for x in batch]
+  grid = grid.long()
+  def step(n):
     for v in sd.values():
       v.grad = None
-    loss = getattr(O, loss_name)(grid, O.corenet_forward(sd, image, v2s, off, training=True))
+    loss = getattr(O, loss_name)(grid[:n], O.corenet_forward(sd, image[:n], v2s[:n], off[:n], training=True))
     loss.backward()
-  t0 = time.time(); step(); warm = time.time() - t0          # warm-up (also bounds the sample)
+  t0 = time.time(); step(1); warm1 = time.time() - t0       # warm-up (also sizes the sample)
+  B = image.shape[0] if warm1 * image.shape[0] * 2.5 < seconds_budget else 1
   n, t0 = 0, time.time()
-  if warm > seconds_budget:
-    n, dt = 1, warm
-  else:
-    while n < 2 or (time.time() - t0 < seconds_budget and n < 20):
-      step(); n += 1
-    dt = (time.time() - t0) / n
-  return {"value": 128 ** 3 / dt, "unit": "voxels/s", "cores": nthreads, "kind": "port",
-          "sample": f"{n} steps of B=1 fwd+loss+bwd (oracle/corenet_oracle.py, torch-CPU fp32)"}
+  while n < 2 or (time.time() - t0 < seconds_budget - 2 * warm1 * B and n < 20):
+    step(B); n += 1
+  dt = (time.time() - t0) / n
+  return {"value": B * 128 ** 3 / dt, "unit": "voxels/s", "cores": nthreads, "threads_used": nthreads,
+          "host_cores": os.cpu_count(), "host_cores_available": avail, "kind": "port", "batch": B,
+          "sample": f"{n} steps of B={B} fwd+loss+bwd (oracle/corenet_oracle.py, torch-CPU fp32, the bench's own "
+                    f"weights and inputs)"}
+
+
+def cpu_baseline_fill(shells_cpu, seconds_budget=5.0):
+  """fill_voxels on the host: the library's own C++ twin (crn_fill_voxels_cpu, csrc/fill_voxels_cpu.cpp; one
+  host thread per grid), same 12 x 128^3 shells as the GPU leg (SURVEY 8(d) last row)."""
+  from corenet_amd.cc import fill_voxels
+  fill_voxels.fill_inside_voxels_cpu(shells_cpu)
+  n, t0 = 0, time.time()
+  while n < 3 or (time.time() - t0 < seconds_budget and n < 50):
+    fill_voxels.fill_inside_voxels_cpu(shells_cpu); n += 1
+  dt = (time.time() - t0) / n
+  threads = min(shells_cpu.shape[0], host_threads())
+  return {"value": shells_cpu.numel() / dt, "unit": "voxels/s", "cores": threads, "threads_used": threads,
+          "host_cores": os.cpu_count(), "kind": "port (library's own C++ operator fill_inside_voxels_cpu)",
+          "sample": f"{n} calls on {shells_cpu.shape[0]} x 128^3 fp32 shells"}
 
 
 def main():
@@ -76,7 +126,6 @@ def main():
 
   from corenet_amd import distributed as D
   from corenet_amd.model.core_net import CoreNet, CoreNetConfig, DecoderConfig
-  from oracle import corenet_oracle as O     # synthetic inputs / deterministic weights only
 
   rank, local, world = D.init_from_env()
   assert world == args.gpus or world == 1, (world, args.gpus)
@@ -87,9 +136,11 @@ def main():
   C, B = args.classes, args.batch
   loss_name = "iou_fgbg" if C == 2 else "xent_times_iou_agnostic"
   model = CoreNet(CoreNetConfig(DecoderConfig((128, 128, 128), C, 2, 64, 0.75)), device=dev)
-  model.load_state_dict(O.make_state(0, C, nbt=0))
+  model.reset_parameters(seed=0)          # the product's own initialiser (resnet50.py:40-47 + torch defaults)
   model.train()
-  image, v2s, off, grid = [x.to(dev) for x in O.synthetic_batch(B, seed=rank, num_classes=C)]
+  state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if rank == 0 else None
+  batch_cpu = synthetic_batch(B, seed=rank, num_classes=C)
+  image, v2s, off, grid = [x.to(dev) for x in batch_cpu]
   grid = grid.to(t.int32)
   sync = D.GradientSync(world)
   plan = model.engine.plan(B)
@@ -101,7 +152,7 @@ def main():
 
   for _ in range(args.warmup):
     step()
-  plan.probes = {"conv3d_stage6_c1_fwd": [], "ray_sample_fwd_64": []}
+  plan.probes = {"conv3d_stage6_c1_fwd": [], "ray_sample_fwd_64": [], "grad_exchange_wait": []}
   if world > 1:
     dist.barrier()
   t.cuda.synchronize()
@@ -124,8 +175,9 @@ def main():
   # HBM bytes per launch from the PMC passes of this same command (profiles/*_pmc_traffic.json;
   # FETCH_SIZE / WRITE_SIZE need their own rocprofv3 runs and cannot be read from inside the process)
   traffic = {}
+  traffic_file = os.path.join("profiles", "r01_pmc_traffic.json")
   try:
-    tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+    tj = json.load(open(os.path.join(ROOT, traffic_file)))
     if B == 4:
       for k, v in tj.get("kernels", {}).items():
         # stage_6.c1 fwd: conv_fwd_kernel<8,1,xvec>, 2048 tiles x 1 N-block.  stage_5.t1 and stage_6.t1 fwd
@@ -200,6 +252,7 @@ def main():
       "roofline": {"kernel": "conv_fwd_kernel<8,1,xvec> (stage_6.c1 Conv3d 28->16 k5 @64^3, fwd)",
                    "bound": "mfma", "achieved": CONV6_FLOP * B / conv_s / 1e12, "peak": PEAK_F32_MFMA / 1e12,
                    "unit": "TFLOP/s", "frac": CONV6_FLOP * B / conv_s / PEAK_F32_MFMA, "traffic": traffic.get("conv"),
+                   "traffic_source": f"{traffic_file} (separate rocprofv3 --pmc passes of this command; not measured in this run)",
                    "avg_launch_ms": conv_s * 1e3},
       # duration = burst of 20 launches on the step's own buffers (12.2 us; rocprofv3 kernel-trace of the in-step
       # launches: 12.6-13.4 us).  The in-step probe brackets ONE launch with a HIP-event pair, which also times
@@ -213,8 +266,17 @@ def main():
                                "frac": fill_bytes / fill_s / PEAK_HBM, "traffic": traffic.get("fill"),
                                "avg_launch_ms": fill_s * 1e3},
   }
+  for k in ("roofline_ray_sample", "roofline_fill_voxels"):
+    out[k]["traffic_source"] = out["roofline"]["traffic_source"]
+  if world > 1:
+    out["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                   "version": ".".join(str(v) for v in t.cuda.nccl.version()) if dist.get_backend() == "nccl" else None,
+                   "NCCL_ALGO": os.environ.get("NCCL_ALGO"), "NCCL_PROTO": os.environ.get("NCCL_PROTO"),
+                   "overlap": bool(sync.overlap), "buckets_mb": [round((hi - lo) * 4 / 1e6, 1) for _, lo, hi in model.engine.grad_buckets],
+                   "exposed_exchange_ms": probes.get("grad_exchange_wait", 0.0) * 1e3}
   if not args.no_cpu_baseline and world == 1:
-    out["cpu_baseline"] = cpu_baseline(C, loss_name)
+    out["cpu_baseline"] = cpu_baseline(state0, batch_cpu, loss_name)
+    out["cpu_baseline_fill_voxels"] = cpu_baseline_fill(shells.cpu())
   print(json.dumps(out))
 
 

@@ -11,6 +11,7 @@ wrapped by DistributedDataParallel.  All arithmetic runs in libcorenet_hip.so.
 """
 from __future__ import annotations
 
+import contextlib
 import dataclasses
 import math
 from typing import Any, Dict, Optional, Tuple
@@ -74,6 +75,11 @@ class _CoreNetFn(t.autograd.Function):
   @staticmethod
   def backward(ctx, glogits):
     model, plan = ctx.model, ctx.plan
+    with model._on_device():
+      return _CoreNetFn._backward(ctx, model, plan, glogits)
+
+  @staticmethod
+  def _backward(ctx, model, plan, glogits):
     if plan.generation != ctx.generation:
       # the saved activations and BatchRenorm statistics of a forward live in the (per batch size) plan: a later
       # forward with the same batch size has overwritten them.  The reference's autograd keeps one set per graph;
@@ -119,6 +125,11 @@ class CoreNet(nn.Module):
   def _mark_dirty(self):
     self.engine.weights_dirty = True
 
+  def _on_device(self):
+    """Kernels go to the current stream of the CURRENT device: make that the model's device for the call."""
+    d = self.engine.device
+    return t.cuda.device(d) if d.type == "cuda" else contextlib.nullcontext()
+
   def reset_parameters(self, seed: int = 0):
     """resnet50.py:40-47 (kaiming-normal convs, BN gamma=1 beta=0) and torch's
     default initialisers for the decoder layers, drawn on the host."""
@@ -150,7 +161,9 @@ class CoreNet(nn.Module):
     # Parameters are views into the engine's flat device slabs; moving them
     # would silently detach them from the kernels.
     probe = fn(t.zeros(1, device=self.engine.device))
-    if probe.device != self.engine.device or probe.dtype != t.float32:
+    same = probe.device.type == self.engine.device.type and (
+        probe.device.index is None or self.engine.device.index is None or probe.device.index == self.engine.device.index)
+    if not same or probe.dtype != t.float32:
       raise RuntimeError("corenet_amd.CoreNet lives on its construction device in fp32; "
                          "construct it with CoreNet(config, device=...) instead of .to()/.half()")
     return self
@@ -168,11 +181,12 @@ class CoreNet(nn.Module):
     image = image.contiguous()
     v2s = voxel_projection_matrix.to(t.float32).contiguous()
     off = voxel_sample_locations.to(t.float32).contiguous()
-    if t.is_grad_enabled() and self.training:
-      params = [self.get_parameter(k) for k in self._param_keys]
-      return _CoreNetFn.apply(self, image, v2s, off, *params)
-    plan = self.engine.plan(B)
-    return plan.forward(image, v2s, off, training=self.training).clone()
+    with self._on_device():
+      if t.is_grad_enabled() and self.training:
+        params = [self.get_parameter(k) for k in self._param_keys]
+        return _CoreNetFn.apply(self, image, v2s, off, *params)
+      plan = self.engine.plan(B)
+      return plan.forward(image, v2s, off, training=self.training).clone()
 
   # multi-offset inference (super_resolution.py:114-129) ------------------------------------
   def multi_offset_pmf(self, image: t.Tensor, voxel_projection_matrix: t.Tensor, grid_offsets: t.Tensor,
@@ -232,7 +246,7 @@ class CoreNet(nn.Module):
     if all_reduce is not None and getattr(all_reduce, "overlap", False):
       all_reduce.pushed.clear()
       plan.backward(plan.glogits, grad_hook=all_reduce.push)   # buckets are reduced while backward runs
-      all_reduce.wait()
+      plan._probe("grad_exchange_wait", all_reduce.wait)       # what is left of the exchange once backward is done
     else:
       plan.backward(plan.glogits)
       if all_reduce is not None:

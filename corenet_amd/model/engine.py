@@ -188,6 +188,8 @@ class Engine:
     assert dtype == t.float32 or getattr(backend, "name", "") == "emu"
     self.dtype = dtype
     self.device = t.device(device)
+    if self.device.type == "cuda" and self.device.index is None:      # "cuda" -> the current device, indexed
+      self.device = t.device("cuda", t.cuda.current_device() if t.cuda.is_available() else 0)
     self.num_classes = num_classes
     self.latent = latent_channels
     self.resolution = tuple(resolution)

@@ -51,9 +51,18 @@ def process_batch(model, batch: List[dataset_lib.DatasetElement], task_type: str
   """One training step from dataset elements (TrainPipeline._process_batch, pipeline.py:215-242): batch ->
   ground-truth grid -> `v2s = camera @ inverse(v2x)` -> forward, loss, backward, gradient exchange, Adam
   (`CoreNet.train_step`).  Returns the loss as a device tensor (the reference syncs on it every step)."""
+  if world_size > 1:
+    # DistributedDataParallel(broadcast_buffers=True) semantics (pipeline.py:199): every forward starts from rank
+    # 0's BatchRenorm running statistics, which feed the r / d clamps (batch_renorm.py:46-49)
+    dist_util.broadcast_buffers(model.engine.store)
   ex = batched_example.batch(batch, device=model.engine.device)
   ex = voxelize_batch(ex, task_type, **voxelization)
-  v2s = ex.camera_transform @ ex.v2x_transform.cpu().inverse().to(ex.camera_transform.device)
+  # v2s = camera @ inverse(v2x) (pipeline.py:219-221).  v2x is scale(m, m, m) built from the host-side resolution
+  # (batched_example.voxelize), so its inverse is taken on the host copy of the same 4x4 and uploaded: no
+  # device -> host read-back inside the step
+  m = float(max(voxelization.get("resolution", (128, 128, 128))))
+  inv_v2x = t.diag(t.tensor([m, m, m, 1.0])).inverse().to(ex.camera_transform.device, non_blocking=True)
+  v2s = ex.camera_transform @ inv_v2x
   return model.train_step(ex.input_image, v2s, ex.grid_sampling_offset, ex.grid, LOSS_OF_TASK[task_type],
                           lr=lr, adam_eps=adam_eps, world_size=world_size, all_reduce=all_reduce)
 

@@ -197,8 +197,48 @@ def gen_losses():
     out[name + "_grad"] = l.grad.numpy()
     vo = getattr(O, name)(gt, logits)
     assert abs(float(vo) - float(v)) < 1e-6
+  # per-voxel loss weights (losses.py:47-49,99-102,134-136), incl. a slab of zeros
+  w = t.rand(2, 6, 7, 8, generator=g) * 1.5
+  w[0, 0] = 0
+  out["weights"] = w.numpy()
+  for name in ("iou_agnostic", "iou_fgbg", "xent", "xent_times_iou_agnostic", "xent_times_iou_fgbg"):
+    l = logits.clone().requires_grad_(True)
+    v = getattr(losses, name)(gt, l, w)
+    v.backward()
+    out[name + "_w"] = np.float32(v.item())
+    out[name + "_w_grad"] = l.grad.numpy()
+    assert abs(float(getattr(O, name)(gt, logits, w)) - float(v)) < 1e-6
   np.savez_compressed(os.path.join(OUT, "losses.npz"), **out)
   print("[losses] ok")
+
+
+def gen_metrics():
+  """Mean IoU exactly as the reference computes it: voxel_metrics.compute_tfpn + compute_voxel_metrics (NaN for a
+  class with tp == 0, voxel_metrics.py:118-138), then the pandas mean over the non-void class columns of
+  evaluation_results.py:188-210,262-266 (`mm.iloc[:, 1:-1].T.mean().iou`, NaNs skipped).  evaluation_results itself
+  cannot be imported here (tensorboard, ...), so those four lines of DataFrame handling are reproduced with pandas."""
+  import dataclasses
+  import pandas
+  g = t.Generator().manual_seed(21)
+  out, cms = {}, []
+  for i, k in enumerate((2, 5, 14, 14, 14)):
+    cm = t.randint(0, 60, (k, k), generator=g)
+    if i == 3:
+      cm[5] = 0; cm[:, 5] = 0; cm[9, 9] = 0        # an absent class and a never-hit class
+    if i == 4:
+      cm[1:] = 0                                   # only void in the ground truth: every class is NaN
+    cms.append(cm)
+    tfpn = voxel_metrics.compute_tfpn(cm.to(t.float64))
+    vm = voxel_metrics.compute_voxel_metrics(tfpn)
+    classes = ["void"] + [f"c{j}" for j in range(1, k)]
+    df = pandas.DataFrame({f.name: getattr(vm, f.name).numpy() for f in dataclasses.fields(vm)}, index=classes).T
+    df = pandas.concat([df, pandas.DataFrame({"iou": [0.0], "precision": [0.0], "recall": [0.0]}, index=["__global__"]).T], axis=1)
+    miou = float(df.iloc[:, 1:-1].T.mean().iou)
+    out[f"cm_{i}"] = cm.numpy(); out[f"miou_{i}"] = np.float64(miou); out[f"iou_{i}"] = vm.iou.numpy()
+    mo = O.mean_iou(cm)
+    assert (np.isnan(miou) and np.isnan(mo)) or abs(mo - miou) < 1e-12, (i, mo, miou)
+  np.savez_compressed(os.path.join(OUT, "metrics.npz"), **out)
+  print("[metrics] ok")
 
 
 def gen_super_resolution():
@@ -366,9 +406,14 @@ if __name__ == "__main__":
   if "--only-data-path" in sys.argv:
     gen_data_path()
     sys.exit(0)
+  if "--only-losses-metrics" in sys.argv:
+    gen_losses()
+    gen_metrics()
+    sys.exit(0)
   gen_batch_renorm()
   gen_sample_grid2d()
   gen_losses()
+  gen_metrics()
   gen_model("h7_train_b1", 2, 0, 1, "iou_fgbg")
   gen_model("h7_train_b2_nbt30k", 2, 30000, 2, "iou_fgbg")
   gen_model("h7_eval_b1", 2, 100, 1, "iou_fgbg", training=False)

@@ -411,6 +411,21 @@ def test_losses_weighted(be, C, kind):
   close(dl, l.grad, 2e-5, name)
 
 
+def test_losses_golden_from_reference(be):
+  """tests/golden/losses.npz: values and gradients produced by the reference's own losses (oracle/gen_golden.py),
+  with and without per-voxel weights, all five loss kinds."""
+  z = np.load(os.path.join(os.path.dirname(__file__), "golden", "losses.npz"))
+  logits, gt, w = t.tensor(z["logits"]), t.tensor(z["gt"]).to(t.int32), t.tensor(z["weights"])
+  B, C = logits.shape[:2]
+  S = logits[0, 0].numel()
+  for kind, name in EmuBackend.LOSSES.items():
+    for suffix, ww in (("", None), ("_w", w)):
+      loss = t.zeros(1, device=DEV); dl = t.zeros(logits.shape, device=DEV)
+      be.loss_fwd_bwd(kind, logits.to(DEV), gt.to(DEV), B, C, S, loss, dl, 1.0, weights=None if ww is None else ww.to(DEV))
+      np.testing.assert_allclose(float(loss), float(z[name + suffix]), rtol=1e-5, atol=1e-6)
+      close(dl, t.tensor(z[name + suffix + "_grad"]), 2e-5, name + suffix)
+
+
 def test_losses_reference_known_answers(be):
   """All six known answers of the reference's test/losses_test.py:25-88 (three of them weighted), through the
   C ABI and through the drop-in functions of corenet_amd.model.losses (autograd, int64 labels)."""
@@ -703,7 +718,7 @@ def test_voxelizer_full_size_bit_exact(be):
                                  conservative_rasterization=True).cpu().numpy()
   ref2 = O.voxelize_mesh(tris[:40000], nt[:2], (R2, R2, R2), (v2v[0] @ t.diag(t.tensor([.5, .5, .5, 1.]))).numpy(),
                          sub_grid_sampling=True, image_resolution_multiplier=9, conservative_rasterization=True)
-  assert g.shape == (2, 129, 129, 129) and ref2.sum() > 50000 and int((g != ref2).sum()) == 0
+  assert g.shape == (2, 129, 129, 129) and ref2.sum() > 20000 and int((g != ref2).sum()) == 0
   labels = batched_example.voxelize_labels(t.tensor(tris), [t.tensor(nt[:2], dtype=t.int32), t.tensor(nt[2:], dtype=t.int32)],
                                            [[3, 5], [7, 2]], off, (R, R, R), image_resolution_multiplier=8).cpu().numpy()
   want = O.merge_labels(fill_oracle_c.fill(ref), [2, 2], [[3, 5], [7, 2]])

@@ -206,6 +206,28 @@ def test_mean_iou_parity_on_trained_weights():
   assert abs(iou_h - iou_o) < 1e-4, (iou_h, iou_o)
 
 
+def _sync_state(dst, src):
+  """dst becomes an exact replica of src (parameters, buffers, step counters, Adam moments)."""
+  de, se = dst.engine, src.engine
+  for a, b in ((de.store.params, se.store.params), (de.store.buffers, se.store.buffers), (de.store.nbt, se.store.nbt)):
+    a.copy_(b)
+  if se.adam_m is not None:
+    if de.adam_m is None:
+      de.adam_m, de.adam_v = t.zeros_like(se.adam_m), t.zeros_like(se.adam_v)
+    de.adam_m.copy_(se.adam_m); de.adam_v.copy_(se.adam_v)
+  de.adam_t = se.adam_t
+  de.weights_dirty = True
+
+
+def _slab_err(ma, m):
+  """worst max-abs-err / max over the gradient buckets of two engines (two runs of the SAME step differ by the
+  summation order of the weight-gradient atomics, measured <= 2e-3; a doubled gradient is 1.0)."""
+  worst = 0.0
+  for _, lo, hi in m.engine.grad_buckets:
+    worst = max(worst, relerr(ma.engine.store.grads[lo:hi], m.engine.store.grads[lo:hi]))
+  return worst
+
+
 def test_train_step_reduces_loss_and_matches_autograd_path():
   """The reference's loop body (pipeline.py:224-230: optimizer.zero_grad(); loss = f(model(...)); loss.backward();
   optimizer.step()) through the drop-in's autograd node + FusedAdam against the fused `train_step`, THREE steps:
@@ -218,24 +240,25 @@ def test_train_step_reduces_loss_and_matches_autograd_path():
   m, ma = _model(2, sd).train(), _model(2, sd).train()
   image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(2, 0, 2)]
   opt = S.FusedAdam(ma, lr=4e-4, eps=1e-4)
-  ls, las = [], []
+  ls = []
   for step in range(3):
-    ls.append(float(m.train_step(image, v2s, off, grid, "iou_fgbg", lr=4e-4, adam_eps=1e-4)))
+    _sync_state(ma, m)                 # same state in: the step itself is what is compared (training at B=2 is
+    ls.append(float(m.train_step(image, v2s, off, grid, "iou_fgbg", lr=4e-4, adam_eps=1e-4)))    # chaotic over steps)
     opt.zero_grad()
     loss = losses.iou_fgbg(grid, ma(image, v2s, off))
     loss.backward()
     opt.step()
-    las.append(float(loss))
+    assert abs(float(loss) - ls[-1]) < 1e-4 * abs(ls[-1]), (step, float(loss), ls[-1])
+    e = _slab_err(ma, m)
+    print(f"autograd path vs train_step, step {step}: gradient slab err {e:.2e}")
+    assert e < 1e-2, (step, e)
+    assert ma.engine.adam_t == m.engine.adam_t == step + 1
     if step == 0:
       t.cuda.synchronize(); mem0 = t.cuda.memory_allocated()
   t.cuda.synchronize()
   assert t.cuda.memory_allocated() <= mem0 + (1 << 20), (mem0, t.cuda.memory_allocated())
   assert np.isfinite(ls[-1]) and ls[-1] < ls[0]
-  for a, b in zip(las, ls):
-    assert abs(a - b) < 3e-3 * abs(b), (las, ls)            # two runs of the same step differ by atomics order
-  # first moments are linear in the gradients: doubled gradients on steps 2, 3 would show as ~1.9x
-  ra = float(ma.engine.adam_m.norm() / m.engine.adam_m.norm())
-  assert abs(ra - 1.0) < 2e-2, ra
+  assert relerr(ma.engine.adam_m, m.engine.adam_m) < 1e-2
   g = ma.get_parameter("decoder.stage_6.t1.weight")
   assert g.grad.data_ptr() != ma.engine.store.view("decoder.stage_6.t1.weight", grad=True).data_ptr()
   # accumulation: backward twice without zero_grad -> g1 + g2 (the same sample twice: 2 * g up to atomics order)
@@ -258,6 +281,66 @@ def test_train_step_reduces_loss_and_matches_autograd_path():
     l1.backward()
 
 
+def test_checkpoint_interop_on_gpu():
+  """N4 (state.py:74-97) on the device: (i) a checkpoint in the reference's format -- model_state +
+  torch.optim.Adam.state_dict() after two Adam steps, built here with torch.optim.Adam on the CPU like the reference
+  would have saved it -- decodes into the HIP model: same eval logits as the oracle on those weights, and the next
+  fused Adam step equals torch.optim.Adam's on the same gradients; (ii) encode_state -> decode_state of a model
+  trained two HIP steps resumes bit-identically (parameters, buffers, moments, step count) and the resumed model
+  takes the same third step."""
+  import io
+  from corenet_amd import state as S
+  sd = O.make_state(3, 2, nbt=7)
+  keys = list(sd.keys())
+  pkeys = [k for k in keys if sd[k].dtype == t.float32 and "running" not in k]
+  g = t.Generator().manual_seed(11)
+  params = [sd[k].clone().requires_grad_(True) for k in pkeys]
+  opt = t.optim.Adam(params, lr=4e-4, eps=1e-4)
+  for _ in range(2):
+    for p in params: p.grad = t.randn(p.shape, generator=g) * 0.01
+    opt.step()
+  model_state = {k: (params[pkeys.index(k)].detach().clone() if k in pkeys else sd[k].clone()) for k in keys}
+  cfg = {"decoder": {"resolution": (128, 128, 128), "num_output_channels": 2, "last_upscale_factor": 2,
+                     "latent_channels": 64, "skip_fraction": 0.75}}
+  buf = io.BytesIO()
+  t.save({"global_step": 77, "model_state": model_state, "model_config": cfg, "optimizer_state": opt.state_dict(),
+          "extra_metadata": None}, buf)
+  st = S.decode_state(buf.getvalue(), "cuda")
+  assert st.global_step == 77 and st.model.engine.adam_t == 2 and st.model.engine.device.type == "cuda"
+  got = st.model.state_dict()
+  assert all(t.equal(got[k].cpu(), model_state[k]) for k in keys)
+  image, v2s, off, grid = O.synthetic_batch(1, 0, 2)
+  st.model.eval()
+  with t.no_grad():
+    lh = st.model(image.cuda(), v2s.cuda(), off.cuda())
+    lo = O.corenet_forward({k: v.clone() for k, v in model_state.items()}, image, v2s, off, training=False)
+  assert relerr(lh, lo) < 1e-4
+  grads = [t.randn(p.shape, generator=g) * 0.01 for p in params]
+  for p, gr in zip(params, grads): p.grad = gr
+  opt.step()
+  for k, gr in zip(pkeys, grads): st.model.engine.store.view(k, grad=True).copy_(gr)
+  st.optimizer.step()
+  for k, p in zip(pkeys, params):
+    assert float((st.model.state_dict()[k].cpu() - p.detach()).abs().max()) < 1e-6, k
+  # (ii) our own checkpoint, written from the GPU
+  m = _model(2, O.make_state(0, 2, nbt=0)).train()
+  o1 = S.FusedAdam(m, lr=4e-4, eps=1e-4)
+  gi = [x.cuda() for x in (image, v2s, off)]; gg = grid.cuda().to(t.int32)
+  for _ in range(2):
+    m.train_step(gi[0], gi[1], gi[2], gg, "iou_fgbg", lr=4e-4, adam_eps=1e-4)
+  raw = S.encode_state(S.State(global_step=2, model=m, optimizer=o1, extra_metadata={"k": 1}))
+  st2 = S.decode_state(raw, "cuda")
+  m2 = st2.model.train()
+  assert st2.extra_metadata == {"k": 1} and m2.engine.adam_t == 2
+  assert t.equal(m2.engine.store.params, m.engine.store.params) and t.equal(m2.engine.store.buffers, m.engine.store.buffers)
+  assert t.equal(m2.engine.store.nbt, m.engine.store.nbt)
+  assert t.equal(m2.engine.adam_m, m.engine.adam_m) and t.equal(m2.engine.adam_v, m.engine.adam_v)
+  assert st2.optimizer.param_groups[0]["lr"] == 4e-4 and st2.optimizer.param_groups[0]["eps"] == 1e-4
+  la = float(m.train_step(gi[0], gi[1], gi[2], gg, "iou_fgbg", lr=4e-4, adam_eps=1e-4))
+  lb = float(m2.train_step(gi[0], gi[1], gi[2], gg, "iou_fgbg", lr=4e-4, adam_eps=1e-4))
+  assert abs(la - lb) < 1e-4 * abs(la) and _slab_err(m2, m) < 1e-2
+
+
 def test_wrapped_in_distributed_data_parallel():
   """pipeline.py:199-200,224-230 unmodified: `DistributedDataParallel(model, device_ids=[dev])`, then
   `loss = f(ddp(...))`, `loss.backward()`, `optimizer.step()` -- world 1 over RCCL.  DDP broadcasts parameters and
@@ -278,16 +361,19 @@ def test_wrapped_in_distributed_data_parallel():
         ma.engine.store.view("decoder.stage_6.t1.weight").data_ptr()           # still views of the slab
     opt = S.FusedAdam(ma, lr=4e-4, eps=1e-4)
     for step in range(3):
+      _sync_state(ma, m)
       lf = float(m.train_step(image, v2s, off, grid, "iou_fgbg", lr=4e-4, adam_eps=1e-4))
       opt.zero_grad()
       loss = losses.iou_fgbg(grid, ddp(image, v2s, off))
       loss.backward()
       opt.step()
-      assert abs(float(loss) - lf) < 3e-3 * abs(lf), (step, float(loss), lf)
-    ra = float(ma.engine.adam_m.norm() / m.engine.adam_m.norm())
-    assert abs(ra - 1.0) < 2e-2, ra
+      assert abs(float(loss) - lf) < 1e-4 * abs(lf), (step, float(loss), lf)
+      e = _slab_err(ma, m)
+      print(f"DDP-wrapped vs train_step, step {step}: gradient slab err {e:.2e}")
+      assert e < 1e-2, (step, e)
+    assert relerr(ma.engine.adam_m, m.engine.adam_m) < 1e-2
     d = (ma.engine.store.params - m.engine.store.params).abs()
-    assert float(d.max()) <= 3 * 2 * 4e-4 * 1.05 and float(d.mean()) < 3e-4
+    assert float(d.max()) <= 2 * 4e-4 * 1.05 and float(d.mean()) < 1e-4
     assert int(ma.state_dict()["decoder.stage_1.b1.num_batches_tracked"]) == 3
   finally:
     dist.destroy_process_group()

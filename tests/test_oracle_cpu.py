@@ -64,6 +64,39 @@ def test_confusion_matrix_known_answer():
                                              [1, 2, 2, 0, 3], [0, 2, 1, 0, 0]])
 
 
+def test_mean_iou_nan_skip_and_product_agrees():
+  """voxel_metrics.py:118-138 + evaluation_results.py:262-266: IoU of a class with tp == 0 is NaN and pandas'
+  mean skips it; void (class 0) is excluded.  Known answer from the reference's own 5-class confusion matrix
+  (test/voxel_metrics_test.py vector above): classes 1..3 have tp 1, 2, 0 -> class 3 is skipped, class 4 (tp 0) too."""
+  from corenet_amd import voxel_metrics as VM
+  cm = t.tensor([[1, 0, 0, 1, 1], [2, 1, 0, 0, 1], [0, 1, 2, 2, 1], [1, 2, 2, 0, 3], [0, 2, 1, 0, 0]])
+  # class 1: tp 1, fp 0+1+2+2=5, fn 2+0+0+1=3 -> 1/9; class 2: tp 2, fp 0+0+2+1=3, fn 0+1+2+1=4 -> 2/9
+  want = (1 / 9 + 2 / 9) / 2
+  assert abs(O.mean_iou(cm) - want) < 1e-12 and abs(VM.mean_iou(cm) - want) < 1e-12
+  # C = 14 with absent classes (m7/m9-like): both sides skip them identically
+  g = t.Generator().manual_seed(2)
+  cm14 = t.randint(0, 50, (14, 14), generator=g)
+  cm14[5] = 0; cm14[:, 5] = 0            # class 5 absent from GT and predictions
+  cm14[9, 9] = 0                          # class 9 never predicted correctly
+  assert abs(O.mean_iou(cm14) - VM.mean_iou(cm14)) < 1e-12
+  naive = float((cm14.double().diag() / (cm14.sum(0) + cm14.sum(1) - cm14.diag()).clamp(min=1))[1:].mean())
+  assert O.mean_iou(cm14) > naive                         # counting absent classes as IoU 0 would lower the mean
+  assert np.isnan(O.mean_iou(t.zeros(3, 3))) and np.isnan(VM.mean_iou(t.zeros(3, 3)))
+
+
+def test_camera_helpers_match_oracle():
+  """corenet_amd.geometry.transformations.{look_at_rh, perspective_rh} (transformations.py:201-262) against the
+  oracle's restatement, incl. the canonical camera of SURVEY 8(d)."""
+  import math
+  from corenet_amd.geometry import transformations as T
+  a = T.perspective_rh(math.radians(60.0), 1.0, 1e-4, 10.0) @ T.look_at_rh([0.5, 0.5, -0.8666666], [0.5, 0.5, 0.5], [0, -1, 0])
+  assert float((a - O.canonical_camera()).abs().max()) < 1e-6
+  np.testing.assert_allclose(T.look_at_rh([1., 2, 3], [0., 0, 1], [0, 0, 1]).numpy(),
+                             O.look_at_rh([1., 2, 3], [0., 0, 1], [0, 0, 1]).numpy(), atol=1e-6)
+  np.testing.assert_allclose(T.perspective_rh(0.7, 1.5, 0.1, 50).numpy(), O.perspective_rh(0.7, 1.5, 0.1, 50).numpy(),
+                             rtol=1e-6)
+
+
 # ---- voxelizer (test/voxelization_test.py:53-147) ---------------------------------------------
 def _cube(d):
   m, x = d, 3 - d
@@ -157,6 +190,23 @@ def test_losses_golden():
     v.backward()
     np.testing.assert_allclose(float(v), z[name], rtol=1e-6)
     np.testing.assert_allclose(l.grad.numpy(), z[name + "_grad"], rtol=1e-5, atol=1e-8)
+    l = logits.clone().requires_grad_(True)                        # per-voxel weights
+    v = getattr(O, name)(gt, l, t.tensor(z["weights"]))
+    v.backward()
+    np.testing.assert_allclose(float(v), z[name + "_w"], rtol=1e-6)
+    np.testing.assert_allclose(l.grad.numpy(), z[name + "_w_grad"], rtol=1e-5, atol=1e-8)
+
+
+def test_mean_iou_golden():
+  """tests/golden/metrics.npz: mean IoU computed by the reference's own voxel_metrics functions + the pandas mean of
+  evaluation_results.py:262-266 (oracle/gen_golden.py:gen_metrics), incl. absent classes and the all-NaN case;
+  the oracle and the product's host function must both reproduce it."""
+  from corenet_amd import voxel_metrics as VM
+  z = np.load(os.path.join(G, "metrics.npz"))
+  for i in range(5):
+    cm, want = t.tensor(z[f"cm_{i}"]), float(z[f"miou_{i}"])
+    for got in (O.mean_iou(cm), VM.mean_iou(cm)):
+      assert (np.isnan(want) and np.isnan(got)) or abs(got - want) < 1e-12, (i, got, want)
 
 
 @pytest.mark.parametrize("tag,nc,nbt,batch,training", [("h7_eval_b1", 2, 100, 1, False),
