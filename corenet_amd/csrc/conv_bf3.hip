@@ -1,0 +1,436 @@
+// Split-bf16 ("bf16x3") MFMA convolution engine for the big decoder layers (gfx950 / CDNA4).
+//
+// Same operation and the same operands as crn_conv_fwd (conv_igemm.hip): one stride-1 window correlation
+// over a logical NCDHW view with packed fp32 weights [Cin][taps][Npad]; it serves the forward pass and the
+// data gradient of Conv3d k5 / ConvTranspose3d k7 s2 of decoder stages 4-6
+// (reconstruction_decoder.py:72-95), where 70 % of the step's FLOPs are.
+//
+// Why: the fp32 MFMA (v_mfma_f32_16x16x4_f32) peaks at 157 TF/s; the bf16 MFMA at 2.5 PF/s.  Every fp32
+// operand is split into two bf16 terms, x = hi + lo (hi = bf16(x), lo = bf16(x - hi); together 16 mantissa
+// bits), and a product is three MFMAs with fp32 accumulation:  hi*hi + hi*lo + lo*hi  (the dropped lo*lo
+// term is 2^-16 relative).  Measured inner loop (tools/mfma_bf3_loop.hip): 540-650 TF/s fp32-equivalent.
+// The fp32 path stays the parity default; this path is selected per layer by the host
+// (Engine(decoder_math="bf16x3")) and is measured against it in tests/test_kernels_gpu.py.
+//
+// Layout (one workgroup = 512 threads = 8 waves, 1 per CU, 2 waves per SIMD):
+//  * tile = 4 x 8 x 16 output positions = 32 sub-tiles of 16 W positions, 4 per wave (MSUB);
+//    N block = NSUB * 16 output channels.
+//  * K of v_mfma_f32_16x16x32_bf16 = 4 window taps (lane group kk = lane >> 4) x 8 input channels
+//    (the 8 bf16 of a lane's operand register).  The in-plane taps (zh, zw) of the window are flattened and
+//    cut into groups of 4 (5x5 -> 7 groups, 4x4 -> 4 groups); the lane's LDS address is its position plus
+//    the offset of ITS tap, so a window tap is still an LDS offset, never a gather.
+//  * LDS: input patch of one chunk of 8 channels as [position][8 x bf16] = 16 B per position, a hi plane
+//    and a lo plane (one ds_read_b128 per operand); weights of one (chunk, zd) slab as
+//    [tap][n][8 x bf16] hi / lo.  Both are split while they are staged (fp32 in HBM, no pre-pass), with the
+//    BatchRenorm-apply + ReLU of the producer fused into the patch staging like in the fp32 engine.
+//  * register-staged pipeline: global loads of the next slab / next chunk's patch fly under the MFMAs.
+#include "conv_kernels.h"
+#include <algorithm>
+#include <cstring>
+#include <cstdio>
+#include <cstdlib>
+
+namespace {
+using namespace crnk;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kThreads = 512, kMSUB = 4, kCK = 8;
+constexpr int kNUX = 3;          // patch units (2 positions x 8 channels) per thread
+constexpr int kNWI = 4;          // weight items (1 tap x 1 column x 8 channels) per thread
+constexpr int kTabC = 256;       // channel tables
+constexpr int kMaxTapSlots = 32; // NG * 4
+
+struct Bf3Geom {
+  crnView x, y;
+  crnInTransform tr;
+  const float* w;
+  const float* bias;
+  int Npad, bias_sB;
+  int kd, kh, kw, pd, ph, pw, T, KHW;
+  int TD, TH;              // tile TD x TH x 16 positions, TD * TH == 32
+  int PD, PH, PW, PHW, NP; // patch dims (positions), PH*PW, PD*PH*PW
+  int pw2, nunits;         // position pairs per row, staging units
+  int NG;                  // groups of 4 in-plane taps
+  int tilesD, tilesH, tilesW;
+  int nchunks;
+  int mode;                // 0 store, 1 accumulate
+  int lead;
+  int vec_store;
+  int n_groups, c_groups;
+  signed char n_box[8][6], c_box[8][6];
+  unsigned magic_pw2, magic_PH, magic_kw;
+  int dbg;
+};
+
+__device__ __forceinline__ void bload2(f32x2& dst, const crn_rsrc& rs, unsigned byte_off) {
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(byte_off), "s"(rs));
+}
+template <typename VT, int A, int B>
+__device__ __forceinline__ void wait_loads2d(VT (&v)[A][B]) {
+#pragma unroll
+  for (int i = 0; i < A; ++i)
+#pragma unroll
+    for (int j = 0; j < B; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[i][j]));
+}
+
+// x = hi + lo with hi = bf16(x) (round to nearest even), lo = bf16(x - hi)
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 h = (__bf16)v[i];
+    hi[i] = h;
+    lo[i] = (__bf16)(v[i] - (float)h);
+  }
+}
+
+template <int XM> struct XLoad;
+template <> struct XLoad<1> {            // unit-stride view: 2 consecutive positions = one 8-byte load
+  typedef f32x2 T;
+  static __device__ __forceinline__ void load(T& d, const crn_rsrc& rs, unsigned off) { bload2(d, rs, off); }
+  static __device__ __forceinline__ float e0(const T& v) { return v[0]; }
+  static __device__ __forceinline__ float e1(const T& v) { return v[1]; }
+};
+template <> struct XLoad<2> {            // stride-2 (space-to-depth) view: elements 0 and 2 of a 12-byte load
+  typedef f32x3 T;
+  static __device__ __forceinline__ void load(T& d, const crn_rsrc& rs, unsigned off) { crn_bload3(d, rs, off); }
+  static __device__ __forceinline__ float e0(const T& v) { return v[0]; }
+  static __device__ __forceinline__ float e1(const T& v) { return v[2]; }
+};
+
+struct Box { int d0, d1, g0, g1; };   // zd range and tap-group range that can hold non-zero weights
+
+template <int NSUB, int XM>
+__global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned* choff = reinterpret_cast<unsigned*>(smem);                    // [kTabC]
+  float* tscale = reinterpret_cast<float*>(smem + kTabC * 4);             // [kTabC]
+  float* tshift = reinterpret_cast<float*>(smem + 2 * kTabC * 4);         // [kTabC]
+  int* toffs = reinterpret_cast<int*>(smem + 3 * kTabC * 4);              // [kMaxTapSlots]
+  constexpr int kHdr = 3 * kTabC * 4 + kMaxTapSlots * 4;                  // 3200, multiple of 16
+  constexpr int NB = NSUB * 16;
+  bf16x8* Ahi = reinterpret_cast<bf16x8*>(smem + kHdr);
+  bf16x8* Alo = Ahi + g.NP;
+  bf16x8* Bhi = Alo + g.NP;                                               // [NG*4][NB]
+  bf16x8* Blo = Bhi + g.NG * 4 * NB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kk = lane >> 4;
+  typedef typename XLoad<XM>::T XT;
+
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int twi = tile % g.tilesW; tile /= g.tilesW;
+  const int thi = tile % g.tilesH; tile /= g.tilesH;
+  const int tdi = tile % g.tilesD; tile /= g.tilesD;
+  const int b = tile;
+  const int d0 = tdi * g.TD, h0 = thi * g.TH, w0 = twi * 16;
+  const int n0 = blockIdx.y * NB;
+
+  // channel tables and the per-lane tap offsets of every group
+  for (int c = tid; c < kTabC; c += kThreads) {
+    const int cc = min(c, g.x.C - 1);
+    choff[c] = g.x.chan_off ? (unsigned)g.x.chan_off[cc] : (unsigned)cc * (unsigned)g.x.sC;
+    tscale[c] = g.tr.scale ? g.tr.scale[cc] : 1.f;
+    tshift[c] = g.tr.scale ? g.tr.shift[cc] : 0.f;
+  }
+  if (tid < kMaxTapSlots) {
+    const int t = tid < g.KHW ? tid : 0;                  // slots past the window carry zero weights
+    const int zh = mdiv(t, g.magic_kw), zw = t - zh * g.kw;
+    toffs[tid] = zh * g.PW + zw;
+  }
+
+  int pa[kMSUB];
+#pragma unroll
+  for (int ms = 0; ms < kMSUB; ++ms) {
+    const int s = wave * kMSUB + ms;
+    const int sh = s % g.TH, sd = s / g.TH;
+    pa[ms] = (sd * g.PH + sh) * g.PW + i16 + g.lead;
+  }
+  f32x4 acc[kMSUB][NSUB];
+#pragma unroll
+  for (int ms = 0; ms < kMSUB; ++ms)
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) acc[ms][ns] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const crn_rsrc xrs = make_rsrc(g.x.base + (int64_t)b * g.x.sB);
+  const crn_rsrc wrs = make_rsrc(g.w);
+  XT pv[kNUX][kCK];
+  float wv[kNWI][kCK];
+  unsigned inmask = 0;
+
+  // ---- patch staging: unit u = (plane row, position pair); all 8 channels of the chunk ----
+  auto unit_of = [&](int j, int& pos, unsigned& sp, bool& in) -> bool {
+    int u = tid + j * kThreads;
+    asm volatile("" : "+v"(u));
+    const int row = mdiv(u, g.magic_pw2), pp = u - row * g.pw2;
+    const int pdz = mdiv(row, g.magic_PH), phy = row - pdz * g.PH;
+    const int gd = d0 + pdz - g.pd, gh = h0 + phy - g.ph, gw = w0 + 2 * pp - g.pw;
+    in = (unsigned)gd < (unsigned)g.x.D && (unsigned)gh < (unsigned)g.x.H && (unsigned)gw < (unsigned)g.x.W;
+    sp = (unsigned)gd * (unsigned)g.x.sD + (unsigned)gh * (unsigned)g.x.sH + (unsigned)gw * (unsigned)(XM == 2 ? 2 : 1);
+    pos = row * g.PW + 2 * pp;
+    return u < g.nunits;
+  };
+  auto patch_issue = [&](int c0) {
+    inmask = 0;
+#pragma unroll
+    for (int j = 0; j < kNUX; ++j) {
+      int pos; unsigned sp; bool in;
+      const bool valid = unit_of(j, pos, sp, in);
+      const bool ld = valid && in;
+      if (ld) inmask |= 1u << j;
+#pragma unroll
+      for (int cl = 0; cl < kCK; ++cl) {
+        const unsigned off = (ld && c0 + cl < g.x.C) ? (choff[c0 + cl] + sp) * 4u : 0x80000000u;
+        XLoad<XM>::load(pv[j][cl], xrs, off);
+      }
+    }
+  };
+  auto patch_commit = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < kNUX; ++j) {
+      if (j * kThreads < g.nunits) {                     // block-uniform
+        int pos; unsigned sp; bool in;
+        const bool valid = unit_of(j, pos, sp, in);
+        if (valid) {
+          float v0[kCK], v1[kCK];
+#pragma unroll
+          for (int cl = 0; cl < kCK; ++cl) { v0[cl] = XLoad<XM>::e0(pv[j][cl]); v1[cl] = XLoad<XM>::e1(pv[j][cl]); }
+          if (g.tr.scale && ((inmask >> j) & 1u)) {        // zero padding stays zero
+#pragma unroll
+            for (int cl = 0; cl < kCK; ++cl) {
+              if (c0 + cl < g.x.C) {
+                const float sc = tscale[c0 + cl], sh = tshift[c0 + cl];
+                float a = v0[cl], c = v1[cl];
+                if (g.tr.pre_relu) { a = fmaxf(a, 0.f); c = fmaxf(c, 0.f); }
+                a = a * sc + sh; c = c * sc + sh;
+                if (g.tr.post_relu) { a = fmaxf(a, 0.f); c = fmaxf(c, 0.f); }
+                v0[cl] = a; v1[cl] = c;
+              }
+            }
+          }
+          bf16x8 h0v, l0v, h1v, l1v;
+          split8(v0, h0v, l0v);
+          split8(v1, h1v, l1v);
+          Ahi[pos] = h0v; Ahi[pos + 1] = h1v;
+          Alo[pos] = l0v; Alo[pos + 1] = l1v;
+        }
+      }
+    }
+  };
+  // ---- weight staging: item = (in-plane tap slot tp, column n), all 8 channels; slab = (chunk, zd) ----
+  const int witems = g.NG * 4 * NB;
+  auto weights_issue = [&](int c0, int zd) {
+#pragma unroll
+    for (int j = 0; j < kNWI; ++j) {
+      int it = tid + j * kThreads;
+      asm volatile("" : "+v"(it));
+      const int n = it & (NB - 1), tp = it / NB;
+      const bool ok = it < witems && tp < g.KHW && n0 + n < g.Npad;
+      const unsigned base = (unsigned)((zd * g.KHW + tp) * g.Npad + n0 + n);
+#pragma unroll
+      for (int cl = 0; cl < kCK; ++cl) {
+        const unsigned off = (ok && c0 + cl < g.x.C) ? ((unsigned)(c0 + cl) * (unsigned)(g.T * g.Npad) + base) * 4u : 0x80000000u;
+        crn_bload(wv[j][cl], wrs, off);
+      }
+    }
+  };
+  auto weights_commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < kNWI; ++j) {
+      if (j * kThreads < witems) {
+        int it = tid + j * kThreads;
+        asm volatile("" : "+v"(it));
+        if (it < witems) {
+          bf16x8 h, l;
+          split8(wv[j], h, l);
+          Bhi[it] = h;                                   // [tp][n] with n = ns*16 + n16: the fragment order
+          Blo[it] = l;
+        }
+      }
+    }
+  };
+
+  const auto nbox = box_union(g.n_box, g.n_groups, g.y.C, n0, min(n0 + NB, g.y.C) - 1, g.kd, g.kh, g.kw);
+  auto chunk_box = [&](int c0) -> Box {
+    const TapBox tb = box_intersect(nbox, box_union(g.c_box, g.c_groups, g.x.C, c0, min(c0 + kCK, g.x.C) - 1,
+                                                    g.kd, g.kh, g.kw));
+    Box o;
+    o.d0 = tb.d0; o.d1 = tb.d1;
+    if (tb.h1 <= tb.h0 || tb.w1 <= tb.w0) { o.d1 = o.d0; o.g0 = o.g1 = 0; return o; }
+    const int t0 = tb.h0 * g.kw + tb.w0, t1 = (tb.h1 - 1) * g.kw + tb.w1;   // flattened in-plane range (superset)
+    o.g0 = t0 >> 2; o.g1 = (t1 + 3) >> 2;
+    return o;
+  };
+  // first (chunk, zd) step with work at or after `chunk`
+  auto first_step = [&](int chunk, int& zd, Box& bx) -> int {
+    for (; chunk < g.nchunks; ++chunk) {
+      bx = chunk_box(chunk * kCK);
+      if (bx.d1 > bx.d0 && bx.g1 > bx.g0) { zd = bx.d0; return chunk; }
+    }
+    return g.nchunks;
+  };
+
+  __syncthreads();                                       // tables are in LDS
+  Box bx{};
+  int zd = 0;
+  int chunk = first_step(0, zd, bx);
+  bool fresh = true;                                     // the patch of `chunk` is in registers, not yet in LDS
+  if (chunk < g.nchunks) {
+    patch_issue(chunk * kCK);
+    weights_issue(chunk * kCK, zd);
+  }
+  while (chunk < g.nchunks) {
+    const int c0 = chunk * kCK;
+    // next step
+    int nchunk = chunk, nzd = zd + 1;
+    Box nbx = bx;
+    if (nzd >= bx.d1) nchunk = first_step(chunk + 1, nzd, nbx);
+    wait_loads2d(pv);
+    wait_loads2d(wv);
+    __syncthreads();                                     // every wave is done reading the LDS of the previous step
+    if (fresh) patch_commit(c0);
+    weights_commit();
+    __syncthreads();
+    if (nchunk < g.nchunks) {
+      if (nchunk != chunk) patch_issue(nchunk * kCK);    // flies under this slab's MFMAs
+      weights_issue(nchunk * kCK, nzd);
+    }
+    if (g.dbg != 1) {
+      const int zoff = zd * g.PHW;
+      for (int gq = bx.g0; gq < bx.g1; ++gq) {
+        const int off = toffs[gq * 4 + kk] + zoff;
+        bf16x8 bh[NSUB], bl[NSUB], ah[kMSUB], al[kMSUB];
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) {
+          bh[ns] = Bhi[(gq * 4 + kk) * NB + ns * 16 + i16];
+          bl[ns] = Blo[(gq * 4 + kk) * NB + ns * 16 + i16];
+        }
+#pragma unroll
+        for (int ms = 0; ms < kMSUB; ++ms) { ah[ms] = Ahi[pa[ms] + off]; al[ms] = Alo[pa[ms] + off]; }
+#pragma unroll
+        for (int ms = 0; ms < kMSUB; ++ms)
+#pragma unroll
+          for (int ns = 0; ns < NSUB; ++ns) {
+            acc[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ms], bh[ns], acc[ms][ns], 0, 0, 0);
+            acc[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ms], bl[ns], acc[ms][ns], 0, 0, 0);
+            acc[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ms], bh[ns], acc[ms][ns], 0, 0, 0);
+          }
+      }
+    }
+    fresh = nchunk != chunk;
+    chunk = nchunk; zd = nzd; bx = nbx;
+  }
+
+  // epilogue: D row = kk*4 + r = W position inside the sub-tile, col = i16 = channel
+  float* yb = g.y.base + (int64_t)b * g.y.sB;
+#pragma unroll
+  for (int ns = 0; ns < NSUB; ++ns) {
+    const int n = n0 + ns * 16 + i16;
+    if (n >= g.y.C) continue;
+    const int64_t co = view_chan(g.y, n);
+    const float bsv = g.bias ? g.bias[(int64_t)b * g.bias_sB + n] : 0.f;
+#pragma unroll
+    for (int ms = 0; ms < kMSUB; ++ms) {
+      const int s = wave * kMSUB + ms;
+      const int od = d0 + s / g.TH, oh = h0 + s % g.TH, ow = w0 + kk * 4;
+      if (od >= g.y.D || oh >= g.y.H || ow >= g.y.W) continue;
+      float* dst = yb + co + (int64_t)od * g.y.sD + (int64_t)oh * g.y.sH + (int64_t)ow * g.y.sW;
+      if (g.vec_store) {
+        f32x4 v = acc[ms][ns] + bsv;
+        if (g.mode == 1) v += *reinterpret_cast<const f32x4*>(dst);
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (ow + r < g.y.W) {
+            float* d = dst + (int64_t)r * g.y.sW;
+            const float v = acc[ms][ns][r] + bsv;
+            *d = g.mode == 1 ? *d + v : v;
+          }
+        }
+      }
+    }
+  }
+}
+
+unsigned magic20b(int d) { return (unsigned)(((1u << 20) + d - 1) / d); }
+
+template <int NSUB, int XM>
+int launch_bf3(const Bf3Geom& g, dim3 grid, size_t lds, hipStream_t st) {
+  auto k = conv_bf3_kernel<NSUB, XM>;
+  if (lds > 65536) CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, st, g);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+bool even_view(const crnView& v) {       // 8-byte staging of position pairs on a unit-stride view
+  return v.chan_off == nullptr && v.sW == 1 && (v.W & 1) == 0 && (v.sH & 1) == 0 && (v.sD & 1) == 0 && (v.sC & 1) == 0 &&
+         (v.sB & 1) == 0 && (((uintptr_t)v.base) & 7) == 0;
+}
+
+}  // namespace
+
+// Returns CRN_EINVAL for shapes this engine does not cover (the caller keeps the fp32 engine for those);
+// crn_conv_fwd_bf3_supported lets the host decide once per layer.
+extern "C" int crn_conv_fwd_bf3(const crnView* x, const crnInTransform* tr, const float* w, int Npad,
+                                const float* bias, int bias_sB, const crnView* y,
+                                int kd, int kh, int kw, int pd, int ph, int pw,
+                                int accumulate, const crnTapBoxes* boxes, crnStream stream) {
+  if (boxes && (boxes->n_groups < 0 || boxes->n_groups > 8 || boxes->c_groups < 0 || boxes->c_groups > 8)) return CRN_EINVAL;
+  if (!x || !y || !w || Npad <= 0 || (Npad & 15) || x->B != y->B || kd < 1 || kh < 1 || kw < 1) return CRN_EINVAL;
+  if (y->C > Npad || x->C > kTabC) return CRN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int xmode = even_view(*x) ? 1 : ((x->sW == 2 && x->chan_off != nullptr && (x->W & 1) == 0) ? 2 : 0);
+  if (!xmode) return CRN_EINVAL;
+  if ((y->W & 15) || y->H < 8 || y->D < 4) return CRN_EINVAL;
+  Bf3Geom g{};
+  g.x = *x; g.y = *y;
+  g.tr = tr ? *tr : crnInTransform{nullptr, nullptr, 0, 0};
+  g.w = w; g.bias = bias; g.Npad = Npad; g.bias_sB = bias_sB;
+  g.lead = ((pw % 2) + 2) % 2;                       // patch rows start on an even column: 8-byte loads stay aligned
+  g.kd = kd; g.kh = kh; g.kw = kw; g.pd = pd; g.ph = ph; g.pw = pw + g.lead;
+  g.T = kd * kh * kw; g.KHW = kh * kw;
+  g.NG = (g.KHW + 3) / 4;
+  if (g.NG * 4 > kMaxTapSlots || kd > 8) return CRN_EINVAL;
+  g.TD = 4; g.TH = 8;
+  g.PD = g.TD + kd - 1; g.PH = g.TH + kh - 1; g.PW = (g.lead + 16 + kw - 1 + 1) & ~1;
+  g.PHW = g.PH * g.PW; g.NP = g.PD * g.PHW;
+  g.pw2 = g.PW / 2; g.nunits = g.PD * g.PH * g.pw2;
+  if (g.nunits > kNUX * kThreads) return CRN_EINVAL;
+  g.tilesD = crn_cdiv(y->D, g.TD); g.tilesH = crn_cdiv(y->H, g.TH); g.tilesW = y->W / 16;
+  g.nchunks = crn_cdiv(x->C, kCK);
+  g.mode = accumulate ? 1 : 0;
+  g.magic_pw2 = magic20b(g.pw2); g.magic_PH = magic20b(g.PH); g.magic_kw = magic20b(kw);
+  g.vec_store = (y->sW == 1 && (y->W & 3) == 0 && (y->sH & 3) == 0 && (y->sD & 3) == 0 && (y->sB & 3) == 0 &&
+                 (y->sC & 3) == 0 && (((uintptr_t)y->base) & 15) == 0 && y->chan_off == nullptr) ? 1 : 0;
+  static const bool no_boxes = getenv("CRN_NO_BOXES") != nullptr;
+  bool have_nbox = false;
+  if (boxes && !no_boxes) {
+    if (boxes->n_groups > 0 && y->C % boxes->n_groups == 0) { g.n_groups = boxes->n_groups; memcpy(g.n_box, boxes->n_box, sizeof(g.n_box)); have_nbox = true; }
+    if (boxes->c_groups > 0 && x->C % boxes->c_groups == 0) { g.c_groups = boxes->c_groups; memcpy(g.c_box, boxes->c_box, sizeof(g.c_box)); }
+  }
+  // N block: wide blocks re-use the staged patch; with per-output-group tap boxes (transposed convolutions)
+  // a 16-column block belongs to one parity and skips that parity's structural zeros instead
+  int NSUB = (Npad % 64 == 0) ? 4 : ((Npad % 32 == 0) ? 2 : 1);
+  if (have_nbox && (y->C / g.n_groups) % 16 == 0) NSUB = 1;
+  if (const char* f = getenv("CRN_BF3_NSUB")) NSUB = atoi(f);
+  auto lds_of = [&](int nsub) { return (size_t)(3 * kTabC * 4 + kMaxTapSlots * 4) + (size_t)2 * g.NP * 16 + (size_t)2 * g.NG * 4 * nsub * 16 * 16; };
+  while (NSUB > 1 && (lds_of(NSUB) > 160 * 1024 - 512 || g.NG * 4 * NSUB * 16 > kNWI * kThreads)) NSUB >>= 1;
+  if (NSUB != 1 && NSUB != 2 && NSUB != 4) return CRN_EINVAL;
+  const size_t lds = lds_of(NSUB);
+  if (lds > 160 * 1024 - 512 || g.NG * 4 * NSUB * 16 > kNWI * kThreads) return CRN_EINVAL;
+  if ((int64_t)x->C * g.T * Npad >= ((int64_t)1 << 29)) return CRN_EINVAL;
+  g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
+  dim3 grid((unsigned)(g.tilesD * g.tilesH * g.tilesW * y->B), (unsigned)crn_cdiv(Npad, NSUB * 16), 1);
+  static const bool dbg = getenv("CRN_DEBUG") != nullptr;
+  if (dbg)
+    fprintf(stderr, "[crn_conv_fwd_bf3] x(C%d %dx%dx%d) y(C%d %dx%dx%d) k%dx%dx%d: NSUB %d xmode %d patch %dx%dx%d units %d "
+            "NG %d grid %ux%u lds %zu\n", x->C, x->D, x->H, x->W, y->C, y->D, y->H, y->W, kd, kh, kw, NSUB, xmode, g.PD, g.PH,
+            g.PW, g.nunits, g.NG, grid.x, grid.y, lds);
+#define CRN_BF3_CASE(N, X) if (NSUB == N && xmode == X) return launch_bf3<N, X>(g, grid, lds, st);
+  CRN_BF3_CASE(1, 1) CRN_BF3_CASE(2, 1) CRN_BF3_CASE(4, 1)
+  CRN_BF3_CASE(1, 2) CRN_BF3_CASE(2, 2) CRN_BF3_CASE(4, 2)
+#undef CRN_BF3_CASE
+  return CRN_EINVAL;
+}

@@ -76,6 +76,17 @@ int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const float* w, int
                  int splits, int accumulate /* y += result instead of y = result */,
                  const crnTapBoxes* boxes /* may be NULL */, crnStream stream);
 
+/* The same operation on the split-bf16 ("bf16x3") MFMA engine (csrc/conv_bf3.hip): every fp32 operand is
+ * split into two bf16 terms and a product is three v_mfma_f32_16x16x32_bf16 with fp32 accumulation
+ * (hi*hi + hi*lo + lo*hi; ~2^-16 relative per product instead of fp32's 2^-24).  A throughput mode for
+ * the big decoder layers (reconstruction_decoder.py:72-95), selected per layer by the host; the fp32
+ * engine above stays the parity default.  Returns CRN_EINVAL for shapes it does not cover
+ * (output W not a multiple of 16, views other than unit-stride / stride-2 space-to-depth, Cin > 256).   */
+int crn_conv_fwd_bf3(const crnView* x, const crnInTransform* tr, const float* w, int Npad,
+                     const float* bias, int bias_sB, const crnView* y,
+                     int kd, int kh, int kw, int pd, int ph, int pw,
+                     int accumulate, const crnTapBoxes* boxes /* may be NULL */, crnStream stream);
+
 /* Weight gradient in the same packed layout:
  *   dw[(c*T+t)*Npad+n] = sum_{b,o} T(x)[b,c,o-pad_lo+t] * dy[b,n,o]
  * dw must be zeroed by the caller or zero_first!=0.  Replaces autograd of the

@@ -71,7 +71,8 @@ class EmuBackend:
   name = "emu"
 
   # -- convolution engine -----------------------------------------------------
-  def conv_fwd(self, x, tr, w, npad, bias, bias_sB, y, window, pad_lo, splits=1, accumulate=False, boxes=None):
+  def conv_fwd(self, x, tr, w, npad, bias, bias_sB, y, window, pad_lo, splits=1, accumulate=False, boxes=None,
+               math="fp32"):
     # boxes only tell where the packed weights are structurally zero: no effect on the result
     xl = _transform(logical(x), tr)
     xp = _padded(xl, window, pad_lo, (y.D, y.H, y.W))

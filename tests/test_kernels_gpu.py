@@ -132,6 +132,68 @@ def test_conv_fwd_dgrad_wgrad(be, name, kind, wshape, pad, dims, B):
   close(gw.view(wshape), wref.grad, 5e-5, name + " wgrad-vs-autograd")
 
 
+BF3_CASES = [c for c in CONV_CASES if c[0] in ("conv3d_k5_32", "conv3d_k5_64", "convT_k7_16", "convT_k7_64_c2", "convT_k7_32_c14")] + [
+    ("conv3d_k5_16_c112", "conv", (64, 112, 5, 5, 5), 2, (16, 16, 16), 2),
+    ("convT_k7_32_c16", "convT", (32, 16, 7, 7, 7), 3, (32, 32, 32), 1),
+]
+
+
+@pytest.mark.parametrize("name,kind,wshape,pad,dims,B", BF3_CASES, ids=[c[0] for c in BF3_CASES])
+def test_conv_bf16x3_fwd_dgrad(be, name, kind, wshape, pad, dims, B):
+  """The split-bf16 MFMA engine (crn_conv_fwd_bf3) on the decoder layer shapes of stages 4-6
+  (reconstruction_decoder.py:72-95), forward with the fused pre-ReLU affine transform + bias into a channel slice,
+  and the data gradient (accumulating), against the same contract emulator as the fp32 engine.
+  Error model: operands carry 16 mantissa bits (hi + lo bf16) and the lo*lo product is dropped, i.e. ~2^-16
+  relative per product with random sign; the bar is 2e-5 of the output range (fp32 engine: 3e-5 on the same data is
+  dominated by summation order), measured values are printed."""
+  if _SELF:
+    return
+  from corenet_amd import views as V
+  from corenet_amd.backend import Transform
+  from corenet_amd.model import conv_geometry as G
+  g = t.Generator().manual_seed(hash(name) % 1000)
+  w = t.randn(wshape, generator=g) / np.sqrt(np.prod(wshape[1:]))
+  D, H, W = dims
+  if kind == "conv":
+    cin, cout = wshape[1], wshape[0]
+    fwd, dgr = G.conv_fwd(wshape, pad), G.conv_dgrad(wshape, pad)
+    odims = dims
+  else:
+    cin, cout = wshape[0], wshape[1]
+    fwd, dgr = G.convt_fwd(wshape, pad), G.convt_dgrad(wshape, pad)
+    odims = (2 * D, 2 * H, 2 * W)
+  x = t.randn((B, cin) + dims, generator=g)
+  scale = t.rand(cin, generator=g) + 0.5; shift = t.randn(cin, generator=g) * 0.3
+  bias = t.randn(cout, generator=g)
+  y = t.zeros((B, cout + 3) + odims)
+  wf = EMU_pack(w, fwd); wd = EMU_pack(w, dgr)
+  bpack = EMU_pack(bias, None, G.bias_index(cout, 8 if kind == "convT" else 1, fwd.npad, parity_major=(kind == "convT")))
+
+  def yview(tens):
+    v = V.view_of(tens).channels(0, cout)
+    return V.space_to_depth_view(v, (2, 2, 2), parity_major=True) if kind == "convT" else v
+
+  xg, yg = x.to(DEV), y.to(DEV)
+  trc = Transform(scale, shift, pre_relu=True); trg = Transform(scale.to(DEV), shift.to(DEV), pre_relu=True)
+  EMU.conv_fwd(V.view_of(x), trc, wf, fwd.npad, bpack, 0, yview(y), fwd.window, fwd.pad_lo)
+  be.conv_fwd(V.view_of(xg), trg, wf.to(DEV), fwd.npad, bpack.to(DEV), 0, yview(yg), fwd.window, fwd.pad_lo, 0,
+              boxes=(fwd.n_boxes, fwd.c_boxes), math="bf16x3")
+  e = float((yg.cpu() - y).abs().max() / y.abs().max())
+  print(f"bf16x3 {name} fwd: max-abs-err/max = {e:.2e}")
+  assert e <= 2e-5, (name, "fwd", e)
+  assert float(yg[:, cout:].abs().max()) == 0.0
+  dy = t.randn((B, cout) + odims, generator=g)
+  dyb = t.zeros_like(y); dyb[:, :cout] = dy
+  dx = t.randn(x.shape, generator=g); dxg = dx.to(DEV)
+  dyg = dyb.to(DEV)
+  EMU.conv_fwd(yview(dyb), None, wd, dgr.npad, None, 0, V.view_of(dx), dgr.window, dgr.pad_lo, accumulate=True)
+  be.conv_fwd(yview(dyg), None, wd.to(DEV), dgr.npad, None, 0, V.view_of(dxg), dgr.window, dgr.pad_lo, 0, True,
+              boxes=(dgr.n_boxes, dgr.c_boxes), math="bf16x3")
+  e = float((dxg.cpu() - dx).abs().max() / dx.abs().max())
+  print(f"bf16x3 {name} dgrad: max-abs-err/max = {e:.2e}")
+  assert e <= 2e-5, (name, "dgrad", e)
+
+
 def EMU_pack(w, geom, index=None):
   idx = t.as_tensor(geom.index if index is None else index)
   out = t.zeros(idx.numel())
