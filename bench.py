@@ -27,6 +27,7 @@ import torch.distributed as dist  # noqa: E402
 CONV6_FLOP = 2 * 64 ** 3 * 28 * 125 * 16          # stage_6 c1: Conv3d 28->16 k5 @64^3
 RAY64_BYTES = 64 ** 3 * 12 * 4 + 64 * 64 * 12 * 4  # ray-sample 64^3 x 12ch: output + map
 PEAK_F32_MFMA = 157.3e12                           # MI355X_MICROARCH.md: fp32 matrix peak
+PEAK_BF16_MFMA = 2500e12                           # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM = 8.0e12                                  # HBM3E spec peak
 
 
@@ -121,6 +122,8 @@ def main():
   ap.add_argument("--warmup", type=int, default=3)
   ap.add_argument("--batch", type=int, default=4, help="samples per GPU (h7.json5:42)")
   ap.add_argument("--classes", type=int, default=2, help="2 = h7 (FG/BG); 14 = m7/m9")
+  ap.add_argument("--math", default=os.environ.get("CRN_DECODER_MATH", "bf16x3"), choices=["fp32", "bf16x3"],
+                  help="decoder stage 4-6 convolutions: fp32 MFMA, or split-bf16 (3 bf16 MFMAs per product, fp32 accumulate)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   args = ap.parse_args()
 
@@ -135,7 +138,7 @@ def main():
   dev = f"cuda:{local}"
   C, B = args.classes, args.batch
   loss_name = "iou_fgbg" if C == 2 else "xent_times_iou_agnostic"
-  model = CoreNet(CoreNetConfig(DecoderConfig((128, 128, 128), C, 2, 64, 0.75)), device=dev)
+  model = CoreNet(CoreNetConfig(DecoderConfig((128, 128, 128), C, 2, 64, 0.75)), device=dev, decoder_math=args.math)
   model.reset_parameters(seed=0)          # the product's own initialiser (resnet50.py:40-47 + torch defaults)
   model.train()
   state0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()} if rank == 0 else None
@@ -145,30 +148,46 @@ def main():
   sync = D.GradientSync(world)
   plan = model.engine.plan(B)
 
-  def step():
-    D.broadcast_buffers(model.engine.store)
-    return model.train_step(image, v2s, off, grid, loss_name, lr=4e-4, adam_eps=1e-4, world_size=world,
+  def timed(mdl, pl):
+    """W warm-up steps, then K steps timed between barrier + synchronize on both sides, max over ranks."""
+    def step():
+      D.broadcast_buffers(mdl.engine.store)
+      return mdl.train_step(image, v2s, off, grid, loss_name, lr=4e-4, adam_eps=1e-4, world_size=world,
                             all_reduce=sync if world > 1 else None)
+    for _ in range(args.warmup):
+      step()
+    pl.probes = {"conv3d_stage6_c1_fwd": [], "ray_sample_fwd_64": [], "grad_exchange_wait": []}
+    if world > 1:
+      dist.barrier()
+    t.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+      loss = step()
+    t.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    dt = time.perf_counter() - t0
+    tt = t.tensor([dt], dtype=t.float64, device=dev)
+    if world > 1:
+      dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    pr = {k: sum(a.elapsed_time(b) for a, b in v) / max(1, len(v)) * 1e-3 for k, v in pl.probes.items()}
+    pl.probes = None
+    return float(tt), pr, loss
 
-  for _ in range(args.warmup):
-    step()
-  plan.probes = {"conv3d_stage6_c1_fwd": [], "ray_sample_fwd_64": [], "grad_exchange_wait": []}
-  if world > 1:
-    dist.barrier()
-  t.cuda.synchronize()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    loss = step()
-  t.cuda.synchronize()
-  if world > 1:
-    dist.barrier()
-  dt = time.perf_counter() - t0
-  tt = t.tensor([dt], dtype=t.float64, device=dev)
-  if world > 1:
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-  dt = float(tt)
-  probes = {k: sum(a.elapsed_time(b) for a, b in v) / max(1, len(v)) * 1e-3 for k, v in plan.probes.items()}
-  plan.probes = None
+  dt, probes, loss = timed(model, plan)
+  fp32_side = None
+  if world == 1 and args.math != "fp32":
+    # the same step with every convolution on the fp32 MFMA engine (the parity default), printed beside the headline
+    m32 = CoreNet(CoreNetConfig(DecoderConfig((128, 128, 128), C, 2, 64, 0.75)), device=dev, decoder_math="fp32")
+    m32.load_state_dict(state0); m32.train()
+    dt32, pr32, loss32 = timed(m32, m32.engine.plan(B))
+    c32 = pr32["conv3d_stage6_c1_fwd"]
+    fp32_side = {"ms_per_step": dt32 / args.steps * 1e3, "value": B * 128 ** 3 * args.steps / dt32, "unit": "voxels/s",
+                 "dtype": "f32", "loss": float(loss32),
+                 "roofline": {"kernel": "conv_fwd_kernel<8,1,xvec> (stage_6.c1 Conv3d 28->16 k5 @64^3, fwd, fp32 MFMA engine)",
+                              "bound": "mfma", "achieved": CONV6_FLOP * B / c32 / 1e12, "peak": PEAK_F32_MFMA / 1e12,
+                              "unit": "TFLOP/s", "frac": CONV6_FLOP * B / c32 / PEAK_F32_MFMA, "avg_launch_ms": c32 * 1e3}}
+    del m32
   if rank != 0:
     return
   conv_s, ray_s = probes["conv3d_stage6_c1_fwd"], probes["ray_sample_fwd_64"]
@@ -238,20 +257,32 @@ def main():
     e1.record(); t.cuda.synchronize()
   eval_s = e0.elapsed_time(e1) / 5 * 1e-3
   model.train()
+  if args.math == "bf16x3":
+    dtype_note = ("f32 (bf16x3 products in the decoder stage 4-6 convolutions: operands split into two bf16 terms, three "
+                  "bf16 MFMAs per fp32 product, fp32 accumulation, ~3e-6 relative per layer; everything else fp32)")
+    conv_kernel_name = "conv_bf3_kernel<NSUB 1, 5x5 plane> (stage_6.c1 Conv3d 28->16 k5 @64^3, fwd, split-bf16 MFMA engine)"
+    conv_peak = PEAK_BF16_MFMA / 3
+    conv_peak_note = "dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-equivalent product; achieved counts the layer's real 2*M*K*N"
+  else:
+    dtype_note = "f32"
+    conv_kernel_name = "conv_fwd_kernel<8,1,xvec> (stage_6.c1 Conv3d 28->16 k5 @64^3, fwd)"
+    conv_peak, conv_peak_note = PEAK_F32_MFMA, "fp32 matrix peak (v_mfma_f32_16x16x4_f32)"
   out = {
       "metric": "voxels/sec fwd+bwd @128^3", "value": world * B * 128 ** 3 * args.steps / dt,
       "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
       "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-      "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+      "vs_baseline": None, "dtype": dtype_note, "data": "synthetic",
       "config": {"workload": f"{'h7' if C == 2 else 'm7/m9'}: CoReNet train step (fwd+{loss_name}+bwd+allreduce+Adam), "
-                             f"256x256 RGB -> 128^3, C={C}, B={B}/GPU, fp32, random-init weights",
+                             f"256x256 RGB -> 128^3, C={C}, B={B}/GPU, decoder_math={args.math}, random-init weights",
                  "global_batch": world * B, "parallelism": f"dp{world}"},
       "loss": float(loss),
       "eval_forward": {"ms_per_batch": eval_s * 1e3, "value": B * 128 ** 3 / eval_s, "unit": "voxels/s",
                        "note": "rank 0, forward only, eval mode, same inputs"},
-      "roofline": {"kernel": "conv_fwd_kernel<8,1,xvec> (stage_6.c1 Conv3d 28->16 k5 @64^3, fwd)",
-                   "bound": "mfma", "achieved": CONV6_FLOP * B / conv_s / 1e12, "peak": PEAK_F32_MFMA / 1e12,
-                   "unit": "TFLOP/s", "frac": CONV6_FLOP * B / conv_s / PEAK_F32_MFMA, "traffic": traffic.get("conv"),
+      "roofline": {"kernel": conv_kernel_name,
+                   "bound": "mfma", "achieved": CONV6_FLOP * B / conv_s / 1e12, "peak": conv_peak / 1e12,
+                   "peak_note": conv_peak_note,
+                   "unit": "TFLOP/s", "frac": CONV6_FLOP * B / conv_s / conv_peak,
+                   "traffic": traffic.get("conv") if args.math == "fp32" else None,
                    "traffic_source": f"{traffic_file} (separate rocprofv3 --pmc passes of this command; not measured in this run)",
                    "avg_launch_ms": conv_s * 1e3},
       # duration = burst of 20 launches on the step's own buffers (12.2 us; rocprofv3 kernel-trace of the in-step
@@ -268,6 +299,8 @@ def main():
   }
   for k in ("roofline_ray_sample", "roofline_fill_voxels"):
     out[k]["traffic_source"] = out["roofline"]["traffic_source"]
+  if fp32_side is not None:
+    out["fp32_math"] = fp32_side
   if world > 1:
     out["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
                    "version": ".".join(str(v) for v in t.cuda.nccl.version()) if dist.get_backend() == "nccl" else None,

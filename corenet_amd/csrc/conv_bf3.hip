@@ -37,8 +37,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 512, kMSUB = 4, kCK = 8;
-constexpr int kNUX = 3;          // patch units (2 positions x 8 channels) per thread
-constexpr int kNWI = 4;          // weight items (1 tap x 1 column x 8 channels) per thread
+constexpr int kNUX = 2;          // patch units (2 positions x 8 channels) per thread
 constexpr int kTabC = 256;       // channel tables
 constexpr int kMaxTapSlots = 32; // NG * 4
 
@@ -101,19 +100,22 @@ template <> struct XLoad<2> {            // stride-2 (space-to-depth) view: elem
 
 struct Box { int d0, d1, g0, g1; };   // zd range and tap-group range that can hold non-zero weights
 
-template <int NSUB, int XM>
+// NG = groups of 4 in-plane taps (7: 5x5 window, 4: 4x4 window): compile time, so that the group loop is
+// straight-line code (LDS reads of the next group issue under the MFMAs of the current one) and every
+// staging loop has exactly the trip count the layer needs
+template <int NSUB, int XM, int NG>
 __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
+  constexpr int kNWI = (NG * 4 * NSUB * 16 + kThreads - 1) / kThreads;    // weight items per thread
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned* choff = reinterpret_cast<unsigned*>(smem);                    // [kTabC]
   float* tscale = reinterpret_cast<float*>(smem + kTabC * 4);             // [kTabC]
   float* tshift = reinterpret_cast<float*>(smem + 2 * kTabC * 4);         // [kTabC]
-  int* toffs = reinterpret_cast<int*>(smem + 3 * kTabC * 4);              // [kMaxTapSlots]
   constexpr int kHdr = 3 * kTabC * 4 + kMaxTapSlots * 4;                  // 3200, multiple of 16
   constexpr int NB = NSUB * 16;
   bf16x8* Ahi = reinterpret_cast<bf16x8*>(smem + kHdr);
   bf16x8* Alo = Ahi + g.NP;
   bf16x8* Bhi = Alo + g.NP;                                               // [NG*4][NB]
-  bf16x8* Blo = Bhi + g.NG * 4 * NB;
+  bf16x8* Blo = Bhi + NG * 4 * NB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kk = lane >> 4;
   typedef typename XLoad<XM>::T XT;
@@ -133,12 +135,14 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
     tscale[c] = g.tr.scale ? g.tr.scale[cc] : 1.f;
     tshift[c] = g.tr.scale ? g.tr.shift[cc] : 0.f;
   }
-  if (tid < kMaxTapSlots) {
-    const int t = tid < g.KHW ? tid : 0;                  // slots past the window carry zero weights
-    const int zh = mdiv(t, g.magic_kw), zw = t - zh * g.kw;
-    toffs[tid] = zh * g.PW + zw;
-  }
 
+  int toff[NG];
+#pragma unroll
+  for (int gq = 0; gq < NG; ++gq) {
+    const int t = gq * 4 + kk < g.KHW ? gq * 4 + kk : 0;   // slots past the window carry zero weights
+    const int zh = mdiv(t, g.magic_kw), zw = t - zh * g.kw;
+    toff[gq] = zh * g.PW + zw;
+  }
   int pa[kMSUB];
 #pragma unroll
   for (int ms = 0; ms < kMSUB; ++ms) {
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
     }
   };
   // ---- weight staging: item = (in-plane tap slot tp, column n), all 8 channels; slab = (chunk, zd) ----
-  const int witems = g.NG * 4 * NB;
+  constexpr int witems = NG * 4 * NB;
   auto weights_issue = [&](int c0, int zd) {
 #pragma unroll
     for (int j = 0; j < kNWI; ++j) {
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
     o.d0 = tb.d0; o.d1 = tb.d1;
     if (tb.h1 <= tb.h0 || tb.w1 <= tb.w0) { o.d1 = o.d0; o.g0 = o.g1 = 0; return o; }
     const int t0 = tb.h0 * g.kw + tb.w0, t1 = (tb.h1 - 1) * g.kw + tb.w1;   // flattened in-plane range (superset)
-    o.g0 = t0 >> 2; o.g1 = (t1 + 3) >> 2;
+    o.g0 = t0 >> 2; o.g1 = (t1 + 3) >> 2;     // (kept for the debug print; every group of a plane runs)
     return o;
   };
   // first (chunk, zd) step with work at or after `chunk`
@@ -274,6 +278,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
   Box bx{};
   int zd = 0;
   int chunk = first_step(0, zd, bx);
+  bool first = true;
   bool fresh = true;                                     // the patch of `chunk` is in registers, not yet in LDS
   if (chunk < g.nchunks) {
     patch_issue(chunk * kCK);
@@ -288,17 +293,23 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
     wait_loads2d(pv);
     wait_loads2d(wv);
     __syncthreads();                                     // every wave is done reading the LDS of the previous step
-    if (fresh) patch_commit(c0);
-    weights_commit();
+    if (g.dbg < 3 || first) {
+      if (fresh) patch_commit(c0);
+      weights_commit();
+    }
+    first = false;
     __syncthreads();
-    if (nchunk < g.nchunks) {
+    if (nchunk < g.nchunks && g.dbg != 2) {
       if (nchunk != chunk) patch_issue(nchunk * kCK);    // flies under this slab's MFMAs
       weights_issue(nchunk * kCK, nzd);
     }
     if (g.dbg != 1) {
       const int zoff = zd * g.PHW;
-      for (int gq = bx.g0; gq < bx.g1; ++gq) {
-        const int off = toffs[gq * 4 + kk] + zoff;
+      // every group of the window row runs (weights outside a tap box are zero): no control flow between the
+      // groups, so the compiler keeps the next group's LDS reads in flight under this group's MFMAs
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) {
+        const int off = toff[gq] + zoff;
         bf16x8 bh[NSUB], bl[NSUB], ah[kMSUB], al[kMSUB];
 #pragma unroll
         for (int ns = 0; ns < NSUB; ++ns) {
@@ -355,9 +366,9 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
 
 unsigned magic20b(int d) { return (unsigned)(((1u << 20) + d - 1) / d); }
 
-template <int NSUB, int XM>
+template <int NSUB, int XM, int NG>
 int launch_bf3(const Bf3Geom& g, dim3 grid, size_t lds, hipStream_t st) {
-  auto k = conv_bf3_kernel<NSUB, XM>;
+  auto k = conv_bf3_kernel<NSUB, XM, NG>;
   if (lds > 65536) CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, st, g);
   CRN_CHECK_LAUNCH();
@@ -392,7 +403,7 @@ extern "C" int crn_conv_fwd_bf3(const crnView* x, const crnInTransform* tr, cons
   g.kd = kd; g.kh = kh; g.kw = kw; g.pd = pd; g.ph = ph; g.pw = pw + g.lead;
   g.T = kd * kh * kw; g.KHW = kh * kw;
   g.NG = (g.KHW + 3) / 4;
-  if (g.NG * 4 > kMaxTapSlots || kd > 8) return CRN_EINVAL;
+  if ((g.NG != 4 && g.NG != 7) || kd > 8) return CRN_EINVAL;           // instantiated: 4x4 and 5x5 window planes
   g.TD = 4; g.TH = 8;
   g.PD = g.TD + kd - 1; g.PH = g.TH + kh - 1; g.PW = (g.lead + 16 + kw - 1 + 1) & ~1;
   g.PHW = g.PH * g.PW; g.NP = g.PD * g.PHW;
@@ -416,10 +427,10 @@ extern "C" int crn_conv_fwd_bf3(const crnView* x, const crnInTransform* tr, cons
   if (have_nbox && (y->C / g.n_groups) % 16 == 0) NSUB = 1;
   if (const char* f = getenv("CRN_BF3_NSUB")) NSUB = atoi(f);
   auto lds_of = [&](int nsub) { return (size_t)(3 * kTabC * 4 + kMaxTapSlots * 4) + (size_t)2 * g.NP * 16 + (size_t)2 * g.NG * 4 * nsub * 16 * 16; };
-  while (NSUB > 1 && (lds_of(NSUB) > 160 * 1024 - 512 || g.NG * 4 * NSUB * 16 > kNWI * kThreads)) NSUB >>= 1;
+  while (NSUB > 1 && lds_of(NSUB) > 160 * 1024 - 512) NSUB >>= 1;
   if (NSUB != 1 && NSUB != 2 && NSUB != 4) return CRN_EINVAL;
   const size_t lds = lds_of(NSUB);
-  if (lds > 160 * 1024 - 512 || g.NG * 4 * NSUB * 16 > kNWI * kThreads) return CRN_EINVAL;
+  if (lds > 160 * 1024 - 512) return CRN_EINVAL;
   if ((int64_t)x->C * g.T * Npad >= ((int64_t)1 << 29)) return CRN_EINVAL;
   g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
   dim3 grid((unsigned)(g.tilesD * g.tilesH * g.tilesW * y->B), (unsigned)crn_cdiv(Npad, NSUB * 16), 1);
@@ -428,9 +439,10 @@ extern "C" int crn_conv_fwd_bf3(const crnView* x, const crnInTransform* tr, cons
     fprintf(stderr, "[crn_conv_fwd_bf3] x(C%d %dx%dx%d) y(C%d %dx%dx%d) k%dx%dx%d: NSUB %d xmode %d patch %dx%dx%d units %d "
             "NG %d grid %ux%u lds %zu\n", x->C, x->D, x->H, x->W, y->C, y->D, y->H, y->W, kd, kh, kw, NSUB, xmode, g.PD, g.PH,
             g.PW, g.nunits, g.NG, grid.x, grid.y, lds);
-#define CRN_BF3_CASE(N, X) if (NSUB == N && xmode == X) return launch_bf3<N, X>(g, grid, lds, st);
-  CRN_BF3_CASE(1, 1) CRN_BF3_CASE(2, 1) CRN_BF3_CASE(4, 1)
-  CRN_BF3_CASE(1, 2) CRN_BF3_CASE(2, 2) CRN_BF3_CASE(4, 2)
+#define CRN_BF3_CASE(N, X, G) if (NSUB == N && xmode == X && g.NG == G) return launch_bf3<N, X, G>(g, grid, lds, st);
+  CRN_BF3_CASE(1, 1, 7) CRN_BF3_CASE(2, 1, 7) CRN_BF3_CASE(4, 1, 7)
+  CRN_BF3_CASE(1, 1, 4) CRN_BF3_CASE(2, 1, 4) CRN_BF3_CASE(4, 1, 4)
+  CRN_BF3_CASE(1, 2, 4) CRN_BF3_CASE(2, 2, 4) CRN_BF3_CASE(4, 2, 4)
 #undef CRN_BF3_CASE
   return CRN_EINVAL;
 }

@@ -99,7 +99,9 @@ class _CoreNetFn(t.autograd.Function):
 class CoreNet(nn.Module):
   """Image to 3D reconstruction with CoReNet (MI355X-native)."""
 
-  def __init__(self, config, device: Optional[str] = None, backend=None):
+  def __init__(self, config, device: Optional[str] = None, backend=None, decoder_math: Optional[str] = None):
+    """decoder_math: "fp32" (default; also env CRN_DECODER_MATH) or "bf16x3" -- the big decoder convolutions on
+    the split-bf16 MFMA engine (engine.BF16X3_LAUNCHES), a throughput mode with ~3e-6 relative error per layer."""
     super().__init__()
     self.config = config
     dc = config.decoder
@@ -107,7 +109,8 @@ class CoreNet(nn.Module):
       device = f"cuda:{t.cuda.current_device()}" if t.cuda.is_available() else "cuda"
     self.engine = Engine(dc.num_output_channels, resolution=tuple(dc.resolution),
                          latent_channels=dc.latent_channels, skip_fraction=dc.skip_fraction,
-                         last_upscale_factor=dc.last_upscale_factor, device=device, backend=backend)
+                         last_upscale_factor=dc.last_upscale_factor, device=device, backend=backend,
+                         decoder_math=decoder_math)
     self._tree_root = _Tree()
     self._param_keys = []
     for key, shape, kind in self.engine.specs:

@@ -43,6 +43,14 @@ ENC_STAGES = (("stage2", "abc", (64, 64, 256), 1), ("stage3", "abcd", (128, 128,
 # gets the same effect from DDP's reverse-order 25 MB buckets.
 GRAD_BUCKET_LABELS = ("decoder.stage_3.", "decoder.stage_0.", "encoder.stage5.c.", "encoder.stage5.b.",
                       "encoder.stage5.a.", "encoder.stage4.a.", "")
+# Layers (and directions) that run on the split-bf16 MFMA engine when Engine(decoder_math="bf16x3"): the
+# Conv3d k5 / ConvTranspose3d k7 of decoder stages 4-6 (reconstruction_decoder.py:72-95), except the two
+# launches whose grids cannot fill the chip with 512-position tiles and are faster on the fp32 engine
+# (measured, profiles/r02_bf16x3_layers.txt).  Everything else -- encoder, stages 0-3, all weight gradients
+# until they have their own kernel -- stays on the fp32 MFMA engine.
+BF16X3_LAUNCHES = frozenset(
+    (f"decoder.stage_{k}.{l}.", d) for k in (4, 5, 6) for l in ("c1", "t1") for d in ("fwd", "dgrad")
+) - {("decoder.stage_4.c1.", "fwd"), ("decoder.stage_4.t1.", "dgrad")}
 LOSS_KINDS = {"iou_fgbg": 0, "xent_times_iou_agnostic": 1, "iou_agnostic": 2, "xent": 3,
               "xent_times_iou_fgbg": 4}
 
@@ -174,7 +182,7 @@ class Engine:
 
   def __init__(self, num_classes: int, resolution=(128, 128, 128), latent_channels: int = 64,
                skip_fraction: float = 0.75, last_upscale_factor: int = 2, device="cuda",
-               backend=None, dtype=t.float32):
+               backend=None, dtype=t.float32, decoder_math: Optional[str] = None):
     if tuple(resolution) != (128, 128, 128) or last_upscale_factor != 2:
       # the reference decoder only runs at 128^3 with factor 2
       raise ValueError("the CoReNet decoder is only defined for resolution 128^3, "
@@ -183,6 +191,11 @@ class Engine:
       from corenet_amd.backend import default_backend
       backend = default_backend()
     self.be = backend
+    # "fp32": v_mfma_f32_16x16x4_f32 everywhere (the parity default, the reference is fp32 end to end);
+    # "bf16x3": BF16X3_LAUNCHES run as three bf16 MFMAs per product with fp32 accumulation (throughput mode)
+    self.decoder_math = decoder_math or os.environ.get("CRN_DECODER_MATH", "fp32")
+    if self.decoder_math not in ("fp32", "bf16x3"):
+      raise ValueError(f"decoder_math must be 'fp32' or 'bf16x3', not {self.decoder_math!r}")
     # fp32 is the only dtype of the HIP kernels; float64 exists so that the CPU
     # contract emulator (tests/) can check the host wiring far below fp32 noise.
     assert dtype == t.float32 or getattr(backend, "name", "") == "emu"
@@ -505,15 +518,20 @@ class Plan:
     a.record(); fn(); b.record()
     self.trace.append((label, a, b))
 
+  def _math(self, cv: Conv, direction: str) -> str:
+    return "bf16x3" if self.eng.decoder_math == "bf16x3" and (cv.name, direction) in BF16X3_LAUNCHES else "fp32"
+
   def _conv(self, cv: Conv, x: V.View, tr, y: V.View, accumulate=False):
     g = cv.fwd
     self._timed("fwd   " + cv.name, lambda: self.be.conv_fwd(
-        x, tr, cv.wf, g.npad, cv.bias, 0, y, g.window, g.pad_lo, 0, accumulate, boxes=(g.n_boxes, g.c_boxes)))
+        x, tr, cv.wf, g.npad, cv.bias, 0, y, g.window, g.pad_lo, 0, accumulate, boxes=(g.n_boxes, g.c_boxes),
+        math=self._math(cv, "fwd")))
 
   def _dgrad(self, cv: Conv, dy: V.View, dx: V.View, accumulate=False):
     g = cv.dgrad
     self._timed("dgrad " + cv.name, lambda: self.be.conv_fwd(
-        dy, None, cv.wd, g.npad, None, 0, dx, g.window, g.pad_lo, 0, accumulate, boxes=(g.n_boxes, g.c_boxes)))
+        dy, None, cv.wd, g.npad, None, 0, dx, g.window, g.pad_lo, 0, accumulate, boxes=(g.n_boxes, g.c_boxes),
+        math=self._math(cv, "dgrad")))
 
   def _wgrad(self, cv: Conv, x: V.View, tr, dy: V.View):
     """Weight gradient of one conv.  On the GPU it goes to a second HIP stream: it only reads

@@ -20,9 +20,9 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _model(nc, sd):
+def _model(nc, sd, decoder_math="fp32"):
   from corenet_amd.model.core_net import CoreNet, CoreNetConfig, DecoderConfig
-  m = CoreNet(CoreNetConfig(DecoderConfig((128, 128, 128), nc, 2, 64, 0.75)), device="cuda")
+  m = CoreNet(CoreNetConfig(DecoderConfig((128, 128, 128), nc, 2, 64, 0.75)), device="cuda", decoder_math=decoder_math)
   missing = m.load_state_dict(sd)
   assert not missing.missing_keys and not missing.unexpected_keys
   return m
@@ -58,6 +58,50 @@ def test_forward_eval_golden():
   assert abs(float(logits.double().sum()) - float(z["logits_sum"])) < 1e-4 * float(z["logits_abs_sum"])
   from corenet_amd.model import losses
   assert abs(float(losses.iou_fgbg(grid.cuda(), logits)) - float(z["loss"])) < 1e-5
+
+
+def test_bf16x3_mode_against_goldens_and_fp32_mode():
+  """Engine(decoder_math="bf16x3"): decoder stages 4-6 on the split-bf16 MFMA engine.  It must hold the same
+  bars as the fp32 mode -- eval logits 1e-4 against the reference fixture, train logits 1e-3 (north_star), loss,
+  last-layer gradient, running statistics -- and stay close to the fp32 mode of this library on the bench batch
+  (B=4, train); measured errors are printed."""
+  from corenet_amd.model import losses
+  z = np.load(os.path.join(G, "model_h7_eval_b1.npz"))
+  m = _model(2, O.make_state(0, 2, nbt=100), "bf16x3").eval()
+  image, v2s, off, grid = O.synthetic_batch(1, 0, 2)
+  with t.no_grad():
+    logits = m(image.cuda(), v2s.cuda(), off.cuda())
+  e = relerr(logits[:, :, ::16, ::16, ::16], z["logits_sub"])
+  print(f"bf16x3 eval logits vs reference fixture: {e:.2e}")
+  assert e < 1e-4
+  assert abs(float(losses.iou_fgbg(grid.cuda(), logits)) - float(z["loss"])) < 1e-5
+  for tag, nc, nbt, B, lossname in (("h7_train_b1", 2, 0, 1, "iou_fgbg"), ("h7_train_b2_nbt30k", 2, 30000, 2, "iou_fgbg"),
+                                    ("m9_train_b1", 14, 0, 1, "xent_times_iou_agnostic")):
+    z = np.load(os.path.join(G, f"model_{tag}.npz"))
+    m = _model(nc, O.make_state(0, nc, nbt=nbt), "bf16x3").train()
+    image, v2s, off, grid = O.synthetic_batch(B, 0, nc)
+    logits = m(image.cuda(), v2s.cuda(), off.cuda())
+    e = relerr(logits[:, :, ::16, ::16, ::16], z["logits_sub"])
+    print(f"bf16x3 {tag} logits vs reference fixture: {e:.2e}")
+    assert e < 1e-3
+    loss = getattr(losses, lossname)(grid.cuda(), logits)
+    assert abs(float(loss) - float(z["loss"])) < 2e-4 * max(1.0, abs(float(z["loss"])))
+    loss.backward()
+    eg = relerr(m.get_parameter("decoder.stage_6.t1.weight").grad, z["grad::decoder.stage_6.t1.weight"])
+    print(f"bf16x3 {tag} grad stage_6.t1.weight: {eg:.2e}")
+    assert eg < 2e-3
+    for k in z.files:
+      if k.startswith("buf::"):
+        assert relerr(m.state_dict()[k[5:]], z[k]) < 1e-4, k
+  # bench batch, train mode, both math modes of this library from the same state
+  sd = O.make_state(0, 2, nbt=0)
+  ma, mb = _model(2, sd, "bf16x3").train(), _model(2, sd, "fp32").train()
+  image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(4, 0, 2)]
+  la = float(ma.train_step(image, v2s, off, grid.to(t.int32), "iou_fgbg", lr=4e-4, adam_eps=1e-4))
+  lb = float(mb.train_step(image, v2s, off, grid.to(t.int32), "iou_fgbg", lr=4e-4, adam_eps=1e-4))
+  e = relerr(ma.engine.plan(4).logits, mb.engine.plan(4).logits)
+  print(f"bf16x3 vs fp32 mode, B=4 train logits: {e:.2e}; loss {la:.6f} vs {lb:.6f}; gradient slab {_slab_err(ma, mb):.2e}")
+  assert e < 1e-3 and abs(la - lb) < 1e-4 * abs(lb)
 
 
 def test_forward_eval_b4_matches_oracle():

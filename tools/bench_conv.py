@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmark of one conv layer through the C ABI (for rocprofv3 --pmc runs).
-usage: bench_conv.py <fwd|dgrad|wgrad> <layer-key> [iters] [B]"""
+usage: bench_conv.py <fwd|dgrad|wgrad> <layer-key> [iters] [B] [fp32|bf16x3]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch as t
@@ -27,6 +27,7 @@ LAYERS = {  # name: (kind, wshape, pad, in dims)
 mode, key = sys.argv[1], sys.argv[2]
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+MATH = sys.argv[5] if len(sys.argv) > 5 else "fp32"
 kind, wshape, pad, dims = LAYERS[key]
 be = HipBackend()
 g = t.Generator().manual_seed(0)
@@ -46,8 +47,8 @@ tr = Transform(sc, shf, pre_relu=True)
 yv = V.space_to_depth_view(V.view_of(y), (2, 2, 2), parity_major=True) if kind == "convT" else V.view_of(y)
 dw = t.zeros(wf.numel()).cuda()
 def run():
-  if mode == "fwd": be.conv_fwd(V.view_of(x), tr, wf, fwd.npad, None, 0, yv, fwd.window, fwd.pad_lo, 0, boxes=(fwd.n_boxes, fwd.c_boxes))
-  elif mode == "dgrad": be.conv_fwd(yv, None, wd, dgr.npad, None, 0, V.view_of(x), dgr.window, dgr.pad_lo, 0, boxes=(dgr.n_boxes, dgr.c_boxes))
+  if mode == "fwd": be.conv_fwd(V.view_of(x), tr, wf, fwd.npad, None, 0, yv, fwd.window, fwd.pad_lo, 0, boxes=(fwd.n_boxes, fwd.c_boxes), math=MATH)
+  elif mode == "dgrad": be.conv_fwd(yv, None, wd, dgr.npad, None, 0, V.view_of(x), dgr.window, dgr.pad_lo, 0, boxes=(dgr.n_boxes, dgr.c_boxes), math=MATH)
   else: be.conv_wgrad(V.view_of(x), tr, yv, dw, fwd.npad, fwd.window, fwd.pad_lo, True, boxes=(fwd.n_boxes, fwd.c_boxes))
 for _ in range(3): run()
 t.cuda.synchronize(); a = t.cuda.Event(enable_timing=True); b = t.cuda.Event(enable_timing=True)
@@ -57,4 +58,4 @@ b.record(); t.cuda.synchronize()
 ms = a.elapsed_time(b) / iters
 import numpy as np
 flop = 2.0 * B * np.prod(dims) * cin * cout * np.prod(wshape[2:])
-print(f"{mode} {key} B={B}: {ms*1e3:.1f} us  {flop/ms/1e9:.1f} TFLOP/s (real flops)")
+print(f"{mode} {key} B={B} {MATH}: {ms*1e3:.1f} us  {flop/ms/1e9:.1f} TFLOP/s (real flops)")

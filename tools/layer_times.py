@@ -8,7 +8,8 @@ from corenet_amd.model.core_net import CoreNet, CoreNetConfig, DecoderConfig
 
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 B = 4
-m = CoreNet(CoreNetConfig(DecoderConfig((128, 128, 128), C, 2, 64, 0.75)), device="cuda")
+MATH = sys.argv[3] if len(sys.argv) > 3 else "fp32"
+m = CoreNet(CoreNetConfig(DecoderConfig((128, 128, 128), C, 2, 64, 0.75)), device="cuda", decoder_math=MATH)
 m.load_state_dict(O.make_state(0, C)); m.train()
 image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(B, 0, C)]
 loss = "iou_fgbg" if C == 2 else "xent_times_iou_agnostic"
