@@ -115,6 +115,9 @@ def cpu_baseline_fill(shells_cpu, seconds_budget=5.0):
           "sample": f"{n} calls on {shells_cpu.shape[0]} x 128^3 fp32 shells"}
 
 
+GRAPH = os.environ.get("CRN_GRAPH", "0") == "1"      # replay the captured HIP graph of the step (off: measured slower)
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -156,7 +159,8 @@ def main():
                             all_reduce=sync if world > 1 else None)
     for _ in range(args.warmup):
       step()
-    pl.probes = {"conv3d_stage6_c1_fwd": [], "ray_sample_fwd_64": [], "grad_exchange_wait": []}
+    if world > 1 or not GRAPH:     # launch-by-launch steps: HIP-event probes ride along in the timed region
+      pl.probes = {"conv3d_stage6_c1_fwd": [], "ray_sample_fwd_64": [], "grad_exchange_wait": []}
     if world > 1:
       dist.barrier()
     t.cuda.synchronize()
@@ -170,6 +174,13 @@ def main():
     tt = t.tensor([dt], dtype=t.float64, device=dev)
     if world > 1:
       dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    if world == 1 and GRAPH:
+      # the timed steps were replays of the captured HIP graph (one launch per step), which cannot carry timing
+      # events: the per-kernel probes come from 3 launch-by-launch steps on the same buffers right after it
+      pl.probes = {"conv3d_stage6_c1_fwd": [], "ray_sample_fwd_64": [], "grad_exchange_wait": []}
+      for _ in range(3):
+        step()
+      t.cuda.synchronize()
     pr = {k: sum(a.elapsed_time(b) for a, b in v) / max(1, len(v)) * 1e-3 for k, v in pl.probes.items()}
     pl.probes = None
     return float(tt), pr, loss
@@ -276,6 +287,8 @@ def main():
                              f"256x256 RGB -> 128^3, C={C}, B={B}/GPU, decoder_math={args.math}, random-init weights",
                  "global_batch": world * B, "parallelism": f"dp{world}"},
       "loss": float(loss),
+      "launch": ("one captured HIP graph per step (CoreNet.train_step); kernel probes from 3 launch-by-launch steps after "
+                 "the timed region" if world == 1 and GRAPH else "launch by launch (kernel probes inside the timed region)"),
       "eval_forward": {"ms_per_batch": eval_s * 1e3, "value": B * 128 ** 3 / eval_s, "unit": "voxels/s",
                        "note": "rank 0, forward only, eval mode, same inputs"},
       "roofline": {"kernel": conv_kernel_name,

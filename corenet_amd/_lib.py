@@ -76,6 +76,8 @@ _SIGS = {
     "crn_argmax_confusion": [vp, vp, i32, i32, i64, vp, vp, vp],
     "crn_softmax_superres": [vp, i32, i32, i32, i32, i32, i32, vp, vp],
     "crn_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp],
+    "crn_adam_set_hyper": [vp, f32, f32, f32, f32, f32, i32, vp],
+    "crn_adam_step_hyper": [vp, vp, vp, vp, i64, vp, vp],
     "crn_fill_voxels": [vp, vp, i32, i32, i32, i32, i32, vp, sz, vp],
     "crn_fill_voxels_cpu": [vp, vp, i32, i32, i32, i32, i32, i32],
     "crn_voxelize_mesh": [vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp],

@@ -212,6 +212,12 @@ class HipBackend:
     self.lib.crn_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), n, lr, b1, b2, eps, grad_scale, step,
                            _lib.stream())
 
+  def adam_set_hyper(self, hyper, lr, b1, b2, eps, grad_scale, step):
+    self.lib.crn_adam_set_hyper(ptr(hyper), lr, b1, b2, eps, grad_scale, step, _lib.stream())
+
+  def adam_step_hyper(self, p, g, m, v, n, hyper):
+    self.lib.crn_adam_step_hyper(ptr(p), ptr(g), ptr(m), ptr(v), n, ptr(hyper), _lib.stream())
+
   def add_i64(self, p, n, v):
     self.lib.crn_add_i64(ptr(p), n, v, _lib.stream())
 

@@ -209,6 +209,45 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// The same step with its scalars in device memory (hyper = lr, beta1, beta2, eps, grad_scale, 1 - beta1^t,
+// sqrt(1 - beta2^t)): the launch carries no per-step host value, so it can sit in a captured HIP graph that is
+// replayed every step (crn_adam_set_hyper refreshes the seven floats with an ordinary launch before the replay).
+__global__ __launch_bounds__(256) void adam_hyper_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, int64_t n4,
+                                                         int64_t n, const float* __restrict__ hyper) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], gs = hyper[4], bc1 = hyper[5], bc2_sqrt = hyper[6];
+  const float step = lr / bc1;
+  auto one = [&](float& pp, float gg, float& mm, float& vv) {
+    gg *= gs;
+    mm = mm + (1.f - b1) * (gg - mm);
+    vv = b2 * vv + (1.f - b2) * gg * gg;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pp -= step * (mm / denom);
+  };
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float P[4], M[4], V[4], G[4];
+    *reinterpret_cast<f32x4*>(P) = reinterpret_cast<f32x4*>(p)[i];
+    *reinterpret_cast<f32x4*>(M) = reinterpret_cast<f32x4*>(m)[i];
+    *reinterpret_cast<f32x4*>(V) = reinterpret_cast<f32x4*>(v)[i];
+    *reinterpret_cast<f32x4*>(G) = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) one(P[k], G[k], M[k], V[k]);
+    reinterpret_cast<f32x4*>(p)[i] = *reinterpret_cast<f32x4*>(P);
+    reinterpret_cast<f32x4*>(m)[i] = *reinterpret_cast<f32x4*>(M);
+    reinterpret_cast<f32x4*>(v)[i] = *reinterpret_cast<f32x4*>(V);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    if (i < n) one(p[i], g[i], m[i], v[i]);
+  }
+}
+
+__global__ void set_hyper_kernel(float* hyper, float a0, float a1, float a2, float a3, float a4, float a5, float a6) {
+  if (threadIdx.x == 0) {
+    hyper[0] = a0; hyper[1] = a1; hyper[2] = a2; hyper[3] = a3; hyper[4] = a4; hyper[5] = a5; hyper[6] = a6;
+  }
+}
+
 inline unsigned nblk(int64_t n, int per = 256) { return (unsigned)std::max<int64_t>(1, (n + per - 1) / per); }
 
 }  // namespace
@@ -337,6 +376,27 @@ extern "C" int crn_adam_step(float* param, const float* grad, float* exp_avg, fl
   const int64_t n4 = n / 4;
   hipLaunchKernelGGL(adam_kernel, dim3(std::min(nblk(n4), 8192u)), dim3(256), 0, (hipStream_t)s, param, grad, exp_avg,
                      exp_avg_sq, n4, n, lr, beta1, beta2, eps, grad_scale, (float)bc1, (float)std::sqrt(bc2));
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_adam_set_hyper(float* hyper, float lr, float beta1, float beta2, float eps, float grad_scale,
+                                  int step, crnStream s) {
+  if (!hyper || step < 1) return CRN_EINVAL;
+  const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
+  hipLaunchKernelGGL(set_hyper_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, hyper, lr, beta1, beta2, eps, grad_scale,
+                     (float)bc1, (float)std::sqrt(bc2));
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_adam_step_hyper(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                   const float* hyper, crnStream s) {
+  if (n < 1 || !hyper) return CRN_EINVAL;
+  if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return CRN_EINVAL;
+  const int64_t n4 = n / 4;
+  hipLaunchKernelGGL(adam_hyper_kernel, dim3(std::min(nblk(n4), 8192u)), dim3(256), 0, (hipStream_t)s, param, grad,
+                     exp_avg, exp_avg_sq, n4, n, hyper);
   CRN_CHECK_LAUNCH();
   return CRN_OK;
 }

@@ -12,6 +12,7 @@ wrapped by DistributedDataParallel.  All arithmetic runs in libcorenet_hip.so.
 from __future__ import annotations
 
 import contextlib
+import os
 import dataclasses
 import math
 from typing import Any, Dict, Optional, Tuple
@@ -45,6 +46,22 @@ class CoreNetConfig:
     dd = dict(d["decoder"])
     dd["resolution"] = tuple(dd["resolution"])
     return cls(decoder=DecoderConfig(**dd))
+
+
+_LIVE_GRAPHS = []      # captured steps; released before interpreter teardown (graph destruction after the HIP
+                       # runtime has started to unload faults)
+
+
+def _release_graphs():
+  while _LIVE_GRAPHS:
+    try:
+      _LIVE_GRAPHS.pop().reset()
+    except Exception:
+      pass
+
+
+import atexit  # noqa: E402
+atexit.register(_release_graphs)
 
 
 class _Tree(nn.Module):
@@ -235,24 +252,75 @@ class CoreNet(nn.Module):
   def train_step(self, image: t.Tensor, voxel_projection_matrix: t.Tensor,
                  voxel_sample_locations: t.Tensor, grid: t.Tensor, loss: str = "iou_fgbg",
                  lr: float = 4e-4, adam_eps: float = 1e-4, world_size: int = 1,
-                 all_reduce=None) -> t.Tensor:
+                 all_reduce=None, graph: Optional[bool] = None) -> t.Tensor:
     """forward -> loss -> backward -> (gradient all-reduce) -> Adam, without
-    autograd bookkeeping.  Returns the loss as a 1-element device tensor (no sync)."""
+    autograd bookkeeping.  Returns the loss as a 1-element device tensor (no sync).
+
+    graph (default: off; env CRN_GRAPH=1 or graph=True turns it on): without a gradient exchange the whole step
+    is static per batch size, so it can be captured once into a HIP graph (second call) and replayed afterwards.
+    The inputs are copied into plan-owned buffers first, and Adam reads its scalars (lr, eps, bias corrections of
+    this step count) from a small device buffer refreshed by an ordinary launch before every replay.
+    Measured on MI355X / ROCm 7.0 (tools/cpu_enqueue.py, profiles/r02_graph_vs_eager.txt): hipGraphLaunch still
+    walks the ~650 kernel nodes on the host (3.6 ms per step vs 6.5 ms launch by launch through ctypes) and the
+    replay loses the overlap of the weight-gradient stream with the data-gradient chain (15.2 vs 13.5 ms per
+    step), so launch by launch stays the default while the GPU needs more than the host's 6.5 ms per step."""
     from corenet_amd.model.engine import LOSS_KINDS
     eng = self.engine
     B, C = image.shape[0], eng.num_classes
-    plan = eng.plan(B)
-    plan.forward(image.contiguous(), voxel_projection_matrix, voxel_sample_locations, training=True)
-    plan.gt.copy_(grid)
-    eng.be.loss_fwd_bwd(LOSS_KINDS[loss], plan.logits, plan.gt, B, C, 128 ** 3, plan.loss,
+    with self._on_device():
+      plan = eng.plan(B)
+      if graph is None:
+        graph = os.environ.get("CRN_GRAPH", "0") == "1"
+      graphable = (all_reduce is None and eng.device.type == "cuda" and plan.probes is None and plan.trace is None)
+      if graph and graphable:
+        return self._train_step_graph(plan, image, voxel_projection_matrix, voxel_sample_locations, grid, loss, lr,
+                                      adam_eps, 1.0 / world_size)
+      plan.forward(image.contiguous(), voxel_projection_matrix, voxel_sample_locations, training=True)
+      plan.gt.copy_(grid)
+      eng.be.loss_fwd_bwd(LOSS_KINDS[loss], plan.logits, plan.gt, B, C, 128 ** 3, plan.loss,
+                          plan.glogits, 1.0)
+      if all_reduce is not None and getattr(all_reduce, "overlap", False):
+        all_reduce.pushed.clear()
+        plan.backward(plan.glogits, grad_hook=all_reduce.push)   # buckets are reduced while backward runs
+        plan._probe("grad_exchange_wait", all_reduce.wait)       # what is left of the exchange once backward is done
+      else:
+        plan.backward(plan.glogits)
+        if all_reduce is not None:
+          all_reduce(eng.store.grads)
+      eng.adam_step(lr, adam_eps, grad_scale=1.0 / world_size)
+      return plan.loss
+
+  def _step_body(self, plan, loss: str):
+    """The static part of a fused step on the plan's own input buffers (what the graph captures)."""
+    from corenet_amd.model.engine import LOSS_KINDS
+    eng = self.engine
+    eng.weights_dirty = True                   # the step starts by packing the (just stepped) parameters
+    plan.forward(plan.in_image, plan.in_v2s, plan.in_off, training=True)
+    eng.be.loss_fwd_bwd(LOSS_KINDS[loss], plan.logits, plan.gt, plan.B, eng.num_classes, 128 ** 3, plan.loss,
                         plan.glogits, 1.0)
-    if all_reduce is not None and getattr(all_reduce, "overlap", False):
-      all_reduce.pushed.clear()
-      plan.backward(plan.glogits, grad_hook=all_reduce.push)   # buckets are reduced while backward runs
-      plan._probe("grad_exchange_wait", all_reduce.wait)       # what is left of the exchange once backward is done
-    else:
-      plan.backward(plan.glogits)
-      if all_reduce is not None:
-        all_reduce(eng.store.grads)
-    eng.adam_step(lr, adam_eps, grad_scale=1.0 / world_size)
+    plan.backward(plan.glogits)
+    eng.adam_update_from_hyper()
+
+  def _train_step_graph(self, plan, image, v2s, offset, grid, loss, lr, adam_eps, grad_scale) -> t.Tensor:
+    eng = self.engine
+    plan.in_image.copy_(image); plan.in_v2s.copy_(v2s); plan.in_off.copy_(offset); plan.gt.copy_(grid)
+    eng.adam_step_graphable(lr, adam_eps, grad_scale=grad_scale, launch=False)
+    g = plan.graphs.get(loss)
+    if g is None and plan.eager_steps < 1:
+      # first step: launch by launch (sizes the workspaces, sets kernel attributes, allocates the split-K scratch:
+      # nothing of that may happen inside a capture)
+      self._step_body(plan, loss)
+      plan.eager_steps += 1
+      return plan.loss
+    if g is None:
+      g = t.cuda.CUDAGraph()
+      cap = t.cuda.Stream(device=eng.device)
+      cap.wait_stream(t.cuda.current_stream())
+      with t.cuda.graph(g, stream=cap):
+        self._step_body(plan, loss)
+      t.cuda.current_stream().wait_stream(cap)
+      plan.graphs[loss] = g
+      _LIVE_GRAPHS.append(g)
+    g.replay()
+    eng.weights_dirty = True                   # for whatever runs next outside the graph (eval forward, autograd path)
     return plan.loss

@@ -215,6 +215,7 @@ class Engine:
     self.adam_m: Optional[t.Tensor] = None
     self.adam_v: Optional[t.Tensor] = None
     self.adam_t = 0
+    self.adam_hyper: Optional[t.Tensor] = None
     self.dgrad_dirty = True
     self.weights_dirty = True
 
@@ -389,6 +390,25 @@ class Engine:
                       self.store.params.numel(), lr, betas[0], betas[1], eps, grad_scale, self.adam_t)
     self.weights_dirty = True
 
+  def adam_step_graphable(self, lr: float, eps: float, betas=(0.9, 0.999), grad_scale: float = 1.0, launch: bool = True):
+    """The same step split for HIP-graph replay: the scalars (incl. the bias corrections of this step count) go to
+    a small device buffer with an ordinary launch, the update itself (`launch`) reads them from there and so can
+    be a node of a captured graph."""
+    if self.adam_m is None:
+      self.adam_m = t.zeros_like(self.store.params)
+      self.adam_v = t.zeros_like(self.store.params)
+    if self.adam_hyper is None:
+      self.adam_hyper = t.zeros(8, dtype=t.float32, device=self.device)
+    self.adam_t += 1
+    self.be.adam_set_hyper(self.adam_hyper, lr, betas[0], betas[1], eps, grad_scale, self.adam_t)
+    if launch:
+      self.adam_update_from_hyper()
+
+  def adam_update_from_hyper(self):
+    self.be.adam_step_hyper(self.store.params, self.store.grads, self.adam_m, self.adam_v,
+                            self.store.params.numel(), self.adam_hyper)
+    self.weights_dirty = True
+
 
 class Plan:
   """Buffers + the explicit forward / backward sequences for one batch size."""
@@ -397,10 +417,16 @@ class Plan:
     self.eng, self.B = eng, B
     self.be = eng.be
     self.generation = 0            # bumped by every forward: CoreNet's autograd node checks it in backward
+    self.graphs = {}               # captured training steps (CoreNet.train_step): loss name -> CUDAGraph
+    self.eager_steps = 0           # fused steps run eagerly on this plan (the first one also sizes every workspace)
     self._views = {}
     dev = eng.device
     self.dev = dev
     f = lambda *shape: t.zeros(*shape, dtype=eng.dtype, device=dev)
+    # static inputs of the captured training step (a replayed graph reads fixed addresses)
+    self.in_image = t.zeros(B, 3, 256, 256, dtype=t.uint8, device=dev)
+    self.in_v2s = f(B, 4, 4)
+    self.in_off = f(B, 3)
     self.img = f(B, 3, 256, 256)
     self.y1 = f(B, 64, 128, 128)
     self.gy1 = f(B, 64, 128, 128); self.gy1b = f(B, 64, 128, 128)

@@ -246,6 +246,14 @@ int crn_softmax_superres(const float* logits, int m, int B, int C, int D, int H,
 int crn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                   int64_t n, float lr, float beta1, float beta2, float eps,
                   float grad_scale, int step, crnStream s);
+/* The same step with its scalars read from device memory, for HIP-graph capture of the training step
+ * (the replayed launch carries no per-step host value): hyper = 7 floats written by crn_adam_set_hyper
+ * (lr, beta1, beta2, eps, grad_scale, 1 - beta1^step, sqrt(1 - beta2^step)) with an ordinary launch
+ * ordered before the graph replay.                                                                     */
+int crn_adam_set_hyper(float* hyper, float lr, float beta1, float beta2, float eps, float grad_scale,
+                       int step, crnStream s);
+int crn_adam_step_hyper(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                        int64_t n, const float* hyper, crnStream s);
 
 /* ---------------- ground-truth side -------------------------------------------
  * fill_inside_voxels_gpu (cc/fill_voxels_gpu.cu:136-171, module.cc:18-29):

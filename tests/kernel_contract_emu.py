@@ -300,6 +300,16 @@ class EmuBackend:
     bc1 = 1 - b1 ** step; bc2 = 1 - b2 ** step
     p.sub_((lr / bc1) * (m / (v.sqrt() / np.sqrt(bc2) + eps)))
 
+  def adam_set_hyper(self, hyper, lr, b1, b2, eps, grad_scale, step):
+    hyper[:7] = t.tensor([lr, b1, b2, eps, grad_scale, 1 - b1 ** step, np.sqrt(1 - b2 ** step)], dtype=hyper.dtype)
+
+  def adam_step_hyper(self, p, g, m, v, n, hyper):
+    lr, b1, b2, eps, gs, bc1, bc2s = [float(x) for x in hyper[:7]]
+    gg = g * gs
+    m.add_((gg - m) * (1 - b1))
+    v.mul_(b2).add_(gg * gg * (1 - b2))
+    p.sub_((lr / bc1) * (m / (v.sqrt() / bc2s + eps)))
+
   def transform_meshes(self, triangles, tri_mesh, mesh_matrix, out):
     m = mesh_matrix[tri_mesh.long()]                                  # [T,4,4]
     pts = t.cat([triangles, t.ones_like(triangles[..., :1])], -1)     # [T,3,4]

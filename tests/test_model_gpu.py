@@ -123,8 +123,9 @@ def test_forward_eval_b4_matches_oracle():
 # tensor below the loss: last layer / its norm / the 64^3 skip compression (through stage_6) / the latent bias
 # (through the whole decoder; BatchRenorm over B=1 has zero gradient there).  The reference itself moves by
 # 4e-5 ... 5e-2 between fp32 and fp64 on these inputs ("Conditioning").
-FULL_GRAD_TOL = {"decoder.stage_6.t1.weight": 2e-3, "decoder.stage_6.b2.weight": 5e-3,
-                 "decoder.rt_skip_5.compress_channels.weight": 2e-2, "decoder.stage_0.bias": 1e-1}
+FULL_GRAD_TOL = {"decoder.stage_6.t1.weight": 5e-4, "decoder.stage_6.b2.weight": 5e-4,
+                 "decoder.rt_skip_5.compress_channels.weight": 2e-2, "decoder.stage_0.bias": 5e-2}
+# measured (MI355X, round 2): 5.8e-5 / 3.0e-5 / 4.2e-3 / 1.6e-2 at worst over the three fixtures
 
 
 @pytest.mark.parametrize("tag,nc,nbt,B,lossname", [("h7_train_b1", 2, 0, 1, "iou_fgbg"),
@@ -295,7 +296,7 @@ def test_train_step_reduces_loss_and_matches_autograd_path():
     assert abs(float(loss) - ls[-1]) < 1e-4 * abs(ls[-1]), (step, float(loss), ls[-1])
     e = _slab_err(ma, m)
     print(f"autograd path vs train_step, step {step}: gradient slab err {e:.2e}")
-    assert e < 1e-2, (step, e)
+    assert e < 1e-3, (step, e)                      # measured 2e-6
     assert ma.engine.adam_t == m.engine.adam_t == step + 1
     if step == 0:
       t.cuda.synchronize(); mem0 = t.cuda.memory_allocated()
@@ -323,6 +324,34 @@ def test_train_step_reduces_loss_and_matches_autograd_path():
     ma(image, v2s, off)
   with pytest.raises(RuntimeError, match="overwritten"):
     l1.backward()
+
+
+def test_train_step_hip_graph_replay_matches_launch_by_launch():
+  """CoreNet.train_step(graph=True): the fused step captured into a HIP graph (inputs in plan-owned buffers, Adam's
+  scalars in device memory) and replayed.  From identical states, every replayed step must equal the launch-by-launch
+  step: loss, gradient slab (up to the atomics' summation order), Adam moments, step counters -- including a change of
+  inputs and of the learning rate between replays."""
+  sd = O.make_state(0, 2, nbt=0)
+  m, mg = _model(2, sd).train(), _model(2, sd).train()
+  batches = [[x.cuda() for x in O.synthetic_batch(2, s, 2)] for s in (0, 1)]
+  for step in range(5):
+    image, v2s, off, grid = batches[step % 2]
+    lr = 4e-4 if step < 3 else 1e-4
+    _sync_state(mg, m)
+    la = float(m.train_step(image, v2s, off, grid.to(t.int32), "iou_fgbg", lr=lr, adam_eps=1e-4, graph=False))
+    lb = float(mg.train_step(image, v2s, off, grid.to(t.int32), "iou_fgbg", lr=lr, adam_eps=1e-4, graph=True))
+    assert abs(la - lb) < 1e-4 * abs(la), (step, la, lb)
+    assert _slab_err(mg, m) < 1e-3, (step, _slab_err(mg, m))
+    assert mg.engine.adam_t == m.engine.adam_t == step + 1
+    d = (mg.engine.store.params - m.engine.store.params).abs()
+    assert float(d.max()) <= 2 * lr * 1.05 and float(d.mean()) < 0.05 * lr, (step, float(d.max()), float(d.mean()))
+    assert t.equal(mg.engine.store.nbt, m.engine.store.nbt)
+  assert len(mg.engine.plan(2).graphs) == 1 and not m.engine.plan(2).graphs
+  # an eval forward after replays sees the stepped parameters
+  mg.eval(); m.eval()
+  _sync_state(mg, m)
+  with t.no_grad():
+    assert relerr(mg(*batches[0][:3]), m(*batches[0][:3])) < 1e-5
 
 
 def test_checkpoint_interop_on_gpu():
@@ -414,7 +443,7 @@ def test_wrapped_in_distributed_data_parallel():
       assert abs(float(loss) - lf) < 1e-4 * abs(lf), (step, float(loss), lf)
       e = _slab_err(ma, m)
       print(f"DDP-wrapped vs train_step, step {step}: gradient slab err {e:.2e}")
-      assert e < 1e-2, (step, e)
+      assert e < 1e-3, (step, e)                    # measured 1.5e-6
     assert relerr(ma.engine.adam_m, m.engine.adam_m) < 1e-2
     d = (ma.engine.store.params - m.engine.store.params).abs()
     assert float(d.max()) <= 2 * 4e-4 * 1.05 and float(d.mean()) < 1e-4
