@@ -96,7 +96,12 @@ class HipBackend:
                           _lib.stream())
 
   def conv_wgrad(self, x: View, tr: Optional[Transform], dy: View, dw: t.Tensor, npad: int,
-                 window, pad_lo, zero_first: bool = True, boxes=None):
+                 window, pad_lo, zero_first: bool = True, boxes=None, math: str = "fp32"):
+    if math == "bf16x3":
+      self.lib.crn_conv_wgrad_bf3(C.byref(_cview(x)), _ctr(tr), C.byref(_cview(dy)), ptr(dw), npad,
+                                  window[0], window[1], window[2], pad_lo[0], pad_lo[1], pad_lo[2],
+                                  int(zero_first), _lib.stream())
+      return
     self.lib.crn_conv_wgrad(C.byref(_cview(x)), _ctr(tr), C.byref(_cview(dy)), ptr(dw), npad,
                             window[0], window[1], window[2], pad_lo[0], pad_lo[1], pad_lo[2],
                             int(zero_first), _ctapboxes(boxes), _lib.stream())

@@ -364,6 +364,258 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
   }
 }
 
+// ------------------------------------ weight gradient ----------------------------------------------------
+// dw[(c*T + t)*Npad + n] += sum over (b, position) of T(x)[b, c, position + t - pad] * dy[b, n, position]
+// (the operation of crn_conv_wgrad) on the same split-bf16 MFMA.
+//  * GEMM view per window tap: D_t[c][n] = X_t^T . dY, K = output positions.  One MFMA covers 32 positions
+//    (two H rows x 16 W) and M = 16 rows = 2 taps x 8 input channels; a workgroup owns 8 input channels
+//    (blockIdx.x), NSUB*16 output channels (blockIdx.y) and a slice of the position tiles (blockIdx.z); its 8
+//    waves split the tap pairs, so every wave keeps its own (tap pair, n block) accumulators for the whole
+//    slice and the partial sums are added to dw with fire-and-forget atomics at the end.
+//  * Both operands have K = positions as the slow index of the LDS images ([position][8 channels] for the
+//    input patch -- the same image as the forward engine -- and [position][NB] for the dy tile), which is the
+//    wrong way round for an MFMA operand register (8 consecutive K per lane): ds_read_b64_tr_b16 transposes
+//    4x4 blocks on the way out of LDS, and because every lane supplies its own address a window tap is
+//    still just an address offset (whole positions, so the reads stay 8-byte aligned).
+constexpr int kWgTile = 512;          // 4 x 8 x 16 positions = 16 K-blocks of 32
+
+struct Bf3WgGeom {
+  crnView x, dy;
+  crnInTransform tr;
+  float* dw;
+  int Npad, ncols;
+  int kd, kh, kw, pd, ph, pw, T, KHW;
+  int PD, PH, PW, PHW, NP, pw2, nunits, lead;
+  int tilesD, tilesH, tilesW, ntiles, tiles_per_split;
+  unsigned magic_pw2, magic_PH, magic_kw, magic_KHW;
+  int dbg;
+};
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+template <int NSUB, int DM, int TPW>
+__global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NB = NSUB * 16;
+  constexpr int kHdr = 1024;
+  unsigned* choff = reinterpret_cast<unsigned*>(smem);                    // [8] x channel offsets
+  float* tscale = reinterpret_cast<float*>(smem + 64);                    // [8]
+  float* tshift = reinterpret_cast<float*>(smem + 128);                   // [8]
+  unsigned* dchoff = reinterpret_cast<unsigned*>(smem + 256);             // [NB <= 64] dy channel offsets
+  char* Xhi = smem + kHdr;
+  char* Xlo = Xhi + (size_t)g.NP * 16;
+  char* Yhi = Xlo + (size_t)g.NP * 16;                                    // [512][NB] bf16
+  char* Ylo = Yhi + (size_t)kWgTile * NB * 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kk = lane >> 4;
+  const int c0 = blockIdx.x * kCK, n0 = blockIdx.y * NB;
+  const int tbeg = min((int)blockIdx.z * g.tiles_per_split, g.ntiles), tend = min(tbeg + g.tiles_per_split, g.ntiles);
+  typedef typename XLoad<DM>::T DT;
+
+  if (tid < kCK) {
+    const int c = min(c0 + tid, g.x.C - 1);
+    choff[tid] = g.x.chan_off ? (unsigned)g.x.chan_off[c] : (unsigned)c * (unsigned)g.x.sC;
+    tscale[tid] = g.tr.scale ? g.tr.scale[c] : 1.f;
+    tshift[tid] = g.tr.scale ? g.tr.shift[c] : 0.f;
+  }
+  if (tid >= 64 && tid < 64 + NB) {
+    const int n = min(n0 + tid - 64, g.dy.C - 1);
+    dchoff[tid - 64] = g.dy.chan_off ? (unsigned)g.dy.chan_off[n] : (unsigned)n * (unsigned)g.dy.sC;
+  }
+
+  // transpose-read source role of this lane: row j of the [4 K][16 M] block of its 16-lane group, column quad q
+  const int j = i16 >> 2, q = i16 & 3;
+  const int k1 = kk * 8 + j;                                   // K index inside the 32-position block (second read: +4)
+  // A (input patch): virtual column quad q = (tap of the pair: q >> 1, channel half: q & 1)
+  const int abase = (((k1 >> 4) * g.PW + (k1 & 15) + g.lead) << 4) + ((q & 1) << 3);
+  int toffL[TPW];
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti) {
+    int tp = 2 * (wave * TPW + ti) + (q >> 1);
+    if (tp >= g.T) tp = 0;                                     // rows of taps past the window are never stored
+    const int zd = mdiv(tp, g.magic_KHW), r = tp - zd * g.KHW;
+    const int zh = mdiv(r, g.magic_kw), zw = r - zh * g.kw;
+    toffL[ti] = ((zd * g.PH + zh) * g.PW + zw) << 4;
+  }
+  // B (dy tile, [position][NB] bf16): column quad q of n block ns
+  const int ybase = k1 * (NB * 2) + (q << 3);
+  const int xlo = g.NP * 16, ylo = kWgTile * NB * 2;
+
+  f32x4 acc[TPW][NSUB];
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti)
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) acc[ti][ns] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  XLoad<1>::T pv[kNUX][kCK];
+  DT dv[NSUB][kCK];
+  unsigned inmask = 0;
+  int b = 0, d0 = 0, h0 = 0, w0 = 0;
+  auto tile_origin = [&](int tl) {
+    int tile = tl;
+    const int twi = tile % g.tilesW; tile /= g.tilesW;
+    const int thi = tile % g.tilesH; tile /= g.tilesH;
+    const int tdi = tile % g.tilesD; tile /= g.tilesD;
+    b = tile; d0 = tdi * 4; h0 = thi * 8; w0 = twi * 16;
+  };
+  auto unit_of = [&](int jx, int& pos, unsigned& sp, bool& in) -> bool {
+    int u = tid + jx * kThreads;
+    asm volatile("" : "+v"(u));
+    const int row = mdiv(u, g.magic_pw2), pp = u - row * g.pw2;
+    const int pdz = mdiv(row, g.magic_PH), phy = row - pdz * g.PH;
+    const int gd = d0 + pdz - g.pd, gh = h0 + phy - g.ph, gw = w0 + 2 * pp - g.pw;
+    in = (unsigned)gd < (unsigned)g.x.D && (unsigned)gh < (unsigned)g.x.H && (unsigned)gw < (unsigned)g.x.W;
+    sp = (unsigned)gd * (unsigned)g.x.sD + (unsigned)gh * (unsigned)g.x.sH + (unsigned)gw;
+    pos = row * g.PW + 2 * pp;
+    return u < g.nunits;
+  };
+  // dy unit: (position pair pq of the 256 of a tile, octet o of the NB columns); thread -> (o = jd, pq = tid & 255) ...
+  // 512 threads: pair = tid & 255, octet = (tid >> 8) + 2 * jd
+  auto dy_unit = [&](int jd, int& pq, int& oct, unsigned& sp, bool& in) {
+    pq = tid & 255; oct = (tid >> 8) + 2 * jd;
+    const int p = pq * 2;                                       // tile-linear position: (d*8 + h)*16 + w
+    const int w = p & 15, h = (p >> 4) & 7, d = p >> 7;
+    const int od = d0 + d, oh = h0 + h, ow = w0 + w;
+    in = od < g.dy.D && oh < g.dy.H && ow < g.dy.W;
+    sp = (unsigned)od * (unsigned)g.dy.sD + (unsigned)oh * (unsigned)g.dy.sH + (unsigned)ow * (unsigned)(DM == 2 ? 2 : 1);
+  };
+  auto stage_issue = [&]() {
+    const crn_rsrc xrs = make_rsrc(g.x.base + (int64_t)b * g.x.sB);
+    const crn_rsrc drs = make_rsrc(g.dy.base + (int64_t)b * g.dy.sB);
+    inmask = 0;
+#pragma unroll
+    for (int jx = 0; jx < kNUX; ++jx) {
+      int pos; unsigned sp; bool in;
+      const bool ld = unit_of(jx, pos, sp, in) && in;
+      if (ld) inmask |= 1u << jx;
+#pragma unroll
+      for (int cl = 0; cl < kCK; ++cl) {
+        const unsigned off = (ld && c0 + cl < g.x.C) ? (choff[cl] + sp) * 4u : 0x80000000u;
+        XLoad<1>::load(pv[jx][cl], xrs, off);
+      }
+    }
+#pragma unroll
+    for (int jd = 0; jd < NSUB; ++jd) {
+      int pq, oct; unsigned sp; bool in;
+      dy_unit(jd, pq, oct, sp, in);
+#pragma unroll
+      for (int cl = 0; cl < kCK; ++cl) {
+        const int n = oct * 8 + cl;
+        const unsigned off = (in && n0 + n < g.ncols && n0 + n < g.dy.C) ? (dchoff[n] + sp) * 4u : 0x80000000u;
+        XLoad<DM>::load(dv[jd][cl], drs, off);
+      }
+    }
+  };
+  auto stage_commit = [&]() {
+#pragma unroll
+    for (int jx = 0; jx < kNUX; ++jx) {
+      if (jx * kThreads < g.nunits) {
+        int pos; unsigned sp; bool in;
+        if (unit_of(jx, pos, sp, in)) {
+          float v0[kCK], v1[kCK];
+#pragma unroll
+          for (int cl = 0; cl < kCK; ++cl) { v0[cl] = pv[jx][cl][0]; v1[cl] = pv[jx][cl][1]; }
+          if (g.tr.scale && ((inmask >> jx) & 1u)) {
+#pragma unroll
+            for (int cl = 0; cl < kCK; ++cl) {
+              if (c0 + cl < g.x.C) {
+                const float sc = tscale[cl], sh = tshift[cl];
+                float a = v0[cl], c = v1[cl];
+                if (g.tr.pre_relu) { a = fmaxf(a, 0.f); c = fmaxf(c, 0.f); }
+                a = a * sc + sh; c = c * sc + sh;
+                if (g.tr.post_relu) { a = fmaxf(a, 0.f); c = fmaxf(c, 0.f); }
+                v0[cl] = a; v1[cl] = c;
+              }
+            }
+          }
+          bf16x8 h0v, l0v, h1v, l1v;
+          split8(v0, h0v, l0v);
+          split8(v1, h1v, l1v);
+          *reinterpret_cast<bf16x8*>(Xhi + (size_t)pos * 16) = h0v; *reinterpret_cast<bf16x8*>(Xhi + (size_t)pos * 16 + 16) = h1v;
+          *reinterpret_cast<bf16x8*>(Xlo + (size_t)pos * 16) = l0v; *reinterpret_cast<bf16x8*>(Xlo + (size_t)pos * 16 + 16) = l1v;
+        }
+      }
+    }
+#pragma unroll
+    for (int jd = 0; jd < NSUB; ++jd) {
+      int pq, oct; unsigned sp; bool in;
+      dy_unit(jd, pq, oct, sp, in);
+      float v0[kCK], v1[kCK];
+#pragma unroll
+      for (int cl = 0; cl < kCK; ++cl) { v0[cl] = XLoad<DM>::e0(dv[jd][cl]); v1[cl] = XLoad<DM>::e1(dv[jd][cl]); }
+      bf16x8 h0v, l0v, h1v, l1v;
+      split8(v0, h0v, l0v);
+      split8(v1, h1v, l1v);
+      const size_t o = ((size_t)(pq * 2) * NB + oct * 8) * 2;
+      *reinterpret_cast<bf16x8*>(Yhi + o) = h0v; *reinterpret_cast<bf16x8*>(Yhi + o + NB * 2) = h1v;
+      *reinterpret_cast<bf16x8*>(Ylo + o) = l0v; *reinterpret_cast<bf16x8*>(Ylo + o + NB * 2) = l1v;
+    }
+  };
+  auto trd = [&](const char* p) -> bf16x4 {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p));
+  };
+  auto cat = [](bf16x4 a, bf16x4 c) -> bf16x8 { return __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7); };
+
+  __syncthreads();
+  if (tbeg < tend) { tile_origin(tbeg); stage_issue(); }
+  for (int tl = tbeg; tl < tend; ++tl) {
+    wait_loads2d(pv);
+    wait_loads2d(dv);
+    __syncthreads();
+    stage_commit();
+    __syncthreads();
+    if (tl + 1 < tend) { tile_origin(tl + 1); stage_issue(); }
+    if (g.dbg == 1) continue;
+    for (int kb = 0; kb < 16; ++kb) {
+      const int kbx = (((kb >> 2) * g.PH + (kb & 3) * 2) * g.PW) << 4;
+      const char* yb = Yhi + ybase + kb * (32 * NB * 2);
+      bf16x8 bh[NSUB], bl[NSUB];
+#pragma unroll
+      for (int ns = 0; ns < NSUB; ++ns) {
+        bh[ns] = cat(trd(yb + ns * 32), trd(yb + ns * 32 + 4 * NB * 2));
+        bl[ns] = cat(trd(yb + ylo + ns * 32), trd(yb + ylo + ns * 32 + 4 * NB * 2));
+      }
+#pragma unroll
+      for (int ti = 0; ti < TPW; ++ti) {
+        const char* xa = Xhi + abase + toffL[ti] + kbx;
+        const bf16x8 ah = cat(trd(xa), trd(xa + 64));
+        const bf16x8 al = cat(trd(xa + xlo), trd(xa + xlo + 64));
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) {
+          acc[ti][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ns], acc[ti][ns], 0, 0, 0);
+          acc[ti][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ns], acc[ti][ns], 0, 0, 0);
+          acc[ti][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ns], acc[ti][ns], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // D row m = kk*4 + r = (tap of the pair: m >> 3, channel m & 7), col = i16 = n
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = kk * 4 + r;
+      const int tp = 2 * (wave * TPW + ti) + (m >> 3), c = c0 + (m & 7);
+      if (tp >= g.T || c >= g.x.C) continue;
+#pragma unroll
+      for (int ns = 0; ns < NSUB; ++ns) {
+        const int n = n0 + ns * 16 + i16;
+        if (n < g.ncols) atomicAdd(g.dw + ((int64_t)c * g.T + tp) * g.Npad + n, acc[ti][ns][r]);
+      }
+    }
+}
+
+template <int NSUB, int DM, int TPW>
+int launch_bf3_wgrad(const Bf3WgGeom& g, dim3 grid, size_t lds, hipStream_t st) {
+  auto k = conv_bf3_wgrad_kernel<NSUB, DM, TPW>;
+  if (lds > 65536) CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, st, g);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
 unsigned magic20b(int d) { return (unsigned)(((1u << 20) + d - 1) / d); }
 
 template <int NSUB, int XM, int NG>
@@ -444,5 +696,58 @@ extern "C" int crn_conv_fwd_bf3(const crnView* x, const crnInTransform* tr, cons
   CRN_BF3_CASE(1, 1, 4) CRN_BF3_CASE(2, 1, 4) CRN_BF3_CASE(4, 1, 4)
   CRN_BF3_CASE(1, 2, 4) CRN_BF3_CASE(2, 2, 4) CRN_BF3_CASE(4, 2, 4)
 #undef CRN_BF3_CASE
+  return CRN_EINVAL;
+}
+
+// Weight gradient on the split-bf16 MFMA engine; same contract as crn_conv_wgrad (dw zeroed by the caller or
+// zero_first).  Returns CRN_EINVAL for shapes it does not cover.
+extern "C" int crn_conv_wgrad_bf3(const crnView* x, const crnInTransform* tr, const crnView* dy, float* dw, int Npad,
+                                  int kd, int kh, int kw, int pd, int ph, int pw, int zero_first, crnStream stream) {
+  if (!x || !dy || !dw || Npad <= 0 || (Npad & 15) || x->B != dy->B || kd < 1 || kh < 1 || kw < 1) return CRN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (!even_view(*x)) return CRN_EINVAL;
+  const int dmode = even_view(*dy) ? 1 : ((dy->sW == 2 && dy->chan_off != nullptr && (dy->W & 1) == 0) ? 2 : 0);
+  if (!dmode) return CRN_EINVAL;
+  if ((dy->W & 15) || dy->H < 8 || dy->D < 4) return CRN_EINVAL;
+  Bf3WgGeom g{};
+  g.x = *x; g.dy = *dy;
+  g.tr = tr ? *tr : crnInTransform{nullptr, nullptr, 0, 0};
+  g.dw = dw; g.Npad = Npad; g.ncols = std::min(Npad, dy->C);
+  g.lead = ((pw % 2) + 2) % 2;
+  g.kd = kd; g.kh = kh; g.kw = kw; g.pd = pd; g.ph = ph; g.pw = pw + g.lead;
+  g.T = kd * kh * kw; g.KHW = kh * kw;
+  g.PD = 4 + kd - 1; g.PH = 8 + kh - 1; g.PW = (g.lead + 16 + kw - 1 + 1) & ~1;
+  g.PHW = g.PH * g.PW; g.NP = g.PD * g.PHW;
+  g.pw2 = g.PW / 2; g.nunits = g.PD * g.PH * g.pw2;
+  if (g.nunits > kNUX * kThreads) return CRN_EINVAL;
+  const int TPW = (((g.T + 1) / 2) + 7) / 8;                  // tap pairs per wave
+  if (TPW != 8 && TPW != 4) return CRN_EINVAL;                // instantiated: 5^3 (63 pairs) and 4^3 (32 pairs) windows
+  g.tilesD = crn_cdiv(dy->D, 4); g.tilesH = crn_cdiv(dy->H, 8); g.tilesW = dy->W / 16;
+  g.ntiles = g.tilesD * g.tilesH * g.tilesW * dy->B;
+  g.magic_pw2 = magic20b(g.pw2); g.magic_PH = magic20b(g.PH); g.magic_kw = magic20b(kw); g.magic_KHW = magic20b(g.KHW);
+  if (zero_first) CRN_HIP(hipMemsetAsync(dw, 0, (size_t)x->C * g.T * Npad * 4, st));
+  int NSUB = (Npad % 32 == 0) ? 2 : 1;
+  if (const char* f = getenv("CRN_BF3_WG_NSUB")) NSUB = atoi(f);
+  if (NSUB != 1 && NSUB != 2) return CRN_EINVAL;
+  const int NB = NSUB * 16;
+  const size_t lds = 1024 + (size_t)2 * g.NP * 16 + (size_t)2 * kWgTile * NB * 2;
+  if (lds > 160 * 1024 - 512) return CRN_EINVAL;
+  const int cblocks = crn_cdiv(x->C, kCK), nblocks = crn_cdiv(Npad, NB);
+  static const int kBlocks = getenv("CRN_BF3_WG_BLOCKS") ? atoi(getenv("CRN_BF3_WG_BLOCKS")) : 256;
+  int splits = std::max(1, std::min(g.ntiles, kBlocks / std::max(1, cblocks * nblocks)));
+  g.tiles_per_split = crn_cdiv(g.ntiles, splits);
+  splits = crn_cdiv(g.ntiles, g.tiles_per_split);
+  g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
+  dim3 grid((unsigned)cblocks, (unsigned)nblocks, (unsigned)splits);
+  static const bool dbg = getenv("CRN_DEBUG") != nullptr;
+  if (dbg)
+    fprintf(stderr, "[crn_conv_wgrad_bf3] x(C%d %dx%dx%d) dy(C%d %dx%dx%d) k%dx%dx%d: NSUB %d dmode %d TPW %d grid %ux%ux%u "
+            "tiles/split %d lds %zu\n", x->C, x->D, x->H, x->W, dy->C, dy->D, dy->H, dy->W, kd, kh, kw, NSUB, dmode, TPW,
+            grid.x, grid.y, grid.z, g.tiles_per_split, lds);
+#define CRN_BF3WG_CASE(N, D, P) if (NSUB == N && dmode == D && TPW == P) return launch_bf3_wgrad<N, D, P>(g, grid, lds, st);
+  CRN_BF3WG_CASE(1, 1, 8) CRN_BF3WG_CASE(2, 1, 8)
+  CRN_BF3WG_CASE(1, 2, 4) CRN_BF3WG_CASE(2, 2, 4)
+  CRN_BF3WG_CASE(1, 1, 4) CRN_BF3WG_CASE(2, 1, 4)
+#undef CRN_BF3WG_CASE
   return CRN_EINVAL;
 }

@@ -49,7 +49,7 @@ GRAD_BUCKET_LABELS = ("decoder.stage_3.", "decoder.stage_0.", "encoder.stage5.c.
 # (measured, profiles/r02_bf16x3_layers.txt).  Everything else -- encoder, stages 0-3, all weight gradients
 # until they have their own kernel -- stays on the fp32 MFMA engine.
 BF16X3_LAUNCHES = frozenset(
-    (f"decoder.stage_{k}.{l}.", d) for k in (4, 5, 6) for l in ("c1", "t1") for d in ("fwd", "dgrad")
+    (f"decoder.stage_{k}.{l}.", d) for k in (4, 5, 6) for l in ("c1", "t1") for d in ("fwd", "dgrad", "wgrad")
 ) - {("decoder.stage_4.c1.", "fwd"), ("decoder.stage_4.t1.", "dgrad")}
 LOSS_KINDS = {"iou_fgbg": 0, "xent_times_iou_agnostic": 1, "iou_agnostic": 2, "xent": 3,
               "xent_times_iou_fgbg": 4}
@@ -564,9 +564,10 @@ class Plan:
     (saved activation, dy) and writes its own slice of the packed gradient slab, so it can run
     beside the data-gradient chain; most layers below 32^3 / 64^2 cannot fill 256 CUs alone."""
     g = cv.fwd
+    math = self._math(cv, "wgrad")
     if self.side is None or self.trace is not None:
       self._timed("wgrad " + cv.name, lambda: self.be.conv_wgrad(
-          x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes)))
+          x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes), math=math))
       return
     if self._side_i == len(self._side_ev):
       self._side_ev.append(t.cuda.Event())
@@ -574,7 +575,7 @@ class Plan:
     ev.record()                                   # dy (and the zeroed slab) are ready on the main stream
     with t.cuda.stream(self.side):
       self.side.wait_event(ev)
-      self.be.conv_wgrad(x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes))
+      self.be.conv_wgrad(x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes), math=math)
 
   def _join_side(self):
     """Main stream waits for every weight gradient issued on the side stream."""

@@ -87,7 +87,7 @@ class EmuBackend:
     write_logical(y, out, accumulate)
 
   @t.enable_grad()        # uses autograd as a calculator; may be called from inside an autograd Function
-  def conv_wgrad(self, x, tr, dy, dw, npad, window, pad_lo, zero_first=True, boxes=None):
+  def conv_wgrad(self, x, tr, dy, dw, npad, window, pad_lo, zero_first=True, boxes=None, math="fp32"):
     xl = _transform(logical(x), tr)
     xp = _padded(xl, window, pad_lo, (dy.D, dy.H, dy.W))
     dyl = logical(dy)

@@ -192,6 +192,22 @@ def test_conv_bf16x3_fwd_dgrad(be, name, kind, wshape, pad, dims, B):
   e = float((dxg.cpu() - dx).abs().max() / dx.abs().max())
   print(f"bf16x3 {name} dgrad: max-abs-err/max = {e:.2e}")
   assert e <= 2e-5, (name, "dgrad", e)
+  # weight gradient (crn_conv_wgrad_bf3): real entries of the packed gradient against the contract, and the
+  # un-packed gradient against autograd of torch's own op
+  dw = t.zeros(wf.numel()); dwg = t.full((wf.numel(),), 7.0, device=DEV)
+  EMU.conv_wgrad(V.view_of(x), trc, yview(dyb), dw, fwd.npad, fwd.window, fwd.pad_lo, True)
+  be.conv_wgrad(V.view_of(xg), trg, yview(dyg), dwg, fwd.npad, fwd.window, fwd.pad_lo, True,
+                boxes=(fwd.n_boxes, fwd.c_boxes), math="bf16x3")
+  real = t.as_tensor(fwd.index) >= 0
+  got = t.where(real, dwg.cpu(), t.zeros(())); want = t.where(real, dw, t.zeros(()))
+  e = float((got - want).abs().max() / want.abs().max())
+  print(f"bf16x3 {name} wgrad: max-abs-err/max = {e:.2e}")
+  assert e <= 2e-5, (name, "wgrad", e)
+  # accumulate into an existing gradient (zero_first = False)
+  dwg2 = dwg.clone()
+  be.conv_wgrad(V.view_of(xg), trg, yview(dyg), dwg2, fwd.npad, fwd.window, fwd.pad_lo, False,
+                boxes=(fwd.n_boxes, fwd.c_boxes), math="bf16x3")
+  assert float((t.where(real, dwg2.cpu(), t.zeros(())) - 2 * want).abs().max() / want.abs().max()) <= 4e-5
 
 
 def EMU_pack(w, geom, index=None):

@@ -49,7 +49,7 @@ dw = t.zeros(wf.numel()).cuda()
 def run():
   if mode == "fwd": be.conv_fwd(V.view_of(x), tr, wf, fwd.npad, None, 0, yv, fwd.window, fwd.pad_lo, 0, boxes=(fwd.n_boxes, fwd.c_boxes), math=MATH)
   elif mode == "dgrad": be.conv_fwd(yv, None, wd, dgr.npad, None, 0, V.view_of(x), dgr.window, dgr.pad_lo, 0, boxes=(dgr.n_boxes, dgr.c_boxes), math=MATH)
-  else: be.conv_wgrad(V.view_of(x), tr, yv, dw, fwd.npad, fwd.window, fwd.pad_lo, True, boxes=(fwd.n_boxes, fwd.c_boxes))
+  else: be.conv_wgrad(V.view_of(x), tr, yv, dw, fwd.npad, fwd.window, fwd.pad_lo, True, boxes=(fwd.n_boxes, fwd.c_boxes), math=MATH)
 for _ in range(3): run()
 t.cuda.synchronize(); a = t.cuda.Event(enable_timing=True); b = t.cuda.Event(enable_timing=True)
 a.record()
