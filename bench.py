@@ -128,6 +128,7 @@ def main():
   ap.add_argument("--math", default=os.environ.get("CRN_DECODER_MATH", "bf16x3"), choices=["fp32", "bf16x3"],
                   help="decoder stage 4-6 convolutions: fp32 MFMA, or split-bf16 (3 bf16 MFMAs per product, fp32 accumulate)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-fp32-side", action="store_true", help="skip the fp32-math run printed beside the headline (profiling)")
   args = ap.parse_args()
 
   from corenet_amd import distributed as D
@@ -187,7 +188,7 @@ def main():
 
   dt, probes, loss = timed(model, plan)
   fp32_side = None
-  if world == 1 and args.math != "fp32":
+  if world == 1 and args.math != "fp32" and not args.no_fp32_side:
     # the same step with every convolution on the fp32 MFMA engine (the parity default), printed beside the headline
     m32 = CoreNet(CoreNetConfig(DecoderConfig((128, 128, 128), C, 2, 64, 0.75)), device=dev, decoder_math="fp32")
     m32.load_state_dict(state0); m32.train()

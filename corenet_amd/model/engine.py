@@ -547,8 +547,12 @@ class Plan:
   def _math(self, cv: Conv, direction: str) -> str:
     return "bf16x3" if self.eng.decoder_math == "bf16x3" and (cv.name, direction) in BF16X3_LAUNCHES else "fp32"
 
+  conv_positions = None     # tools/layer_times.py: {layer name: logical output positions per sample} when tracing
+
   def _conv(self, cv: Conv, x: V.View, tr, y: V.View, accumulate=False):
     g = cv.fwd
+    if self.trace is not None and self.conv_positions is not None:
+      self.conv_positions[cv.name] = y.D * y.H * y.W
     self._timed("fwd   " + cv.name, lambda: self.be.conv_fwd(
         x, tr, cv.wf, g.npad, cv.bias, 0, y, g.window, g.pad_lo, 0, accumulate, boxes=(g.n_boxes, g.c_boxes),
         math=self._math(cv, "fwd")))
