@@ -38,7 +38,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 512, kMSUB = 4, kCK = 8;
 constexpr int kNUX = 2;          // patch units (2 positions x 8 channels) per thread
-constexpr int kTabC = 256;       // channel tables
+constexpr int kTabC = 512;       // channel tables
 constexpr int kMaxTapSlots = 32; // NG * 4
 
 struct Bf3Geom {
@@ -48,13 +48,15 @@ struct Bf3Geom {
   const float* bias;
   int Npad, bias_sB;
   int kd, kh, kw, pd, ph, pw, T, KHW;
-  int TD, TH;              // tile TD x TH x 16 positions, TD * TH == 32
+  int mw, mh, nsw, nsh;    // sub-tile = mh x mw positions (16 MFMA rows), tile = TD x (nsh*mh) x (nsw*mw), 32 sub-tiles
+  int TD, TH, TW;
   int PD, PH, PW, PHW, NP; // patch dims (positions), PH*PW, PD*PH*PW
   int pw2, nunits;         // position pairs per row, staging units
   int NG;                  // groups of 4 in-plane taps
   int tilesD, tilesH, tilesW;
-  int nchunks;
-  int mode;                // 0 store, 1 accumulate
+  int nchunks, chunks_per_split;
+  int ctab;                // entries of the per-channel LDS tables (multiple of 16)
+  int mode;                // 0 store, 1 accumulate, 3 split-K partial sums to a dense scratch [split][b][n][pos]
   int lead;
   int vec_store;
   int n_groups, c_groups;
@@ -98,24 +100,27 @@ template <> struct XLoad<2> {            // stride-2 (space-to-depth) view: elem
   static __device__ __forceinline__ float e1(const T& v) { return v[2]; }
 };
 
-struct Box { int d0, d1, g0, g1; };   // zd range and tap-group range that can hold non-zero weights
-
 // NG = groups of 4 in-plane taps (7: 5x5 window, 4: 4x4 window): compile time, so that the group loop is
 // straight-line code (LDS reads of the next group issue under the MFMAs of the current one) and every
-// staging loop has exactly the trip count the layer needs
-template <int NSUB, int XM, int NG>
+// staging loop has exactly the trip count the layer needs.
+// ZS = window planes (zd) per weight slab: the slab of one chunk is staged ZS planes at a time; with ZS = the
+// whole window depth a chunk is ONE staging step (two barriers) instead of one per plane.
+template <int NSUB, int XM, int NG, int ZS>
 __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
-  constexpr int kNWI = (NG * 4 * NSUB * 16 + kThreads - 1) / kThreads;    // weight items per thread
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned* choff = reinterpret_cast<unsigned*>(smem);                    // [kTabC]
-  float* tscale = reinterpret_cast<float*>(smem + kTabC * 4);             // [kTabC]
-  float* tshift = reinterpret_cast<float*>(smem + 2 * kTabC * 4);         // [kTabC]
-  constexpr int kHdr = 3 * kTabC * 4 + kMaxTapSlots * 4;                  // 3200, multiple of 16
   constexpr int NB = NSUB * 16;
-  bf16x8* Ahi = reinterpret_cast<bf16x8*>(smem + kHdr);
+  constexpr int kSlab = ZS * NG * 4 * NB;                                 // weight items (16-byte units) per slab
+  constexpr int kNWI = (kSlab + kThreads - 1) / kThreads;                 // ... per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // channel tables sized for this layer (ctab = channels rounded up to 16): with 28..32 channels the k5 / N 16
+  // configuration stays under 80 KiB of LDS and two workgroups share a CU (measured: stage_6.c1 forward 391 us
+  // with two, 509 us with one)
+  unsigned* choff = reinterpret_cast<unsigned*>(smem);                    // [ctab]
+  float* tscale = reinterpret_cast<float*>(smem + g.ctab * 4);            // [ctab]
+  float* tshift = reinterpret_cast<float*>(smem + 2 * g.ctab * 4);        // [ctab]
+  bf16x8* Ahi = reinterpret_cast<bf16x8*>(smem + 3 * g.ctab * 4);
   bf16x8* Alo = Ahi + g.NP;
-  bf16x8* Bhi = Alo + g.NP;                                               // [NG*4][NB]
-  bf16x8* Blo = Bhi + NG * 4 * NB;
+  bf16x8* Bhi = Alo + g.NP;                                               // [ZS][NG*4][NB]
+  bf16x8* Blo = Bhi + kSlab;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kk = lane >> 4;
   typedef typename XLoad<XM>::T XT;
@@ -125,11 +130,12 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
   const int thi = tile % g.tilesH; tile /= g.tilesH;
   const int tdi = tile % g.tilesD; tile /= g.tilesD;
   const int b = tile;
-  const int d0 = tdi * g.TD, h0 = thi * g.TH, w0 = twi * 16;
+  const int d0 = tdi * g.TD, h0 = thi * g.TH, w0 = twi * g.TW;
   const int n0 = blockIdx.y * NB;
+  const int split = blockIdx.z;
+  const int cbeg = split * g.chunks_per_split, cend = min(cbeg + g.chunks_per_split, g.nchunks);
 
-  // channel tables and the per-lane tap offsets of every group
-  for (int c = tid; c < kTabC; c += kThreads) {
+  for (int c = tid; c < g.ctab; c += kThreads) {
     const int cc = min(c, g.x.C - 1);
     choff[c] = g.x.chan_off ? (unsigned)g.x.chan_off[cc] : (unsigned)cc * (unsigned)g.x.sC;
     tscale[c] = g.tr.scale ? g.tr.scale[cc] : 1.f;
@@ -143,12 +149,14 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
     const int zh = mdiv(t, g.magic_kw), zw = t - zh * g.kw;
     toff[gq] = zh * g.PW + zw;
   }
+  const int ri = i16 / g.mw, rj = i16 - ri * g.mw;
   int pa[kMSUB];
 #pragma unroll
   for (int ms = 0; ms < kMSUB; ++ms) {
-    const int s = wave * kMSUB + ms;
-    const int sh = s % g.TH, sd = s / g.TH;
-    pa[ms] = (sd * g.PH + sh) * g.PW + i16 + g.lead;
+    int s_ = wave * kMSUB + ms;
+    const int sw = s_ % g.nsw; s_ /= g.nsw;
+    const int sh = s_ % g.nsh, sd = s_ / g.nsh;
+    pa[ms] = (sd * g.PH + sh * g.mh + ri) * g.PW + sw * g.mw + rj + g.lead;
   }
   f32x4 acc[kMSUB][NSUB];
 #pragma unroll
@@ -221,16 +229,16 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
       }
     }
   };
-  // ---- weight staging: item = (in-plane tap slot tp, column n), all 8 channels; slab = (chunk, zd) ----
-  constexpr int witems = NG * 4 * NB;
-  auto weights_issue = [&](int c0, int zd) {
+  // ---- weight staging: item = (plane zs of the slab, in-plane tap slot tp, column n), all 8 channels ----
+  auto weights_issue = [&](int c0, int zd0) {
 #pragma unroll
     for (int j = 0; j < kNWI; ++j) {
       int it = tid + j * kThreads;
       asm volatile("" : "+v"(it));
-      const int n = it & (NB - 1), tp = it / NB;
-      const bool ok = it < witems && tp < g.KHW && n0 + n < g.Npad;
-      const unsigned base = (unsigned)((zd * g.KHW + tp) * g.Npad + n0 + n);
+      const int n = it & (NB - 1), zt = it / NB;              // zt = zs * NG*4 + tp
+      const int zs = ZS == 1 ? 0 : zt / (NG * 4), tp = zt - zs * (NG * 4);
+      const bool ok = it < kSlab && tp < g.KHW && zd0 + zs < g.kd && n0 + n < g.Npad;
+      const unsigned base = (unsigned)(((zd0 + zs) * g.KHW + tp) * g.Npad + n0 + n);
 #pragma unroll
       for (int cl = 0; cl < kCK; ++cl) {
         const unsigned off = (ok && c0 + cl < g.x.C) ? ((unsigned)(c0 + cl) * (unsigned)(g.T * g.Npad) + base) * 4u : 0x80000000u;
@@ -241,13 +249,13 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
   auto weights_commit = [&]() {
 #pragma unroll
     for (int j = 0; j < kNWI; ++j) {
-      if (j * kThreads < witems) {
+      if (j * kThreads < kSlab) {
         int it = tid + j * kThreads;
         asm volatile("" : "+v"(it));
-        if (it < witems) {
+        if (it < kSlab) {
           bf16x8 h, l;
           split8(wv[j], h, l);
-          Bhi[it] = h;                                   // [tp][n] with n = ns*16 + n16: the fragment order
+          Bhi[it] = h;                                   // [zs][tp][n] with n = ns*16 + n16: the fragment order
           Blo[it] = l;
         }
       }
@@ -255,41 +263,37 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
   };
 
   const auto nbox = box_union(g.n_box, g.n_groups, g.y.C, n0, min(n0 + NB, g.y.C) - 1, g.kd, g.kh, g.kw);
-  auto chunk_box = [&](int c0) -> Box {
+  // zd range of a chunk that can hold non-zero weights (tap boxes of transposed convolutions)
+  auto chunk_zrange = [&](int c0, int& z0, int& z1) {
     const TapBox tb = box_intersect(nbox, box_union(g.c_box, g.c_groups, g.x.C, c0, min(c0 + kCK, g.x.C) - 1,
                                                     g.kd, g.kh, g.kw));
-    Box o;
-    o.d0 = tb.d0; o.d1 = tb.d1;
-    if (tb.h1 <= tb.h0 || tb.w1 <= tb.w0) { o.d1 = o.d0; o.g0 = o.g1 = 0; return o; }
-    const int t0 = tb.h0 * g.kw + tb.w0, t1 = (tb.h1 - 1) * g.kw + tb.w1;   // flattened in-plane range (superset)
-    o.g0 = t0 >> 2; o.g1 = (t1 + 3) >> 2;     // (kept for the debug print; every group of a plane runs)
-    return o;
+    z0 = tb.d0; z1 = tb.d1;
+    if (tb.h1 <= tb.h0 || tb.w1 <= tb.w0) z1 = z0;
   };
-  // first (chunk, zd) step with work at or after `chunk`
-  auto first_step = [&](int chunk, int& zd, Box& bx) -> int {
-    for (; chunk < g.nchunks; ++chunk) {
-      bx = chunk_box(chunk * kCK);
-      if (bx.d1 > bx.d0 && bx.g1 > bx.g0) { zd = bx.d0; return chunk; }
+  // first (chunk, slab) step with work at or after `chunk`
+  auto first_step = [&](int chunk, int& zd, int& z1) -> int {
+    for (; chunk < cend; ++chunk) {
+      int z0;
+      chunk_zrange(chunk * kCK, z0, z1);
+      if (z1 > z0) { zd = ZS == 1 ? z0 : 0; return chunk; }
     }
-    return g.nchunks;
+    return cend;
   };
 
   __syncthreads();                                       // tables are in LDS
-  Box bx{};
-  int zd = 0;
-  int chunk = first_step(0, zd, bx);
+  int zd = 0, zend = 0;
+  int chunk = first_step(cbeg, zd, zend);
   bool first = true;
   bool fresh = true;                                     // the patch of `chunk` is in registers, not yet in LDS
-  if (chunk < g.nchunks) {
+  if (chunk < cend) {
     patch_issue(chunk * kCK);
     weights_issue(chunk * kCK, zd);
   }
-  while (chunk < g.nchunks) {
+  while (chunk < cend) {
     const int c0 = chunk * kCK;
     // next step
-    int nchunk = chunk, nzd = zd + 1;
-    Box nbx = bx;
-    if (nzd >= bx.d1) nchunk = first_step(chunk + 1, nzd, nbx);
+    int nchunk = chunk, nzd = zd + ZS, nzend = zend;
+    if (nzd >= zend) nchunk = first_step(chunk + 1, nzd, nzend);
     wait_loads2d(pv);
     wait_loads2d(wv);
     __syncthreads();                                     // every wave is done reading the LDS of the previous step
@@ -299,52 +303,72 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
     }
     first = false;
     __syncthreads();
-    if (nchunk < g.nchunks && g.dbg != 2) {
+    if (nchunk < cend && g.dbg != 2) {
       if (nchunk != chunk) patch_issue(nchunk * kCK);    // flies under this slab's MFMAs
       weights_issue(nchunk * kCK, nzd);
     }
     if (g.dbg != 1) {
-      const int zoff = zd * g.PHW;
-      // every group of the window row runs (weights outside a tap box are zero): no control flow between the
+      // one window plane: every group runs (weights outside a tap box are zero): no control flow between the
       // groups, so the compiler keeps the next group's LDS reads in flight under this group's MFMAs
+      auto plane = [&](int z, const bf16x8* bh0, const bf16x8* bl0) {
+        const int zoff = z * g.PHW;
 #pragma unroll
-      for (int gq = 0; gq < NG; ++gq) {
-        const int off = toff[gq] + zoff;
-        bf16x8 bh[NSUB], bl[NSUB], ah[kMSUB], al[kMSUB];
-#pragma unroll
-        for (int ns = 0; ns < NSUB; ++ns) {
-          bh[ns] = Bhi[(gq * 4 + kk) * NB + ns * 16 + i16];
-          bl[ns] = Blo[(gq * 4 + kk) * NB + ns * 16 + i16];
-        }
-#pragma unroll
-        for (int ms = 0; ms < kMSUB; ++ms) { ah[ms] = Ahi[pa[ms] + off]; al[ms] = Alo[pa[ms] + off]; }
-#pragma unroll
-        for (int ms = 0; ms < kMSUB; ++ms)
+        for (int gq = 0; gq < NG; ++gq) {
+          const int off = toff[gq] + zoff;
+          bf16x8 bh[NSUB], bl[NSUB], ah[kMSUB], al[kMSUB];
 #pragma unroll
           for (int ns = 0; ns < NSUB; ++ns) {
-            acc[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ms], bh[ns], acc[ms][ns], 0, 0, 0);
-            acc[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ms], bl[ns], acc[ms][ns], 0, 0, 0);
-            acc[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ms], bh[ns], acc[ms][ns], 0, 0, 0);
+            bh[ns] = bh0[(gq * 4 + kk) * NB + ns * 16 + i16];
+            bl[ns] = bl0[(gq * 4 + kk) * NB + ns * 16 + i16];
           }
+#pragma unroll
+          for (int ms = 0; ms < kMSUB; ++ms) { ah[ms] = Ahi[pa[ms] + off]; al[ms] = Alo[pa[ms] + off]; }
+#pragma unroll
+          for (int ms = 0; ms < kMSUB; ++ms)
+#pragma unroll
+            for (int ns = 0; ns < NSUB; ++ns) {
+              acc[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ms], bh[ns], acc[ms][ns], 0, 0, 0);
+              acc[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ms], bl[ns], acc[ms][ns], 0, 0, 0);
+              acc[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ms], bh[ns], acc[ms][ns], 0, 0, 0);
+            }
+        }
+      };
+      if constexpr (ZS == 1) {
+        plane(zd, Bhi, Blo);
+      } else {
+        int z0, z1;
+        chunk_zrange(c0, z0, z1);
+        const int zlo = max(zd, z0), zhi = min(zd + ZS, zend);
+#pragma unroll 1
+        for (int z = zlo; z < zhi; ++z) {
+          int zz = z;
+          asm volatile("" : "+v"(zz));                    // keep the planes a real loop (registers: one plane in flight)
+          plane(zz, Bhi + (zz - zd) * (NG * 4 * NB), Blo + (zz - zd) * (NG * 4 * NB));
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     fresh = nchunk != chunk;
-    chunk = nchunk; zd = nzd; bx = nbx;
+    chunk = nchunk; zd = nzd; zend = nzend;
   }
 
-  // epilogue: D row = kk*4 + r = W position inside the sub-tile, col = i16 = channel
-  float* yb = g.y.base + (int64_t)b * g.y.sB;
+  // epilogue: D row = kk*4 + r = position (kk*4 + r) of the mh x mw sub-tile, col = i16 = channel.
+  // mode 3: split-K partial sums go to a dense scratch tensor [split][b][n][pos]; a reduction launch adds them up
+  float* yb = g.y.base + (int64_t)(g.mode == 3 ? split * g.x.B + b : b) * g.y.sB;
 #pragma unroll
   for (int ns = 0; ns < NSUB; ++ns) {
     const int n = n0 + ns * 16 + i16;
     if (n >= g.y.C) continue;
     const int64_t co = view_chan(g.y, n);
-    const float bsv = g.bias ? g.bias[(int64_t)b * g.bias_sB + n] : 0.f;
+    const float bsv = (g.bias && split == 0) ? g.bias[(int64_t)b * g.bias_sB + n] : 0.f;
 #pragma unroll
     for (int ms = 0; ms < kMSUB; ++ms) {
-      const int s = wave * kMSUB + ms;
-      const int od = d0 + s / g.TH, oh = h0 + s % g.TH, ow = w0 + kk * 4;
-      if (od >= g.y.D || oh >= g.y.H || ow >= g.y.W) continue;
+      int s_ = wave * kMSUB + ms;
+      const int sw = s_ % g.nsw; s_ /= g.nsw;
+      const int sh = s_ % g.nsh, sd = s_ / g.nsh;
+      const int p0 = kk * 4;                                        // first of this lane's 4 rows
+      const int od = d0 + sd, oh = h0 + sh * g.mh + p0 / g.mw, ow = w0 + sw * g.mw + p0 % g.mw;
+      if (od >= g.y.D || oh >= g.y.H || ow >= g.y.W) continue;    // (mw >= 4: the 4 rows are 4 consecutive W positions)
       float* dst = yb + co + (int64_t)od * g.y.sD + (int64_t)oh * g.y.sH + (int64_t)ow * g.y.sW;
       if (g.vec_store) {
         f32x4 v = acc[ms][ns] + bsv;
@@ -618,9 +642,9 @@ int launch_bf3_wgrad(const Bf3WgGeom& g, dim3 grid, size_t lds, hipStream_t st) 
 
 unsigned magic20b(int d) { return (unsigned)(((1u << 20) + d - 1) / d); }
 
-template <int NSUB, int XM, int NG>
+template <int NSUB, int XM, int NG, int ZS>
 int launch_bf3(const Bf3Geom& g, dim3 grid, size_t lds, hipStream_t st) {
-  auto k = conv_bf3_kernel<NSUB, XM, NG>;
+  auto k = conv_bf3_kernel<NSUB, XM, NG, ZS>;
   if (lds > 65536) CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, st, g);
   CRN_CHECK_LAUNCH();
@@ -632,10 +656,11 @@ bool even_view(const crnView& v) {       // 8-byte staging of position pairs on 
          (v.sB & 1) == 0 && (((uintptr_t)v.base) & 7) == 0;
 }
 
+constexpr size_t kLdsMax = 160 * 1024 - 512;
+
 }  // namespace
 
-// Returns CRN_EINVAL for shapes this engine does not cover (the caller keeps the fp32 engine for those);
-// crn_conv_fwd_bf3_supported lets the host decide once per layer.
+// Returns CRN_EINVAL for shapes this engine does not cover (the caller keeps the fp32 engine for those).
 extern "C" int crn_conv_fwd_bf3(const crnView* x, const crnInTransform* tr, const float* w, int Npad,
                                 const float* bias, int bias_sB, const crnView* y,
                                 int kd, int kh, int kw, int pd, int ph, int pw,
@@ -646,7 +671,6 @@ extern "C" int crn_conv_fwd_bf3(const crnView* x, const crnInTransform* tr, cons
   hipStream_t st = (hipStream_t)stream;
   const int xmode = even_view(*x) ? 1 : ((x->sW == 2 && x->chan_off != nullptr && (x->W & 1) == 0) ? 2 : 0);
   if (!xmode) return CRN_EINVAL;
-  if ((y->W & 15) || y->H < 8 || y->D < 4) return CRN_EINVAL;
   Bf3Geom g{};
   g.x = *x; g.y = *y;
   g.tr = tr ? *tr : crnInTransform{nullptr, nullptr, 0, 0};
@@ -656,47 +680,83 @@ extern "C" int crn_conv_fwd_bf3(const crnView* x, const crnInTransform* tr, cons
   g.T = kd * kh * kw; g.KHW = kh * kw;
   g.NG = (g.KHW + 3) / 4;
   if ((g.NG != 4 && g.NG != 7) || kd > 8) return CRN_EINVAL;           // instantiated: 4x4 and 5x5 window planes
-  g.TD = 4; g.TH = 8;
-  g.PD = g.TD + kd - 1; g.PH = g.TH + kh - 1; g.PW = (g.lead + 16 + kw - 1 + 1) & ~1;
+  // tile: 32 sub-tiles of 16 positions.  W >= 16: sub-tile = 16 W positions, tile 4 x 8 x 16; W == 8: sub-tile =
+  // 2 x 8 (two H rows), tile 8 x 8 x 8 (a whole 8^3 sample)
+  if (y->W % 16 == 0 && y->H >= 8 && y->D >= 4) { g.mw = 16; g.mh = 1; g.nsw = 1; g.nsh = 8; g.TD = 4; }
+  else if (y->W == 8 && y->H % 2 == 0 && y->H >= 8 && y->D >= 8) { g.mw = 8; g.mh = 2; g.nsw = 1; g.nsh = 4; g.TD = 8; }
+  else return CRN_EINVAL;
+  g.TH = g.nsh * g.mh; g.TW = g.nsw * g.mw;
+  g.PD = g.TD + kd - 1; g.PH = g.TH + kh - 1; g.PW = (g.lead + g.TW + kw - 1 + 1) & ~1;
   g.PHW = g.PH * g.PW; g.NP = g.PD * g.PHW;
   g.pw2 = g.PW / 2; g.nunits = g.PD * g.PH * g.pw2;
   if (g.nunits > kNUX * kThreads) return CRN_EINVAL;
-  g.tilesD = crn_cdiv(y->D, g.TD); g.tilesH = crn_cdiv(y->H, g.TH); g.tilesW = y->W / 16;
+  g.tilesD = crn_cdiv(y->D, g.TD); g.tilesH = crn_cdiv(y->H, g.TH); g.tilesW = crn_cdiv(y->W, g.TW);
   g.nchunks = crn_cdiv(x->C, kCK);
-  g.mode = accumulate ? 1 : 0;
   g.magic_pw2 = magic20b(g.pw2); g.magic_PH = magic20b(g.PH); g.magic_kw = magic20b(kw);
-  g.vec_store = (y->sW == 1 && (y->W & 3) == 0 && (y->sH & 3) == 0 && (y->sD & 3) == 0 && (y->sB & 3) == 0 &&
-                 (y->sC & 3) == 0 && (((uintptr_t)y->base) & 15) == 0 && y->chan_off == nullptr) ? 1 : 0;
   static const bool no_boxes = getenv("CRN_NO_BOXES") != nullptr;
   bool have_nbox = false;
   if (boxes && !no_boxes) {
     if (boxes->n_groups > 0 && y->C % boxes->n_groups == 0) { g.n_groups = boxes->n_groups; memcpy(g.n_box, boxes->n_box, sizeof(g.n_box)); have_nbox = true; }
     if (boxes->c_groups > 0 && x->C % boxes->c_groups == 0) { g.c_groups = boxes->c_groups; memcpy(g.c_box, boxes->c_box, sizeof(g.c_box)); }
   }
-  // N block: wide blocks re-use the staged patch; with per-output-group tap boxes (transposed convolutions)
-  // a 16-column block belongs to one parity and skips that parity's structural zeros instead
+  const int64_t tiles = (int64_t)g.tilesD * g.tilesH * g.tilesW * y->B;
+  const int KD = g.NG == 7 ? 5 : 4;                   // window depth of the instantiated whole-window slabs
+  g.ctab = (x->C + 15) & ~15;
+  auto lds_of = [&](int nsub, int zs) { return (size_t)(3 * g.ctab * 4) + (size_t)2 * g.NP * 16 + (size_t)2 * zs * g.NG * 4 * nsub * 16 * 16; };
+  // N block: wide blocks re-use the staged patch; with per-output-group tap boxes (transposed convolutions) a
+  // 16-column block belongs to one parity and skips that parity's structural zeros instead.  When the tiles
+  // alone cannot fill the chip, narrower N blocks (more workgroups) come first, then split-K over the chunks.
   int NSUB = (Npad % 64 == 0) ? 4 : ((Npad % 32 == 0) ? 2 : 1);
   if (have_nbox && (y->C / g.n_groups) % 16 == 0) NSUB = 1;
+  while (NSUB > 1 && (lds_of(NSUB, 1) > kLdsMax || tiles * crn_cdiv(Npad, NSUB * 16) < 192)) NSUB >>= 1;
   if (const char* f = getenv("CRN_BF3_NSUB")) NSUB = atoi(f);
-  auto lds_of = [&](int nsub) { return (size_t)(3 * kTabC * 4 + kMaxTapSlots * 4) + (size_t)2 * g.NP * 16 + (size_t)2 * g.NG * 4 * nsub * 16 * 16; };
-  while (NSUB > 1 && lds_of(NSUB) > 160 * 1024 - 512) NSUB >>= 1;
   if (NSUB != 1 && NSUB != 2 && NSUB != 4) return CRN_EINVAL;
-  const size_t lds = lds_of(NSUB);
-  if (lds > 160 * 1024 - 512) return CRN_EINVAL;
+  // Whole-window slabs (ZS = kd: one staging step per chunk instead of one per window plane) were measured
+  // SLOWER than plane-by-plane slabs (s6c1 fwd 584 vs 464 us, s5t1 fwd 343 vs 270 us): the long commit phase
+  // stalls all eight waves at once, while short steps let the two waves of a SIMD overlap.  ZS stays 1.
+  const int ZS = 1;
+  (void)KD;
+  const size_t lds = lds_of(NSUB, ZS);
+  if (lds > kLdsMax) return CRN_EINVAL;
   if ((int64_t)x->C * g.T * Npad >= ((int64_t)1 << 29)) return CRN_EINVAL;
+  // split-K over the channel chunks: partial sums to the shared scratch, one reduction launch
+  const int64_t blocks = tiles * crn_cdiv(Npad, NSUB * 16);
+  int splits = 1;
+  if (blocks < 192) splits = (int)std::min<int64_t>(std::min(g.nchunks, 16), crn_cdiv(256, blocks));
+  if (const char* f = getenv("CRN_BF3_SPLITS")) splits = std::max(1, std::min(atoi(f), g.nchunks));
+  g.chunks_per_split = crn_cdiv(g.nchunks, splits);
+  splits = crn_cdiv(g.nchunks, g.chunks_per_split);
+  g.mode = accumulate ? 1 : 0;
+  const crnView yreal = *y;
+  float* scratch = nullptr;
+  if (splits > 1) {
+    const int64_t S = (int64_t)y->D * y->H * y->W, ytot = (int64_t)y->B * y->C * S;
+    scratch = crn_splitk_scratch((size_t)splits * ytot);
+    if (!scratch) { splits = 1; g.chunks_per_split = g.nchunks; }
+    else {
+      g.mode = 3;
+      g.y.base = scratch; g.y.chan_off = nullptr;
+      g.y.sW = 1; g.y.sH = y->W; g.y.sD = y->H * y->W; g.y.sC = S; g.y.sB = (int64_t)y->C * S;
+    }
+  }
+  const crnView& yo = g.y;
+  g.vec_store = (g.mw >= 4 && yo.sW == 1 && (yo.W & 3) == 0 && (yo.sH & 3) == 0 && (yo.sD & 3) == 0 && (yo.sB & 3) == 0 &&
+                 (yo.sC & 3) == 0 && (((uintptr_t)yo.base) & 15) == 0 && yo.chan_off == nullptr) ? 1 : 0;
   g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
-  dim3 grid((unsigned)(g.tilesD * g.tilesH * g.tilesW * y->B), (unsigned)crn_cdiv(Npad, NSUB * 16), 1);
+  dim3 grid((unsigned)tiles, (unsigned)crn_cdiv(Npad, NSUB * 16), (unsigned)splits);
   static const bool dbg = getenv("CRN_DEBUG") != nullptr;
   if (dbg)
-    fprintf(stderr, "[crn_conv_fwd_bf3] x(C%d %dx%dx%d) y(C%d %dx%dx%d) k%dx%dx%d: NSUB %d xmode %d patch %dx%dx%d units %d "
-            "NG %d grid %ux%u lds %zu\n", x->C, x->D, x->H, x->W, y->C, y->D, y->H, y->W, kd, kh, kw, NSUB, xmode, g.PD, g.PH,
-            g.PW, g.nunits, g.NG, grid.x, grid.y, lds);
-#define CRN_BF3_CASE(N, X, G) if (NSUB == N && xmode == X && g.NG == G) return launch_bf3<N, X, G>(g, grid, lds, st);
-  CRN_BF3_CASE(1, 1, 7) CRN_BF3_CASE(2, 1, 7) CRN_BF3_CASE(4, 1, 7)
-  CRN_BF3_CASE(1, 1, 4) CRN_BF3_CASE(2, 1, 4) CRN_BF3_CASE(4, 1, 4)
-  CRN_BF3_CASE(1, 2, 4) CRN_BF3_CASE(2, 2, 4) CRN_BF3_CASE(4, 2, 4)
+    fprintf(stderr, "[crn_conv_fwd_bf3] x(C%d %dx%dx%d) y(C%d %dx%dx%d) k%dx%dx%d: NSUB %d ZS %d xmode %d tile %dx%dx%d patch "
+            "%dx%dx%d units %d NG %d grid %ux%ux%u lds %zu\n", x->C, x->D, x->H, x->W, y->C, y->D, y->H, y->W, kd, kh, kw, NSUB,
+            ZS, xmode, g.TD, g.TH, g.TW, g.PD, g.PH, g.PW, g.nunits, g.NG, grid.x, grid.y, grid.z, lds);
+  int rc = CRN_EINVAL;
+#define CRN_BF3_CASE(N, X, G, Z) if (NSUB == N && xmode == X && g.NG == G && ZS == Z) rc = launch_bf3<N, X, G, Z>(g, grid, lds, st);
+  CRN_BF3_CASE(1, 1, 7, 1) CRN_BF3_CASE(2, 1, 7, 1) CRN_BF3_CASE(4, 1, 7, 1)
+  CRN_BF3_CASE(1, 1, 4, 1) CRN_BF3_CASE(2, 1, 4, 1) CRN_BF3_CASE(4, 1, 4, 1)
+  CRN_BF3_CASE(1, 2, 4, 1) CRN_BF3_CASE(2, 2, 4, 1) CRN_BF3_CASE(4, 2, 4, 1)
 #undef CRN_BF3_CASE
-  return CRN_EINVAL;
+  if (rc == CRN_OK && g.mode == 3) rc = crn_splitk_reduce(yreal, scratch, splits, accumulate, st);
+  return rc;
 }
 
 // Weight gradient on the split-bf16 MFMA engine; same contract as crn_conv_wgrad (dw zeroed by the caller or

@@ -270,6 +270,15 @@ bool fwd_cfg(int MSUB, int NSUB, int B, int Cin, int Npad, int D, int H, int W, 
 
 }  // namespace
 
+float* crn_splitk_scratch(size_t floats) { return splitk_scratch(floats); }
+int crn_splitk_reduce(const crnView& y, const float* scratch, int splits, int accumulate, hipStream_t st) {
+  const int64_t ytot = (int64_t)y.B * y.C * y.D * y.H * y.W;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(crn_cdiv(ytot, 256), 4096)), dim3(256), 0, st,
+                     y, scratch, splits, accumulate);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
 extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const float* w, int Npad,
                             const float* bias, int bias_sB, const crnView* y,
                             int kd, int kh, int kw, int pd, int ph, int pw,

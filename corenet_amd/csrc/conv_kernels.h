@@ -1029,6 +1029,10 @@ inline int launch_wgrad(const WgradGeom& g, dim3 grid, size_t lds_bytes, hipStre
 
 }  // namespace crnk
 
+// split-K scratch + reduction shared by the fp32 and the bf16x3 engine (defined in conv_igemm.hip)
+float* crn_splitk_scratch(size_t floats);
+int crn_splitk_reduce(const crnView& y, const float* scratch, int splits, int accumulate, hipStream_t st);
+
 // launchers defined in conv_inst.hip (one object per configuration)
 #define CRN_FWD_CONFIGS(X) X(8, 1) X(4, 2) X(4, 1) X(2, 4) X(2, 2) X(2, 1) X(1, 4) X(1, 2) X(1, 1)
 #define CRN_WG_CONFIGS(X) X(8, 1) X(4, 2) X(4, 1) X(2, 4) X(2, 2) X(2, 1) X(1, 4) X(1, 2) X(1, 1)

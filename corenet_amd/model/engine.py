@@ -44,13 +44,13 @@ ENC_STAGES = (("stage2", "abc", (64, 64, 256), 1), ("stage3", "abcd", (128, 128,
 GRAD_BUCKET_LABELS = ("decoder.stage_3.", "decoder.stage_0.", "encoder.stage5.c.", "encoder.stage5.b.",
                       "encoder.stage5.a.", "encoder.stage4.a.", "")
 # Layers (and directions) that run on the split-bf16 MFMA engine when Engine(decoder_math="bf16x3"): the
-# Conv3d k5 / ConvTranspose3d k7 of decoder stages 4-6 (reconstruction_decoder.py:72-95), except the two
-# launches whose grids cannot fill the chip with 512-position tiles and are faster on the fp32 engine
-# (measured, profiles/r02_bf16x3_layers.txt).  Everything else -- encoder, stages 0-3, all weight gradients
-# until they have their own kernel -- stays on the fp32 MFMA engine.
+# Conv3d k5 / ConvTranspose3d k7 of decoder stages 3-6 (reconstruction_decoder.py:64-95) forward and
+# data-gradient, and the weight gradients of stages 4-6 (the bf16x3 weight-gradient kernel tiles 16 W
+# positions).  Everything else -- encoder, stages 0-2, the stage-3 weight gradients -- stays on the fp32
+# MFMA engine (measured per layer: profiles/r02_layer_times_bf16x3.txt).
 BF16X3_LAUNCHES = frozenset(
-    (f"decoder.stage_{k}.{l}.", d) for k in (4, 5, 6) for l in ("c1", "t1") for d in ("fwd", "dgrad", "wgrad")
-) - {("decoder.stage_4.c1.", "fwd"), ("decoder.stage_4.t1.", "dgrad")}
+    [(f"decoder.stage_{k}.{l}.", d) for k in (3, 4, 5, 6) for l in ("c1", "t1") for d in ("fwd", "dgrad")] +
+    [(f"decoder.stage_{k}.{l}.", "wgrad") for k in (4, 5, 6) for l in ("c1", "t1")])
 LOSS_KINDS = {"iou_fgbg": 0, "xent_times_iou_agnostic": 1, "iou_agnostic": 2, "xent": 3,
               "xent_times_iou_fgbg": 4}
 
