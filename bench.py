@@ -206,14 +206,18 @@ def main():
   # HBM bytes per launch from the PMC passes of this same command (profiles/*_pmc_traffic.json;
   # FETCH_SIZE / WRITE_SIZE need their own rocprofv3 runs and cannot be read from inside the process)
   traffic = {}
-  traffic_file = os.path.join("profiles", "r01_pmc_traffic.json")
+  traffic_file = os.path.join("profiles", "r02_pmc_traffic.json" if args.math == "bf16x3" else "r01_pmc_traffic.json")
   try:
     tj = json.load(open(os.path.join(ROOT, traffic_file)))
-    if B == 4:
+    if B == 4 and C == 2:
       for k, v in tj.get("kernels", {}).items():
-        # stage_6.c1 fwd: conv_fwd_kernel<8,1,xvec>, 2048 tiles x 1 N-block.  stage_5.t1 and stage_6.t1 fwd
+        if args.math == "bf16x3":
+          # stage_6.c1 fwd is the only launch of conv_bf3_kernel<NSUB 1, unit-stride x, 5x5 plane> on 2048 tiles
+          if "conv_bf3_kernel<1, 1, 7, 1>" in k and k.endswith(f"grid {2048 * 512}"):
+            traffic["conv"] = v["hbm_bytes"]
+        # stage_6.c1 fwd (fp32 engine): conv_fwd_kernel<8,1,xvec>, 2048 tiles x 1 N-block.  stage_5.t1 and stage_6.t1 fwd
         # share that (kernel, grid); per step the dispatch order is s5.t1, s6.c1, s6.t1 -> every 3rd from 1
-        if "conv_fwd_kernel<8, 1, 1>" in k and k.endswith(f"grid {2048 * 256}"):
+        elif "conv_fwd_kernel<8, 1, 1>" in k and k.endswith(f"grid {2048 * 256}"):
           pl = v.get("per_launch_hbm_bytes", [])
           if len(pl) >= 3 and len(pl) % 3 == 0:
             mine = pl[1::3]
@@ -272,7 +276,7 @@ def main():
   if args.math == "bf16x3":
     dtype_note = ("f32 (bf16x3 products in the decoder stage 4-6 convolutions: operands split into two bf16 terms, three "
                   "bf16 MFMAs per fp32 product, fp32 accumulation, ~3e-6 relative per layer; everything else fp32)")
-    conv_kernel_name = "conv_bf3_kernel<NSUB 1, 5x5 plane> (stage_6.c1 Conv3d 28->16 k5 @64^3, fwd, split-bf16 MFMA engine)"
+    conv_kernel_name = "conv_bf3_kernel<1,1,7,1> (stage_6.c1 Conv3d 28->16 k5 @64^3, fwd, split-bf16 MFMA engine)"
     conv_peak = PEAK_BF16_MFMA / 3
     conv_peak_note = "dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-equivalent product; achieved counts the layer's real 2*M*K*N"
   else:
@@ -296,7 +300,7 @@ def main():
                    "bound": "mfma", "achieved": CONV6_FLOP * B / conv_s / 1e12, "peak": conv_peak / 1e12,
                    "peak_note": conv_peak_note,
                    "unit": "TFLOP/s", "frac": CONV6_FLOP * B / conv_s / conv_peak,
-                   "traffic": traffic.get("conv") if args.math == "fp32" else None,
+                   "traffic": traffic.get("conv"),
                    "traffic_source": f"{traffic_file} (separate rocprofv3 --pmc passes of this command; not measured in this run)",
                    "avg_launch_ms": conv_s * 1e3},
       # duration = burst of 20 launches on the step's own buffers (12.2 us; rocprofv3 kernel-trace of the in-step
