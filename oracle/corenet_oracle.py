@@ -690,7 +690,7 @@ def param_specs(num_classes: int = 2, latent: int = 64, skip_fraction: float = 0
 
 
 def make_state(seed: int = 0, num_classes: int = 2, nbt: int = 0,
-               perturb_bn: bool = True) -> State:
+               perturb_bn: bool = True, logit_scale: float = 1.0) -> State:
   """Deterministic He-normal conv weights; BN gamma/beta/running stats mildly
   perturbed (so that parity tests exercise them); reproducible on any host
   from the seed alone (torch CPU generator)."""
@@ -716,6 +716,11 @@ def make_state(seed: int = 0, num_classes: int = 2, nbt: int = 0,
       sd[key] = 1.0 + (t.rand(shape, generator=g) * 0.5 if perturb_bn else t.zeros(shape))
     elif kind == "nbt":
       sd[key] = t.tensor(nbt, dtype=t.int64)
+  if logit_scale != 1.0:
+    # random-init eval-mode logits reach |x| ~ 1.5e4 and saturate the softmax; a scaled last layer keeps them
+    # O(1), so that probabilities (super-resolution fixtures) are a well-conditioned function of the logits
+    sd["decoder.stage_6.t1.weight"] = sd["decoder.stage_6.t1.weight"] * logit_scale
+    sd["decoder.stage_6.t1.bias"] = sd["decoder.stage_6.t1.bias"] * logit_scale
   return sd
 
 

@@ -252,7 +252,7 @@ def gen_super_resolution():
   import corenet as _c
   _c.pipeline, _c.state = pm, sm
   from corenet import super_resolution as SR
-  sd = O.make_state(seed=0, num_classes=2, nbt=100)
+  sd = O.make_state(seed=0, num_classes=2, nbt=100, logit_scale=2e-4)     # logits O(1): the pmf is well conditioned
   image, v2s, off, _ = O.synthetic_batch(1, seed=0, num_classes=2)
   net = ref_model(2, sd); net.eval()
   state = sm.State(); state.model = net

@@ -46,3 +46,27 @@ def test_two_ranks_one_gpu_overlapped_train_steps(tmp_path):
   assert sum(a["pushed"]) == a["n"] and len(a["pushed"]) == 7
   assert a["losses"][0] != b["losses"][0]                              # different samples per rank
   assert a["losses"][-1] < a["losses"][0] and b["losses"][-1] < b["losses"][0]
+
+
+def test_bench_two_rank_launch_path_dry_run():
+  """The driver's N > 1 command line, `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+  127.0.0.1 --master-port P bench.py --gpus 2 ...`, on this one-GPU box with CRN_DIST_BACKEND=gloo (two ranks
+  share the GPU): rank 0 prints ONE JSON line with the contract's keys, n_gpus 2, whole-job throughput, the
+  exchange description, and no CPU baseline on N > 1."""
+  import json, subprocess
+  env = dict(os.environ, CRN_DIST_BACKEND="gloo")
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+         "127.0.0.1", "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+         "--steps", "2", "--warmup", "1"]
+  r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+  assert r.returncode == 0, r.stderr[-3000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+  assert len(lines) == 1, r.stdout[-2000:]
+  d = json.loads(lines[0])
+  for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"):
+    assert k in d, k
+  assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
+  assert abs(d["value"] - 8 * 128 ** 3 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
+  assert d["rccl"]["ranks"] == 2 and d["rccl"]["backend"] == "gloo" and len(d["rccl"]["buckets_mb"]) == 7
+  assert "cpu_baseline" not in d

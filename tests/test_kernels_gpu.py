@@ -135,6 +135,7 @@ def test_conv_fwd_dgrad_wgrad(be, name, kind, wshape, pad, dims, B):
 BF3_CASES = [c for c in CONV_CASES if c[0] in ("conv3d_k5_32", "conv3d_k5_64", "convT_k7_16", "convT_k7_64_c2", "convT_k7_32_c14")] + [
     ("conv3d_k5_16_c112", "conv", (64, 112, 5, 5, 5), 2, (16, 16, 16), 2),
     ("convT_k7_32_c16", "convT", (32, 16, 7, 7, 7), 3, (32, 32, 32), 1),
+    ("convT_k7_64_c14", "convT", (16, 14, 7, 7, 7), 3, (64, 64, 64), 1),       # m7 / m9 logits layer at full size
     ("conv3d_k5_8_c224", "conv", (128, 224, 5, 5, 5), 2, (8, 8, 8), 2),       # stage 3: 8^3 tiles, split-K
     ("convT_k7_8_c128", "convT", (128, 64, 7, 7, 7), 3, (8, 8, 8), 2),
 ]
@@ -608,6 +609,40 @@ def test_fill_random_bit_exact(be, shape, seed):
       gi = t.tensor(g).to(t.int32).to(DEV); oi = t.empty_like(gi)
       be.fill_voxels(gi, oi)
       np.testing.assert_array_equal(oi.cpu().numpy(), fill_oracle_c.fill(g).astype(np.int32))
+
+
+def test_fill_y1_sub_grid_65(be):
+  """The y1 eval configuration (generate_configs.py:205-208: 32^3 grid, sub-grid sampling): conservative
+  sub-grid voxelization into (2*32+1)^3 = 65^3 grids, fill on the 65^3 grids (odd sizes, W not a multiple of 64),
+  centres extracted: HIP chain == oracle chain on every voxel, and the fill alone bit-exact on random 65^3 grids."""
+  import fill_oracle_c
+  from corenet_amd.cc import fill_voxels
+  from corenet_amd.data import batched_example
+  from corenet_amd.geometry import voxelization
+  rng = np.random.RandomState(65)
+  g = (rng.rand(3, 65, 65, 65) < 0.35).astype(np.float32)
+  out = t.empty(g.shape, device=DEV)
+  be.fill_voxels(t.tensor(g).to(DEV), out)
+  np.testing.assert_array_equal(out.cpu().numpy(), fill_oracle_c.fill(g))
+  if _SELF:
+    return
+  R = 32
+  tris = np.concatenate([_uv_sphere(24, 48, np.array([0.45, 0.5, 0.5]), 0.25), _uv_sphere(24, 48, np.array([0.6, 0.55, 0.5]), 0.2)])
+  nt = [24 * 48 * 2] * 2
+  v2v = batched_example.view2voxel_matrices(t.full((1, 3), 0.5), (R, R, R))[0]
+  kw = dict(sub_grid_sampling=True, image_resolution_multiplier=9, conservative_rasterization=True)
+  gg = voxelization.voxelize_mesh(t.tensor(tris), nt, (R, R, R), v2v, **kw)
+  assert gg.shape == (2, 65, 65, 65)
+  ref = O.voxelize_mesh(tris, nt, (R, R, R), v2v.numpy(), **kw)
+  np.testing.assert_array_equal(gg.cpu().numpy(), ref)
+  filled = fill_voxels.fill_inside_voxels_gpu(gg)
+  np.testing.assert_array_equal(filled.cpu().numpy(), fill_oracle_c.fill(ref))
+  c = voxelization.get_sub_grid_centers(filled).cpu().numpy()
+  np.testing.assert_array_equal(c, O.get_sub_grid_centers(fill_oracle_c.fill(ref)))
+  assert c.shape == (2, 32, 32, 32) and c.sum() > 1000
+  labels = batched_example.voxelize_labels(t.tensor(tris), [t.tensor(nt, dtype=t.int32)], [[2, 7]], t.full((1, 3), 0.5), (R, R, R),
+                                           **kw).cpu().numpy()
+  np.testing.assert_array_equal(labels, O.merge_labels(O.get_sub_grid_centers(fill_oracle_c.fill(ref)), [2], [[2, 7]]))
 
 
 def test_fill_full_size_shells(be):

@@ -226,7 +226,7 @@ def test_super_resolution_golden_and_host_logic():
   (tests/golden/super_resolution_h7_x2.npz), and the product's host-side class (no GPU: a stand-in
   inference function) against the same offsets / interleave rule."""
   z = np.load(os.path.join(os.path.dirname(__file__), "golden", "super_resolution_h7_x2.npz"))
-  sd = O.make_state(0, 2, nbt=100)
+  sd = O.make_state(0, 2, nbt=100, logit_scale=2e-4)
   image, v2s, off, _ = O.synthetic_batch(1, 0, 2)
   camera = O.canonical_camera()[None]; v2v = O.scale([128.0] * 3)[None]; go = t.full((1, 3), 0.5)
   np.testing.assert_array_equal(O.super_resolution_offsets(2, go).numpy(), z["native_offsets"])
