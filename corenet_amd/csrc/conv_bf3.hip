@@ -57,6 +57,8 @@ struct Bf3Geom {
   int nchunks, chunks_per_split;
   int ctab;                // entries of the per-channel LDS tables (multiple of 16)
   int mode;                // 0 store, 1 accumulate, 3 split-K partial sums to a dense scratch [split][b][n][pos]
+                           // (+ reduction launch), 4 the same, summed by the last workgroup of each tile
+  crnView yreal; int accumulate_real; int* counters;      // mode 4
   int lead;
   int vec_store;
   int n_groups, c_groups;
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
 
   // epilogue: D row = kk*4 + r = position (kk*4 + r) of the mh x mw sub-tile, col = i16 = channel.
   // mode 3: split-K partial sums go to a dense scratch tensor [split][b][n][pos]; a reduction launch adds them up
-  float* yb = g.y.base + (int64_t)(g.mode == 3 ? split * g.x.B + b : b) * g.y.sB;
+  float* yb = g.y.base + (int64_t)(g.mode >= 3 ? split * g.x.B + b : b) * g.y.sB;
 #pragma unroll
   for (int ns = 0; ns < NSUB; ++ns) {
     const int n = n0 + ns * 16 + i16;
@@ -381,6 +383,49 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
             float* d = dst + (int64_t)r * g.y.sW;
             const float v = acc[ms][ns][r] + bsv;
             *d = g.mode == 1 ? *d + v : v;
+          }
+        }
+      }
+    }
+  }
+  if (g.mode == 4) {      // fused split-K reduction by the last workgroup of the tile (see conv_fwd_kernel, mode 4)
+    __threadfence();
+    int* s_last = reinterpret_cast<int*>(smem);           // the channel tables are dead by now
+    __syncthreads();
+    if (tid == 0) {
+      const int id = blockIdx.x + gridDim.x * blockIdx.y;
+      const int ticket = atomicAdd(g.counters + id, 1);
+      const int last = ticket == (int)gridDim.z - 1;
+      if (last) g.counters[id] = 0;
+      *s_last = last;
+    }
+    __syncthreads();
+    if (!*s_last) return;
+    __threadfence();
+    const int64_t slab = (int64_t)g.x.B * g.y.sB;
+    const int nsplit = gridDim.z;
+    const float* sb = g.y.base + (int64_t)b * g.y.sB;
+    float* yr = g.yreal.base + (int64_t)b * g.yreal.sB;
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) {
+      const int n = n0 + ns * 16 + i16;
+      if (n >= g.y.C) continue;
+      const int64_t co = view_chan(g.y, n), cor = view_chan(g.yreal, n);
+#pragma unroll
+      for (int ms = 0; ms < kMSUB; ++ms) {
+        int s_ = wave * kMSUB + ms;
+        const int sw = s_ % g.nsw; s_ /= g.nsw;
+        const int sh = s_ % g.nsh, sd = s_ / g.nsh;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = kk * 4 + r;
+          const int od = d0 + sd, oh = h0 + sh * g.mh + p / g.mw, ow = w0 + sw * g.mw + p % g.mw;
+          if (od < g.y.D && oh < g.y.H && ow < g.y.W) {
+            const float* src = sb + co + (int64_t)od * g.y.sD + (int64_t)oh * g.y.sH + (int64_t)ow * g.y.sW;
+            float sum = 0.f;
+            for (int sp = 0; sp < nsplit; ++sp) sum += __builtin_nontemporal_load(src + sp * slab);
+            float* dst = yr + cor + (int64_t)od * g.yreal.sD + (int64_t)oh * g.yreal.sH + (int64_t)ow * g.yreal.sW;
+            *dst = g.accumulate_real ? *dst + sum : sum;
           }
         }
       }
@@ -735,6 +780,9 @@ extern "C" int crn_conv_fwd_bf3(const crnView* x, const crnInTransform* tr, cons
     if (!scratch) { splits = 1; g.chunks_per_split = g.nchunks; }
     else {
       g.mode = 3;
+      g.yreal = *y; g.accumulate_real = accumulate ? 1 : 0;
+      static const bool sk_launch = getenv("CRN_SPLITK_FUSED") == nullptr;   // default: separate reduction launch
+      if (!sk_launch && (g.counters = crn_splitk_counters((size_t)tiles * crn_cdiv(Npad, NSUB * 16))) != nullptr) g.mode = 4;
       g.y.base = scratch; g.y.chan_off = nullptr;
       g.y.sW = 1; g.y.sH = y->W; g.y.sD = y->H * y->W; g.y.sC = S; g.y.sB = (int64_t)y->C * S;
     }

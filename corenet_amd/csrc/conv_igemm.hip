@@ -47,6 +47,8 @@ struct PwGeom {
   int bias_sB, mode;
   int splits, cps;                 // split-K: blockIdx.z = split*B + b, cps input channels per split (multiple
                                    // of 32); partial sums go to the dense scratch y (mode 0), split*B + b as batch
+  // fused reduction (counters != nullptr): the last workgroup of a tile adds the splits up and writes yr
+  float* yr; int64_t yr_sB, yr_sC, yr_sP; int yr_accumulate; int* counters;
 };
 
 __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
@@ -125,6 +127,41 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
       }
     }
   }
+  if (g.counters) {       // fused split-K reduction: see conv_fwd_kernel (mode 4)
+    __threadfence();
+    __shared__ int s_last;
+    __syncthreads();
+    if (tid == 0) {
+      const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * b);
+      const int ticket = atomicAdd(g.counters + id, 1);
+      const int last = ticket == g.splits - 1;
+      if (last) g.counters[id] = 0;
+      s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (m < g.S) {
+      const int64_t slab = (int64_t)g.B * g.ysB;
+#pragma unroll
+      for (int ns = 0; ns < 2; ++ns) {
+        const int n = n0 + ns * 16 + i16;
+        if (n < g.N) {
+          const float* src = g.y + (int64_t)b * g.ysB + (int64_t)n * g.ysC + m;      // scratch: dense [n][pos]
+          f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int sp = 0; sp < g.splits; ++sp) sum += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + sp * slab));
+          float* dst = g.yr + (int64_t)b * g.yr_sB + (int64_t)n * g.yr_sC + (int64_t)m * g.yr_sP;
+          if (g.yr_sP == 1) {
+            if (g.yr_accumulate) sum += *reinterpret_cast<const f32x4*>(dst);
+            *reinterpret_cast<f32x4*>(dst) = sum;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[i * g.yr_sP] = g.yr_accumulate ? dst[i * g.yr_sP] + sum[i] : sum[i];
+          }
+        }
+      }
+    }
+  }
 }
 
 // 16-byte staging: unit W stride and every offset a multiple of 4 floats
@@ -194,6 +231,20 @@ float* splitk_scratch(size_t floats) {
     if (buf[dev]) (void)hipFree(buf[dev]);
     cap[dev] = std::max(floats, ((size_t)16 << 20) / 4);
     if (hipMalloc(&buf[dev], cap[dev] * 4) != hipSuccess) { buf[dev] = nullptr; cap[dev] = 0; }
+  }
+  return buf[dev];
+}
+
+// arrival counters of the fused split-K reduction (mode 4): zero at allocation, every call leaves them zero
+int* splitk_counters(size_t n) {
+  constexpr int kMaxDev = 16;
+  constexpr size_t kCap = 1 << 16;
+  static int* buf[kMaxDev] = {};
+  int dev = 0;
+  if (n > kCap || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+  if (!buf[dev]) {
+    if (hipMalloc(&buf[dev], kCap * sizeof(int)) != hipSuccess) { buf[dev] = nullptr; return nullptr; }
+    if (hipMemset(buf[dev], 0, kCap * sizeof(int)) != hipSuccess) return nullptr;
   }
   return buf[dev];
 }
@@ -271,6 +322,7 @@ bool fwd_cfg(int MSUB, int NSUB, int B, int Cin, int Npad, int D, int H, int W, 
 }  // namespace
 
 float* crn_splitk_scratch(size_t floats) { return splitk_scratch(floats); }
+int* crn_splitk_counters(size_t n) { return splitk_counters(n); }
 int crn_splitk_reduce(const crnView& y, const float* scratch, int splits, int accumulate, hipStream_t st) {
   const int64_t ytot = (int64_t)y.B * y.C * y.D * y.H * y.W;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(crn_cdiv(ytot, 256), 4096)), dim3(256), 0, st,
@@ -310,7 +362,10 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
         p.cps = (crn_cdiv(x->C, sp) + 31) & ~31;
         sp = crn_cdiv(x->C, p.cps);
         if (sp > 1 && (scratch = splitk_scratch((size_t)sp * ytot)) != nullptr) {
+          p.yr = y->base; p.yr_sB = y->sB; p.yr_sC = y->sC; p.yr_sP = y->sW; p.yr_accumulate = accumulate ? 1 : 0;
           p.splits = sp; p.y = scratch; p.ysB = (int64_t)y->C * Sx; p.ysC = Sx; p.ysP = 1; p.mode = 0;
+          static const bool sk_launch_pw = getenv("CRN_SPLITK_FUSED") == nullptr;
+          if (!sk_launch_pw) p.counters = splitk_counters((size_t)crn_cdiv(Sx, 64) * crn_cdiv(y->C, 32) * x->B);
         } else {
           p.cps = (x->C + 31) & ~31;
         }
@@ -319,7 +374,7 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
     dim3 grid((unsigned)crn_cdiv(Sx, 64), (unsigned)crn_cdiv(y->C, 32), (unsigned)(x->B * p.splits));
     hipLaunchKernelGGL(pointwise_fwd_kernel, grid, dim3(256), 0, st, p);
     CRN_CHECK_LAUNCH();
-    if (p.splits > 1) {
+    if (p.splits > 1 && !p.counters) {
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(crn_cdiv(ytot, 256), 4096)), dim3(256), 0, st,
                          *y, scratch, p.splits, accumulate);
       CRN_CHECK_LAUNCH();
@@ -414,8 +469,10 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   const int64_t ytot = (int64_t)y->B * y->C * y->D * y->H * y->W;
   static const bool sk_atomic = getenv("CRN_SPLITK_ATOMIC") != nullptr;
   float* scratch = (g.mode == 2 && !sk_atomic) ? splitk_scratch((size_t)splits * ytot) : nullptr;
+  static const bool sk_launch = getenv("CRN_SPLITK_FUSED") == nullptr;   // default: the separate reduction launch (see conv_kernels.h, mode 4)
   if (scratch) {
     g.mode = 3;
+    g.yreal = *y; g.accumulate_real = accumulate ? 1 : 0;
     const int64_t S = (int64_t)y->D * y->H * y->W;
     g.y.base = scratch; g.y.chan_off = nullptr;
     g.y.sW = 1; g.y.sH = y->W; g.y.sD = y->H * y->W; g.y.sC = S; g.y.sB = (int64_t)y->C * S;
@@ -428,6 +485,7 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   }
   dim3 grid((unsigned)(g.tilesD * g.tilesH * g.tilesW * y->B), (unsigned)crn_cdiv(Npad, NSUB * 16),
             (unsigned)splits);
+  if (g.mode == 3 && !sk_launch && (g.counters = splitk_counters((size_t)grid.x * grid.y)) != nullptr) g.mode = 4;
   const size_t lds_bytes = best.lds;
   {
     bool al = y->sW == 1 && g.mw >= 4 && (y->W & 3) == 0 && (y->sH & 3) == 0 && (y->sD & 3) == 0 && (y->sB & 3) == 0 &&

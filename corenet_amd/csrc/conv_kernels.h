@@ -27,7 +27,11 @@ struct ConvGeom {
   int CC;                  // channels per chunk (multiple of 4)
   int tilesD, tilesH, tilesW;
   int nchunks, chunks_per_split;
-  int mode;                // 0 store, 1 accumulate (rmw), 2 atomic add
+  int mode;                // 0 store, 1 accumulate (rmw), 2 atomic add, 3 split-K partials to scratch (+ reduce
+                           // launch), 4 split-K partials to scratch, summed by the last workgroup of each tile
+  crnView yreal;           // mode 4: the tensor the sums go to, accumulate_real: += instead of =
+  int accumulate_real;
+  int* counters;           // mode 4: one arrival counter per (tile, N block), zero between calls
   int lg2, npass;          // patch staging: plane padded to 2^lg2 slots, passes of 256 slots
   unsigned magic_PW, magic_PD, magic_T;
   int vec_store;           // epilogue may use 16-B stores (unit W stride, 4-aligned rows)
@@ -587,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
   // epilogue: D row = kk*4 + r (position), col = i16 (channel)
   // mode 3: split-K partial sums go to a dense scratch tensor [split][b][n][pos] (plain stores); a second
   // launch adds them up.  Device-scope float atomics (mode 2) leave the XCD's L2 and cost ~30 us per launch.
-  float* yb = g.y.base + (int64_t)(g.mode == 3 ? split * g.x.B + b : b) * g.y.sB;
+  float* yb = g.y.base + (int64_t)(g.mode >= 3 ? split * g.x.B + b : b) * g.y.sB;
 #pragma unroll
   for (int ns = 0; ns < NSUB; ++ns) {
     const int n = n0 + ns * 16 + i16;
@@ -621,9 +625,60 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
         if (od < g.y.D && oh < g.y.H && ow < g.y.W) {
           float* dst = yb + co + (int64_t)od * g.y.sD + (int64_t)oh * g.y.sH + (int64_t)ow * g.y.sW;
           const float v = acc[ms][ns][r] + bsv;
-          if (g.mode == 0 || g.mode == 3) *dst = v;
+          if (g.mode == 0 || g.mode >= 3) *dst = v;
           else if (g.mode == 1) *dst += v;
           else atomicAdd(dst, v);
+        }
+      }
+    }
+  }
+  // mode 4: the split-K reduction without a second launch.  Every workgroup of a tile publishes its partial sums
+  // (release fence), takes a ticket, and the one that arrives last adds up all splits in a fixed order (split 0
+  // first: the result does not depend on who arrives last) and writes the real output.
+  // MEASURED AND NOT USED BY DEFAULT (env CRN_SPLITK_FUSED=1 turns it on): the agent-scope release / acquire fences
+  // every workgroup needs write back / invalidate the XCD's L2 (MI355X: 8 XCDs, L2 not coherent across them), which
+  // cost far more than the 66 reduction launches (0.48 ms) they save: 18.7 ms per training step instead of 10.5.
+  if (g.mode == 4) {
+    __threadfence();
+    int* s_last = reinterpret_cast<int*>(lds);            // the channel tables are dead by now
+    __syncthreads();
+    if (tid == 0) {
+      const int id = blockIdx.x + gridDim.x * blockIdx.y;
+      const int ticket = atomicAdd(g.counters + id, 1);
+      const int last = ticket == (int)gridDim.z - 1;
+      if (last) g.counters[id] = 0;                       // ready for the next call on this stream
+      *s_last = last;
+    }
+    __syncthreads();
+    if (!*s_last) return;
+    __threadfence();
+    const int64_t slab = (int64_t)g.x.B * g.y.sB;          // one split of the scratch tensor
+    const int nsplit = gridDim.z;
+    const float* sb = g.y.base + (int64_t)b * g.y.sB;
+    float* yr = g.yreal.base + (int64_t)b * g.yreal.sB;
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) {
+      const int n = n0 + ns * 16 + i16;
+      if (n >= g.y.C) continue;
+      const int64_t co = view_chan(g.y, n), cor = view_chan(g.yreal, n);
+#pragma unroll
+      for (int ms = 0; ms < MSUB; ++ms) {
+        int s = wave * MSUB + ms;
+        const int sw = s % g.nsw; s /= g.nsw;
+        const int sh = s % g.nsh; s /= g.nsh;
+        const int sd = s;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row_ = kk * 4 + r;
+          const int rr = row_ / g.mw, rc = row_ - rr * g.mw;
+          const int od = d0 + sd, oh = h0 + sh * g.mh + rr, ow = w0 + sw * g.mw + rc;
+          if (od < g.y.D && oh < g.y.H && ow < g.y.W) {
+            const float* src = sb + co + (int64_t)od * g.y.sD + (int64_t)oh * g.y.sH + (int64_t)ow * g.y.sW;
+            float sum = 0.f;
+            for (int sp = 0; sp < nsplit; ++sp) sum += __builtin_nontemporal_load(src + sp * slab);
+            float* dst = yr + cor + (int64_t)od * g.yreal.sD + (int64_t)oh * g.yreal.sH + (int64_t)ow * g.yreal.sW;
+            *dst = g.accumulate_real ? *dst + sum : sum;
+          }
         }
       }
     }
@@ -1031,6 +1086,7 @@ inline int launch_wgrad(const WgradGeom& g, dim3 grid, size_t lds_bytes, hipStre
 
 // split-K scratch + reduction shared by the fp32 and the bf16x3 engine (defined in conv_igemm.hip)
 float* crn_splitk_scratch(size_t floats);
+int* crn_splitk_counters(size_t n);          // n zero-initialised arrival counters (self-resetting), or nullptr
 int crn_splitk_reduce(const crnView& y, const float* scratch, int splits, int accumulate, hipStream_t st);
 
 // launchers defined in conv_inst.hip (one object per configuration)
