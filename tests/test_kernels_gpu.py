@@ -435,6 +435,37 @@ def test_ray_sample_decoder_scales(be, res, C):
   assert int((out2.cpu() != ref).sum()) == 0
 
 
+@pytest.mark.parametrize("res,C", [(8, 96), (16, 48), (32, 24), (64, 12), (16, 10)])
+def test_ray_sample_backward_cameras_and_accumulate(be, res, C):
+  """crn_ray_sample_bwd against the oracle's autograd (index_put_ accumulate) at the four decoder scales:
+  sample 0 canonical camera, sample 1 shifted so that part of the grid leaves the image and a slab is behind the
+  camera, sample 2 rolled 20 degrees about the optical axis (general
+  matrix), incl. accumulation into an existing gradient (zero_first = False)."""
+  g = t.Generator().manual_seed(res + C)
+  B = 3
+  base = O.canonical_camera() @ O.scale([1.0 / 128] * 3) @ O.scale([128.0 / res] * 3)
+  shift = O.translate([0.9, -0.4, -0.95]) @ base
+  a = np.deg2rad(20.0)
+  roll = t.tensor([[np.cos(a), -np.sin(a), 0, 0], [np.sin(a), np.cos(a), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=t.float32) @ base
+  m = t.stack([base, shift, roll])
+  off = t.tensor([[0.5, 0.5, 0.5], [0.25, 0.5, 0.75], [0.5, 0.5, 0.5]])
+  cmap = t.randn(B, C, res, res, generator=g).requires_grad_(True)
+  gy = t.randn(B, C, res, res, res, generator=g)
+  y = O.ray_sample(cmap, m, off, (res,) * 3)
+  y.backward(gy)
+  dmap = t.full((B, C, res, res), 5.0, device=DEV)
+  be.ray_sample_bwd(gy.to(DEV), C * res ** 3, B, C, res, res, res, m.reshape(B, 16).to(DEV), off.to(DEV), dmap,
+                    C * res * res, res, res, True)
+  for b in range(B):
+    close(dmap[b], cmap.grad[b], 2e-5, f"ray bwd sample {b}")
+  assert float(cmap.grad[1].abs().sum()) > 0 and float((y[1] == 0).float().mean()) > 0.05     # the edge case is live
+  prev = t.randn(B, C, res, res, generator=g)
+  dm2 = prev.to(DEV).clone()
+  be.ray_sample_bwd(gy.to(DEV), C * res ** 3, B, C, res, res, res, m.reshape(B, 16).to(DEV), off.to(DEV), dm2,
+                    C * res * res, res, res, False)
+  close(dm2, prev + cmap.grad, 2e-5, "ray bwd accumulate")
+
+
 @pytest.mark.parametrize("Cin,N,hw", [(2048, 96, 8), (256, 12, 64), (96, 20, 16)])
 def test_pointwise_conv_channel_last_output(be, Cin, N, hw):
   """1x1 conv writing a channel-last view (compress_channels -> skip map), with and without split-K, against
