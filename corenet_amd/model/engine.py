@@ -316,6 +316,12 @@ class Engine:
     # two packs: what forward reads (forward weights + biases) and what only backward reads (data-gradient
     # weights) -- the second one runs on the side stream under the forward pass, and never in eval mode
     self.pack_tiles = dev(G.tile_index([pp for pp, bwd in zip(pack_parts, pack_is_bwd) if not bwd]))
+    # ... and the forward pack once more in two pieces: the encoder's weights are needed at once, the decoder's
+    # ~1.4 ms later, so in training the decoder piece is packed on the side stream under the encoder
+    pack_names = [name for (name, *_rest) in reg for _ in range(3 if _rest[1] is not None else 2)]
+    sel = lambda pred: [pp for pp, bwd, nm in zip(pack_parts, pack_is_bwd, pack_names) if not bwd and pred(nm)]
+    self.pack_tiles_enc = dev(G.tile_index(sel(lambda nm: nm.startswith("encoder."))))
+    self.pack_tiles_dec = dev(G.tile_index(sel(lambda nm: not nm.startswith("encoder."))))
     self.pack_tiles_bwd = dev(G.tile_index([pp for pp, bwd in zip(pack_parts, pack_is_bwd) if bwd]))
     self.unpack_tiles = dev(G.tile_index(unpack_parts))
     # gradient buckets for the overlapped exchange (corenet_amd/distributed.py): contiguous ranges of the
@@ -361,10 +367,12 @@ class Engine:
     if v:
       self.dgrad_dirty = True
 
-  def pack_weights(self):
-    """flat parameter slab -> packed forward weights and biases (1 launch)."""
-    self.be.copy_tiles(self.store.params, self.packed, self.pack_tiles)
-    self._weights_dirty = False
+  def pack_weights(self, part: str = "all"):
+    """flat parameter slab -> packed forward weights and biases (1 launch; "enc" / "dec": one of the two pieces)."""
+    tiles = {"all": self.pack_tiles, "enc": self.pack_tiles_enc, "dec": self.pack_tiles_dec}[part]
+    self.be.copy_tiles(self.store.params, self.packed, tiles)
+    if part != "enc":
+      self._weights_dirty = False
 
   def pack_dgrad_weights(self):
     """flat parameter slab -> packed data-gradient weights (1 launch; backward only)."""
@@ -408,6 +416,10 @@ class Engine:
     self.be.adam_step_hyper(self.store.params, self.store.grads, self.adam_m, self.adam_v,
                             self.store.params.numel(), self.adam_hyper)
     self.weights_dirty = True
+
+
+def _no_exchange(grads: t.Tensor):
+  """Bucket hook of a step without a gradient exchange."""
 
 
 class Plan:
@@ -479,7 +491,11 @@ class Plan:
     # compressed skip maps are channel-last [B][h][w][C]: the ray-sample gather then fetches four channels of a
     # pixel per load (crn_ray_sample_fwd); their gradients stay channel-major (scatter-add per channel plane)
     self.smap = {k: f(B, self.skip_hw[k], self.skip_hw[k], sk[k]) for k in sk}
-    self.gsmap = {k: f(B, sk[k], self.skip_hw[k], self.skip_hw[k]) for k in sk}
+    gs_n = {k: B * sk[k] * self.skip_hw[k] ** 2 for k in sk}
+    self.gsmap_slab = f(sum(gs_n.values()))
+    self.gsmap, o = {}, 0
+    for k in sk:
+      self.gsmap[k] = self.gsmap_slab[o:o + gs_n[k]].view(B, sk[k], self.skip_hw[k], self.skip_hw[k]); o += gs_n[k]
     self.layer_mats = f(4, B, 16)
     self.layer_scales = t.tensor([[128.0 / (2 * self.dec[k]["r"])] * 3 + [1.0] for k in (2, 3, 4, 5)],
                                  dtype=eng.dtype, device=dev).reshape(4, 1, 1, 4)
@@ -493,7 +509,10 @@ class Plan:
     self._bucket_ev = [t.cuda.Event() for _ in GRAD_BUCKET_LABELS] if use_side else None
     self._pack_ev = t.cuda.Event() if use_side else None
     self._dgrad_packed = t.cuda.Event() if use_side else None
+    self._dec_packed = t.cuda.Event() if use_side else None
     self._dgrad_pack_pending = False
+    self._dec_pack_pending = False
+    self._gpacked_zeroed = False
 
   # ------------------------------------------------------------------ cached views
   def _cached(self, key, fn):
@@ -601,17 +620,30 @@ class Plan:
     on the sampling offset, so multi-offset inference (super_resolution.py:123-125) runs it once."""
     eng, be, B = self.eng, self.be, self.B
     self.generation += 1
-    if eng.weights_dirty:
-      eng.pack_weights()
-    self._dgrad_pack_pending = False
-    if training and eng.dgrad_dirty and self.side is not None:
-      # the data-gradient weights are not needed before backward: pack them beside the forward pass
+    # (_dgrad_pack_pending / _gpacked_zeroed stay set until a backward consumes them: a second forward before
+    # the backward must not forget that the side stream still owes it the data-gradient weights)
+    if training and self.side is not None and (eng.dgrad_dirty or eng.weights_dirty):
+      # work that nothing on the main stream needs yet goes to the side stream, under the encoder: the decoder's
+      # forward weights (needed ~1.4 ms later), the data-gradient weights and the zeroing of the packed gradient
+      # slab (needed by backward)
+      dec_later = eng.weights_dirty
+      if dec_later:
+        eng.pack_weights("enc")
       self._pack_ev.record()                      # the parameters are final on the main stream
       with t.cuda.stream(self.side):
         self.side.wait_event(self._pack_ev)
-        eng.pack_dgrad_weights()
+        if dec_later:
+          eng.pack_weights("dec")
+          self._dec_packed.record(self.side)
+        if eng.dgrad_dirty:
+          eng.pack_dgrad_weights()
+        be.zero(eng.gpacked)
         self._dgrad_packed.record(self.side)
       self._dgrad_pack_pending = True
+      self._dec_pack_pending = dec_later
+      self._gpacked_zeroed = True
+    elif eng.weights_dirty:
+      eng.pack_weights()
     cv, bn = eng.convs, eng.bns
     self.training = training
     if not training:
@@ -634,6 +666,9 @@ class Plan:
     eng, be, B = self.eng, self.be, self.B
     cv, bn = eng.convs, eng.bns
     self.generation += 1
+    if self._dec_pack_pending:
+      t.cuda.current_stream().wait_event(self._dec_packed)
+      self._dec_pack_pending = False
     self.offset.copy_(offset)
     # layer matrices v2s @ scale(128 / r) for the four skip grids (reconstruction_decoder.py:111-116)
     v = v2s.to(self.layer_mats.dtype).reshape(1, B, 4, 4)
@@ -743,7 +778,12 @@ class Plan:
       self._dgrad_pack_pending = False
     elif eng.dgrad_dirty:
       eng.pack_dgrad_weights()
-    be.zero(eng.gpacked)
+    if not self._gpacked_zeroed:
+      be.zero(eng.gpacked)
+    self._gpacked_zeroed = False
+    be.zero(self.gsmap_slab)                       # the four skip-map gradients: one launch instead of four memsets
+    if grad_hook is None and self.side is not None and self.trace is None:
+      grad_hook = _no_exchange                     # un-pack the finished buckets on the side stream all the same
     L = eng.latent
     g_out = glogits
     for k in range(6, 1, -1):
@@ -758,7 +798,7 @@ class Plan:
         ns = eng.skip_ch[k]
         be.ray_sample_bwd(g_out[:, d["cout"]:], g_out.stride(0), B, ns, ro, ro, ro,
                           self.layer_mats[k - 2], self.offset, self.gsmap[k], self.gsmap[k].stride(0),
-                          hw, hw, True)
+                          hw, hw, False)
         cs = cv[f"decoder.rt_skip_{k}.compress_channels."]
         ft = self.feat[self.skip_src[k]]
         self._wgrad(cs, self.vw(ft), None, self.vw(self.gsmap[k]))
