@@ -759,6 +759,11 @@ extern "C" int crn_conv_fwd_bf3(const crnView* x, const crnInTransform* tr, cons
   // Whole-window slabs (ZS = kd: one staging step per chunk instead of one per window plane) were measured
   // SLOWER than plane-by-plane slabs (s6c1 fwd 584 vs 464 us, s5t1 fwd 343 vs 270 us): the long commit phase
   // stalls all eight waves at once, while short steps let the two waves of a SIMD overlap.  ZS stays 1.
+  // Also measured and dropped: double-buffered weight slabs with ONE barrier per step (the next slab is written
+  // right after the barrier into the idle buffer): no gain on any layer, and the extra 14 KiB of LDS costs
+  // stage_6.c1 forward its second workgroup per CU (556 vs 455 us).  Ablations of that launch (tools/bf3dbg.sh):
+  // 462 us complete, 170 us without the MFMA loop, 438 us without global loads, 420 us without LDS commits --
+  // the MFMA + LDS-read phase itself runs at ~60 % of the free-running loop of tools/mfma_bf3_loop.hip.
   const int ZS = 1;
   (void)KD;
   const size_t lds = lds_of(NSUB, ZS);
