@@ -389,6 +389,21 @@ __global__ __launch_bounds__(kThreads) void bias_grad_partial_kernel(const float
   }
 }
 
+// small tensors (the skip-compress convs: <= 64 k elements per channel): one workgroup owns a channel and reduces it
+// over batch and positions -- one launch instead of partial + final
+__global__ __launch_bounds__(kThreads) void bias_grad_owner_kernel(const float* dy, int B, int64_t S, int64_t sB,
+                                                                    float* db, int accumulate) {
+  __shared__ double red[kThreads / 64];
+  const int c = blockIdx.x;
+  double s1 = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float* p = dy + (int64_t)b * sB + (int64_t)c * S;
+    for (int64_t i = threadIdx.x; i < S; i += kThreads) s1 += (double)p[i];
+  }
+  const double t1 = crn_block_sum(s1, red);
+  if (threadIdx.x == 0) db[c] = accumulate ? db[c] + (float)t1 : (float)t1;
+}
+
 __global__ void bias_grad_final_kernel(const double* ws, int nparts, int C, float* db, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -545,6 +560,11 @@ extern "C" int crn_bias_grad(const float* dy, int B, int C, int64_t S, int64_t s
                              int accumulate, double* ws, size_t ws_bytes, crnStream stream) {
   hipStream_t st = (hipStream_t)stream;
   if (B < 1 || C < 1 || S < 1 || B > 64) return CRN_EINVAL;
+  if ((int64_t)B * S <= 65536) {
+    hipLaunchKernelGGL(bias_grad_owner_kernel, dim3(C), dim3(kThreads), 0, st, dy, B, S, sB, db, accumulate);
+    CRN_CHECK_LAUNCH();
+    return CRN_OK;
+  }
   const int ns = nsplit_for(S, C, B);
   const int nparts = ns * B;
   if (ws_bytes < (size_t)C * nparts * sizeof(double)) return CRN_ENOMEM;

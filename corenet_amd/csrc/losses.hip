@@ -73,29 +73,32 @@ __global__ __launch_bounds__(kThreads) void loss_pass1_kernel(const float* logit
 }
 
 // coef layout (floats): [0]=loss, [1]=kIouFg, [2]=kIouAg, [3]=kX, then per b: I_fg,U_fg,I_ag,U_ag
-__global__ void loss_finalize_kernel(const double* part, int nblk, int B, int64_t S, int kind,
-                                     float grad_scale, float* loss, float* coef) {
-  // one wave: lanes stride over the per-block partials of each (sample, quantity)
-  const int lane = threadIdx.x;
+// One workgroup of 256 threads: wave w reduces the (sample, quantity) pairs w, w+4, ... (the per-block partials of
+// a pair are summed in a fixed order: lane-strided, then the wave tree), thread 0 combines them.  (A single wave
+// walking all B*5 pairs one after the other took 25 us of the step's critical path.)
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const double* part, int nblk, int B, int64_t S, int kind,
+                                                            float grad_scale, float* loss, float* coef) {
+  __shared__ double sums[64 * kNQ];                      // B <= 64
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int pair = wave; pair < B * kNQ; pair += 4) {
+    const int b = pair / kNQ, k = pair - b * kNQ;
+    double s = 0.0;
+    for (int i = lane; i < nblk; i += 64) s += part[((int64_t)b * nblk + i) * kNQ + k];
+    s = crn_wave_sum(s);
+    if (lane == 0) sums[pair] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   double iou_fg = 0.0, iou_ag = 0.0, xs = 0.0;
   for (int b = 0; b < B; ++b) {
-    double q[kNQ];
-    for (int k = 0; k < kNQ; ++k) {
-      double s = 0.0;
-      for (int i = lane; i < nblk; i += 64) s += part[((int64_t)b * nblk + i) * kNQ + k];
-      s = crn_wave_sum(s);
-      q[k] = __shfl(s, 0, 64);
-    }
+    const double* q = sums + b * kNQ;
     // losses.py:57,110: union==0 -> divide by 1
     const float ifg = (float)q[0], ufg = (float)q[1] == 0.f ? 1.f : (float)q[1];
     const float iag = (float)q[2], uag = (float)q[3] == 0.f ? 1.f : (float)q[3];
     iou_fg += (double)(ifg / ufg); iou_ag += (double)(iag / uag);
     xs += q[4];
-    if (lane == 0) {
-      coef[4 + b * 4 + 0] = ifg; coef[4 + b * 4 + 1] = ufg; coef[4 + b * 4 + 2] = iag; coef[4 + b * 4 + 3] = uag;
-    }
+    coef[4 + b * 4 + 0] = ifg; coef[4 + b * 4 + 1] = ufg; coef[4 + b * 4 + 2] = iag; coef[4 + b * 4 + 3] = uag;
   }
-  if (lane != 0) return;
   const float Lfg = 1.f - (float)(iou_fg / B), Lag = 1.f - (float)(iou_ag / B);
   const float X = (float)(xs / ((double)B * (double)S));
   float L = 0.f, kfg = 0.f, kag = 0.f, kx = 0.f;
@@ -217,7 +220,8 @@ extern "C" int crn_loss_fwd_bwd(int kind, const float* logits, const int32_t* gt
   else if (C <= 16) CRN_LOSS_P1(16); else CRN_LOSS_P1(32);
 #undef CRN_LOSS_P1
   CRN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, part, nblk, B, S, kind, grad_scale, loss, coef);
+  if (B > 64) return CRN_EINVAL;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, part, nblk, B, S, kind, grad_scale, loss, coef);
   CRN_CHECK_LAUNCH();
   if (dlogits) {
 #define CRN_LOSS_P2(CT) hipLaunchKernelGGL(loss_pass2_kernel<CT>, grid, dim3(kThreads), 0, st, logits, gt, weights, C, S, coef, dlogits)
