@@ -753,6 +753,9 @@ extern "C" int crn_conv_fwd_bf3(const crnView* x, const crnInTransform* tr, cons
   // alone cannot fill the chip, narrower N blocks (more workgroups) come first, then split-K over the chunks.
   int NSUB = (Npad % 64 == 0) ? 4 : ((Npad % 32 == 0) ? 2 : 1);
   if (have_nbox && (y->C / g.n_groups) % 16 == 0) NSUB = 1;
+  // 32 columns: two 16-column workgroups per tile instead of one 32-column one keep the launch under 80 KiB of LDS
+  // and 128 VGPRs, i.e. two workgroups per CU (stage_6.c1 data gradient 374 vs 408 us, stage_5.c1 forward unchanged)
+  if (Npad <= 32) NSUB = 1;
   while (NSUB > 1 && (lds_of(NSUB, 1) > kLdsMax || tiles * crn_cdiv(Npad, NSUB * 16) < 192)) NSUB >>= 1;
   if (const char* f = getenv("CRN_BF3_NSUB")) NSUB = atoi(f);
   if (NSUB != 1 && NSUB != 2 && NSUB != 4) return CRN_EINVAL;
