@@ -178,6 +178,16 @@ class HipBackend:
     self.lib.crn_linear_bwd(ptr(x), ptr(w), ptr(dy), lddy, B, K, N, ptr(dx), ptr(dw), ptr(db),
                             _lib.stream())
 
+  def stride2_gather(self, x, y):
+    """y[b,c,i,j] = x[b,c,2i,2j] (contiguous tensors)."""
+    B, Cn, h, w = y.shape
+    self.lib.crn_stride2_gather(ptr(x), ptr(y), B, Cn, h, w, _lib.stream())
+
+  def stride2_scatter(self, dy, dx):
+    """dx[b,c,2i,2j] = dy[b,c,i,j], zeros elsewhere."""
+    B, Cn, h, w = dy.shape
+    self.lib.crn_stride2_scatter(ptr(dy), ptr(dx), B, Cn, h, w, _lib.stream())
+
   def fill_offset_channels(self, x, B, sB, S, c0, offset):
     self.lib.crn_fill_offset_channels(ptr(x), B, sB, S, c0, ptr(offset), _lib.stream())
 

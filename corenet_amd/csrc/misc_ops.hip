@@ -401,4 +401,60 @@ extern "C" int crn_adam_step_hyper(float* param, const float* grad, float* exp_a
   return CRN_OK;
 }
 
+// Stride-2 1x1 convolutions of the ResNet downscale blocks (resnet50.py:94-97: stride on the first 1x1 and on the
+// shortcut): the sub-sampled input is compacted once, y[b,c,i,j] = x[b,c,2i,2j], so that both convolutions (and
+// their weight gradients) run on a plain tensor with the pointwise kernel instead of on a strided view; the
+// data gradient goes the other way, dx[b,c,2i,2j] = dy[b,c,i,j], zeros elsewhere (which also replaces the memset).
+namespace {
+__global__ __launch_bounds__(256) void stride2_gather_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             int h, int w, int64_t planes) {
+  // one thread = 2 output elements (one float4 of input: elements 0 and 2)
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int w2 = w >> 1;
+  const int64_t n = planes * h * w2;
+  if (t >= n) return;
+  const int j2 = (int)(t % w2);
+  const int64_t r = t / w2;
+  const int i = (int)(r % h);
+  const int64_t p = r / h;
+  const f32x4 v = *reinterpret_cast<const f32x4*>(x + (p * (2 * h) + 2 * i) * (int64_t)(2 * w) + 4 * j2);
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  *reinterpret_cast<f32x2*>(y + (p * h + i) * (int64_t)w + 2 * j2) = (f32x2){v[0], v[2]};
+}
+__global__ __launch_bounds__(256) void stride2_scatter_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                              int h, int w, int64_t planes) {
+  // one thread = one float4 of the output row (2i or 2i+1): 2 input elements on even rows, zeros on odd rows
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int w2 = w >> 1;
+  const int64_t n = planes * (2 * h) * w2;
+  if (t >= n) return;
+  const int j2 = (int)(t % w2);
+  const int64_t r = t / w2;
+  const int io = (int)(r % (2 * h));
+  const int64_t p = r / (2 * h);
+  f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if ((io & 1) == 0) {
+    const float* s = dy + (p * h + (io >> 1)) * (int64_t)w + 2 * j2;
+    v[0] = s[0]; v[2] = s[1];
+  }
+  *reinterpret_cast<f32x4*>(dx + (p * (2 * h) + io) * (int64_t)(2 * w) + 4 * j2) = v;
+}
+}  // namespace
+
+extern "C" int crn_stride2_gather(const float* x, float* y, int B, int C, int h, int w, crnStream s) {
+  if (!x || !y || B < 1 || C < 1 || h < 1 || w < 2 || (w & 1) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 7)) return CRN_EINVAL;
+  const int64_t planes = (int64_t)B * C, n = planes * h * (w >> 1);
+  hipLaunchKernelGGL(stride2_gather_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)s, x, y, h, w, planes);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_stride2_scatter(const float* dy, float* dx, int B, int C, int h, int w, crnStream s) {
+  if (!dy || !dx || B < 1 || C < 1 || h < 1 || w < 2 || (w & 1) || (((uintptr_t)dx) & 15)) return CRN_EINVAL;
+  const int64_t planes = (int64_t)B * C, n = planes * (2 * h) * (w >> 1);
+  hipLaunchKernelGGL(stride2_scatter_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)s, dy, dx, h, w, planes);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
 extern "C" const char* crn_version(void) { return "corenet_hip 0.1 (gfx950)"; }

@@ -464,6 +464,11 @@ class Plan:
         if blk["down"]:
           blk["gys"] = f(B, filt[2], ho, ho)
           blk["gin"] = f(B, cin, hw, hw)
+          if st == 2:
+            # the stride-2 1x1 convs (op_a and the shortcut, resnet50.py:94-97) read a compacted copy of the
+            # sub-sampled block input, and their data gradients meet in a compact buffer before they are
+            # scattered back: plain tensors -> the pointwise kernel instead of strided views
+            blk["xs"] = f(B, cin, ho, ho); blk["gxs"] = f(B, cin, ho, ho)
         self.blocks.append(blk)
         cin, hw = filt[2], ho
     # stage-final pre-ReLU features + the 3 offset channels (Q6), and their grads
@@ -719,7 +724,11 @@ class Plan:
     p = blk["prefix"]
     h = blk["h"]; S = h * h
     f1, f2, f3 = blk["f"]
-    xin = self.strided(cur, (1, 2, 2)) if blk["stride"] == 2 else self.vw(cur)
+    if blk["stride"] == 2:
+      be.stride2_gather(cur, blk["xs"])
+      xin = self.vw(blk["xs"])
+    else:
+      xin = self.vw(cur)
     ba, bb, bc = bn[p + "op_a.bn."], bn[p + "op_b.bn."], bn[p + "op_c.bn."]
     self._conv(cv[p + "op_a.conv."], xin, None, self.vw(blk["ya"]))
     self._stats(ba, blk["ya"], S, f1 * S, False, training)
@@ -897,7 +906,7 @@ class Plan:
     be.bn_bwd(blk["ya"], f1 * S, blk["gaa"], f1 * S, B, f1, S, False, True, ba.gamma, ba.scale, ba.shift,
               ba.saved, blk["gya"], f1 * S, ba.dgamma, ba.dbeta, dsum=ca.dbias, ndsum=ca.n_ref)
     cur = blk["in"]
-    xin = self.strided(cur, (1, 2, 2)) if blk["stride"] == 2 else self.vw(cur)
+    xin = self.vw(blk["xs"]) if blk["stride"] == 2 else self.vw(cur)
     self._wgrad(ca, xin, None, self.vw(blk["gya"]))
     if blk["down"]:
       bs = bn[p + "shortcut.bn."]
@@ -906,14 +915,11 @@ class Plan:
                 bs.saved, blk["gys"], f3 * S, bs.dgamma, bs.dbeta, dsum=csn.dbias, ndsum=csn.n_ref)
       self._wgrad(csn, xin, None, self.vw(blk["gys"]))
       gin = blk["gin"]
-      gv = self.vw(gin)
-      if blk["stride"] == 2:
-        be.zero(gin)
-        gv = self.strided(gin, (1, 2, 2))
-        self._dgrad(ca, self.vw(blk["gya"]), gv, accumulate=True)
-      else:
-        self._dgrad(ca, self.vw(blk["gya"]), gv)
+      gv = self.vw(blk["gxs"]) if blk["stride"] == 2 else self.vw(gin)
+      self._dgrad(ca, self.vw(blk["gya"]), gv)
       self._dgrad(csn, self.vw(blk["gys"]), gv, accumulate=True)
+      if blk["stride"] == 2:
+        be.stride2_scatter(blk["gxs"], gin)           # every element of gin is written (zeros between the samples)
       return gin
     # identity block: d in = d pre + dgrad(op_a)
     self._dgrad(ca, self.vw(blk["gya"]), self.vw(gpre), accumulate=True)

@@ -241,6 +241,13 @@ class EmuBackend:
     if dw is not None: dw.copy_(g.t() @ x.view(B, K))
     if db is not None: db.copy_(g.sum(0))
 
+  def stride2_gather(self, x, y):
+    y.copy_(x[:, :, ::2, ::2])
+
+  def stride2_scatter(self, dy, dx):
+    dx.zero_()
+    dx[:, :, ::2, ::2] = dy
+
   def fill_offset_channels(self, x, B, sB, S, c0, offset):
     t.as_strided(x, (B, 3, S), (sB, S, 1), x.storage_offset() + c0 * S).copy_(
         offset.view(B, 3, 1).expand(B, 3, S))

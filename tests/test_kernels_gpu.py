@@ -388,6 +388,23 @@ def test_encoder_misc(be):
   close(out[DEV][1], ref, 1e-6, "maxpool vs torch")
 
 
+def test_stride2_gather_scatter(be):
+  """crn_stride2_gather / crn_stride2_scatter (the compacted input of the ResNet downscale blocks' stride-2 1x1
+  convs and the adjoint): exact copies; the scatter writes every element (zeros between the samples)."""
+  g = t.Generator().manual_seed(2)
+  for shape in ((2, 5, 8, 8), (4, 256, 32, 32), (1, 3, 6, 10)):
+    B, C, h, w = shape
+    x = t.randn(B, C, 2 * h, 2 * w, generator=g)
+    y = t.full(shape, 9.0, device=DEV)
+    be.stride2_gather(x.to(DEV), y)
+    assert t.equal(y.cpu(), x[:, :, ::2, ::2])
+    dy = t.randn(shape, generator=g)
+    dx = t.full((B, C, 2 * h, 2 * w), 9.0, device=DEV)
+    be.stride2_scatter(dy.to(DEV), dx)
+    want = t.zeros(B, C, 2 * h, 2 * w); want[:, :, ::2, ::2] = dy
+    assert t.equal(dx.cpu(), want)
+
+
 # ------------------------------------------------------------------ ray-traced skip
 def test_ray_sample_golden_and_edge(be, golden_dir):
   import os
