@@ -164,6 +164,91 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
   }
 }
 
+// --------------------------- dense layers on 1^3 grids ------------------------------------------------------
+// decoder stage_1 (reconstruction_decoder.py:52-54): ConvTranspose3d(k=4) from a 1^3 grid = a dense layer from
+// 67 channels onto 16384 logical channels, i.e. ONE position per sample.  The tile engine needs 16 positions per
+// MFMA row block and spent 67 / 76 / 47 us (forward / data gradient / weight gradient) on 1.1 M multiply-adds per
+// sample; these three loops are bandwidth bound on the 4.4 MB of weights instead.
+constexpr int kDenseB = 8;      // samples per launch
+// many output columns, few input channels: one thread per column
+__global__ __launch_bounds__(256) void dense_cols_kernel(const float* x, int64_t xsB, int64_t xsC, crnInTransform tr,
+                                                         const float* w, int Npad, int N, int C, int B,
+                                                         const float* bias, int bias_sB, float* y, int64_t ysB,
+                                                         int64_t ysC, int accumulate) {
+  extern __shared__ float xs[];                        // [B][C] transformed inputs
+  for (int i = threadIdx.x; i < B * C; i += blockDim.x) {
+    const int b = i / C, c = i - b * C;
+    float v = x[b * xsB + c * xsC];
+    if (tr.scale) {
+      if (tr.pre_relu) v = fmaxf(v, 0.f);
+      v = v * tr.scale[c] + tr.shift[c];
+      if (tr.post_relu) v = fmaxf(v, 0.f);
+    }
+    xs[i] = v;
+  }
+  __syncthreads();
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float acc[kDenseB];
+#pragma unroll
+  for (int b = 0; b < kDenseB; ++b) acc[b] = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float wv = w[(int64_t)c * Npad + n];
+#pragma unroll
+    for (int b = 0; b < kDenseB; ++b)
+      if (b < B) acc[b] += xs[b * C + c] * wv;
+  }
+#pragma unroll
+  for (int b = 0; b < kDenseB; ++b)
+    if (b < B) {
+      float* d = y + b * ysB + n * ysC;
+      const float v = acc[b] + (bias ? bias[(int64_t)b * bias_sB + n] : 0.f);
+      *d = accumulate ? *d + v : v;
+    }
+}
+// few output columns, many input channels: a workgroup reduces a slice of the channels for all columns, partial
+// sums to the split-K scratch [slice][b][n]
+__global__ __launch_bounds__(128) void dense_rows_kernel(const float* x, int64_t xsB, int64_t xsC, const float* w,
+                                                         int Npad, int N, int C, int B, int cps, const float* bias,
+                                                         int bias_sB, float* scratch) {
+  const int n = threadIdx.x, c0 = blockIdx.x * cps, c1 = min(C, c0 + cps);
+  float acc[kDenseB];
+#pragma unroll
+  for (int b = 0; b < kDenseB; ++b) acc[b] = 0.f;
+  if (n < N) {
+    for (int c = c0; c < c1; ++c) {
+      const float wv = w[(int64_t)c * Npad + n];
+#pragma unroll
+      for (int b = 0; b < kDenseB; ++b)
+        if (b < B) acc[b] += x[b * xsB + c * xsC] * wv;        // wave-uniform address: scalar load
+    }
+#pragma unroll
+    for (int b = 0; b < kDenseB; ++b)
+      if (b < B)
+        scratch[((int64_t)blockIdx.x * B + b) * N + n] = acc[b] + ((bias && blockIdx.x == 0) ? bias[(int64_t)b * bias_sB + n] : 0.f);
+  }
+}
+// weight gradient: dw[c][n] += sum_b T(x)[b][c] * dy[b][n]
+__global__ __launch_bounds__(256) void dense_wgrad_kernel(const float* x, int64_t xsB, int64_t xsC, crnInTransform tr,
+                                                          const float* dy, int64_t dsB, int64_t dsC, float* dw,
+                                                          int Npad, int N, int C, int B) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (n >= N) return;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    float v = x[b * xsB + c * xsC];
+    if (tr.scale) {
+      if (tr.pre_relu) v = fmaxf(v, 0.f);
+      v = v * tr.scale[c] + tr.shift[c];
+      if (tr.post_relu) v = fmaxf(v, 0.f);
+    }
+    acc += v * dy[b * dsB + n * dsC];
+  }
+  dw[(int64_t)c * Npad + n] += acc;
+}
+
+bool one_position(const crnView& v) { return v.D == 1 && v.H == 1 && v.W == 1 && v.chan_off == nullptr; }
+
 // 16-byte staging: unit W stride and every offset a multiple of 4 floats
 bool vec_view(const crnView& v) {
   return v.chan_off == nullptr && v.sW == 1 && (v.W & 3) == 0 && (v.sH & 3) == 0 && (v.sD & 3) == 0 &&
@@ -341,6 +426,27 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   if (y->C > Npad) return CRN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int64_t Sx = (int64_t)x->D * x->H * x->W;
+  if (kd * kh * kw == 1 && pd == 0 && ph == 0 && pw == 0 && splits <= 1 && one_position(*x) && one_position(*y) &&
+      x->B <= kDenseB) {
+    const crnInTransform trv = tr ? *tr : crnInTransform{nullptr, nullptr, 0, 0};
+    if (y->C >= 1024 && x->C <= 2048) {              // wide output: a thread per column
+      hipLaunchKernelGGL(dense_cols_kernel, dim3((unsigned)crn_cdiv(y->C, 256)), dim3(256), (size_t)x->B * x->C * 4, st,
+                         x->base, x->sB, x->sC, trv, w, Npad, y->C, x->C, x->B, bias, bias_sB, y->base, y->sB, y->sC,
+                         accumulate);
+      CRN_CHECK_LAUNCH();
+      return CRN_OK;
+    }
+    if (y->C <= 128 && !trv.scale) {                 // long reduction onto few columns: slices + the split-K reduction
+      const int cps = 256, slices = crn_cdiv(x->C, cps);
+      float* scratch = splitk_scratch((size_t)slices * x->B * y->C);
+      if (scratch) {
+        hipLaunchKernelGGL(dense_rows_kernel, dim3((unsigned)slices), dim3(128), 0, st, x->base, x->sB, x->sC, w, Npad,
+                           y->C, x->C, x->B, cps, bias, bias_sB, scratch);
+        CRN_CHECK_LAUNCH();
+        return crn_splitk_reduce(*y, scratch, slices, accumulate, st);
+      }
+    }
+  }
   if (kd * kh * kw == 1 && pd == 0 && ph == 0 && pw == 0 && splits <= 1 && plain_view(*x) && flat_out_view(*y) &&
       Sx == (int64_t)y->D * y->H * y->W && (Sx & 3) == 0 && (((uintptr_t)w) & 15) == 0) {
     PwGeom p{};
@@ -689,6 +795,13 @@ extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const 
   const int T = kd * kh * kw;
   if (T > 512) return CRN_EINVAL;
   if (zero_first) CRN_HIP(hipMemsetAsync(dw, 0, (size_t)x->C * T * Npad * 4, st));
+  if (T == 1 && one_position(*x) && one_position(*dy) && dy->C >= 1024) {      // dense layer on a 1^3 grid (stage_1)
+    const crnInTransform trv = tr ? *tr : crnInTransform{nullptr, nullptr, 0, 0};
+    hipLaunchKernelGGL(dense_wgrad_kernel, dim3((unsigned)crn_cdiv(dy->C, 256), (unsigned)x->C), dim3(256), 0, st, x->base,
+                       x->sB, x->sC, trv, dy->base, dy->sB, dy->sC, dw, Npad, dy->C, x->C, x->B);
+    CRN_CHECK_LAUNCH();
+    return CRN_OK;
+  }
   // Tap boxes: inside the single launch every block enumerates only the (channel, tap) rows of its output
   // group's box (conv_wgrad_kernel).  The alternative -- one launch per output parity with a smaller
   // window -- LOSES on MI355X (eight prologues and atomic epilogues: s5t1 1.02 ms vs 0.94 ms) and stays an

@@ -281,6 +281,23 @@ def test_conv_1to4(be):
   xr = x.clone().requires_grad_(True)
   t.nn.functional.conv_transpose3d(xr.view(B, 67, 1, 1, 1), w, None, stride=4).backward(dy)
   close(dxg, xr.grad, 2e-5, "1->4 dgrad")
+  # weight gradient with the fused pre-ReLU affine input transform, accumulating into an existing gradient
+  from corenet_amd.backend import Transform
+  sc, sh = t.rand(67, generator=g) + 0.5, t.randn(67, generator=g) * 0.3
+  xt = (x.relu() * sc + sh)
+  wr = w.clone().requires_grad_(True)
+  t.nn.functional.conv_transpose3d(xt.view(B, 67, 1, 1, 1), wr, None, stride=4).backward(dy)
+  prev = t.randn(wf.numel(), generator=g)
+  dwg = prev.to(DEV).clone()
+  be.conv_wgrad(V.view_of(xg.view(B, 67, 1, 1, 1)), Transform(sc.to(DEV), sh.to(DEV), pre_relu=True),
+                V.flat_channel_view(V.view_of(dyg)), dwg, geo.npad, geo.window, geo.pad_lo, False)
+  gw = t.zeros(w.numel()); EMU.scatter(dwg.cpu() - prev, t.as_tensor(geo.index), gw)
+  close(gw.view(w.shape), wr.grad, 2e-5, "1->4 wgrad")
+  # forward with the same transform and accumulation
+  y2 = t.randn(B, 256, 4, 4, 4, generator=g); y2g = y2.to(DEV)
+  be.conv_fwd(V.view_of(xg.view(B, 67, 1, 1, 1)), Transform(sc.to(DEV), sh.to(DEV), pre_relu=True), wf.to(DEV), geo.npad,
+              bp.to(DEV), 0, V.flat_channel_view(V.view_of(y2g)), geo.window, geo.pad_lo, 0, True)
+  close(y2g, y2 + t.nn.functional.conv_transpose3d(xt.view(B, 67, 1, 1, 1), w, b, stride=4), 2e-5, "1->4 fwd transform+accumulate")
 
 
 # ------------------------------------------------------------------ BatchRenorm & elementwise
