@@ -206,26 +206,37 @@ __global__ __launch_bounds__(256) void dense_cols_kernel(const float* x, int64_t
       *d = accumulate ? *d + v : v;
     }
 }
-// few output columns, many input channels: a workgroup reduces a slice of the channels for all columns, partial
-// sums to the split-K scratch [slice][b][n]
-__global__ __launch_bounds__(128) void dense_rows_kernel(const float* x, int64_t xsB, int64_t xsC, const float* w,
-                                                         int Npad, int N, int C, int B, int cps, const float* bias,
-                                                         int bias_sB, float* scratch) {
-  const int n = threadIdx.x, c0 = blockIdx.x * cps, c1 = min(C, c0 + cps);
-  float acc[kDenseB];
+// few output columns, many input channels: a workgroup owns (sample b, 8 columns), its 256 threads stride over the
+// channels (two float4 of weights per channel), and the 256 partial sums of every column are added in the workgroup
+__global__ __launch_bounds__(256) void dense_rows_kernel(const float* x, int64_t xsB, int64_t xsC, const float* w,
+                                                         int Npad, int N, int C, const float* bias, int bias_sB,
+                                                         float* y, int64_t ysB, int64_t ysC, int accumulate) {
+  __shared__ float red[4][8];
+  const int b = blockIdx.y, n0 = blockIdx.x * 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc[8];
 #pragma unroll
-  for (int b = 0; b < kDenseB; ++b) acc[b] = 0.f;
-  if (n < N) {
-    for (int c = c0; c < c1; ++c) {
-      const float wv = w[(int64_t)c * Npad + n];
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const float* xb = x + b * xsB;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float xv = xb[c * xsC];
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + (int64_t)c * Npad + n0);
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + (int64_t)c * Npad + n0 + 4);
 #pragma unroll
-      for (int b = 0; b < kDenseB; ++b)
-        if (b < B) acc[b] += x[b * xsB + c * xsC] * wv;        // wave-uniform address: scalar load
-    }
+    for (int j = 0; j < 4; ++j) { acc[j] += xv * w0[j]; acc[4 + j] += xv * w1[j]; }
+  }
 #pragma unroll
-    for (int b = 0; b < kDenseB; ++b)
-      if (b < B)
-        scratch[((int64_t)blockIdx.x * B + b) * N + n] = acc[b] + ((bias && blockIdx.x == 0) ? bias[(int64_t)b * bias_sB + n] : 0.f);
+  for (int j = 0; j < 8; ++j) {
+    const float v = crn_wave_sum(acc[j]);
+    if (lane == 0) red[wave][j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && n0 + (int)threadIdx.x < N) {
+    const int n = n0 + threadIdx.x;
+    float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (bias) v += bias[(int64_t)b * bias_sB + n];
+    float* d = y + b * ysB + n * ysC;
+    *d = accumulate ? *d + v : v;
   }
 }
 // weight gradient: dw[c][n] += sum_b T(x)[b][c] * dy[b][n]
@@ -436,15 +447,11 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
       CRN_CHECK_LAUNCH();
       return CRN_OK;
     }
-    if (y->C <= 128 && !trv.scale) {                 // long reduction onto few columns: slices + the split-K reduction
-      const int cps = 256, slices = crn_cdiv(x->C, cps);
-      float* scratch = splitk_scratch((size_t)slices * x->B * y->C);
-      if (scratch) {
-        hipLaunchKernelGGL(dense_rows_kernel, dim3((unsigned)slices), dim3(128), 0, st, x->base, x->sB, x->sC, w, Npad,
-                           y->C, x->C, x->B, cps, bias, bias_sB, scratch);
-        CRN_CHECK_LAUNCH();
-        return crn_splitk_reduce(*y, scratch, slices, accumulate, st);
-      }
+    if (y->C <= 256 && !trv.scale && x->C >= 1024) {   // long reduction onto few columns
+      hipLaunchKernelGGL(dense_rows_kernel, dim3((unsigned)crn_cdiv(y->C, 8), (unsigned)x->B), dim3(256), 0, st, x->base,
+                         x->sB, x->sC, w, Npad, y->C, x->C, bias, bias_sB, y->base, y->sB, y->sC, accumulate);
+      CRN_CHECK_LAUNCH();
+      return CRN_OK;
     }
   }
   if (kd * kh * kw == 1 && pd == 0 && ph == 0 && pw == 0 && splits <= 1 && plain_view(*x) && flat_out_view(*y) &&
