@@ -51,8 +51,11 @@ struct PwGeom {
   float* yr; int64_t yr_sB, yr_sC, yr_sP; int yr_accumulate; int* counters;
 };
 
+// NS = 16-column blocks per workgroup (2: 64 x 32 tiles; 4: 64 x 64 tiles -- half the workgroups and half the
+// re-reads of x for the wide layers)
+template <int NS>
 __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
-  constexpr int BM = 64, BN = 32, KC = 32, SA = BM + 16, SB = BN + 16;
+  constexpr int BM = 64, BN = NS * 16, KC = 32, SA = BM + 16, SB = BN + 16;
   __shared__ __attribute__((aligned(16))) float ldsA[KC * SA];
   __shared__ __attribute__((aligned(16))) float ldsB[KC * SB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -63,16 +66,21 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
   const float* xb = g.x + (int64_t)b * g.xsB;
   // staging roles: A: 2 float4 per thread (rows ka0, ka0+16), B: 1 float4 per thread
   const int ka = tid >> 4, ca = (tid & 15) * 4;       // A row / column
-  const int kb = tid >> 3, cb = (tid & 7) * 4;        // B row / column
+  constexpr int BQ = BN / 4, BROWS = 256 / BQ, NRB = KC / BROWS;   // B: float4 per row, rows per pass, passes (1 or 2)
+  const int kb = tid / BQ, cb = (tid % BQ) * 4;       // B row / column
   const bool a_ok = (m0 + ca) < g.S;                  // S % 4 == 0 (checked on the host)
   const bool b_ok = (n0 + cb) < g.Npad;
-  f32x4 ra0, ra1, rb;
+  f32x4 ra0, ra1, rb[NRB];
   auto issue = [&](int c0) {
     const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int c_a0 = c0 + ka, c_a1 = c0 + ka + 16, c_b = c0 + kb;
+    const int c_a0 = c0 + ka, c_a1 = c0 + ka + 16;
     ra0 = (a_ok && c_a0 < cend) ? *reinterpret_cast<const f32x4*>(xb + (int64_t)c_a0 * g.S + m0 + ca) : z;
     ra1 = (a_ok && c_a1 < cend) ? *reinterpret_cast<const f32x4*>(xb + (int64_t)c_a1 * g.S + m0 + ca) : z;
-    rb = (b_ok && c_b < cend) ? *reinterpret_cast<const f32x4*>(g.w + (int64_t)c_b * g.Npad + n0 + cb) : z;
+#pragma unroll
+    for (int q = 0; q < NRB; ++q) {
+      const int c_b = c0 + kb + q * BROWS;
+      rb[q] = (b_ok && c_b < cend) ? *reinterpret_cast<const f32x4*>(g.w + (int64_t)c_b * g.Npad + n0 + cb) : z;
+    }
   };
   auto xform = [&](f32x4 v, int c) -> f32x4 {
     if (g.tr.scale && a_ok && c < cend) {
@@ -88,13 +96,16 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
     }
     return v;
   };
-  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  f32x4 acc[NS];
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) acc[ns] = (f32x4){0.f, 0.f, 0.f, 0.f};
   issue(cbeg);
   for (int c0 = cbeg; c0 < cend; c0 += KC) {
     __syncthreads();
     *reinterpret_cast<f32x4*>(ldsA + ka * SA + ca) = xform(ra0, c0 + ka);
     *reinterpret_cast<f32x4*>(ldsA + (ka + 16) * SA + ca) = xform(ra1, c0 + ka + 16);
-    *reinterpret_cast<f32x4*>(ldsB + kb * SB + cb) = rb;
+#pragma unroll
+    for (int q = 0; q < NRB; ++q) *reinterpret_cast<f32x4*>(ldsB + (kb + q * BROWS) * SB + cb) = rb[q];
     __syncthreads();
     if (c0 + KC < cend) issue(c0 + KC);
     const float* pa = ldsA + kk * SA + wave * 16 + i16;
@@ -102,16 +113,18 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
 #pragma unroll
     for (int ks = 0; ks < KC / 4; ++ks) {
       const float a = pa[ks * 4 * SA];
-      const float b0 = pb[ks * 4 * SB], b1 = pb[ks * 4 * SB + 16];
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[1], 0, 0, 0);
+      float bv[NS];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) bv[ns] = pb[ks * 4 * SB + ns * 16];
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) acc[ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[ns], acc[ns], 0, 0, 0);
     }
   }
   // D: rows kk*4..kk*4+3 = 4 consecutive positions, col i16 = channel -> one float4 per lane
   const int m = m0 + wave * 16 + kk * 4;
   if (m < g.S) {
 #pragma unroll
-    for (int ns = 0; ns < 2; ++ns) {
+    for (int ns = 0; ns < NS; ++ns) {
       const int n = n0 + ns * 16 + i16;
       if (n < g.N) {
         const float bsv = (g.bias && split == 0) ? g.bias[(int64_t)b * g.bias_sB + n] : 0.f;
@@ -144,7 +157,7 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
     if (m < g.S) {
       const int64_t slab = (int64_t)g.B * g.ysB;
 #pragma unroll
-      for (int ns = 0; ns < 2; ++ns) {
+      for (int ns = 0; ns < NS; ++ns) {
         const int n = n0 + ns * 16 + i16;
         if (n < g.N) {
           const float* src = g.y + (int64_t)b * g.ysB + (int64_t)n * g.ysC + m;      // scratch: dense [n][pos]
@@ -465,7 +478,12 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
     p.splits = 1; p.cps = (x->C + 31) & ~31;
     // long reductions over few positions (stage4/5 of the encoder: K = 1024..2048, 64..256 positions per sample):
     // split the channels over blocks, partial sums to the split-K scratch, one reduction launch
-    const int64_t blocks = crn_cdiv(Sx, 64) * crn_cdiv(y->C, 32) * (int64_t)x->B;
+    // 64-column tiles (CRN_PW_NS=4) were measured equal to 32-column ones on the whole step (10.07 vs 10.04 ms): these
+    // launches are latency bound, not operand-traffic bound; 32 stays the default
+    static const char* pw_ns_env = getenv("CRN_PW_NS");
+    const bool wide = pw_ns_env && atoi(pw_ns_env) == 4 && Npad % 64 == 0;
+    const int BNh = wide ? 64 : 32;
+    const int64_t blocks = crn_cdiv(Sx, 64) * crn_cdiv(y->C, BNh) * (int64_t)x->B;
     const int64_t ytot = (int64_t)y->B * y->C * Sx;
     static const bool pw_nosplit = getenv("CRN_PW_NOSPLIT") != nullptr;
     float* scratch = nullptr;
@@ -478,14 +496,15 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
           p.yr = y->base; p.yr_sB = y->sB; p.yr_sC = y->sC; p.yr_sP = y->sW; p.yr_accumulate = accumulate ? 1 : 0;
           p.splits = sp; p.y = scratch; p.ysB = (int64_t)y->C * Sx; p.ysC = Sx; p.ysP = 1; p.mode = 0;
           static const bool sk_launch_pw = getenv("CRN_SPLITK_FUSED") == nullptr;
-          if (!sk_launch_pw) p.counters = splitk_counters((size_t)crn_cdiv(Sx, 64) * crn_cdiv(y->C, 32) * x->B);
+          if (!sk_launch_pw) p.counters = splitk_counters((size_t)crn_cdiv(Sx, 64) * crn_cdiv(y->C, BNh) * x->B);
         } else {
           p.cps = (x->C + 31) & ~31;
         }
       }
     }
-    dim3 grid((unsigned)crn_cdiv(Sx, 64), (unsigned)crn_cdiv(y->C, 32), (unsigned)(x->B * p.splits));
-    hipLaunchKernelGGL(pointwise_fwd_kernel, grid, dim3(256), 0, st, p);
+    dim3 grid((unsigned)crn_cdiv(Sx, 64), (unsigned)crn_cdiv(y->C, BNh), (unsigned)(x->B * p.splits));
+    if (wide) hipLaunchKernelGGL(pointwise_fwd_kernel<4>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(pointwise_fwd_kernel<2>, grid, dim3(256), 0, st, p);
     CRN_CHECK_LAUNCH();
     if (p.splits > 1 && !p.counters) {
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(crn_cdiv(ytot, 256), 4096)), dim3(256), 0, st,
