@@ -55,7 +55,8 @@ struct PwGeom {
 // re-reads of x for the wide layers)
 template <int NS>
 __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
-  constexpr int BM = 64, BN = NS * 16, KC = 32, SA = BM + 16, SB = BN + 16;
+  constexpr int BM = 64, BN = NS * 16, KC = 64, SA = BM + 16, SB = BN + 16;   // KC 64: half the barriers of KC 32
+  constexpr int NRA = KC / 16;
   __shared__ __attribute__((aligned(16))) float ldsA[KC * SA];
   __shared__ __attribute__((aligned(16))) float ldsB[KC * SB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -64,18 +65,20 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
   const int split = blockIdx.z / g.B, b = blockIdx.z - split * g.B;
   const int cbeg = split * g.cps, cend = min(g.C, cbeg + g.cps);
   const float* xb = g.x + (int64_t)b * g.xsB;
-  // staging roles: A: 2 float4 per thread (rows ka0, ka0+16), B: 1 float4 per thread
+  // staging roles: A: KC/16 float4 per thread (rows ka, ka+16, ...), B: NRB float4 per thread
   const int ka = tid >> 4, ca = (tid & 15) * 4;       // A row / column
   constexpr int BQ = BN / 4, BROWS = 256 / BQ, NRB = KC / BROWS;   // B: float4 per row, rows per pass, passes (1 or 2)
   const int kb = tid / BQ, cb = (tid % BQ) * 4;       // B row / column
   const bool a_ok = (m0 + ca) < g.S;                  // S % 4 == 0 (checked on the host)
   const bool b_ok = (n0 + cb) < g.Npad;
-  f32x4 ra0, ra1, rb[NRB];
+  f32x4 ra[NRA], rb[NRB];
   auto issue = [&](int c0) {
     const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int c_a0 = c0 + ka, c_a1 = c0 + ka + 16;
-    ra0 = (a_ok && c_a0 < cend) ? *reinterpret_cast<const f32x4*>(xb + (int64_t)c_a0 * g.S + m0 + ca) : z;
-    ra1 = (a_ok && c_a1 < cend) ? *reinterpret_cast<const f32x4*>(xb + (int64_t)c_a1 * g.S + m0 + ca) : z;
+#pragma unroll
+    for (int q = 0; q < NRA; ++q) {
+      const int c_a = c0 + ka + q * 16;
+      ra[q] = (a_ok && c_a < cend) ? *reinterpret_cast<const f32x4*>(xb + (int64_t)c_a * g.S + m0 + ca) : z;
+    }
 #pragma unroll
     for (int q = 0; q < NRB; ++q) {
       const int c_b = c0 + kb + q * BROWS;
@@ -102,8 +105,8 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
   issue(cbeg);
   for (int c0 = cbeg; c0 < cend; c0 += KC) {
     __syncthreads();
-    *reinterpret_cast<f32x4*>(ldsA + ka * SA + ca) = xform(ra0, c0 + ka);
-    *reinterpret_cast<f32x4*>(ldsA + (ka + 16) * SA + ca) = xform(ra1, c0 + ka + 16);
+#pragma unroll
+    for (int q = 0; q < NRA; ++q) *reinterpret_cast<f32x4*>(ldsA + (ka + q * 16) * SA + ca) = xform(ra[q], c0 + ka + q * 16);
 #pragma unroll
     for (int q = 0; q < NRB; ++q) *reinterpret_cast<f32x4*>(ldsB + (kb + q * BROWS) * SB + cb) = rb[q];
     __syncthreads();
@@ -475,7 +478,7 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
     p.B = x->B; p.C = x->C; p.N = y->C; p.Npad = Npad; p.S = (int)Sx;
     p.xsB = x->sB; p.ysB = y->sB; p.bias_sB = bias_sB; p.mode = accumulate ? 1 : 0;
     p.ysC = y->sC; p.ysP = y->sW;
-    p.splits = 1; p.cps = (x->C + 31) & ~31;
+    p.splits = 1; p.cps = (x->C + 63) & ~63;
     // long reductions over few positions (stage4/5 of the encoder: K = 1024..2048, 64..256 positions per sample):
     // split the channels over blocks, partial sums to the split-K scratch, one reduction launch
     // 64-column tiles (CRN_PW_NS=4) were measured equal to 32-column ones on the whole step (10.07 vs 10.04 ms): these
