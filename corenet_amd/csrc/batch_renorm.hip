@@ -151,6 +151,117 @@ __global__ __launch_bounds__(kThreads) void bn_owner_stats_kernel(
                         momentum, scale, shift, saved);
 }
 
+// Register-resident owner kernels: when all of (B, S) of a channel fits in NV float4 per thread (B*S <= 1024*NV), every
+// thread issues its NV loads at once (the loops above walk them one latency after the other: these launches are
+// latency bound) and the backward kernel makes its second pass over registers instead of re-reading x and dy.
+template <int NV>
+__global__ __launch_bounds__(kThreads) void bn_owner_stats_reg_kernel(
+    const float* x, int B, int C, int S4, int64_t sB, int pre_relu, const float* gamma, const float* beta,
+    float* running_mean, float* running_var, const int64_t* nbt, float eps, float momentum, float* scale,
+    float* shift, float* saved) {
+  __shared__ double red[kThreads / 64];
+  const int c = blockIdx.x, total4 = B * S4;
+  f32x4 v[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int e = threadIdx.x + k * kThreads;
+    const int b = e / S4, s4 = e - b * S4;
+    v[k] = e < total4 ? *reinterpret_cast<const f32x4*>(x + (int64_t)b * sB + ((int64_t)c * S4 + s4) * 4)
+                      : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float t = v[k][i];
+      if (pre_relu) t = fmaxf(t, 0.f);
+      s1 += (double)t;
+      s2 += (double)t * (double)t;
+    }
+  const double t1 = crn_block_sum(s1, red);
+  const double t2 = crn_block_sum(s2, red);
+  if (threadIdx.x == 0)
+    bn_finalize_channel(c, C, t1, t2, (double)B * (double)S4 * 4.0, gamma, beta, running_mean, running_var, nbt, eps,
+                        momentum, scale, shift, saved);
+}
+
+template <int NV>
+__global__ __launch_bounds__(kThreads) void bn_owner_bwd_reg_kernel(
+    const float* x, int64_t sBx, const float* dy, int64_t sBdy, int B, int S4, int C, int pre_relu,
+    int post_relu, const float* gamma, const float* scale, const float* shift, const float* saved, float* dx,
+    int64_t sBdx, float* dgamma, float* dbeta, int accumulate, float* dsum, int ndsum) {
+  __shared__ double red[kThreads / 64];
+  __shared__ float sm[2];
+  __shared__ float redf[kThreads / 64];
+  const int c = blockIdx.x, total4 = B * S4;
+  const float sc = scale[c], sh = shift[c], mu = saved[c], rstd = saved[C + c];
+  f32x4 xv[NV], gv[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int e = threadIdx.x + k * kThreads;
+    const int b = e / S4, s4 = e - b * S4;
+    const int64_t o = ((int64_t)c * S4 + s4) * 4;
+    const bool ok = e < total4;
+    xv[k] = ok ? *reinterpret_cast<const f32x4*>(x + (int64_t)b * sBx + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    gv[k] = ok ? *reinterpret_cast<const f32x4*>(dy + (int64_t)b * sBdy + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a = xv[k][i], g = gv[k][i];
+      if (pre_relu) a = fmaxf(a, 0.f);
+      if (post_relu && !(a * sc + sh > 0.f)) g = 0.f;
+      s1 += (double)g;
+      s2 += (double)g * (double)((a - mu) * rstd);
+    }
+  const double t1 = crn_block_sum(s1, red);
+  const double t2 = crn_block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    const double count = (double)B * (double)S4 * 4.0;
+    sm[0] = (float)(t1 / count); sm[1] = (float)(t2 / count);
+    const float r = saved[2 * C + c], d = saved[3 * C + c];
+    const float dg = (float)(r * t2 + d * t1), db = (float)t1;
+    if (accumulate) { dgamma[c] += dg; dbeta[c] += db; } else { dgamma[c] = dg; dbeta[c] = db; }
+  }
+  __syncthreads();
+  const float mg = sm[0], mgx = sm[1];
+  const float kf = gamma[c] * saved[2 * C + c] * rstd;
+  float lsum = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int e = threadIdx.x + k * kThreads;
+    if (e < total4) {
+      const int b = e / S4, s4 = e - b * S4;
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float xr = xv[k][i];
+        const float a = pre_relu ? fmaxf(xr, 0.f) : xr;
+        float g = gv[k][i];
+        if (post_relu && !(a * sc + sh > 0.f)) g = 0.f;
+        float r = kf * (g - mg - (a - mu) * rstd * mgx);
+        if (pre_relu && !(xr > 0.f)) r = 0.f;
+        lsum += r;
+        o[i] = r;
+      }
+      *reinterpret_cast<f32x4*>(dx + (int64_t)b * sBdx + ((int64_t)c * S4 + s4) * 4) = o;
+    }
+  }
+  if (dsum && c < ndsum) {       // bias gradient of the convolution that produced x: sum of dx
+    const float w = crn_wave_sum(lsum);
+    if ((threadIdx.x & 63) == 0) redf[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tsum = 0.f;
+      for (int i = 0; i < kThreads / 64; ++i) tsum += redf[i];
+      dsum[c] = tsum;
+    }
+  }
+}
+
 // ---- backward ----------------------------------------------------------------
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void bn_bwd_partial_kernel(
@@ -442,6 +553,17 @@ extern "C" int crn_batch_renorm_stats(const float* x, int B, int C, int64_t S, i
   hipStream_t st = (hipStream_t)stream;
   if (B < 1 || C < 1 || S < 1 || B > 64) return CRN_EINVAL;
   int nparts = 1;
+  if (training && owner_form(S, C, B) && vec_ok(S, {sB}, {x}) && (int64_t)B * S <= 16384) {
+    const int per = (int)crn_cdiv((int64_t)B * S / 4, kThreads);       // float4 per thread
+#define CRN_BN_STATS_REG(NV)                                                                                      \
+  hipLaunchKernelGGL(bn_owner_stats_reg_kernel<NV>, dim3(C), dim3(kThreads), 0, st, x, B, C, (int)(S / 4), sB, pre_relu, \
+                     gamma, beta, running_mean, running_var, nbt, eps, momentum, scale, shift, saved)
+    if (per <= 1) CRN_BN_STATS_REG(1); else if (per <= 2) CRN_BN_STATS_REG(2); else if (per <= 4) CRN_BN_STATS_REG(4);
+    else if (per <= 8) CRN_BN_STATS_REG(8); else CRN_BN_STATS_REG(16);
+#undef CRN_BN_STATS_REG
+    CRN_CHECK_LAUNCH();
+    return CRN_OK;
+  }
   if (training && owner_form(S, C, B)) {
     if (vec_ok(S, {sB}, {x}))
       hipLaunchKernelGGL(bn_owner_stats_kernel<true>, dim3(C), dim3(kThreads), 0, st, x, B, C, S, sB, pre_relu, gamma,
@@ -489,6 +611,17 @@ extern "C" int crn_batch_renorm_bwd(const float* x, int64_t sB_x, const float* d
   hipStream_t st = (hipStream_t)stream;
   if (B < 1 || C < 1 || S < 1 || B > 64) return CRN_EINVAL;
   const bool v = vec_ok(S, {sB_x, sB_dy, sB_dx}, {x, dy, dx});
+  if (owner_form(S, C, B) && v && (int64_t)B * S <= 16384) {
+    const int per = (int)crn_cdiv((int64_t)B * S / 4, kThreads);       // float4 per thread (of x and of dy)
+#define CRN_BN_BWD_REG(NV)                                                                                          \
+  hipLaunchKernelGGL(bn_owner_bwd_reg_kernel<NV>, dim3(C), dim3(kThreads), 0, st, x, sB_x, dy, sB_dy, B, (int)(S / 4), C, \
+                     pre_relu, post_relu, gamma, scale, shift, saved, dx, sB_dx, dgamma, dbeta, accumulate, dsum, ndsum)
+    if (per <= 1) CRN_BN_BWD_REG(1); else if (per <= 2) CRN_BN_BWD_REG(2); else if (per <= 4) CRN_BN_BWD_REG(4);
+    else if (per <= 8) CRN_BN_BWD_REG(8); else CRN_BN_BWD_REG(16);
+#undef CRN_BN_BWD_REG
+    CRN_CHECK_LAUNCH();
+    return CRN_OK;
+  }
   if (owner_form(S, C, B)) {
     if (v)
       hipLaunchKernelGGL(bn_owner_bwd_kernel<true>, dim3(C), dim3(kThreads), 0, st, x, sB_x, dy, sB_dy, B, S, C, pre_relu,
