@@ -23,6 +23,7 @@ __device__ __forceinline__ Slice block_slice(int64_t S) {
 template <bool VEC, typename F4, typename F1>
 __device__ __forceinline__ void for_slice(Slice sl, F4 f4, F1 f1) {
   if (VEC) {
+#pragma unroll 4
     for (int64_t s = sl.s0 + (int64_t)threadIdx.x * 4; s + 3 < sl.s1; s += (int64_t)kThreads * 4) f4(s);
     const int64_t nfull = (sl.s1 > sl.s0) ? ((sl.s1 - sl.s0) & ~(int64_t)3) : 0;
     for (int64_t s = sl.s0 + nfull + threadIdx.x; s < sl.s1; s += kThreads) f1(s);
