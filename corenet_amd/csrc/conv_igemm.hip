@@ -330,6 +330,28 @@ __global__ void splitk_reduce_kernel(crnView v, const float* scratch, int splits
   }
 }
 
+// the same reduction for plain outputs (every sample a contiguous [C][D][H][W] block): float4 elements, no index
+// arithmetic, and the loads of four splits in flight at a time (the generic kernel walks its splits one load latency
+// after the other and spends five integer divisions per element; 60 of these launches sit on the step's critical path)
+__global__ __launch_bounds__(256) void splitk_reduce_plain_kernel(float* y, int64_t ysB, const float* scratch,
+                                                                  int64_t per_b4, int64_t total4, int splits,
+                                                                  int accumulate) {
+  const f32x4* sc4 = reinterpret_cast<const f32x4*>(scratch);
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total4; e += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 4 <= splits; s += 4) {
+      const f32x4 a = sc4[(int64_t)s * total4 + e], b = sc4[(int64_t)(s + 1) * total4 + e];
+      const f32x4 c = sc4[(int64_t)(s + 2) * total4 + e], d = sc4[(int64_t)(s + 3) * total4 + e];
+      sum += a; sum += b; sum += c; sum += d;               // same order as the generic kernel: split 0 first
+    }
+    for (; s < splits; ++s) sum += sc4[(int64_t)s * total4 + e];
+    const int64_t b = e / per_b4, r = e - b * per_b4;
+    f32x4* dst = reinterpret_cast<f32x4*>(y + b * ysB) + r;
+    *dst = accumulate ? *dst + sum : sum;
+  }
+}
+
 // per-device scratch for split-K partial sums (one process drives one GPU; calls that use it on different
 // streams of the same device must not overlap)
 float* splitk_scratch(size_t floats) {
@@ -437,6 +459,14 @@ float* crn_splitk_scratch(size_t floats) { return splitk_scratch(floats); }
 int* crn_splitk_counters(size_t n) { return splitk_counters(n); }
 int crn_splitk_reduce(const crnView& y, const float* scratch, int splits, int accumulate, hipStream_t st) {
   const int64_t ytot = (int64_t)y.B * y.C * y.D * y.H * y.W;
+  const int64_t per_b = (int64_t)y.C * y.D * y.H * y.W;
+  if (plain_view(y) && (per_b & 3) == 0 && (((uintptr_t)scratch) & 15) == 0) {
+    const int64_t total4 = ytot / 4;
+    hipLaunchKernelGGL(splitk_reduce_plain_kernel, dim3((unsigned)std::min<int64_t>(crn_cdiv(total4, 256), 4096)), dim3(256),
+                       0, st, y.base, y.sB, scratch, per_b / 4, total4, splits, accumulate);
+    CRN_CHECK_LAUNCH();
+    return CRN_OK;
+  }
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(crn_cdiv(ytot, 256), 4096)), dim3(256), 0, st,
                      y, scratch, splits, accumulate);
   CRN_CHECK_LAUNCH();
@@ -509,11 +539,7 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
     if (wide) hipLaunchKernelGGL(pointwise_fwd_kernel<4>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(pointwise_fwd_kernel<2>, grid, dim3(256), 0, st, p);
     CRN_CHECK_LAUNCH();
-    if (p.splits > 1 && !p.counters) {
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(crn_cdiv(ytot, 256), 4096)), dim3(256), 0, st,
-                         *y, scratch, p.splits, accumulate);
-      CRN_CHECK_LAUNCH();
-    }
+    if (p.splits > 1 && !p.counters) return crn_splitk_reduce(*y, scratch, p.splits, accumulate, st);
     return CRN_OK;
   }
   // Score every (MSUB, NSUB) tile: useful MFMA rows x operand reuse of the tile x how well
@@ -643,11 +669,7 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
 #define CRN_FWD_CASE(M, N) if (best.MSUB == M && NSUB == N) rc = crn_launch_fwd_##M##_##N(g, xvec, grid, lds_bytes, st);
   CRN_FWD_CONFIGS(CRN_FWD_CASE)
 #undef CRN_FWD_CASE
-  if (rc == CRN_OK && g.mode == 3) {
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>(crn_cdiv(ytot, 256), 4096)), dim3(256), 0, st,
-                       yreal, scratch, splits, accumulate);
-    CRN_CHECK_LAUNCH();
-  }
+  if (rc == CRN_OK && g.mode == 3) rc = crn_splitk_reduce(yreal, scratch, splits, accumulate, st);
   return rc;
 }
 
