@@ -320,7 +320,10 @@ class Engine:
     # ~1.4 ms later, so in training the decoder piece is packed on the side stream under the encoder
     pack_names = [name for (name, *_rest) in reg for _ in range(3 if _rest[1] is not None else 2)]
     sel = lambda pred: [pp for pp, bwd, nm in zip(pack_parts, pack_is_bwd, pack_names) if not bwd and pred(nm)]
+    early = lambda nm: nm.startswith("encoder.stage1") or nm.startswith("encoder.stage2")
     self.pack_tiles_enc = dev(G.tile_index(sel(lambda nm: nm.startswith("encoder."))))
+    self.pack_tiles_enc_early = dev(G.tile_index(sel(early)))                                   # stem + stage2: 0.2 M
+    self.pack_tiles_enc_late = dev(G.tile_index(sel(lambda nm: nm.startswith("encoder.") and not early(nm))))  # 23 M
     self.pack_tiles_dec = dev(G.tile_index(sel(lambda nm: not nm.startswith("encoder."))))
     self.pack_tiles_bwd = dev(G.tile_index([pp for pp, bwd in zip(pack_parts, pack_is_bwd) if bwd]))
     self.unpack_tiles = dev(G.tile_index(unpack_parts))
@@ -369,9 +372,10 @@ class Engine:
 
   def pack_weights(self, part: str = "all"):
     """flat parameter slab -> packed forward weights and biases (1 launch; "enc" / "dec": one of the two pieces)."""
-    tiles = {"all": self.pack_tiles, "enc": self.pack_tiles_enc, "dec": self.pack_tiles_dec}[part]
+    tiles = {"all": self.pack_tiles, "enc": self.pack_tiles_enc, "dec": self.pack_tiles_dec,
+             "enc_early": self.pack_tiles_enc_early, "enc_late": self.pack_tiles_enc_late}[part]
     self.be.copy_tiles(self.store.params, self.packed, tiles)
-    if part != "enc":
+    if part in ("all", "dec"):
       self._weights_dirty = False
 
   def pack_dgrad_weights(self):
@@ -515,6 +519,8 @@ class Plan:
     self._pack_ev = t.cuda.Event() if use_side else None
     self._dgrad_packed = t.cuda.Event() if use_side else None
     self._dec_packed = t.cuda.Event() if use_side else None
+    self._enc_late_packed = t.cuda.Event() if use_side else None
+    self._enc_late_pending = False
     self._dgrad_pack_pending = False
     self._dec_pack_pending = False
     self._gpacked_zeroed = False
@@ -633,11 +639,13 @@ class Plan:
       # slab (needed by backward)
       dec_later = eng.weights_dirty
       if dec_later:
-        eng.pack_weights("enc")
+        eng.pack_weights("enc_early")             # stem + stage2 (0.2 M weights): needed at once
       self._pack_ev.record()                      # the parameters are final on the main stream
       with t.cuda.stream(self.side):
         self.side.wait_event(self._pack_ev)
         if dec_later:
+          eng.pack_weights("enc_late")            # stage3-5 (23 M): needed ~0.5 ms into the encoder
+          self._enc_late_packed.record(self.side)
           eng.pack_weights("dec")
           self._dec_packed.record(self.side)
         if eng.dgrad_dirty:
@@ -646,6 +654,7 @@ class Plan:
         self._dgrad_packed.record(self.side)
       self._dgrad_pack_pending = True
       self._dec_pack_pending = dec_later
+      self._enc_late_pending = dec_later
       self._gpacked_zeroed = True
     elif eng.weights_dirty:
       eng.pack_weights()
@@ -662,6 +671,9 @@ class Plan:
     be.maxpool_fwd(self.y1, b1.scale, b1.shift, B, 64, 128, 128, self.p1, self.p1_arg)
     cur = self.p1
     for blk in self.blocks:
+      if self._enc_late_pending and blk["stage"] != "stage2":
+        t.cuda.current_stream().wait_event(self._enc_late_packed)
+        self._enc_late_pending = False
       cur = self._block_fwd(blk, cur, training)
     f5 = self.feat["stage5"]
     be.relu_mean_fwd(f5, B, 2048, 64, f5.stride(0), self.avg)
