@@ -95,6 +95,18 @@ class HipBackend:
                           pad_lo[0], pad_lo[1], pad_lo[2], splits, int(accumulate), _ctapboxes(boxes),
                           _lib.stream())
 
+  def bf3_operands(self, packed: t.Tensor, table, out: t.Tensor):
+    """table = (desc int64 [n, 6] on the device, total workgroups): conv_geometry.operand_table."""
+    desc, blocks = table
+    self.lib.crn_bf3_operands(ptr(packed), ptr(desc), desc.shape[0], blocks, ptr(out), _lib.stream())
+
+  def conv2d_bf3(self, x: View, tr: Optional[Transform], wop: t.Tensor, npad: int, bias: Optional[t.Tensor],
+                 bias_sB: int, y: View, window, pad_lo, accumulate: bool = False):
+    """The encoder engine (csrc/conv_e2d.hip): 1x1 / 3x3 stride-1 convs on operand blocks from bf3_operands."""
+    assert window[0] == 1 and pad_lo[0] == 0
+    self.lib.crn_conv2d_bf3(C.byref(_cview(x)), _ctr(tr), ptr(wop), npad, ptr(bias), bias_sB, C.byref(_cview(y)),
+                            window[1], window[2], pad_lo[1], pad_lo[2], int(accumulate), _lib.stream())
+
   def conv_wgrad(self, x: View, tr: Optional[Transform], dy: View, dw: t.Tensor, npad: int,
                  window, pad_lo, zero_first: bool = True, boxes=None, math: str = "fp32"):
     if math == "bf16x3":

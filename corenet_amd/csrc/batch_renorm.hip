@@ -59,6 +59,41 @@ __global__ __launch_bounds__(kThreads) void bn_partial_kernel(const float* x, in
 }
 
 // One channel's statistics -> scale/shift, saved values, running statistics (batch_renorm.py:33-62).
+// The five per-channel inputs of bn_finalize_channel, loaded at the START of an owner kernel (they do not depend on the
+// statistics): their round trip to memory then overlaps the one of x instead of following the reduction.
+struct BnChannelIn { float g, bt, rmean, rvar, nt; };
+__device__ __forceinline__ BnChannelIn bn_channel_in(int c, const float* gamma, const float* beta,
+                                                     const float* running_mean, const float* running_var,
+                                                     const int64_t* nbt) {
+  return BnChannelIn{gamma[c], beta[c], running_mean[c], running_var[c], (float)nbt[0]};
+}
+__device__ __forceinline__ void bn_finalize_channel_in(int c, int C, double s1, double s2, double count,
+                                                       const BnChannelIn& in, float* running_mean, float* running_var,
+                                                       float eps, float momentum, float* scale, float* shift,
+                                                       float* saved) {
+  const float g = in.g, bt = in.bt;
+  const double mean_d = s1 / count;
+  double var_d = s2 / count - mean_d * mean_d;
+  if (var_d < 0.0) var_d = 0.0;
+  const float b_mean = (float)mean_d, b_var = (float)var_d;
+  const float b_std = sqrtf(b_var + eps);
+  const float run_std = sqrtf(in.rvar + eps);
+  const float nt = in.nt;
+  const float d_max = fminf(fmaxf(5.0f * (nt - 5000.f) / (25000.f - 5000.f), 0.f), 5.f);
+  const float r_max = 1.0f + fminf(fmaxf(2.0f * (nt - 5000.f) / (40000.f - 5000.f), 0.f), 2.f);
+  float r = b_std / run_std;
+  r = fminf(fmaxf(r, 1.0f / r_max), r_max);
+  float d = (b_mean - in.rmean) / run_std;
+  d = fminf(fmaxf(d, -d_max), d_max);
+  const float rstd = 1.0f / b_std;
+  scale[c] = g * r * rstd;
+  shift[c] = bt + g * (d - b_mean * r * rstd);
+  saved[c] = b_mean; saved[C + c] = rstd; saved[2 * C + c] = r; saved[3 * C + c] = d;
+  const float unbiased = b_var * (float)C / (float)(C - 1);
+  running_var[c] = in.rvar + momentum * (unbiased - in.rvar);
+  running_mean[c] = in.rmean + momentum * (b_mean - in.rmean);
+}
+
 __device__ __forceinline__ void bn_finalize_channel(int c, int C, double s1, double s2, double count,
                                                     const float* gamma, const float* beta, float* running_mean,
                                                     float* running_var, const int64_t* nbt, float eps,
@@ -160,8 +195,11 @@ __global__ __launch_bounds__(kThreads) void bn_owner_stats_reg_kernel(
     const float* x, int B, int C, int S4, int64_t sB, int pre_relu, const float* gamma, const float* beta,
     float* running_mean, float* running_var, const int64_t* nbt, float eps, float momentum, float* scale,
     float* shift, float* saved) {
-  __shared__ double red[kThreads / 64];
+  __shared__ double red[2 * (kThreads / 64)];
+  crn_kernargs_now(x, B, C, S4, sB, pre_relu, gamma, beta, running_mean, running_var, nbt, eps, momentum, scale, shift,
+                   saved);
   const int c = blockIdx.x, total4 = B * S4;
+  const BnChannelIn cin = bn_channel_in(c, gamma, beta, running_mean, running_var, nbt);
   f32x4 v[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -180,11 +218,11 @@ __global__ __launch_bounds__(kThreads) void bn_owner_stats_reg_kernel(
       s1 += (double)t;
       s2 += (double)t * (double)t;
     }
-  const double t1 = crn_block_sum(s1, red);
-  const double t2 = crn_block_sum(s2, red);
+  double t1, t2;
+  crn_block_sum2(s1, s2, red, t1, t2);
   if (threadIdx.x == 0)
-    bn_finalize_channel(c, C, t1, t2, (double)B * (double)S4 * 4.0, gamma, beta, running_mean, running_var, nbt, eps,
-                        momentum, scale, shift, saved);
+    bn_finalize_channel_in(c, C, t1, t2, (double)B * (double)S4 * 4.0, cin, running_mean, running_var, eps, momentum,
+                           scale, shift, saved);
 }
 
 template <int NV>
@@ -192,11 +230,17 @@ __global__ __launch_bounds__(kThreads) void bn_owner_bwd_reg_kernel(
     const float* x, int64_t sBx, const float* dy, int64_t sBdy, int B, int S4, int C, int pre_relu,
     int post_relu, const float* gamma, const float* scale, const float* shift, const float* saved, float* dx,
     int64_t sBdx, float* dgamma, float* dbeta, int accumulate, float* dsum, int ndsum) {
-  __shared__ double red[kThreads / 64];
+  __shared__ double red[2 * (kThreads / 64)];
   __shared__ float sm[2];
   __shared__ float redf[kThreads / 64];
+  crn_kernargs_now(x, sBx, dy, sBdy, B, S4, C, pre_relu, post_relu, gamma, scale, shift, saved, dx, sBdx, dgamma, dbeta,
+                   accumulate, dsum, ndsum);
   const int c = blockIdx.x, total4 = B * S4;
+  // every per-channel scalar of the kernel is loaded here, next to x and dy: one round trip to memory, not three
   const float sc = scale[c], sh = shift[c], mu = saved[c], rstd = saved[C + c];
+  const float rr = saved[2 * C + c], dd = saved[3 * C + c], gam = gamma[c];
+  float dg0 = 0.f, db0 = 0.f;
+  if (accumulate && threadIdx.x == 0) { dg0 = dgamma[c]; db0 = dbeta[c]; }
   f32x4 xv[NV], gv[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -218,18 +262,17 @@ __global__ __launch_bounds__(kThreads) void bn_owner_bwd_reg_kernel(
       s1 += (double)g;
       s2 += (double)g * (double)((a - mu) * rstd);
     }
-  const double t1 = crn_block_sum(s1, red);
-  const double t2 = crn_block_sum(s2, red);
+  double t1, t2;
+  crn_block_sum2(s1, s2, red, t1, t2);
   if (threadIdx.x == 0) {
     const double count = (double)B * (double)S4 * 4.0;
     sm[0] = (float)(t1 / count); sm[1] = (float)(t2 / count);
-    const float r = saved[2 * C + c], d = saved[3 * C + c];
-    const float dg = (float)(r * t2 + d * t1), db = (float)t1;
-    if (accumulate) { dgamma[c] += dg; dbeta[c] += db; } else { dgamma[c] = dg; dbeta[c] = db; }
+    const float dg = (float)(rr * t2 + dd * t1), db = (float)t1;
+    dgamma[c] = dg0 + dg; dbeta[c] = db0 + db;
   }
   __syncthreads();
   const float mg = sm[0], mgx = sm[1];
-  const float kf = gamma[c] * saved[2 * C + c] * rstd;
+  const float kf = gam * rr * rstd;
   float lsum = 0.f;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -433,6 +476,7 @@ __global__ __launch_bounds__(kThreads) void affine_add_relu_kernel(
     const float* x, const float* scale, const float* shift, const float* r, const float* rscale,
     const float* rshift, int64_t S, int64_t sBx, int64_t sBr, float* y_pre, int64_t sBpre,
     float* y, int64_t sBy, int relu) {
+  crn_kernargs_now(x, scale, shift, r, rscale, rshift, S, sBx, sBr, y_pre, sBpre, y, sBy, relu);
   const int c = blockIdx.y, b = blockIdx.z;
   const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
   const float rsc = rscale ? rscale[c] : 1.f, rsh = rshift ? rshift[c] : 0.f;
@@ -464,6 +508,7 @@ template <bool VEC>
 __global__ __launch_bounds__(kThreads) void relu_bwd_add_kernel(
     const float* dy, const float* y_pre, const float* dy2, int64_t S, int64_t sBdy, int64_t sBpre,
     int64_t sBdy2, float* dx, int64_t sBdx) {
+  crn_kernargs_now(dy, y_pre, dy2, S, sBdy, sBpre, sBdy2, dx, sBdx);
   const int c = blockIdx.y, b = blockIdx.z;
   const float* pg = dy ? dy + (int64_t)b * sBdy + (int64_t)c * S : nullptr;
   const float* pp = y_pre + (int64_t)b * sBpre + (int64_t)c * S;
@@ -506,6 +551,7 @@ __global__ __launch_bounds__(kThreads) void bias_grad_partial_kernel(const float
 __global__ __launch_bounds__(kThreads) void bias_grad_owner_kernel(const float* dy, int B, int64_t S, int64_t sB,
                                                                     float* db, int accumulate) {
   __shared__ double red[kThreads / 64];
+  crn_kernargs_now(dy, B, S, sB, db, accumulate);
   const int c = blockIdx.x;
   double s1 = 0.0;
   for (int b = 0; b < B; ++b) {

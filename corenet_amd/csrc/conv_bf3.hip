@@ -109,6 +109,7 @@ template <> struct XLoad<2> {            // stride-2 (space-to-depth) view: elem
 // whole window depth a chunk is ONE staging step (two barriers) instead of one per plane.
 template <int NSUB, int XM, int NG, int ZS>
 __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
+  crn_kernarg_touch(g);
   constexpr int NB = NSUB * 16;
   constexpr int kSlab = ZS * NG * 4 * NB;                                 // weight items (16-byte units) per slab
   constexpr int kNWI = (kSlab + kThreads - 1) / kThreads;                 // ... per thread
@@ -465,6 +466,7 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 template <int NSUB, int DM, int TPW>
 __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
+  crn_kernarg_touch(g);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NB = NSUB * 16;
   constexpr int kHdr = 1024;

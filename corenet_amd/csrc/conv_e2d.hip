@@ -1,0 +1,516 @@
+// Split-bf16 ("bf16x3") MFMA engine for the encoder's small convolutions (gfx950 / CDNA4).
+//
+// The ResNet-50 encoder (resnet50.py:49-115) at batch 4 is 52 convolutions of 0.5-1.2 GFLOP each: 1x1 and 3x3
+// windows over 64^2 ... 8^2 images with 64 ... 2048 channels.  None of them is bound by arithmetic (1.2 GFLOP is
+// 8 us of fp32 MFMA on the whole chip); what the general engines (conv_igemm.hip / conv_bf3.hip) spend on them is
+// a chain of load -> barrier -> MFMA steps, 14 us per 1x1 and 30 + 5 us (kernel + split-K reduction) per 3x3.
+// This engine is built around that chain instead of around MFMA throughput:
+//
+//  * weights arrive ALREADY in MFMA operand order and already split into bf16 hi / lo terms (crn_bf3_operands,
+//    one launch per weight pack for all layers): operand block (K step, 16 output columns) = 64 lanes x 32 bytes,
+//    so a wave reads the B operand of a K step with two coalesced 16-byte buffer loads straight into the
+//    registers the MFMA reads.  Weights never touch LDS, and there is no barrier and no VALU work on their path.
+//  * a workgroup = 4 waves = 64 output positions x 64 output columns (wave w owns columns 16w..16w+15 for all 64
+//    positions: 4 accumulator tiles); 256 ... 1024 workgroups per layer, split-K over input channels when the
+//    tiles alone do not fill the 256 CUs (partial sums to the shared scratch + crn_splitk_reduce).
+//  * a chunk = KS K steps of 32 (3x3: 32 channels x 9 taps; 1x1: 128 channels).  The B registers of a whole
+//    chunk are resident; the registers of K step s are re-loaded with the next chunk's step s right after the
+//    MFMAs that consumed them, and the next chunk's input patch is loaded before the MFMAs of this chunk start,
+//    so every load has one chunk of MFMAs (0.3-0.8 us) to land and a chunk costs ONE barrier.  Outstanding loads
+//    are tracked by hand (s_waitcnt vmcnt(N) with the N the issue order implies): the compiler's own waitcnt
+//    pass would serialise them.
+//  * the input patch is staged like in conv_bf3.hip: fp32 from HBM, BatchRenorm-apply + ReLU of the producer
+//    fused, split into bf16 hi / lo, stored as [position][32 channels] rows (one ds_read_b128 per operand).
+//    K of v_mfma_f32_16x16x32_bf16 = 32 input channels of ONE window tap, so a tap is an LDS row offset.
+//
+// Same operation as crn_conv_fwd (y = bias + window correlation of T(x) with packed weights); serves the forward
+// pass and the data gradient (packed data-gradient weights).  Numerics: hi*hi + hi*lo + lo*hi with fp32
+// accumulation, ~2^-16 relative per product, as conv_bf3.hip.
+#include "conv_kernels.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace {
+using namespace crnk;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct E2dGeom {
+  crnView x, y;
+  crnInTransform tr;
+  const void* wop;        // operand blocks [K step][n tile][64 lanes][hi 16 B | lo 16 B]
+  const float* bias;
+  int bias_sB;
+  int ntn;                // n tiles of 16 columns (Npad / 16)
+  int nblk;               // 32-channel blocks of the input (Cin / 32)
+  int ph, pw;             // window origin (3x3)
+  int tilesH, tilesW;     // 3x3: tiles per image; 1x1: tilesW = tiles per sample, tilesH = 1
+  int nchunks, chunks_per_split;
+  int tab;                // entries of the scale / shift tables in LDS (channels of one split)
+  int mode;               // 0 store, 1 accumulate (read-modify-write), 3 split-K partial sums [split][b][n][pos]
+  int dbg;                // tuning aid (CRN_E2D_DBG): 1 return at once, 2 no chunk loop, 4 no MFMAs, 8 no stores,
+                          // 16 shader-clock stamps of workgroup 0 / wave 0 into stamps[] (crn_e2d_debug_stamps)
+  long long* stamps;
+};
+
+// crn_bf3_operands: one row of the layer table = (first float of the packed [Cin][T][Npad] weights, first 32-byte
+// entry of the operand blocks, Cin, T, Npad, first workgroup of the layer)
+constexpr int kOpFields = 6;
+
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 h = (__bf16)v[i];
+    hi[i] = h;
+    lo[i] = (__bf16)(v[i] - (float)h);
+  }
+}
+
+// packed fp32 weights -> operand blocks.  entry (kg, ntile, lane = kk*16 + i16): the 8 channels
+// c = 32*(kg / T) + 8*kk + j of tap kg % T for output column 16*ntile + i16, as 8 hi and 8 lo bf16.
+__global__ __launch_bounds__(256) void bf3_operands_kernel(const float* packed, const long long* desc, int nlayers,
+                                                           char* out) {
+  int lo = 0, hi = nlayers - 1;
+  while (lo < hi) {                                   // last layer whose first workgroup is <= blockIdx.x
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid * kOpFields + 5] <= (long long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const long long* d = desc + lo * kOpFields;
+  const int Cin = (int)d[2], T = (int)d[3], Npad = (int)d[4];
+  const int ntn = Npad >> 4;
+  const long long entries = (long long)(Cin >> 5) * T * ntn * 64;
+  const long long e = ((long long)blockIdx.x - d[5]) * 256 + threadIdx.x;
+  if (e >= entries) return;
+  const int lane = (int)(e & 63);
+  const long long rest = e >> 6;
+  const int ntile = (int)(rest % ntn);
+  const int kg = (int)(rest / ntn);
+  const int cbg = kg / T, t = kg - cbg * T;
+  const int kk = lane >> 4, i16 = lane & 15;
+  const float* src = packed + d[0] + ((long long)(cbg * 32 + kk * 8) * T + t) * Npad + ntile * 16 + i16;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = src[(long long)j * T * Npad];
+  bf16x8 h, l;
+  split8(v, h, l);
+  bf16x8* dst = reinterpret_cast<bf16x8*>(out + (d[1] + e) * 32);
+  dst[0] = h;
+  dst[1] = l;
+}
+
+constexpr unsigned kOOB = 0x80000000u;     // buffer offset outside the 2 GiB range of make_rsrc: the load returns 0
+
+template <int N>
+__device__ __forceinline__ void wait_vm(f32x4& a, f32x4& b) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+
+// T = window taps (9: 3x3, 1: 1x1); CB = 32-channel blocks per chunk; TW = tile width (3x3: 16 or 8, tile = 64/TW
+// rows; 1x1: the 64 positions of a tile are consecutive in the flattened image and TW only names the instance)
+template <int T, int CB, int TW>
+__global__ __launch_bounds__(256, 2) void conv_e2d_kernel(E2dGeom g) {
+  constexpr int KW = T == 9 ? 3 : 1;
+  constexpr int TH = 64 / TW, PH = TH + KW - 1, PW = TW + KW - 1, NPOS = PH * PW;
+  constexpr int NPA = T == 9 ? 128 : 64;               // position rows per channel block in LDS
+  constexpr int KS = CB * T;                           // K steps per chunk
+  constexpr int NPL = T == 9 ? 16 : 8;                 // patch load instructions per thread and chunk
+  // LDS layout of a patch plane (hi or lo): [channel block][kk = 8-channel group][position], 16-byte units; the
+  // 16 lanes of an MFMA row group read 16 consecutive units.  PS = NPA + 4: consecutive kk planes start 16 banks
+  // apart, so the staging writes (4 kk x 16 positions per wave instruction) are conflict free as well
+  constexpr int PS = NPA + 4;
+  constexpr int PLANE = CB * 4 * PS;                   // units of one plane of one buffer
+  static_assert(T == 9 ? CB == 1 : CB == 4, "thread -> patch element mapping");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tscale = reinterpret_cast<float*>(smem);
+  float* tshift = tscale + g.tab;
+  bf16x8* Abuf = reinterpret_cast<bf16x8*>(smem + (size_t)g.tab * 8);      // [2 buffers][hi, lo][PLANE]
+
+  const long long t_entry = (long long)__builtin_amdgcn_s_memtime();
+  crn_kernargs_now(g.x.base, g.x.B, g.x.C, g.x.H, g.x.W, g.x.sB, g.x.sC, g.x.sH, g.y.base, g.y.C, g.y.sB, g.y.sC, g.y.sH,
+               g.tr.scale, g.tr.shift, g.tr.pre_relu, g.tr.post_relu, g.wop, g.bias, g.bias_sB, g.ntn, g.nblk, g.ph,
+               g.pw, g.tilesH, g.tilesW, g.nchunks, g.chunks_per_split, g.tab, g.mode, g.dbg, g.stamps, gridDim.x);
+  if (g.dbg & 1) return;
+  const bool stamp = (g.dbg & 16) && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
+  auto mark = [&](int i) { if (stamp) g.stamps[i] = (long long)__builtin_amdgcn_s_memtime() - t_entry; };
+  mark(0);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kk = lane >> 4;
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int twi = tile % g.tilesW; tile /= g.tilesW;
+  const int thi = tile % g.tilesH; tile /= g.tilesH;
+  const int b = tile;
+  const int split = blockIdx.z;
+  const int cbeg = split * g.chunks_per_split, cend = min(cbeg + g.chunks_per_split, g.nchunks);
+  const int ch0 = cbeg * CB * 32;                       // first channel of this split (origin of the tables)
+  const bool has_tr = g.tr.scale != nullptr;
+
+  const crn_rsrc xrs = make_rsrc(g.x.base + (int64_t)b * g.x.sB);
+  const crn_rsrc wrs = make_rsrc(reinterpret_cast<const float*>(g.wop));
+
+  // ---- patch staging geometry ----
+  // 3x3: thread = (kk8 = tid & 3: channels 8*kk8 .. +7 of the chunk, patch position q = (tid >> 2) + 64*pass)
+  // 1x1: thread = (kk8 = tid & 3, position quad pq = (tid >> 2) & 15, channel block cbl = wave); the four
+  //      positions 4*pq + i of a quad go to LDS rows i*16 + pq, so that M tile ms = rows 16*ms .. +15 holds the
+  //      positions 4*i16 + ms and both the staging writes and the operand reads are contiguous per instruction
+  const int kk8 = tid & 3;
+  unsigned poff[2];                                    // byte offset of the thread's position(s) in the sample
+  bool pin[2] = {false, false};
+  int h0 = 0, w0 = 0, p0 = 0;
+  if constexpr (T == 9) {
+    h0 = thi * TH; w0 = twi * TW;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int q = (tid >> 2) + 64 * p;
+      const int r = q / PW, c = q - r * PW;
+      const int gh = h0 - g.ph + r, gw = w0 - g.pw + c;
+      pin[p] = q < NPOS && gh >= 0 && gh < g.x.H && gw >= 0 && gw < g.x.W;
+      poff[p] = pin[p] ? (unsigned)(gh * g.x.sH + gw) * 4u : kOOB;
+    }
+  } else {
+    p0 = twi * 64;
+    poff[0] = (unsigned)(p0 + 4 * ((tid >> 2) & 15)) * 4u;
+    poff[1] = 0;
+  }
+  const unsigned sC4 = (unsigned)g.x.sC * 4u;
+
+  float pf[T == 9 ? 16 : 1];                           // 3x3: 2 positions x 8 channels, one dword load each
+  f32x4 pv[T == 9 ? 1 : 8];                            // 1x1: 8 channels x 4 consecutive positions, 16-byte loads
+  auto patch_issue = [&](int chunk) {
+    if constexpr (T == 9) {
+      const unsigned oob = chunk < cend ? 0u : kOOB;   // poff already carries kOOB for padding positions
+      const unsigned cbase = (unsigned)(chunk * 32 + kk8 * 8) * sC4;
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) crn_bload(pf[p * 8 + j], xrs, (poff[p] + cbase + (unsigned)j * sC4) | oob);
+    } else {
+      const int cbg = chunk * CB + wave;
+      const unsigned oob = (chunk < cend && cbg < g.nblk) ? 0u : kOOB;
+      const unsigned cbase = (unsigned)(cbg * 32 + kk8 * 8) * sC4;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) crn_bload4(pv[j], xrs, (poff[0] + cbase + (unsigned)j * sC4) | oob);
+    }
+  };
+  auto transform8 = [&](float (&v)[8], int ctab) {     // ctab = table index of the first of the 8 channels
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a = v[j];
+      if (g.tr.pre_relu) a = fmaxf(a, 0.f);
+      a = a * tscale[ctab + j] + tshift[ctab + j];
+      if (g.tr.post_relu) a = fmaxf(a, 0.f);
+      v[j] = a;
+    }
+  };
+  auto patch_commit = [&](int chunk, bf16x8* Ahi, bf16x8* Alo) {
+    if constexpr (T == 9) {
+      const int ctab = (chunk - cbeg) * 32 + kk8 * 8;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = pf[p * 8 + j];
+        if (has_tr && pin[p]) transform8(v, ctab);     // zero padding stays zero
+        bf16x8 h, l;
+        split8(v, h, l);
+        const int q = (tid >> 2) + 64 * p;
+        Ahi[kk8 * PS + q] = h;
+        Alo[kk8 * PS + q] = l;
+      }
+    } else {
+      const int cbg = chunk * CB + wave;
+      const int ctab = (chunk - cbeg) * CB * 32 + wave * 32 + kk8 * 8;
+      const int pq = (tid >> 2) & 15;
+      const bool live = cbg < g.nblk;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = pv[j][i];
+        if (has_tr && live) transform8(v, ctab);
+        bf16x8 h, l;
+        split8(v, h, l);
+        const int row = i * 16 + pq;
+        Ahi[(wave * 4 + kk8) * PS + row] = h;
+        Alo[(wave * 4 + kk8) * PS + row] = l;
+      }
+    }
+  };
+  auto patch_wait = [&]() {                            // the B loads of the next chunk (2 per K step) were issued later
+    if constexpr (T == 9) {
+#pragma unroll
+      for (int i = 0; i < 16; i += 8)
+        asm volatile("s_waitcnt vmcnt(%8)"
+                     : "+v"(pf[i]), "+v"(pf[i + 1]), "+v"(pf[i + 2]), "+v"(pf[i + 3]), "+v"(pf[i + 4]), "+v"(pf[i + 5]),
+                       "+v"(pf[i + 6]), "+v"(pf[i + 7])
+                     : "n"(2 * KS));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pv[i]) : "n"(2 * KS));
+    }
+  };
+
+  // ---- weight operands: registers of a whole chunk ----
+  f32x4 bh[KS], bl[KS];
+  const int ntile = blockIdx.y * 4 + wave;
+  const unsigned lb = (unsigned)(ntile * 64 + lane) * 32u;
+  const unsigned kstride = (unsigned)g.ntn * 2048u;    // bytes between consecutive K steps
+  // oob = 0, or kOOB for a K step that does not exist (offsets stay below 2^31, so OR-ing the top bit moves the
+  // load out of the buffer's range: zeros, no memory traffic, no branch)
+  auto b_issue = [&](int chunk, int s, unsigned oob, f32x4& h, f32x4& l) {
+    const unsigned off = (lb + (unsigned)(chunk * KS + s) * kstride) | oob;
+    crn_bload4(h, wrs, off);
+    crn_bload4(l, wrs, off + 16u);
+  };
+  auto step_oob = [&](int chunk, int s) -> unsigned {   // wave-uniform
+    return (chunk < cend && chunk * CB + s / T < g.nblk) ? 0u : kOOB;
+  };
+  // operand read offsets (bf16x8 units) of the lane's 4 M tiles at tap (0, 0)
+  int aoff[4];
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms) {
+    if constexpr (T == 9) aoff[ms] = kk * PS + (ms * (16 / TW) + i16 / TW) * PW + (i16 % TW);
+    else aoff[ms] = kk * PS + 16 * ms + i16;
+  }
+
+  // two accumulator sets: hi*hi, and the two small cross terms (12 MFMAs per K step, consecutive ones independent)
+  f32x4 acc[4], acx[4];
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms) { acc[ms] = (f32x4){0.f, 0.f, 0.f, 0.f}; acx[ms] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  if (cbeg < cend) {
+    // prologue: everything of the first chunk in flight at once, one wait
+#pragma unroll
+    for (int s = 0; s < KS; ++s) b_issue(cbeg, s, step_oob(cbeg, s), bh[s], bl[s]);
+    patch_issue(cbeg);
+    mark(1);
+    // scale / shift of this split's channels (compiler-visible loads, issued behind the hand-tracked ones: the
+    // compiler's wait for them is the prologue's one round trip to memory)
+    if (has_tr)
+      for (int c = tid; c < g.tab; c += 256) {
+        const int cc = min(ch0 + c, g.x.C - 1);
+        tscale[c] = g.tr.scale[cc];
+        tshift[c] = g.tr.shift[cc];
+      }
+    if constexpr (T == 9) {
+#pragma unroll
+      for (int i = 0; i < 16; i += 8)
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(pf[i]), "+v"(pf[i + 1]), "+v"(pf[i + 2]), "+v"(pf[i + 3]), "+v"(pf[i + 4]), "+v"(pf[i + 5]),
+                       "+v"(pf[i + 6]), "+v"(pf[i + 7]));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv[i]));
+    }
+    mark(2);
+    __syncthreads();                                   // the tables
+    patch_commit(cbeg, Abuf, Abuf + PLANE);
+    __syncthreads();
+    mark(3);
+
+    for (int chunk = cbeg; chunk < ((g.dbg & 2) ? cbeg : cend); ++chunk) {
+      const int buf = (chunk - cbeg) & 1;
+      const bf16x8* Ahi = Abuf + buf * 2 * PLANE;
+      const bf16x8* Alo = Ahi + PLANE;
+      patch_issue(chunk + 1);                          // out-of-range (zeros, no traffic) after the last chunk
+      // the A operands of K step s + 1 are read from LDS before the MFMAs of step s are issued (a workgroup may be
+      // alone on its CU, one wave per SIMD: nothing else hides the LDS latency)
+      bf16x8 ah[4], al[4];
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) { ah[ms] = Ahi[aoff[ms]]; al[ms] = Alo[aoff[ms]]; }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        // loads issued after this step's: the rest of this chunk's steps, the next patch, the next chunk's steps < s
+        wait_vm<2 * (KS - 1) + NPL>(bh[s], bl[s]);
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, bh[s]);
+        const bf16x8 wl = __builtin_bit_cast(bf16x8, bl[s]);
+        bf16x8 nh[4], nl[4];
+        if (s + 1 < KS && !(g.dbg & 32)) {
+          const int cbl = (s + 1) / T, t = (s + 1) % T;
+          const int toff = cbl * 4 * PS + (t / KW) * PW + (t % KW);
+#pragma unroll
+          for (int ms = 0; ms < 4; ++ms) { nh[ms] = Ahi[aoff[ms] + toff]; nl[ms] = Alo[aoff[ms] + toff]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);             // (the scheduler would sink the reads below the MFMAs)
+        // (1x1: channel blocks past Cin are zeros on both sides -- out-of-range loads -- and are multiplied anyway)
+        if (!(g.dbg & 4)) {
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) acc[ms] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ms], wh, acc[ms], 0, 0, 0);
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) acx[ms] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ms], wl, acx[ms], 0, 0, 0);
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) acx[ms] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ms], wh, acx[ms], 0, 0, 0);
+        }
+        b_issue(chunk + 1, s, (g.dbg & 64) ? kOOB : step_oob(chunk + 1, s), bh[s], bl[s]);
+        if (s + 1 < KS && !(g.dbg & 32)) {
+#pragma unroll
+          for (int ms = 0; ms < 4; ++ms) { ah[ms] = nh[ms]; al[ms] = nl[ms]; }
+        }
+      }
+      mark(4 + 2 * (chunk - cbeg));
+      patch_wait();
+      mark(5 + 2 * (chunk - cbeg));
+      if (chunk + 1 < cend) {
+        bf16x8* Nhi = Abuf + (buf ^ 1) * 2 * PLANE;
+        patch_commit(chunk + 1, Nhi, Nhi + PLANE);
+      }
+      __syncthreads();
+    }
+  }
+
+  // the loads issued for "the chunk after the last" (out of range: zeros) still target these registers: keep them
+  // allocated until the loads have landed
+#pragma unroll
+  for (int s = 0; s < KS; ++s) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bh[s]), "+v"(bl[s]));
+  if constexpr (T == 9) {
+#pragma unroll
+    for (int i = 0; i < 16; i += 8)
+      asm volatile("s_waitcnt vmcnt(0)"
+                   : "+v"(pf[i]), "+v"(pf[i + 1]), "+v"(pf[i + 2]), "+v"(pf[i + 3]), "+v"(pf[i + 4]), "+v"(pf[i + 5]),
+                     "+v"(pf[i + 6]), "+v"(pf[i + 7]));
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv[i]));
+  }
+
+  mark(30);
+#pragma unroll
+  for (int ms = 0; ms < 4; ++ms) acc[ms] += acx[ms];
+  // ---- epilogue: D row = 4*kk + r (position of the M tile), col = i16 (output column) ----
+  const int n = ntile * 16 + i16;
+  if (n >= g.y.C || (g.dbg & 8)) return;
+  const float bsv = (g.bias && split == 0) ? g.bias[(int64_t)b * g.bias_sB + n] : 0.f;
+  float* yb = g.y.base + (int64_t)(g.mode == 3 ? split * g.x.B + b : b) * g.y.sB + (int64_t)n * g.y.sC;
+  if constexpr (T == 9) {
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) {
+      const int rr = 4 * kk;                            // first of the lane's 4 positions inside the M tile
+      const int oh = h0 + ms * (16 / TW) + rr / TW, ow = w0 + rr % TW;
+      float* dst = yb + (int64_t)oh * g.y.sH + ow;
+      f32x4 v = acc[ms] + bsv;
+      if (g.mode == 1) v += *reinterpret_cast<const f32x4*>(dst);
+      *reinterpret_cast<f32x4*>(dst) = v;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float* dst = yb + p0 + 16 * kk + 4 * r;           // positions 4*(4*kk + r) + ms, ms = 0..3
+      f32x4 v = (f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]} + bsv;
+      if (g.mode == 1) v += *reinterpret_cast<const f32x4*>(dst);
+      *reinterpret_cast<f32x4*>(dst) = v;
+    }
+  }
+  mark(31);
+}
+
+bool dense_2d(const crnView& v) {   // unit W stride, rows back to back, 16-byte aligned channel planes
+  return v.chan_off == nullptr && v.sW == 1 && v.sH == v.W && (v.D == 1 || v.sD == v.H * v.W) && (v.sC & 3) == 0 &&
+         (v.sB & 3) == 0 && (((uintptr_t)v.base) & 15) == 0;
+}
+
+}  // namespace
+
+extern "C" int crn_bf3_operands(const float* packed, const int64_t* desc, int nlayers, int64_t total_blocks, void* out,
+                                crnStream stream) {
+  if (!packed || !desc || !out || nlayers < 1 || total_blocks < 1 || total_blocks > 0x7fffffff) return CRN_EINVAL;
+  hipLaunchKernelGGL(bf3_operands_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, packed,
+                     reinterpret_cast<const long long*>(desc), nlayers, reinterpret_cast<char*>(out));
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+namespace {
+long long* g_stamps = nullptr;
+template <int T, int CB, int TW>
+int launch_e2d(const E2dGeom& g, dim3 grid, size_t lds, hipStream_t st) {
+  static bool attr_done = false;                      // > 64 KiB of dynamic LDS needs the attribute (once per kernel)
+  if (!attr_done) {
+    CRN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_e2d_kernel<T, CB, TW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_e2d_kernel<T, CB, TW>), grid, dim3(256), lds, st, g);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+}  // namespace
+
+extern "C" int crn_conv2d_bf3(const crnView* x, const crnInTransform* tr, const void* wop, int Npad, const float* bias,
+                              int bias_sB, const crnView* y, int kh, int kw, int ph, int pw, int accumulate,
+                              crnStream stream) {
+  if (!x || !y || !wop || x->B != y->B || x->B < 1) return CRN_EINVAL;
+  if (!dense_2d(*x) || !dense_2d(*y)) return CRN_EINVAL;
+  if ((x->C & 31) || (y->C & 63) || Npad != y->C) return CRN_EINVAL;
+  if (x->D != y->D || x->H != y->H || x->W != y->W) return CRN_EINVAL;
+  const bool k3 = kh == 3 && kw == 3, k1 = kh == 1 && kw == 1;
+  if (!k3 && !k1) return CRN_EINVAL;
+  if (k1 && (ph || pw)) return CRN_EINVAL;
+  const int64_t S = (int64_t)x->D * x->H * x->W;
+  if (S * x->C * 4 >= ((int64_t)1 << 31)) return CRN_EINVAL;           // one sample inside the 2 GiB buffer range
+  hipStream_t st = (hipStream_t)stream;
+  E2dGeom g{};
+  g.x = *x; g.y = *y;
+  if (tr) g.tr = *tr; else g.tr = crnInTransform{nullptr, nullptr, 0, 0};
+  g.wop = wop; g.bias = bias; g.bias_sB = bias_sB;
+  g.ntn = Npad / 16; g.nblk = x->C / 32; g.ph = ph; g.pw = pw;
+  static const int dbg = getenv("CRN_E2D_DBG") ? atoi(getenv("CRN_E2D_DBG")) : 0;
+  g.dbg = dbg;
+  if (dbg & 16) {
+    if (!g_stamps) CRN_HIP(hipMalloc(&g_stamps, 32 * sizeof(long long)));
+    g.stamps = g_stamps;
+  }
+  int TW = 16, CB = 1;
+  int64_t tiles;
+  if (k3) {
+    if (x->D != 1 || ph < 0 || ph > 2 || pw < 0 || pw > 2) return CRN_EINVAL;
+    TW = (x->W % 16 == 0) ? 16 : 8;
+    const int TH = 64 / TW;
+    if (x->W % TW || x->H % TH) return CRN_EINVAL;
+    g.tilesW = x->W / TW; g.tilesH = x->H / TH;
+    tiles = (int64_t)g.tilesW * g.tilesH;
+    g.nchunks = g.nblk;
+  } else {
+    if (S % 64) return CRN_EINVAL;
+    CB = 4;
+    g.tilesW = (int)(S / 64); g.tilesH = 1;
+    tiles = g.tilesW;
+    g.nchunks = (g.nblk + CB - 1) / CB;
+  }
+  const int64_t base_blocks = tiles * x->B * (y->C / 64);
+  static const int kFill = getenv("CRN_E2D_FILL") ? atoi(getenv("CRN_E2D_FILL")) : 256;
+  static const int force_splits = getenv("CRN_E2D_SPLITS") ? atoi(getenv("CRN_E2D_SPLITS")) : 0;
+  int splits = 1;
+  while (base_blocks * splits < kFill && splits * 2 <= g.nchunks && splits < 16) splits *= 2;
+  if (force_splits > 0) splits = std::min(force_splits, g.nchunks);
+  g.chunks_per_split = (g.nchunks + splits - 1) / splits;
+  splits = (g.nchunks + g.chunks_per_split - 1) / g.chunks_per_split;
+  g.tab = g.tr.scale ? g.chunks_per_split * CB * 32 : 0;
+  crnView yreal = *y;
+  const float* scratch = nullptr;
+  if (splits > 1) {
+    float* sc = crn_splitk_scratch((size_t)splits * x->B * y->C * S);
+    if (!sc) return CRN_ENOMEM;
+    scratch = sc;
+    g.y.base = sc; g.y.sC = S; g.y.sB = (int64_t)y->C * S; g.y.sH = x->W; g.y.sD = x->H * x->W;
+    g.mode = 3;
+  } else {
+    g.mode = accumulate ? 1 : 0;
+  }
+  const size_t plane_bytes = (size_t)(k3 ? 4 * (128 + 4) : 16 * (64 + 4)) * 16;   // conv_e2d_kernel: PLANE
+  const size_t lds = (size_t)g.tab * 8 + 4 * plane_bytes;
+  if (lds > 160 * 1024) return CRN_EINVAL;
+  const dim3 grid((unsigned)(tiles * x->B), (unsigned)(y->C / 64), (unsigned)splits);
+  int rc;
+  if (k1) rc = launch_e2d<1, 4, 16>(g, grid, lds, st);
+  else if (TW == 16) rc = launch_e2d<9, 1, 16>(g, grid, lds, st);
+  else rc = launch_e2d<9, 1, 8>(g, grid, lds, st);
+  if (rc == CRN_OK && splits > 1) rc = crn_splitk_reduce(yreal, scratch, splits, accumulate, st);
+  return rc;
+}
+
+// tuning aid (CRN_E2D_DBG=16): the shader-clock stamps of the last crn_conv2d_bf3 call (synchronises the device)
+extern "C" int crn_e2d_debug_stamps(long long* out32) {
+  if (!g_stamps) return CRN_EINVAL;
+  CRN_HIP(hipDeviceSynchronize());
+  CRN_HIP(hipMemcpy(out32, g_stamps, 32 * sizeof(long long), hipMemcpyDeviceToHost));
+  return CRN_OK;
+}

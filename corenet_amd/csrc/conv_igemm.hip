@@ -59,6 +59,8 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
   constexpr int NRA = KC / 16;
   __shared__ __attribute__((aligned(16))) float ldsA[KC * SA];
   __shared__ __attribute__((aligned(16))) float ldsB[KC * SB];
+  crn_kernargs_now(g.x, g.y, g.w, g.bias, g.tr.scale, g.tr.shift, g.tr.pre_relu, g.tr.post_relu, g.B, g.C, g.N, g.Npad,
+                   g.S, g.xsB, g.ysB, g.ysC, g.ysP, g.bias_sB, g.mode, g.splits, g.cps, g.counters);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kk = lane >> 4;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -336,6 +338,7 @@ __global__ void splitk_reduce_kernel(crnView v, const float* scratch, int splits
 __global__ __launch_bounds__(256) void splitk_reduce_plain_kernel(float* y, int64_t ysB, const float* scratch,
                                                                   int64_t per_b4, int64_t total4, int splits,
                                                                   int accumulate) {
+  crn_kernargs_now(y, ysB, scratch, per_b4, total4, splits, accumulate);
   const f32x4* sc4 = reinterpret_cast<const f32x4*>(scratch);
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total4; e += (int64_t)gridDim.x * blockDim.x) {
     f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};

@@ -444,6 +444,7 @@ __device__ __forceinline__ void mfma_rows(f32x4 (&acc)[MSUB][NSUB], const float*
 // ------------------------------- forward -----------------------------------
 template <int MSUB, int NSUB, int XV>
 __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvGeom g) {
+  crn_kernarg_touch(g);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned* choff = reinterpret_cast<unsigned*>(lds);      // 2 x kChTab per-chunk channel tables
   float* ldsA = lds + 2 * kChTab;
@@ -814,6 +815,7 @@ __device__ __forceinline__ void dy_commit_v(const WgradGeom& g, float* ldsB, con
 
 template <int RSUB, int NSUB, bool XV, int DV>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradGeom g) {
+  crn_kernarg_touch(g);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned* choff = reinterpret_cast<unsigned*>(lds);   // x channel table; dy channel offsets at [192,256)
   float* ldsA = lds + 2 * kChTab;           // CC * PSP   (input patch)

@@ -47,3 +47,37 @@ __device__ __forceinline__ double crn_block_sum(double v, double* smem) {
   }
   return r;
 }
+
+// Block-wide sums of two doubles per thread with one barrier pair (thread 0 gets both); `smem`: 2 * blockDim.x/64.
+__device__ __forceinline__ void crn_block_sum2(double a, double b, double* smem, double& ra, double& rb) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nw = (blockDim.x + 63) >> 6;
+  a = crn_wave_sum(a);
+  b = crn_wave_sum(b);
+  __syncthreads();
+  if (lane == 0) { smem[wid] = a; smem[nw + wid] = b; }
+  __syncthreads();
+  ra = 0.0; rb = 0.0;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < nw; ++i) { ra += smem[i]; rb += smem[nw + i]; }
+}
+
+// Kernel arguments live in host-visible memory: a scalar load of one costs 0.2-0.35 us (measured with shader-clock
+// stamps in conv_e2d.hip), and the compiler places each s_load next to the first use of the argument -- in kernels
+// with control flow that becomes 4-8 dependent round trips before the first global load is issued.  Naming the
+// arguments in the entry block turns them into one.
+template <typename A>
+__device__ __forceinline__ int crn_kernarg_now(const A& a) { asm volatile("" ::"s"(a)); return 0; }
+template <typename... A>
+__device__ __forceinline__ void crn_kernargs_now(const A&... a) { const int u[] = {crn_kernarg_now(a)...}; (void)u; }
+// The same for a by-value argument struct too large to keep in SGPRs: one dword per 64-byte line of it is loaded
+// in the entry block, which pulls the whole struct into the scalar cache in ONE round trip; the loads the compiler
+// places later (and the re-loads it emits under SGPR pressure) then hit the cache.
+template <typename T>
+__device__ __forceinline__ void crn_kernarg_touch(const T& g) {
+  const unsigned* p = reinterpret_cast<const unsigned*>(&g);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; i += 16) asm volatile("" ::"s"(p[i]));
+  asm volatile("" ::"s"(p[sizeof(T) / 4 - 1]));
+}
+

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void ray_sample_fwd_kernel(
     const float* __restrict__ map, int64_t map_sB, int64_t map_sC, int64_t map_sP, int C, int h, int w,
     const float* matrix, const float* offset, float* __restrict__ out, int64_t out_sB, int D, int H, int W,
     int64_t per_b) {
+  crn_kernargs_now(map, map_sB, map_sC, map_sP, C, h, w, matrix, offset, out, out_sB, D, H, W, per_b);
   const int b = blockIdx.y;
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t >= per_b) return;
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(kTMax * kTMax) void ray_sample_bwd_kernel(
     const float* offset, float* dmap, int64_t dmap_sB, int h, int w, int zseg, int tilesX, int tilesY, int kTX, int kTY) {
   __shared__ float win[kWinFloats];
   __shared__ int wbox[4];
+  crn_kernargs_now(dout, dout_sB, C, D, H, W, matrix, offset, dmap, dmap_sB, h, w, zseg, tilesX, tilesY, kTX, kTY);
   const int b = blockIdx.z;
   const int cbase = blockIdx.y * CN;
   int tile = blockIdx.x;

@@ -263,3 +263,25 @@ def tile_index(parts):
   assert np.abs(desc).max(initial=0) < 2 ** 31
   ex = np.concatenate(exs) if exs else np.zeros((0,), np.int64)
   return desc.astype(np.int32), (np.concatenate(masks) if masks else np.zeros((0,), np.uint64)), ex.astype(np.int32)
+
+
+# ---- operand blocks of the encoder engine (csrc/conv_e2d.hip, include/corenet_hip.h crn_bf3_operands) ----
+def operand_eligible(g: Geom) -> bool:
+  """Layers crn_conv2d_bf3 covers: 1x1 / 3x3 windows over 2-D images, Cin % 32 == 0, Cout % 64 == 0 == Npad."""
+  return (g.window in ((1, 1, 1), (1, 3, 3)) and g.cin % 32 == 0 and g.nout % 64 == 0 and g.npad == g.nout
+          and not g.n_boxes and not g.c_boxes)
+
+
+def operand_entries(g: Geom) -> int:
+  """32-byte entries of one layer's operand blocks."""
+  return (g.cin // 32) * g.taps * (g.npad // 16) * 64
+
+
+def operand_table(layers):
+  """layers: [(first float in the packed buffer, first entry in the operand buffer, Geom)] ->
+  (int64 [n, 6] rows (src, dst, Cin, T, Npad, first workgroup), total workgroups of 256 entries)."""
+  rows, blocks = [], 0
+  for src, dst, g in layers:
+    rows.append((src, dst, g.cin, g.taps, g.npad, blocks))
+    blocks += (operand_entries(g) + 255) // 256
+  return np.asarray(rows, dtype=np.int64).reshape(-1, 6), blocks

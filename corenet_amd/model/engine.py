@@ -175,6 +175,8 @@ class Conv:
   gwf: t.Tensor             # packed weight gradient     (slice of eng.gpacked)
   dbias: t.Tensor           # reference-layout bias grad (slice of the grad slab)
   n_ref: int                # reference output channels (bias length)
+  wop_f: Optional[t.Tensor] = None   # encoder engine: forward / data-gradient weights as MFMA operand blocks
+  wop_d: Optional[t.Tensor] = None   # (slices of eng.wop; None: the layer stays on the general engines)
 
 
 class Engine:
@@ -196,6 +198,9 @@ class Engine:
     self.decoder_math = decoder_math or os.environ.get("CRN_DECODER_MATH", "fp32")
     if self.decoder_math not in ("fp32", "bf16x3"):
       raise ValueError(f"decoder_math must be 'fp32' or 'bf16x3', not {self.decoder_math!r}")
+    # in bf16x3 mode the encoder's stride-1 1x1 / 3x3 convs (forward and data gradient) run on the encoder
+    # engine (csrc/conv_e2d.hip: the same split-bf16 products, weights pre-arranged as MFMA operand blocks)
+    self.encoder_e2d = self.decoder_math == "bf16x3" and os.environ.get("CRN_E2D", "1") != "0"
     # fp32 is the only dtype of the HIP kernels; float64 exists so that the CPU
     # contract emulator (tests/) can check the host wiring far below fp32 noise.
     assert dtype == t.float32 or getattr(backend, "name", "") == "emu"
@@ -352,6 +357,54 @@ class Engine:
       gwf = self.gpacked[go:go + nwf]; go += nwf
       self.convs[name] = Conv(name, fwd, dgrad, wf, wd, bias, gwf,
                               s.view(name + "bias", grad=True), nref)
+    self._build_operands(reg, idx_parts)
+
+  def _build_operands(self, reg, idx_parts):
+    """Operand blocks of the encoder engine: which layers, where in eng.wop, and the layer tables of the
+    conversion launches that follow each weight pack (conv_geometry.operand_table)."""
+    self.wop = None
+    self.op_tables = {}
+    if not self.encoder_e2d:
+      return
+    groups = {"enc_early": [], "enc_late": [], "bwd": []}
+    slices = []
+    po, eo = 0, 0
+    # Which layers: measured (tools/e2d_parity.py, profiles/r02_e2d_parity.txt).  The B=1 / nbt=0 training fixtures
+    # amplify any rounding difference ~400x (the fp32 engine itself sits 5.7e-4 from the reference there); the
+    # forward pass of stages 2-3 in split-bf16 would raise that to 1.2e-3, stages 4-5 leave it where it is, and
+    # the data gradient does not enter the logits at all.  The 1x1 layers gain nothing over the fp32 pointwise
+    # kernel yet (13 vs 14 us) and stay there.  CRN_E2D_KINDS=all / CRN_E2D_FWD_STAGES=2345: tuning aids.
+    kinds = os.environ.get("CRN_E2D_KINDS", "3x3")
+    for (name, fwd, dgrad, repeat, nref), parts in zip(reg, idx_parts):
+      src_f = po; po += len(parts[0]) + len(parts[1])
+      src_d = po
+      if dgrad is not None:
+        po += len(parts[2])
+      if not name.startswith("encoder.") or name.startswith("encoder.stage1"):
+        continue
+      if kinds == "3x3" and fwd.window != (1, 3, 3):
+        continue
+      fwd_stages = os.environ.get("CRN_E2D_FWD_STAGES", "45")
+      if G.operand_eligible(fwd) and name[len("encoder.stage")] in fwd_stages:
+        groups["enc_early" if name.startswith("encoder.stage2") else "enc_late"].append((src_f, eo, fwd))
+        slices.append((name, "wop_f", eo, G.operand_entries(fwd))); eo += G.operand_entries(fwd)
+      if dgrad is not None and G.operand_eligible(dgrad):
+        groups["bwd"].append((src_d, eo, dgrad))
+        slices.append((name, "wop_d", eo, G.operand_entries(dgrad))); eo += G.operand_entries(dgrad)
+    if not eo:
+      return
+    self.wop = t.zeros(eo * 32, dtype=t.uint8, device=self.device)
+    for name, field, e0, n in slices:
+      setattr(self.convs[name], field, self.wop[e0 * 32:(e0 + n) * 32])
+    for k, layers in groups.items():
+      if layers:
+        desc, blocks = G.operand_table(layers)
+        self.op_tables[k] = (t.as_tensor(desc, device=self.device), blocks)
+
+  def _operands(self, *groups):
+    for k in groups:
+      if k in self.op_tables:
+        self.be.bf3_operands(self.packed, self.op_tables[k], self.wop)
 
   def bucket_unpack_tiles(self, i: int):
     if self._bucket_dev is None:
@@ -375,12 +428,15 @@ class Engine:
     tiles = {"all": self.pack_tiles, "enc": self.pack_tiles_enc, "dec": self.pack_tiles_dec,
              "enc_early": self.pack_tiles_enc_early, "enc_late": self.pack_tiles_enc_late}[part]
     self.be.copy_tiles(self.store.params, self.packed, tiles)
+    self._operands(*{"all": ("enc_early", "enc_late"), "enc": ("enc_early", "enc_late"), "dec": (),
+                     "enc_early": ("enc_early",), "enc_late": ("enc_late",)}[part])
     if part in ("all", "dec"):
       self._weights_dirty = False
 
   def pack_dgrad_weights(self):
     """flat parameter slab -> packed data-gradient weights (1 launch; backward only)."""
     self.be.copy_tiles(self.store.params, self.packed, self.pack_tiles_bwd)
+    self._operands("bwd")
     self.dgrad_dirty = False
 
   # -------------------------------------------------------------------- plans
@@ -575,6 +631,8 @@ class Plan:
     self.trace.append((label, a, b))
 
   def _math(self, cv: Conv, direction: str) -> str:
+    if direction == "fwd" and cv.wop_f is not None or direction == "dgrad" and cv.wop_d is not None:
+      return "e2d"
     return "bf16x3" if self.eng.decoder_math == "bf16x3" and (cv.name, direction) in BF16X3_LAUNCHES else "fp32"
 
   conv_positions = None     # tools/layer_times.py: {layer name: logical output positions per sample} when tracing
@@ -583,12 +641,20 @@ class Plan:
     g = cv.fwd
     if self.trace is not None and self.conv_positions is not None:
       self.conv_positions[cv.name] = y.D * y.H * y.W
+    if cv.wop_f is not None:
+      self._timed("fwd   " + cv.name, lambda: self.be.conv2d_bf3(
+          x, tr, cv.wop_f, g.npad, cv.bias, 0, y, g.window, g.pad_lo, accumulate))
+      return
     self._timed("fwd   " + cv.name, lambda: self.be.conv_fwd(
         x, tr, cv.wf, g.npad, cv.bias, 0, y, g.window, g.pad_lo, 0, accumulate, boxes=(g.n_boxes, g.c_boxes),
         math=self._math(cv, "fwd")))
 
   def _dgrad(self, cv: Conv, dy: V.View, dx: V.View, accumulate=False):
     g = cv.dgrad
+    if cv.wop_d is not None:
+      self._timed("dgrad " + cv.name, lambda: self.be.conv2d_bf3(
+          dy, None, cv.wop_d, g.npad, None, 0, dx, g.window, g.pad_lo, accumulate))
+      return
     self._timed("dgrad " + cv.name, lambda: self.be.conv_fwd(
         dy, None, cv.wd, g.npad, None, 0, dx, g.window, g.pad_lo, 0, accumulate, boxes=(g.n_boxes, g.c_boxes),
         math=self._math(cv, "dgrad")))

@@ -103,6 +103,27 @@ int crn_conv_wgrad_bf3(const crnView* x, const crnInTransform* tr, const crnView
                        float* dw, int Npad, int kd, int kh, int kw, int pd, int ph, int pw,
                        int zero_first, crnStream stream);
 
+/* Encoder engine (csrc/conv_e2d.hip): the ResNet-50 encoder's stride-1 Conv2d 1x1 / 3x3 layers (resnet50.py:49-115;
+ * the stride of a down-sampling block is applied by crn_stride2_gather before its first 1x1) at batch sizes where
+ * a layer is 1 GFLOP: split-bf16 MFMA like crn_conv_fwd_bf3, with the weights pre-arranged in MFMA operand order.
+ *
+ * crn_bf3_operands: packed fp32 weights [Cin][T][Npad] (the layout crn_conv_fwd reads) -> operand blocks, for
+ * `nlayers` layers in one launch.  desc (DEVICE, int64 [nlayers][6]) = (first float of the layer in `packed`,
+ * first 32-byte entry of the layer in `out`, Cin (multiple of 32), T taps, Npad (multiple of 16), first workgroup of
+ * the layer); a layer has (Cin/32)*T*(Npad/16)*64 entries and ceil(entries/256) workgroups, total_blocks = their
+ * sum.  Entry ((cb*T + t)*(Npad/16) + ntile)*64 + kk*16 + i holds, for output column 16*ntile + i and tap t, the 8
+ * channels 32*cb + 8*kk .. +7 as 8 bf16 hi terms followed by 8 bf16 lo terms (w = hi + lo, hi = bf16(w)).        */
+int crn_bf3_operands(const float* packed, const int64_t* desc, int nlayers, int64_t total_blocks, void* out,
+                     crnStream stream);
+/* y = bias + window correlation of T(x) with the operand blocks `wop` of one layer (same operation, transform and
+ * bias contract as crn_conv_fwd; forward pass, or data gradient with the packed data-gradient weights).
+ * Covers: window 1x1 (pads 0) or 3x3, dense NC(D)HW views (unit W stride, rows and planes back to back), x and y of
+ * the same extent, Cin % 32 == 0, Cout % 64 == 0 (= Npad), H*W a multiple of 64 (3x3: W % 8 == 0 and tiles of
+ * 4x16 / 8x8 positions divide the image); CRN_EINVAL otherwise (callers keep such layers on crn_conv_fwd).
+ * Split-K partial sums use the scratch shared with crn_conv_fwd: calls on different streams must not overlap.    */
+int crn_conv2d_bf3(const crnView* x, const crnInTransform* tr, const void* wop, int Npad, const float* bias,
+                   int bias_sB, const crnView* y, int kh, int kw, int ph, int pw, int accumulate, crnStream stream);
+
 /* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0        (weight packing)            */
 /* Tiled index copy between a reference-layout buffer and a packed buffer (weight pack / gradient un-pack).
  * Tile t covers packed positions desc[t][0] + r*desc[t][1] + c (r, c in 0..7); bit (r*8+c) of mask[t] says

@@ -86,6 +86,26 @@ class EmuBackend:
         out = out + bias[:y.C].view(1, -1, 1, 1, 1)
     write_logical(y, out, accumulate)
 
+  # encoder engine (csrc/conv_e2d.hip): operand blocks [(cb*T + t)][ntile][kk*16 + i][hi 8 | lo 8] bf16
+  def bf3_operands(self, packed, table, out):
+    desc, _blocks = table
+    o16 = out.view(t.int16)
+    for src, dst, cin, T, npad, _first in desc.cpu().tolist():
+      w = packed[src:src + cin * T * npad].view(cin // 32, 4, 8, T, npad // 16, 16)       # cb kk j t ntile i
+      blk = w.permute(0, 3, 4, 1, 5, 2).contiguous()                                       # cb t ntile kk i j
+      hi = blk.to(t.bfloat16)
+      lo = (blk - hi.float()).to(t.bfloat16)
+      ent = t.stack([hi, lo], dim=-2).reshape(-1)                                          # ... [hi 8 | lo 8]
+      o16[dst * 16:dst * 16 + ent.numel()] = ent.view(t.int16)
+
+  def conv2d_bf3(self, x, tr, wop, npad, bias, bias_sB, y, window, pad_lo, accumulate=False):
+    T = window[1] * window[2]
+    n = (x.C // 32) * T * (npad // 16) * 64 * 16
+    ent = wop.view(t.int16)[:n].view(t.bfloat16).view(x.C // 32, T, npad // 16, 4, 16, 2, 8).float()
+    blk = ent[..., 0, :] + ent[..., 1, :]                                                  # cb t ntile kk i j
+    w = blk.permute(0, 3, 5, 1, 2, 4).reshape(-1)                                          # [c][t][n]
+    self.conv_fwd(x, tr, w, npad, bias, bias_sB, y, window, pad_lo, 1, accumulate)
+
   @t.enable_grad()        # uses autograd as a calculator; may be called from inside an autograd Function
   def conv_wgrad(self, x, tr, dy, dw, npad, window, pad_lo, zero_first=True, boxes=None, math="fp32"):
     xl = _transform(logical(x), tr)

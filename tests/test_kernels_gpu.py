@@ -132,6 +132,69 @@ def test_conv_fwd_dgrad_wgrad(be, name, kind, wshape, pad, dims, B):
   close(gw.view(wshape), wref.grad, 5e-5, name + " wgrad-vs-autograd")
 
 
+E2D_CASES = [   # name, (Cout, Cin, k, k), (H, W), B: the encoder's stride-1 layers (resnet50.py:49-115) at batch 4 / 2
+    ("s2_3x3", (64, 64, 3, 3), (64, 64), 2),
+    ("s3_3x3", (128, 128, 3, 3), (32, 32), 4),
+    ("s4_3x3", (256, 256, 3, 3), (16, 16), 4),          # split-K
+    ("s5_3x3", (512, 512, 3, 3), (8, 8), 4),            # 8x8 tiles, split-K
+    ("s2_1x1_64_256", (256, 64, 1, 1), (64, 64), 2),    # half a channel chunk
+    ("s2_1x1_256_64", (64, 256, 1, 1), (64, 64), 2),
+    ("s3_1x1_512_128", (128, 512, 1, 1), (32, 32), 4),
+    ("s4_1x1_1024_256", (256, 1024, 1, 1), (16, 16), 4),
+    ("s5_1x1_2048_512", (512, 2048, 1, 1), (8, 8), 4),
+    ("s5_1x1_512_2048", (2048, 512, 1, 1), (8, 8), 1),
+    ("1x1_192_64_b1", (64, 192, 1, 1), (8, 8), 1),      # one and a half chunks, a single tile
+]
+
+
+@pytest.mark.parametrize("name,wshape,hw,B", E2D_CASES, ids=[c[0] for c in E2D_CASES])
+def test_conv2d_bf3_encoder_engine(be, name, wshape, hw, B):
+  """crn_bf3_operands + crn_conv2d_bf3 (csrc/conv_e2d.hip) on the encoder's layer shapes: forward with the fused
+  BatchRenorm-apply + ReLU transform and bias, and the accumulating data gradient, against the contract emulator on
+  the fp32 packed weights (same 2e-5-of-range bar as the decoder's bf16x3 engine); the operand blocks themselves
+  are compared bit for bit with the emulator's."""
+  if _SELF:
+    return
+  from corenet_amd import views as V
+  from corenet_amd.backend import Transform
+  from corenet_amd.model import conv_geometry as G
+  g = t.Generator().manual_seed(len(name))
+  w = t.randn(wshape, generator=g) / np.sqrt(np.prod(wshape[1:]))
+  cout, cin, k = wshape[0], wshape[1], wshape[2]
+  pad = k // 2
+  fwd, dgr = G.conv_fwd(wshape, pad), G.conv_dgrad(wshape, pad)
+  assert G.operand_eligible(fwd) and G.operand_eligible(dgr)
+  H, W = hw
+  x = t.randn((B, cin, H, W), generator=g)
+  scale = t.rand(cin, generator=g) + 0.5; shift = t.randn(cin, generator=g) * 0.3
+  bias = t.randn(cout, generator=g)
+  wf, wd = EMU_pack(w, fwd), EMU_pack(w, dgr)
+  packed = t.cat([wf, wd])
+  nf, nd = G.operand_entries(fwd), G.operand_entries(dgr)
+  desc, blocks = G.operand_table([(0, 0, fwd), (wf.numel(), nf, dgr)])
+  wop = t.zeros((nf + nd) * 32, dtype=t.uint8)
+  EMU.bf3_operands(packed, (t.as_tensor(desc), blocks), wop)
+  wopg = t.zeros_like(wop).to(DEV)
+  be.bf3_operands(packed.to(DEV), (t.as_tensor(desc).to(DEV), blocks), wopg)
+  assert t.equal(wopg.cpu(), wop), name
+  y = t.zeros((B, cout, H, W)); yg = y.to(DEV)
+  trc = Transform(scale, shift, post_relu=True); trg = Transform(scale.to(DEV), shift.to(DEV), post_relu=True)
+  xg = x.to(DEV)
+  EMU.conv_fwd(V.view_of(x), trc, wf, fwd.npad, bias, 0, V.view_of(y), fwd.window, fwd.pad_lo)
+  be.conv2d_bf3(V.view_of(xg), trg, wopg[:nf * 32], fwd.npad, bias.to(DEV), 0, V.view_of(yg), fwd.window, fwd.pad_lo)
+  e = float((yg.cpu() - y).abs().max() / y.abs().max())
+  print(f"e2d {name} fwd: max-abs-err/max = {e:.2e}")
+  assert e <= 2e-5, (name, "fwd", e)
+  dy = t.randn((B, cout, H, W), generator=g)
+  dx = t.randn(x.shape, generator=g); dxg = dx.to(DEV)
+  EMU.conv_fwd(V.view_of(dy), None, wd, dgr.npad, None, 0, V.view_of(dx), dgr.window, dgr.pad_lo, accumulate=True)
+  be.conv2d_bf3(V.view_of(dy.to(DEV)), None, wopg[nf * 32:], dgr.npad, None, 0, V.view_of(dxg), dgr.window, dgr.pad_lo,
+                accumulate=True)
+  e = float((dxg.cpu() - dx).abs().max() / dx.abs().max())
+  print(f"e2d {name} dgrad: max-abs-err/max = {e:.2e}")
+  assert e <= 2e-5, (name, "dgrad", e)
+
+
 BF3_CASES = [c for c in CONV_CASES if c[0] in ("conv3d_k5_32", "conv3d_k5_64", "convT_k7_16", "convT_k7_64_c2", "convT_k7_32_c14")] + [
     ("conv3d_k5_16_c112", "conv", (64, 112, 5, 5, 5), 2, (16, 16, 16), 2),
     ("convT_k7_32_c16", "convT", (32, 16, 7, 7, 7), 3, (32, 32, 32), 1),
