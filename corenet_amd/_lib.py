@@ -50,6 +50,8 @@ _SIGS = {
                      C.POINTER(CrnView), i32, i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "crn_conv_fwd_bf3": [C.POINTER(CrnView), C.POINTER(CrnInTransform), vp, i32, vp, i32,
                          C.POINTER(CrnView), i32, i32, i32, i32, i32, i32, i32, vp, vp],
+    "crn_conv_fwd_bf3_slabs": [C.POINTER(CrnView), C.POINTER(CrnInTransform), vp, i32, vp, i32,
+                               C.POINTER(CrnView), i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "crn_conv_wgrad_bf3": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32,
                            i32, i32, i32, i32, i32, i32, i32, vp],
     "crn_conv_wgrad": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32,

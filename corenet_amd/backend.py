@@ -82,9 +82,15 @@ class HipBackend:
   # -- convolution engine -----------------------------------------------------
   def conv_fwd(self, x: View, tr: Optional[Transform], w: t.Tensor, npad: int,
                bias: Optional[t.Tensor], bias_sB: int, y: View, window, pad_lo,
-               splits: int = 1, accumulate: bool = False, boxes=None, math: str = "fp32"):
+               splits: int = 1, accumulate: bool = False, boxes=None, math: str = "fp32", wslab=None):
     """boxes: (n_boxes, c_boxes) tuples of conv_geometry.Geom (structural zeros of transposed convs).
-    math: "fp32" (v_mfma_f32_16x16x4_f32, the parity default) or "bf16x3" (split-bf16 MFMA engine)."""
+    math: "fp32" (v_mfma_f32_16x16x4_f32, the parity default) or "bf16x3" (split-bf16 MFMA engine; wslab: the
+    weights pre-arranged by bf3_operands in slab order -- same results, cheaper staging)."""
+    if math == "bf16x3" and wslab is not None:
+      self.lib.crn_conv_fwd_bf3_slabs(C.byref(_cview(x)), _ctr(tr), ptr(wslab), npad, ptr(bias), bias_sB,
+                                      C.byref(_cview(y)), window[0], window[1], window[2],
+                                      pad_lo[0], pad_lo[1], pad_lo[2], int(accumulate), _ctapboxes(boxes), _lib.stream())
+      return
     if math == "bf16x3":
       self.lib.crn_conv_fwd_bf3(C.byref(_cview(x)), _ctr(tr), ptr(w), npad, ptr(bias), bias_sB,
                                 C.byref(_cview(y)), window[0], window[1], window[2],

@@ -64,7 +64,9 @@ struct Bf3Geom {
   int n_groups, c_groups;
   signed char n_box[8][6], c_box[8][6];
   unsigned magic_pw2, magic_PH, magic_kw;
+  const void* wslab;       // weights pre-arranged as slab images (crn_bf3_operands, slab order), or nullptr: w is staged
   int dbg;
+  long long* stamps;       // tuning aid (CRN_BF3_STAMPS=1): shader-clock stamps of workgroup 0, 4 per staging step
 };
 
 __device__ __forceinline__ void bload2(f32x2& dst, const crn_rsrc& rs, unsigned byte_off) {
@@ -107,7 +109,11 @@ template <> struct XLoad<2> {            // stride-2 (space-to-depth) view: elem
 // staging loop has exactly the trip count the layer needs.
 // ZS = window planes (zd) per weight slab: the slab of one chunk is staged ZS planes at a time; with ZS = the
 // whole window depth a chunk is ONE staging step (two barriers) instead of one per plane.
-template <int NSUB, int XM, int NG, int ZS>
+// WS: the weights come pre-split and pre-arranged in the order of the LDS slab ([chunk][zd][tap slot][n] entries of
+// 8 hi + 8 lo bf16, crn_bf3_operands): staging a slab is then two 16-byte loads and two LDS writes per item instead of
+// eight dword loads, eight splits and two writes (per staging step: ~930 -> ~300 cycles of load issue and ~400 -> ~150
+// of commit, CRN_BF3_STAMPS; both sit outside the MFMA phase).
+template <int NSUB, int XM, int NG, int ZS, bool WS>
 __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
   crn_kernarg_touch(g);
   constexpr int NB = NSUB * 16;
@@ -169,8 +175,10 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
 
   const crn_rsrc xrs = make_rsrc(g.x.base + (int64_t)b * g.x.sB);
   const crn_rsrc wrs = make_rsrc(g.w);
+  const crn_rsrc wsrs = make_rsrc(reinterpret_cast<const float*>(g.wslab));
   XT pv[kNUX][kCK];
-  float wv[kNWI][kCK];
+  float wv[WS ? 1 : kNWI][kCK];
+  f32x4 wq[WS ? kNWI : 1][2];
   unsigned inmask = 0;
 
   // ---- patch staging: unit u = (plane row, position pair); all 8 channels of the chunk ----
@@ -234,6 +242,21 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
   };
   // ---- weight staging: item = (plane zs of the slab, in-plane tap slot tp, column n), all 8 channels ----
   auto weights_issue = [&](int c0, int zd0) {
+    if constexpr (WS) {
+      static_assert(!WS || ZS == 1, "slab operands are one window plane per slab");
+      const unsigned sbase = (unsigned)((c0 / kCK) * g.kd + zd0) * (unsigned)(NG * 4);
+#pragma unroll
+      for (int j = 0; j < kNWI; ++j) {
+        int it = tid + j * kThreads;
+        asm volatile("" : "+v"(it));
+        const int n = it & (NB - 1), tp = it / NB;
+        const bool ok = it < kSlab && n0 + n < g.Npad;
+        const unsigned off = ok ? ((sbase + (unsigned)tp) * (unsigned)g.Npad + (unsigned)(n0 + n)) * 32u : 0x80000000u;
+        crn_bload4(wq[j][0], wsrs, off);
+        crn_bload4(wq[j][1], wsrs, ok ? off + 16u : 0x80000000u);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < kNWI; ++j) {
       int it = tid + j * kThreads;
@@ -257,7 +280,8 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
         asm volatile("" : "+v"(it));
         if (it < kSlab) {
           bf16x8 h, l;
-          split8(wv[j], h, l);
+          if constexpr (WS) { h = __builtin_bit_cast(bf16x8, wq[j][0]); l = __builtin_bit_cast(bf16x8, wq[j][1]); }
+          else split8(wv[j], h, l);
           Bhi[it] = h;                                   // [zs][tp][n] with n = ns*16 + n16: the fragment order
           Blo[it] = l;
         }
@@ -284,6 +308,9 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
   };
 
   __syncthreads();                                       // tables are in LDS
+  int step_no = 0;
+  const bool stamp = g.stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+  auto mark = [&](int i) { if (stamp && step_no < 24) g.stamps[step_no * 8 + i] = (long long)__builtin_amdgcn_s_memtime(); };
   int zd = 0, zend = 0;
   int chunk = first_step(cbeg, zd, zend);
   bool first = true;
@@ -297,19 +324,25 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
     // next step
     int nchunk = chunk, nzd = zd + ZS, nzend = zend;
     if (nzd >= zend) nchunk = first_step(chunk + 1, nzd, nzend);
+    mark(0);
     wait_loads2d(pv);
-    wait_loads2d(wv);
+    if constexpr (WS) wait_loads2d(wq); else wait_loads2d(wv);
+    mark(1);
     __syncthreads();                                     // every wave is done reading the LDS of the previous step
+    mark(2);
     if (g.dbg < 3 || first) {
       if (fresh) patch_commit(c0);
       weights_commit();
     }
     first = false;
+    mark(3);
     __syncthreads();
+    mark(4);
     if (nchunk < cend && g.dbg != 2) {
       if (nchunk != chunk) patch_issue(nchunk * kCK);    // flies under this slab's MFMAs
       weights_issue(nchunk * kCK, nzd);
     }
+    mark(5);
     if (g.dbg != 1) {
       // one window plane: every group runs (weights outside a tap box are zero): no control flow between the
       // groups, so the compiler keeps the next group's LDS reads in flight under this group's MFMAs
@@ -351,6 +384,8 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
         }
       }
     }
+    mark(6);
+    ++step_no;
     fresh = nchunk != chunk;
     chunk = nchunk; zd = nzd; zend = nzend;
   }
@@ -433,6 +468,13 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
     }
   }
 }
+
+// MEASURED AND REMOVED: a "sliding" variant of the kernel above (K = 4 (zd, zw) tap pairs x 8 channels, the zh taps
+// in time, so that the KH + 3 patch rows of a wave's four H-consecutive sub-tiles are read once per group: 1.9x
+// fewer LDS bytes per MFMA).  Bit-identical results, 0-10 % SLOWER on every decoder layer: the MFMA phase of a
+// staging step already runs the matrix pipe at full rate (2 waves x 84 MFMAs in 2900 cycles, CRN_BF3_STAMPS);
+// what the kernel loses is the ~3400 cycles per step in which a workgroup issues loads, commits and sits in
+// barriers while only the other resident workgroup can feed the pipe.
 
 // ------------------------------------ weight gradient ----------------------------------------------------
 // dw[(c*T + t)*Npad + n] += sum over (b, position) of T(x)[b, c, position + t - pad] * dy[b, n, position]
@@ -691,7 +733,7 @@ unsigned magic20b(int d) { return (unsigned)(((1u << 20) + d - 1) / d); }
 
 template <int NSUB, int XM, int NG, int ZS>
 int launch_bf3(const Bf3Geom& g, dim3 grid, size_t lds, hipStream_t st) {
-  auto k = conv_bf3_kernel<NSUB, XM, NG, ZS>;
+  auto k = g.wslab ? conv_bf3_kernel<NSUB, XM, NG, ZS, true> : conv_bf3_kernel<NSUB, XM, NG, ZS, false>;
   if (lds > 65536) CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, st, g);
   CRN_CHECK_LAUNCH();
@@ -704,16 +746,45 @@ bool even_view(const crnView& v) {       // 8-byte staging of position pairs on 
 }
 
 constexpr size_t kLdsMax = 160 * 1024 - 512;
+long long* g_bf3_stamps = nullptr;
 
 }  // namespace
 
+// tuning aid (CRN_BF3_STAMPS=1): shader-clock stamps of workgroup 0 of the last crn_conv_fwd_bf3 launch
+// (24 staging steps x 8: loop top, loads landed, barrier, commit done, barrier, next loads issued, MFMAs issued)
+extern "C" int crn_bf3_debug_stamps(long long* out192) {
+  if (!g_bf3_stamps) return CRN_EINVAL;
+  CRN_HIP(hipDeviceSynchronize());
+  CRN_HIP(hipMemcpy(out192, g_bf3_stamps, 24 * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+  return CRN_OK;
+}
+
 // Returns CRN_EINVAL for shapes this engine does not cover (the caller keeps the fp32 engine for those).
+namespace {
+int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w, const void* wslab, int Npad,
+                      const float* bias, int bias_sB, const crnView* y, int kd, int kh, int kw, int pd, int ph, int pw,
+                      int accumulate, const crnTapBoxes* boxes, crnStream stream);
+}
 extern "C" int crn_conv_fwd_bf3(const crnView* x, const crnInTransform* tr, const float* w, int Npad,
                                 const float* bias, int bias_sB, const crnView* y,
                                 int kd, int kh, int kw, int pd, int ph, int pw,
                                 int accumulate, const crnTapBoxes* boxes, crnStream stream) {
+  if (!w) return CRN_EINVAL;
+  return conv_fwd_bf3_impl(x, tr, w, nullptr, Npad, bias, bias_sB, y, kd, kh, kw, pd, ph, pw, accumulate, boxes, stream);
+}
+extern "C" int crn_conv_fwd_bf3_slabs(const crnView* x, const crnInTransform* tr, const void* wslab, int Npad,
+                                      const float* bias, int bias_sB, const crnView* y,
+                                      int kd, int kh, int kw, int pd, int ph, int pw,
+                                      int accumulate, const crnTapBoxes* boxes, crnStream stream) {
+  if (!wslab) return CRN_EINVAL;
+  return conv_fwd_bf3_impl(x, tr, nullptr, wslab, Npad, bias, bias_sB, y, kd, kh, kw, pd, ph, pw, accumulate, boxes, stream);
+}
+namespace {
+int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w, const void* wslab, int Npad,
+                      const float* bias, int bias_sB, const crnView* y, int kd, int kh, int kw, int pd, int ph, int pw,
+                      int accumulate, const crnTapBoxes* boxes, crnStream stream) {
   if (boxes && (boxes->n_groups < 0 || boxes->n_groups > 8 || boxes->c_groups < 0 || boxes->c_groups > 8)) return CRN_EINVAL;
-  if (!x || !y || !w || Npad <= 0 || (Npad & 15) || x->B != y->B || kd < 1 || kh < 1 || kw < 1) return CRN_EINVAL;
+  if (!x || !y || (!w && !wslab) || Npad <= 0 || (Npad & 15) || x->B != y->B || kd < 1 || kh < 1 || kw < 1) return CRN_EINVAL;
   if (y->C > Npad || x->C > kTabC) return CRN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int xmode = even_view(*x) ? 1 : ((x->sW == 2 && x->chan_off != nullptr && (x->W & 1) == 0) ? 2 : 0);
@@ -721,7 +792,7 @@ extern "C" int crn_conv_fwd_bf3(const crnView* x, const crnInTransform* tr, cons
   Bf3Geom g{};
   g.x = *x; g.y = *y;
   g.tr = tr ? *tr : crnInTransform{nullptr, nullptr, 0, 0};
-  g.w = w; g.bias = bias; g.Npad = Npad; g.bias_sB = bias_sB;
+  g.w = w; g.wslab = wslab; g.bias = bias; g.Npad = Npad; g.bias_sB = bias_sB;
   g.lead = ((pw % 2) + 2) % 2;                       // patch rows start on an even column: 8-byte loads stay aligned
   g.kd = kd; g.kh = kh; g.kw = kw; g.pd = pd; g.ph = ph; g.pw = pw + g.lead;
   g.T = kd * kh * kw; g.KHW = kh * kw;
@@ -801,6 +872,12 @@ extern "C" int crn_conv_fwd_bf3(const crnView* x, const crnInTransform* tr, cons
   g.vec_store = (g.mw >= 4 && yo.sW == 1 && (yo.W & 3) == 0 && (yo.sH & 3) == 0 && (yo.sD & 3) == 0 && (yo.sB & 3) == 0 &&
                  (yo.sC & 3) == 0 && (((uintptr_t)yo.base) & 15) == 0 && yo.chan_off == nullptr) ? 1 : 0;
   g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
+  static const bool want_stamps = getenv("CRN_BF3_STAMPS") != nullptr;
+  if (want_stamps) {
+    if (!g_bf3_stamps) CRN_HIP(hipMalloc(&g_bf3_stamps, 24 * 8 * sizeof(long long)));
+    CRN_HIP(hipMemsetAsync(g_bf3_stamps, 0, 24 * 8 * sizeof(long long), st));
+    g.stamps = g_bf3_stamps;
+  }
   dim3 grid((unsigned)tiles, (unsigned)crn_cdiv(Npad, NSUB * 16), (unsigned)splits);
   static const bool dbg = getenv("CRN_DEBUG") != nullptr;
   if (dbg)
@@ -816,6 +893,7 @@ extern "C" int crn_conv_fwd_bf3(const crnView* x, const crnInTransform* tr, cons
   if (rc == CRN_OK && g.mode == 3) rc = crn_splitk_reduce(yreal, scratch, splits, accumulate, st);
   return rc;
 }
+}  // namespace
 
 // Weight gradient on the split-bf16 MFMA engine; same contract as crn_conv_wgrad (dw zeroed by the caller or
 // zero_first).  Returns CRN_EINVAL for shapes it does not cover.

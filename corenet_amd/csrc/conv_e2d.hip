@@ -54,8 +54,9 @@ struct E2dGeom {
 };
 
 // crn_bf3_operands: one row of the layer table = (first float of the packed [Cin][T][Npad] weights, first 32-byte
-// entry of the operand blocks, Cin, T, Npad, first workgroup of the layer)
-constexpr int kOpFields = 6;
+// entry of the layer in the output, Cin, T, Npad, first workgroup of the layer, KHW: 0 = MFMA operand blocks of the
+// encoder engine below; kh*kw > 0 = slab order of conv_bf3.hip, [chunk of 8 channels][zd][tap slot][n])
+constexpr int kOpFields = 7;
 
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
@@ -77,6 +78,29 @@ __global__ __launch_bounds__(256) void bf3_operands_kernel(const float* packed, 
   }
   const long long* d = desc + lo * kOpFields;
   const int Cin = (int)d[2], T = (int)d[3], Npad = (int)d[4];
+  if (d[6] > 0) {                                     // slab order: entry ((chunk*kd + zd)*TP + tp)*Npad + n
+    const int KHW = (int)d[6], kd = T / KHW, TP = (KHW + 3) & ~3;
+    const long long entries = (long long)((Cin + 7) >> 3) * kd * TP * Npad;
+    const long long e = ((long long)blockIdx.x - d[5]) * 256 + threadIdx.x;
+    if (e >= entries) return;
+    const int n = (int)(e % Npad);
+    long long r = e / Npad;
+    const int tp = (int)(r % TP); r /= TP;
+    const int zd = (int)(r % kd);
+    const int chunk = (int)(r / kd);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = chunk * 8 + j;
+      v[j] = (c < Cin && tp < KHW) ? packed[d[0] + ((long long)c * T + zd * KHW + tp) * Npad + n] : 0.f;
+    }
+    bf16x8 h, l;
+    split8(v, h, l);
+    bf16x8* dst = reinterpret_cast<bf16x8*>(out + (d[1] + e) * 32);
+    dst[0] = h;
+    dst[1] = l;
+    return;
+  }
   const int ntn = Npad >> 4;
   const long long entries = (long long)(Cin >> 5) * T * ntn * 64;
   const long long e = ((long long)blockIdx.x - d[5]) * 256 + threadIdx.x;

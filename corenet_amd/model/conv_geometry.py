@@ -277,11 +277,19 @@ def operand_entries(g: Geom) -> int:
   return (g.cin // 32) * g.taps * (g.npad // 16) * 64
 
 
+def slab_entries(g: Geom) -> int:
+  """32-byte entries of one layer in slab order (decoder engine, crn_conv_fwd_bf3_slabs)."""
+  khw = g.window[1] * g.window[2]
+  return ((g.cin + 7) // 8) * g.window[0] * ((khw + 3) // 4 * 4) * g.npad
+
+
 def operand_table(layers):
-  """layers: [(first float in the packed buffer, first entry in the operand buffer, Geom)] ->
-  (int64 [n, 6] rows (src, dst, Cin, T, Npad, first workgroup), total workgroups of 256 entries)."""
+  """layers: [(first float in the packed buffer, first entry in the operand buffer, Geom, slab order?)] ->
+  (int64 [n, 7] rows (src, dst, Cin, T, Npad, first workgroup, KHW or 0), total workgroups of 256 entries)."""
   rows, blocks = [], 0
-  for src, dst, g in layers:
-    rows.append((src, dst, g.cin, g.taps, g.npad, blocks))
-    blocks += (operand_entries(g) + 255) // 256
-  return np.asarray(rows, dtype=np.int64).reshape(-1, 6), blocks
+  for layer in layers:
+    src, dst, g = layer[:3]
+    slab = len(layer) > 3 and layer[3]
+    rows.append((src, dst, g.cin, g.taps, g.npad, blocks, g.window[1] * g.window[2] if slab else 0))
+    blocks += ((slab_entries(g) if slab else operand_entries(g)) + 255) // 256
+  return np.asarray(rows, dtype=np.int64).reshape(-1, 7), blocks

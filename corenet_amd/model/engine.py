@@ -175,8 +175,9 @@ class Conv:
   gwf: t.Tensor             # packed weight gradient     (slice of eng.gpacked)
   dbias: t.Tensor           # reference-layout bias grad (slice of the grad slab)
   n_ref: int                # reference output channels (bias length)
-  wop_f: Optional[t.Tensor] = None   # encoder engine: forward / data-gradient weights as MFMA operand blocks
-  wop_d: Optional[t.Tensor] = None   # (slices of eng.wop; None: the layer stays on the general engines)
+  wop_f: Optional[t.Tensor] = None   # forward / data-gradient weights pre-split to bf16 hi + lo and pre-arranged
+  wop_d: Optional[t.Tensor] = None   # (slices of eng.wop): MFMA operand blocks for the encoder engine ("e2d"),
+  wop_kind: str = ""                 # slab images for the decoder's bf16x3 engine ("slab"); None: not used
 
 
 class Engine:
@@ -364,9 +365,9 @@ class Engine:
     conversion launches that follow each weight pack (conv_geometry.operand_table)."""
     self.wop = None
     self.op_tables = {}
-    if not self.encoder_e2d:
+    if self.decoder_math != "bf16x3":
       return
-    groups = {"enc_early": [], "enc_late": [], "bwd": []}
+    groups = {"enc_early": [], "enc_late": [], "dec": [], "bwd": []}
     slices = []
     po, eo = 0, 0
     # Which layers: measured (tools/e2d_parity.py, profiles/r02_e2d_parity.txt).  The B=1 / nbt=0 training fixtures
@@ -380,8 +381,17 @@ class Engine:
       src_d = po
       if dgrad is not None:
         po += len(parts[2])
-      if not name.startswith("encoder.") or name.startswith("encoder.stage1"):
+      if (name, "fwd") in BF16X3_LAUNCHES and os.environ.get("CRN_BF3_SLABS", "1") != "0":
+        # decoder bf16x3 layers: slab images of the forward and the data-gradient weights
+        groups["dec"].append((src_f, eo, fwd, True))
+        slices.append((name, "wop_f", eo, G.slab_entries(fwd))); eo += G.slab_entries(fwd)
+        groups["bwd"].append((src_d, eo, dgrad, True))
+        slices.append((name, "wop_d", eo, G.slab_entries(dgrad))); eo += G.slab_entries(dgrad)
+        self.convs[name].wop_kind = "slab"
         continue
+      if not self.encoder_e2d or not name.startswith("encoder.") or name.startswith("encoder.stage1"):
+        continue
+      self.convs[name].wop_kind = "e2d"
       if kinds == "3x3" and fwd.window != (1, 3, 3):
         continue
       fwd_stages = os.environ.get("CRN_E2D_FWD_STAGES", "45")
@@ -428,7 +438,7 @@ class Engine:
     tiles = {"all": self.pack_tiles, "enc": self.pack_tiles_enc, "dec": self.pack_tiles_dec,
              "enc_early": self.pack_tiles_enc_early, "enc_late": self.pack_tiles_enc_late}[part]
     self.be.copy_tiles(self.store.params, self.packed, tiles)
-    self._operands(*{"all": ("enc_early", "enc_late"), "enc": ("enc_early", "enc_late"), "dec": (),
+    self._operands(*{"all": ("enc_early", "enc_late", "dec"), "enc": ("enc_early", "enc_late"), "dec": ("dec",),
                      "enc_early": ("enc_early",), "enc_late": ("enc_late",)}[part])
     if part in ("all", "dec"):
       self._weights_dirty = False
@@ -631,7 +641,8 @@ class Plan:
     self.trace.append((label, a, b))
 
   def _math(self, cv: Conv, direction: str) -> str:
-    if direction == "fwd" and cv.wop_f is not None or direction == "dgrad" and cv.wop_d is not None:
+    if cv.wop_kind == "e2d" and (direction == "fwd" and cv.wop_f is not None or
+                                 direction == "dgrad" and cv.wop_d is not None):
       return "e2d"
     return "bf16x3" if self.eng.decoder_math == "bf16x3" and (cv.name, direction) in BF16X3_LAUNCHES else "fp32"
 
@@ -641,23 +652,23 @@ class Plan:
     g = cv.fwd
     if self.trace is not None and self.conv_positions is not None:
       self.conv_positions[cv.name] = y.D * y.H * y.W
-    if cv.wop_f is not None:
+    if cv.wop_f is not None and cv.wop_kind == "e2d":
       self._timed("fwd   " + cv.name, lambda: self.be.conv2d_bf3(
           x, tr, cv.wop_f, g.npad, cv.bias, 0, y, g.window, g.pad_lo, accumulate))
       return
     self._timed("fwd   " + cv.name, lambda: self.be.conv_fwd(
         x, tr, cv.wf, g.npad, cv.bias, 0, y, g.window, g.pad_lo, 0, accumulate, boxes=(g.n_boxes, g.c_boxes),
-        math=self._math(cv, "fwd")))
+        math=self._math(cv, "fwd"), wslab=cv.wop_f if cv.wop_kind == "slab" else None))
 
   def _dgrad(self, cv: Conv, dy: V.View, dx: V.View, accumulate=False):
     g = cv.dgrad
-    if cv.wop_d is not None:
+    if cv.wop_d is not None and cv.wop_kind == "e2d":
       self._timed("dgrad " + cv.name, lambda: self.be.conv2d_bf3(
           dy, None, cv.wop_d, g.npad, None, 0, dx, g.window, g.pad_lo, accumulate))
       return
     self._timed("dgrad " + cv.name, lambda: self.be.conv_fwd(
         dy, None, cv.wd, g.npad, None, 0, dx, g.window, g.pad_lo, 0, accumulate, boxes=(g.n_boxes, g.c_boxes),
-        math=self._math(cv, "dgrad")))
+        math=self._math(cv, "dgrad"), wslab=cv.wop_d if cv.wop_kind == "slab" else None))
 
   def _wgrad(self, cv: Conv, x: V.View, tr, dy: V.View):
     """Weight gradient of one conv.  On the GPU it goes to a second HIP stream: it only reads

@@ -87,6 +87,13 @@ int crn_conv_fwd_bf3(const crnView* x, const crnInTransform* tr, const float* w,
                      int kd, int kh, int kw, int pd, int ph, int pw,
                      int accumulate, const crnTapBoxes* boxes /* may be NULL */, crnStream stream);
 
+/* crn_conv_fwd_bf3 with the weights pre-split and pre-arranged by crn_bf3_operands (slab order): the kernel copies
+ * its weight slabs instead of gathering and splitting them at every staging step.  Same results bit for bit.     */
+int crn_conv_fwd_bf3_slabs(const crnView* x, const crnInTransform* tr, const void* wslab, int Npad,
+                           const float* bias, int bias_sB, const crnView* y,
+                           int kd, int kh, int kw, int pd, int ph, int pw,
+                           int accumulate, const crnTapBoxes* boxes /* may be NULL */, crnStream stream);
+
 /* Weight gradient in the same packed layout:
  *   dw[(c*T+t)*Npad+n] = sum_{b,o} T(x)[b,c,o-pad_lo+t] * dy[b,n,o]
  * dw must be zeroed by the caller or zero_first!=0.  Replaces autograd of the
@@ -108,11 +115,15 @@ int crn_conv_wgrad_bf3(const crnView* x, const crnInTransform* tr, const crnView
  * a layer is 1 GFLOP: split-bf16 MFMA like crn_conv_fwd_bf3, with the weights pre-arranged in MFMA operand order.
  *
  * crn_bf3_operands: packed fp32 weights [Cin][T][Npad] (the layout crn_conv_fwd reads) -> operand blocks, for
- * `nlayers` layers in one launch.  desc (DEVICE, int64 [nlayers][6]) = (first float of the layer in `packed`,
- * first 32-byte entry of the layer in `out`, Cin (multiple of 32), T taps, Npad (multiple of 16), first workgroup of
- * the layer); a layer has (Cin/32)*T*(Npad/16)*64 entries and ceil(entries/256) workgroups, total_blocks = their
- * sum.  Entry ((cb*T + t)*(Npad/16) + ntile)*64 + kk*16 + i holds, for output column 16*ntile + i and tap t, the 8
- * channels 32*cb + 8*kk .. +7 as 8 bf16 hi terms followed by 8 bf16 lo terms (w = hi + lo, hi = bf16(w)).        */
+ * `nlayers` layers in one launch.  desc (DEVICE, int64 [nlayers][7]) = (first float of the layer in `packed`,
+ * first 32-byte entry of the layer in `out`, Cin, T taps, Npad (multiple of 16), first workgroup of the layer,
+ * KHW); ceil(entries/256) workgroups per layer, total_blocks = their sum.  An entry is 8 bf16 hi terms followed by
+ * 8 bf16 lo terms of 8 consecutive input channels (w = hi + lo, hi = bf16(w)).
+ * KHW == 0, encoder engine (Cin % 32 == 0): (Cin/32)*T*(Npad/16)*64 entries, entry ((cb*T + t)*(Npad/16) + ntile)*64
+ *   + kk*16 + i = output column 16*ntile + i, tap t, channels 32*cb + 8*kk .. +7.
+ * KHW == kh*kw, decoder engine (crn_conv_fwd_bf3_slabs): ceil(Cin/8)*kd*TP*Npad entries, TP = KHW rounded up to 4,
+ *   entry ((chunk*kd + zd)*TP + tp)*Npad + n = output column n, tap zd*KHW + tp (zeros for tp >= KHW), channels
+ *   8*chunk .. +7 (zeros past Cin).                                                                              */
 int crn_bf3_operands(const float* packed, const int64_t* desc, int nlayers, int64_t total_blocks, void* out,
                      crnStream stream);
 /* y = bias + window correlation of T(x) with the operand blocks `wop` of one layer (same operation, transform and

@@ -72,8 +72,14 @@ class EmuBackend:
 
   # -- convolution engine -----------------------------------------------------
   def conv_fwd(self, x, tr, w, npad, bias, bias_sB, y, window, pad_lo, splits=1, accumulate=False, boxes=None,
-               math="fp32"):
+               math="fp32", wslab=None):
     # boxes only tell where the packed weights are structurally zero: no effect on the result
+    if wslab is not None:        # slab order (crn_bf3_operands, KHW > 0): [chunk][zd][tap slot][n][hi 8 | lo 8]
+      kd, khw = window[0], window[1] * window[2]
+      tp, nch = (khw + 3) // 4 * 4, (x.C + 7) // 8
+      ent = wslab.view(t.int16)[:nch * kd * tp * npad * 16].view(t.bfloat16).view(nch, kd, tp, npad, 2, 8).float()
+      w = (ent[..., 0, :] + ent[..., 1, :])[:, :, :khw].permute(0, 4, 1, 2, 3).reshape(nch * 8, kd * khw, npad)[:x.C]
+      w = w.reshape(-1).to(logical(x).dtype)
     xl = _transform(logical(x), tr)
     xp = _padded(xl, window, pad_lo, (y.D, y.H, y.W))
     T = window[0] * window[1] * window[2]
@@ -90,7 +96,17 @@ class EmuBackend:
   def bf3_operands(self, packed, table, out):
     desc, _blocks = table
     o16 = out.view(t.int16)
-    for src, dst, cin, T, npad, _first in desc.cpu().tolist():
+    for src, dst, cin, T, npad, _first, khw in desc.cpu().tolist():
+      if khw:                                                                              # slab order
+        kd, tp, nch = T // khw, (khw + 3) // 4 * 4, (cin + 7) // 8
+        w = t.zeros(nch * 8, kd, tp, npad, dtype=t.float32)
+        w[:cin, :, :khw] = packed[src:src + cin * T * npad].float().view(cin, kd, khw, npad)
+        blk = w.view(nch, 8, kd, tp, npad).permute(0, 2, 3, 4, 1).contiguous()             # chunk zd tp n j
+        hi = blk.to(t.bfloat16)
+        lo = (blk - hi.float()).to(t.bfloat16)
+        ent = t.stack([hi, lo], dim=-2).reshape(-1)
+        o16[dst * 16:dst * 16 + ent.numel()] = ent.view(t.int16)
+        continue
       w = packed[src:src + cin * T * npad].view(cin // 32, 4, 8, T, npad // 16, 16)       # cb kk j t ntile i
       blk = w.permute(0, 3, 4, 1, 5, 2).contiguous()                                       # cb t ntile kk i j
       hi = blk.to(t.bfloat16)

@@ -248,16 +248,36 @@ def test_conv_bf16x3_fwd_dgrad(be, name, kind, wshape, pad, dims, B):
   print(f"bf16x3 {name} fwd: max-abs-err/max = {e:.2e}")
   assert e <= 2e-5, (name, "fwd", e)
   assert float(yg[:, cout:].abs().max()) == 0.0
+  # the same launches with the weights pre-arranged as slab images (crn_bf3_operands + crn_conv_fwd_bf3_slabs):
+  # the images equal the emulator's bit for bit, and so do the results of the two forms of the kernel
+  nsf, nsd = G.slab_entries(fwd), G.slab_entries(dgr)
+  desc, blocks = G.operand_table([(0, 0, fwd, True), (wf.numel(), nsf, dgr, True)])
+  slabs = t.zeros((nsf + nsd) * 32, dtype=t.uint8)
+  EMU.bf3_operands(t.cat([wf, wd]), (t.as_tensor(desc), blocks), slabs)
+  slabs_g = t.zeros_like(slabs).to(DEV)
+  be.bf3_operands(t.cat([wf, wd]).to(DEV), (t.as_tensor(desc).to(DEV), blocks), slabs_g)
+  assert t.equal(slabs_g.cpu(), slabs), name
+  yg2 = t.zeros_like(yg)
+  be.conv_fwd(V.view_of(xg), trg, None, fwd.npad, bpack.to(DEV), 0, yview(yg2), fwd.window, fwd.pad_lo, 0,
+              boxes=(fwd.n_boxes, fwd.c_boxes), math="bf16x3", wslab=slabs_g[:nsf * 32])
+  assert t.equal(yg2, yg), (name, "fwd slabs")
+  ye = t.zeros_like(y)
+  EMU.conv_fwd(V.view_of(x), trc, None, fwd.npad, bpack, 0, yview(ye), fwd.window, fwd.pad_lo, wslab=slabs[:nsf * 32])
+  assert float((ye - y).abs().max() / y.abs().max()) < 2e-5
   dy = t.randn((B, cout) + odims, generator=g)
   dyb = t.zeros_like(y); dyb[:, :cout] = dy
   dx = t.randn(x.shape, generator=g); dxg = dx.to(DEV)
   dyg = dyb.to(DEV)
   EMU.conv_fwd(yview(dyb), None, wd, dgr.npad, None, 0, V.view_of(dx), dgr.window, dgr.pad_lo, accumulate=True)
+  dxg2 = dxg.clone()
   be.conv_fwd(yview(dyg), None, wd.to(DEV), dgr.npad, None, 0, V.view_of(dxg), dgr.window, dgr.pad_lo, 0, True,
               boxes=(dgr.n_boxes, dgr.c_boxes), math="bf16x3")
   e = float((dxg.cpu() - dx).abs().max() / dx.abs().max())
   print(f"bf16x3 {name} dgrad: max-abs-err/max = {e:.2e}")
   assert e <= 2e-5, (name, "dgrad", e)
+  be.conv_fwd(yview(dyg), None, None, dgr.npad, None, 0, V.view_of(dxg2), dgr.window, dgr.pad_lo, 0, True,
+              boxes=(dgr.n_boxes, dgr.c_boxes), math="bf16x3", wslab=slabs_g[nsf * 32:])
+  assert t.equal(dxg2, dxg), (name, "dgrad slabs")
   if dims[-1] < 16:
     return                      # the bf16x3 weight gradient covers W >= 16 grids (stages 4-6) only
   # weight gradient (crn_conv_wgrad_bf3): real entries of the packed gradient against the contract, and the

@@ -46,9 +46,16 @@ sc, shf = (t.rand(cin) + 0.5).cuda(), t.randn(cin).cuda()
 tr = Transform(sc, shf, pre_relu=True)
 yv = V.space_to_depth_view(V.view_of(y), (2, 2, 2), parity_major=True) if kind == "convT" else V.view_of(y)
 dw = t.zeros(wf.numel()).cuda()
+sf = sd = None
+if MATH == "bf16x3" and os.environ.get("CRN_BF3_SLABS", "1") != "0":      # weights pre-arranged as slab images
+  nsf, nsd = G.slab_entries(fwd), G.slab_entries(dgr)
+  desc, blocks = G.operand_table([(0, 0, fwd, True), (wf.numel(), nsf, dgr, True)])
+  slabs = t.zeros((nsf + nsd) * 32, dtype=t.uint8, device="cuda")
+  be.bf3_operands(t.cat([wf, wd]), (t.as_tensor(desc).cuda(), blocks), slabs)
+  sf, sd = slabs[:nsf * 32], slabs[nsf * 32:]
 def run():
-  if mode == "fwd": be.conv_fwd(V.view_of(x), tr, wf, fwd.npad, None, 0, yv, fwd.window, fwd.pad_lo, 0, boxes=(fwd.n_boxes, fwd.c_boxes), math=MATH)
-  elif mode == "dgrad": be.conv_fwd(yv, None, wd, dgr.npad, None, 0, V.view_of(x), dgr.window, dgr.pad_lo, 0, boxes=(dgr.n_boxes, dgr.c_boxes), math=MATH)
+  if mode == "fwd": be.conv_fwd(V.view_of(x), tr, wf, fwd.npad, None, 0, yv, fwd.window, fwd.pad_lo, 0, boxes=(fwd.n_boxes, fwd.c_boxes), math=MATH, wslab=sf)
+  elif mode == "dgrad": be.conv_fwd(yv, None, wd, dgr.npad, None, 0, V.view_of(x), dgr.window, dgr.pad_lo, 0, boxes=(dgr.n_boxes, dgr.c_boxes), math=MATH, wslab=sd)
   else: be.conv_wgrad(V.view_of(x), tr, yv, dw, fwd.npad, fwd.window, fwd.pad_lo, True, boxes=(fwd.n_boxes, fwd.c_boxes), math=MATH)
 for _ in range(3): run()
 t.cuda.synchronize(); a = t.cuda.Event(enable_timing=True); b = t.cuda.Event(enable_timing=True)
@@ -59,3 +66,19 @@ ms = a.elapsed_time(b) / iters
 import numpy as np
 flop = 2.0 * B * np.prod(dims) * cin * cout * np.prod(wshape[2:])
 print(f"{mode} {key} B={B} {MATH}: {ms*1e3:.1f} us  {flop/ms/1e9:.1f} TFLOP/s (real flops)")
+
+if os.environ.get("CRN_BF3_STAMPS"):        # per-step phases of workgroup 0 (conv_bf3.hip, crn_bf3_debug_stamps)
+  import ctypes
+  st = (ctypes.c_longlong * 192)()
+  be.lib.cdll.crn_bf3_debug_stamps(st)
+  names = ["wait", "barrier", "commit", "barrier", "issue", "mfma"]
+  tot = [0] * 6
+  n = 0
+  for i in range(24):
+    r = st[i * 8:i * 8 + 7]
+    if r[6] == 0: break
+    d = [r[j + 1] - r[j] for j in range(6)]
+    print(f"step {i:2d}: " + "  ".join(f"{nm} {v:6d}" for nm, v in zip(names, d)) + (f"   gap {r[0] - prev:6d}" if i else ""))
+    prev = r[6]; n += 1
+    for j in range(6): tot[j] += d[j]
+  if n: print("mean   : " + "  ".join(f"{nm} {v // n:6d}" for nm, v in zip(names, tot)))
