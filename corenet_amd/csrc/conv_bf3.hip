@@ -475,6 +475,15 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
 // staging step already runs the matrix pipe at full rate (2 waves x 84 MFMAs in 2900 cycles, CRN_BF3_STAMPS);
 // what the kernel loses is the ~3400 cycles per step in which a workgroup issues loads, commits and sits in
 // barriers while only the other resident workgroup can feed the pipe.
+// Also measured without effect on stage_6.c1 forward (447 us in tools/bench_conv.py): tap offsets as LDS immediates
+// (compile-time row pitch, a 5x5 slot order whose groups differ by a per-lane constant; the 70 address adds per
+// plane go away, the time does not), MFMAs ordered so that consecutive ones use different accumulators, and a start
+// delay for the second resident workgroup (s_sleep of 1-6 k clocks keyed on HW_REG_LDS_ALLOC.lds_base).  Ablations:
+// 151 us without the MFMA loop, 418 us without LDS commits, 434 us without global loads after the first step, and
+// the MFMA loop with its LDS reads removed still leaves 413 us of a (slower, 525 us) instrumented build: the two
+// resident workgroups do not overlap one's staging with the other's MFMAs, T ~ T_mfma + T_staging.  The next
+// thing to try is one 16-wave workgroup whose two 8-wave halves alternate roles under block barriers (shared patch,
+// window planes split by parity, one LDS reduction at the end).
 
 // ------------------------------------ weight gradient ----------------------------------------------------
 // dw[(c*T + t)*Npad + n] += sum over (b, position) of T(x)[b, c, position + t - pad] * dy[b, n, position]

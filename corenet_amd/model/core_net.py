@@ -283,6 +283,12 @@ class CoreNet(nn.Module):
         all_reduce.pushed.clear()
         plan.backward(plan.glogits, grad_hook=all_reduce.push)   # buckets are reduced while backward runs
         plan._probe("grad_exchange_wait", all_reduce.wait)       # what is left of the exchange once backward is done
+      elif all_reduce is None and plan.side is not None and plan.trace is None:
+        # no exchange: every finished bucket of the grad slab is un-packed AND stepped on the side stream
+        eng.adam_step_graphable(lr, adam_eps, grad_scale=1.0 / world_size, launch=False)
+        plan.backward(plan.glogits, grad_hook=eng.adam_bucket_hook())
+        eng.weights_dirty = True
+        return plan.loss
       else:
         plan.backward(plan.glogits)
         if all_reduce is not None:

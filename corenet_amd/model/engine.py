@@ -482,6 +482,17 @@ class Engine:
     if launch:
       self.adam_update_from_hyper()
 
+  def adam_bucket_hook(self):
+    """Bucket hook of a step without a gradient exchange (Plan.backward): Adam on the finished slice of the slab,
+    on the side stream right behind the bucket's un-pack -- the update of everything but the last, small bucket
+    (stem + encoder stages 2-3) then runs under the rest of backward instead of after it (0.16 ms for the 36 M
+    parameters in one piece).  The scalars come from adam_step_graphable(launch=False)."""
+    def hook(gslice: t.Tensor):
+      lo, n = gslice.storage_offset(), gslice.numel()
+      self.be.adam_step_hyper(self.store.params[lo:lo + n], gslice, self.adam_m[lo:lo + n], self.adam_v[lo:lo + n], n,
+                              self.adam_hyper)
+    return hook
+
   def adam_update_from_hyper(self):
     self.be.adam_step_hyper(self.store.params, self.store.grads, self.adam_m, self.adam_v,
                             self.store.params.numel(), self.adam_hyper)
