@@ -515,9 +515,12 @@ struct Bf3WgGeom {
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
-template <int NSUB, int DM, int TPW>
+// TWT: tile width: 16 (tile 4 x 8 x 16, a K block of 32 positions = 2 H rows x 16 W) or 8 (tile 8 x 8 x 8 -- the 8^3
+// maps of decoder stage 3 --, a K block = 4 H rows x 8 W)
+template <int NSUB, int DM, int TPW, int TWT>
 __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
   crn_kernarg_touch(g);
+  constexpr int TDT = TWT == 16 ? 4 : 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NB = NSUB * 16;
   constexpr int kHdr = 1024;
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
   const int j = i16 >> 2, q = i16 & 3;
   const int k1 = kk * 8 + j;                                   // K index inside the 32-position block (second read: +4)
   // A (input patch): virtual column quad q = (tap of the pair: q >> 1, channel half: q & 1)
-  const int abase = (((k1 >> 4) * g.PW + (k1 & 15) + g.lead) << 4) + ((q & 1) << 3);
+  const int abase = (((k1 / TWT) * g.PW + (k1 % TWT) + g.lead) << 4) + ((q & 1) << 3);
   int toffL[TPW];
 #pragma unroll
   for (int ti = 0; ti < TPW; ++ti) {
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
     const int twi = tile % g.tilesW; tile /= g.tilesW;
     const int thi = tile % g.tilesH; tile /= g.tilesH;
     const int tdi = tile % g.tilesD; tile /= g.tilesD;
-    b = tile; d0 = tdi * 4; h0 = thi * 8; w0 = twi * 16;
+    b = tile; d0 = tdi * TDT; h0 = thi * 8; w0 = twi * TWT;
   };
   auto unit_of = [&](int jx, int& pos, unsigned& sp, bool& in) -> bool {
     int u = tid + jx * kThreads;
@@ -596,8 +599,8 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
   // 512 threads: pair = tid & 255, octet = (tid >> 8) + 2 * jd
   auto dy_unit = [&](int jd, int& pq, int& oct, unsigned& sp, bool& in) {
     pq = tid & 255; oct = (tid >> 8) + 2 * jd;
-    const int p = pq * 2;                                       // tile-linear position: (d*8 + h)*16 + w
-    const int w = p & 15, h = (p >> 4) & 7, d = p >> 7;
+    const int p = pq * 2;                                       // tile-linear position: (d*8 + h)*TWT + w
+    const int w = p % TWT, h = (p / TWT) & 7, d = p / (TWT * 8);
     const int od = d0 + d, oh = h0 + h, ow = w0 + w;
     in = od < g.dy.D && oh < g.dy.H && ow < g.dy.W;
     sp = (unsigned)od * (unsigned)g.dy.sD + (unsigned)oh * (unsigned)g.dy.sH + (unsigned)ow * (unsigned)(DM == 2 ? 2 : 1);
@@ -690,7 +693,8 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
     if (tl + 1 < tend) { tile_origin(tl + 1); stage_issue(); }
     if (g.dbg == 1) continue;
     for (int kb = 0; kb < 16; ++kb) {
-      const int kbx = (((kb >> 2) * g.PH + (kb & 3) * 2) * g.PW) << 4;
+      const int kbx = TWT == 16 ? (((kb >> 2) * g.PH + (kb & 3) * 2) * g.PW) << 4      // K block kb = (d, H row pair)
+                                : (((kb >> 1) * g.PH + (kb & 1) * 4) * g.PW) << 4;     //            = (d, H row quad)
       const char* yb = Yhi + ybase + kb * (32 * NB * 2);
       bf16x8 bh[NSUB], bl[NSUB];
 #pragma unroll
@@ -729,9 +733,9 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
     }
 }
 
-template <int NSUB, int DM, int TPW>
+template <int NSUB, int DM, int TPW, int TWT>
 int launch_bf3_wgrad(const Bf3WgGeom& g, dim3 grid, size_t lds, hipStream_t st) {
-  auto k = conv_bf3_wgrad_kernel<NSUB, DM, TPW>;
+  auto k = conv_bf3_wgrad_kernel<NSUB, DM, TPW, TWT>;
   if (lds > 65536) CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, st, g);
   CRN_CHECK_LAUNCH();
@@ -913,7 +917,8 @@ extern "C" int crn_conv_wgrad_bf3(const crnView* x, const crnInTransform* tr, co
   if (!even_view(*x)) return CRN_EINVAL;
   const int dmode = even_view(*dy) ? 1 : ((dy->sW == 2 && dy->chan_off != nullptr && (dy->W & 1) == 0) ? 2 : 0);
   if (!dmode) return CRN_EINVAL;
-  if ((dy->W & 15) || dy->H < 8 || dy->D < 4) return CRN_EINVAL;
+  const int TWT = (dy->W % 16 == 0) ? 16 : 8, TDT = TWT == 16 ? 4 : 8;
+  if (dy->W % TWT || dy->H < 8 || dy->D < TDT) return CRN_EINVAL;
   Bf3WgGeom g{};
   g.x = *x; g.dy = *dy;
   g.tr = tr ? *tr : crnInTransform{nullptr, nullptr, 0, 0};
@@ -921,13 +926,13 @@ extern "C" int crn_conv_wgrad_bf3(const crnView* x, const crnInTransform* tr, co
   g.lead = ((pw % 2) + 2) % 2;
   g.kd = kd; g.kh = kh; g.kw = kw; g.pd = pd; g.ph = ph; g.pw = pw + g.lead;
   g.T = kd * kh * kw; g.KHW = kh * kw;
-  g.PD = 4 + kd - 1; g.PH = 8 + kh - 1; g.PW = (g.lead + 16 + kw - 1 + 1) & ~1;
+  g.PD = TDT + kd - 1; g.PH = 8 + kh - 1; g.PW = (g.lead + TWT + kw - 1 + 1) & ~1;
   g.PHW = g.PH * g.PW; g.NP = g.PD * g.PHW;
   g.pw2 = g.PW / 2; g.nunits = g.PD * g.PH * g.pw2;
   if (g.nunits > kNUX * kThreads) return CRN_EINVAL;
   const int TPW = (((g.T + 1) / 2) + 7) / 8;                  // tap pairs per wave
   if (TPW != 8 && TPW != 4) return CRN_EINVAL;                // instantiated: 5^3 (63 pairs) and 4^3 (32 pairs) windows
-  g.tilesD = crn_cdiv(dy->D, 4); g.tilesH = crn_cdiv(dy->H, 8); g.tilesW = dy->W / 16;
+  g.tilesD = crn_cdiv(dy->D, TDT); g.tilesH = crn_cdiv(dy->H, 8); g.tilesW = dy->W / TWT;
   g.ntiles = g.tilesD * g.tilesH * g.tilesW * dy->B;
   g.magic_pw2 = magic20b(g.pw2); g.magic_PH = magic20b(g.PH); g.magic_kw = magic20b(kw); g.magic_KHW = magic20b(g.KHW);
   if (zero_first) CRN_HIP(hipMemsetAsync(dw, 0, (size_t)x->C * g.T * Npad * 4, st));
@@ -949,10 +954,12 @@ extern "C" int crn_conv_wgrad_bf3(const crnView* x, const crnInTransform* tr, co
     fprintf(stderr, "[crn_conv_wgrad_bf3] x(C%d %dx%dx%d) dy(C%d %dx%dx%d) k%dx%dx%d: NSUB %d dmode %d TPW %d grid %ux%ux%u "
             "tiles/split %d lds %zu\n", x->C, x->D, x->H, x->W, dy->C, dy->D, dy->H, dy->W, kd, kh, kw, NSUB, dmode, TPW,
             grid.x, grid.y, grid.z, g.tiles_per_split, lds);
-#define CRN_BF3WG_CASE(N, D, P) if (NSUB == N && dmode == D && TPW == P) return launch_bf3_wgrad<N, D, P>(g, grid, lds, st);
-  CRN_BF3WG_CASE(1, 1, 8) CRN_BF3WG_CASE(2, 1, 8)
-  CRN_BF3WG_CASE(1, 2, 4) CRN_BF3WG_CASE(2, 2, 4)
-  CRN_BF3WG_CASE(1, 1, 4) CRN_BF3WG_CASE(2, 1, 4)
+#define CRN_BF3WG_CASE(N, D, P, W) if (NSUB == N && dmode == D && TPW == P && TWT == W) return launch_bf3_wgrad<N, D, P, W>(g, grid, lds, st);
+  CRN_BF3WG_CASE(1, 1, 8, 16) CRN_BF3WG_CASE(2, 1, 8, 16)
+  CRN_BF3WG_CASE(1, 2, 4, 16) CRN_BF3WG_CASE(2, 2, 4, 16)
+  CRN_BF3WG_CASE(1, 1, 4, 16) CRN_BF3WG_CASE(2, 1, 4, 16)
+  CRN_BF3WG_CASE(1, 1, 8, 8) CRN_BF3WG_CASE(2, 1, 8, 8)
+  CRN_BF3WG_CASE(1, 2, 4, 8) CRN_BF3WG_CASE(2, 2, 4, 8)
 #undef CRN_BF3WG_CASE
   return CRN_EINVAL;
 }

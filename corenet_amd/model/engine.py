@@ -44,13 +44,12 @@ ENC_STAGES = (("stage2", "abc", (64, 64, 256), 1), ("stage3", "abcd", (128, 128,
 GRAD_BUCKET_LABELS = ("decoder.stage_3.", "decoder.stage_0.", "encoder.stage5.c.", "encoder.stage5.b.",
                       "encoder.stage5.a.", "encoder.stage4.a.", "")
 # Layers (and directions) that run on the split-bf16 MFMA engine when Engine(decoder_math="bf16x3"): the
-# Conv3d k5 / ConvTranspose3d k7 of decoder stages 3-6 (reconstruction_decoder.py:64-95) forward and
-# data-gradient, and the weight gradients of stages 4-6 (the bf16x3 weight-gradient kernel tiles 16 W
-# positions).  Everything else -- encoder, stages 0-2, the stage-3 weight gradients -- stays on the fp32
-# MFMA engine (measured per layer: profiles/r02_layer_times_bf16x3.txt).
+# Conv3d k5 / ConvTranspose3d k7 of decoder stages 3-6 (reconstruction_decoder.py:64-95): forward, data gradient
+# and weight gradient.  Decoder stages 0-2 and the stem stay on the fp32 MFMA engine, the encoder's 3x3 layers go to
+# the encoder engine (Engine._build_operands); measured per layer: profiles/r02_layer_times_bf16x3.txt.
 BF16X3_LAUNCHES = frozenset(
     [(f"decoder.stage_{k}.{l}.", d) for k in (3, 4, 5, 6) for l in ("c1", "t1") for d in ("fwd", "dgrad")] +
-    [(f"decoder.stage_{k}.{l}.", "wgrad") for k in (4, 5, 6) for l in ("c1", "t1")])
+    [(f"decoder.stage_{k}.{l}.", "wgrad") for k in (3, 4, 5, 6) for l in ("c1", "t1")])
 LOSS_KINDS = {"iou_fgbg": 0, "xent_times_iou_agnostic": 1, "iou_agnostic": 2, "xent": 3,
               "xent_times_iou_fgbg": 4}
 

@@ -104,8 +104,8 @@ int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const crnView* dy
                    crnStream stream);
 
 /* The weight gradient on the split-bf16 MFMA engine (csrc/conv_bf3.hip; see crn_conv_fwd_bf3): same packed
- * dw, same zero_first contract; CRN_EINVAL for shapes it does not cover (windows other than 5^3 / 4^3, dy W not
- * a multiple of 16, views other than unit-stride x and unit-stride / stride-2 space-to-depth dy).            */
+ * dw, same zero_first contract; CRN_EINVAL for shapes it does not cover (windows other than 5^3 / 4^3, dy W neither
+ * a multiple of 16 nor 8, views other than unit-stride x and unit-stride / stride-2 space-to-depth dy).       */
 int crn_conv_wgrad_bf3(const crnView* x, const crnInTransform* tr, const crnView* dy,
                        float* dw, int Npad, int kd, int kh, int kw, int pd, int ph, int pw,
                        int zero_first, crnStream stream);

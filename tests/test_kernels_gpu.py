@@ -278,8 +278,6 @@ def test_conv_bf16x3_fwd_dgrad(be, name, kind, wshape, pad, dims, B):
   be.conv_fwd(yview(dyg), None, None, dgr.npad, None, 0, V.view_of(dxg2), dgr.window, dgr.pad_lo, 0, True,
               boxes=(dgr.n_boxes, dgr.c_boxes), math="bf16x3", wslab=slabs_g[nsf * 32:])
   assert t.equal(dxg2, dxg), (name, "dgrad slabs")
-  if dims[-1] < 16:
-    return                      # the bf16x3 weight gradient covers W >= 16 grids (stages 4-6) only
   # weight gradient (crn_conv_wgrad_bf3): real entries of the packed gradient against the contract, and the
   # un-packed gradient against autograd of torch's own op
   dw = t.zeros(wf.numel()); dwg = t.full((wf.numel(),), 7.0, device=DEV)

@@ -19,6 +19,7 @@ plan.in_image.copy_(image); plan.in_v2s.copy_(v2s); plan.in_off.copy_(off); plan
 names = ["enc fwd", "dec fwd", "loss", "backward", "adam"]
 ev = [[t.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)] for _ in range(steps)]
 t.cuda.synchronize()
+joins = []
 for s in range(steps):
   e = ev[s]
   eng.adam_step_graphable(4e-4 * 5, 1e-3, grad_scale=1.0, launch=False)
@@ -28,12 +29,20 @@ for s in range(steps):
   plan.forward_decoder(plan.in_v2s, plan.in_off, True); e[2].record()
   eng.be.loss_fwd_bwd(LOSS_KINDS["iou_fgbg"], plan.logits, plan.gt, plan.B, eng.num_classes, 128 ** 3, plan.loss, plan.glogits, 1.0)
   e[3].record()
-  plan.backward(plan.glogits); e[4].record()
-  eng.adam_update_from_hyper(); e[5].record()
+  orig_join = plan._join_side
+  def timed_join():
+    j0.record(); orig_join(); j1.record()
+  j0, j1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+  joins.append((j0, j1))
+  plan._join_side = timed_join
+  plan.backward(plan.glogits, grad_hook=eng.adam_bucket_hook()); e[4].record()
+  plan._join_side = orig_join
+  e[5].record()
 t.cuda.synchronize()
 tot = 0.0
 for i, nm in enumerate(names):
   ms = sum(ev[s][i].elapsed_time(ev[s][i + 1]) for s in range(2, steps)) / (steps - 2)
   tot += ms
   print(f"{nm:10s} {ms:7.3f} ms")
+print(f"main stream waits {sum(a.elapsed_time(b) for a, b in joins[2:]) / (steps - 2):.3f} ms for the side stream at the end of backward")
 print(f"{'sum':10s} {tot:7.3f} ms; step to step {ev[2][0].elapsed_time(ev[steps - 1][0]) / (steps - 3):.3f} ms")
