@@ -28,13 +28,16 @@ for l, x, y in plan.trace:
   d, name = l.split()
   ms = x.elapsed_time(y)
   gf = 2.0 * B * plan.conv_positions[name] * nreal[name] / 1e9
-  bf3 = MATH == "bf16x3" and (name, d) in BF16X3_LAUNCHES
+  cvo = m.engine.convs[name]
+  e2d = cvo.wop_kind == "e2d" and ((d == "fwd" and cvo.wop_f is not None) or (d == "dgrad" and cvo.wop_d is not None))
+  bf3 = e2d or (MATH == "bf16x3" and (name, d) in BF16X3_LAUNCHES)
   peak = 2500.0 / 3 if bf3 else 157.3
-  rows.append((ms, d, name, gf, gf / ms, gf / ms / peak, "bf16x3" if bf3 else "fp32"))
+  rows.append((ms, d, name, gf, gf / ms, gf / ms / peak, "e2d" if e2d else ("bf16x3" if bf3 else "fp32")))
 tot = sum(r[0] for r in rows)
 print(f"decoder_math={MATH} C={C} B={B}: step (serialized, with event overhead) {a.elapsed_time(b):.2f} ms; "
       f"{len(rows)} conv launches, {tot:.2f} ms, {sum(r[3] for r in rows):.0f} GFLOP")
-print(f"{'us':>9} {'GFLOP':>8} {'TFLOP/s':>8} {'frac':>6} {'engine':>7}  launch      (frac: of 157.3 fp32 MFMA / of 2500/3 bf16x3)")
+print(f"{'us':>9} {'GFLOP':>8} {'TFLOP/s':>8} {'frac':>6} {'engine':>7}  launch      (frac: of 157.3 fp32 MFMA / of 2500/3 for bf16x3 and e2d = the encoder's split-bf16 engine;"
+      " every launch is bracketed by HIP events on one stream: small launches include ~5 us of launch overhead)")
 for ms, d, name, gf, tf, fr, eng in sorted(rows, reverse=True)[:int(sys.argv[2]) if len(sys.argv) > 2 else 60]:
   print(f"{ms*1e3:9.1f} {gf:8.2f} {tf:8.1f} {fr:6.2f} {eng:>7}  {d:5s} {name}")
 grp = {}
