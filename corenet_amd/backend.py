@@ -115,6 +115,10 @@ class HipBackend:
 
   def conv_wgrad(self, x: View, tr: Optional[Transform], dy: View, dw: t.Tensor, npad: int,
                  window, pad_lo, zero_first: bool = True, boxes=None, math: str = "fp32"):
+    if math == "bf16x3_1x1":       # 1x1 layers: both operands straight from HBM (csrc/conv_e2d.hip)
+      self.lib.crn_conv_wgrad_1x1_bf3(C.byref(_cview(x)), _ctr(tr), C.byref(_cview(dy)), ptr(dw), npad, int(zero_first),
+                                      _lib.stream())
+      return
     if math == "bf16x3":
       self.lib.crn_conv_wgrad_bf3(C.byref(_cview(x)), _ctr(tr), C.byref(_cview(dy)), ptr(dw), npad,
                                   window[0], window[1], window[2], pad_lo[0], pad_lo[1], pad_lo[2],

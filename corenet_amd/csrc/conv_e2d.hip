@@ -426,6 +426,141 @@ __global__ __launch_bounds__(256, 2) void conv_e2d_kernel(E2dGeom g) {
   mark(31);
 }
 
+// ---- weight gradient of the 1x1 layers ---------------------------------------------------------------------------
+// dw[c][n] += sum over (b, position) of T(x)[b, c, position] * dy[b, n, position]: a [C x positions] . [positions x N]
+// GEMM whose K = positions is the contiguous index of BOTH operands in memory, and an MFMA operand register holds 8
+// consecutive K of one row: lane (row i16, K slice kk) loads x[b][c0 + i16][s + 8*kk .. +7] (and the same of dy) with two
+// 16-byte loads, splits them to bf16 hi / lo in registers and multiplies -- no LDS on the operand path, no barrier.
+// Workgroup = 4 waves on one 64 (c) x 32 (n) tile, each wave every fourth K step of the workgroup's K range (the 36
+// launches per step have K = 256 ... 16384 positions); the four partial tiles meet in LDS and go to dw with
+// fire-and-forget atomics (dw is zeroed by the caller or by zero_first, like crn_conv_wgrad).
+struct Wg1Geom {
+  const float* x; const float* dy; float* dw;
+  const float* scale; const float* shift;
+  int pre_relu, post_relu;
+  long long xsB, dsB;      // sample strides
+  int C, N, Npad, S;       // S = positions per sample (multiple of 32)
+  int ksteps, ksteps_per_block;   // K steps of 32 positions: B * S / 32 in total
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad1x1_bf3_kernel(Wg1Geom g) {
+  crn_kernargs_now(g.x, g.dy, g.dw, g.scale, g.shift, g.pre_relu, g.post_relu, g.xsB, g.dsB, g.C, g.N, g.Npad, g.S,
+                   g.ksteps, g.ksteps_per_block);
+  __shared__ __attribute__((aligned(16))) f32x4 red[4][8][64];          // [wave][tile][lane]: 32 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // scalar: the buffer descriptors depend on it
+  const int i16 = lane & 15, kk = lane >> 4;
+  const int c0 = blockIdx.x * 64, n0 = blockIdx.y * 32;
+  const int kbeg = blockIdx.z * g.ksteps_per_block, kend = min(kbeg + g.ksteps_per_block, g.ksteps);
+  // rows of this lane: 4 x channels (A), 2 x output columns (B); rows past the tensors are loaded as zeros
+  unsigned arow[4], brow[2];
+  float sc[4], sh[4];
+  const bool has_tr = g.scale != nullptr;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int c = c0 + 16 * mt + i16;
+    arow[mt] = c < g.C ? (unsigned)c * (unsigned)g.S * 4u : kOOB;
+    sc[mt] = (has_tr && c < g.C) ? g.scale[c] : 1.f;
+    sh[mt] = (has_tr && c < g.C) ? g.shift[c] : 0.f;
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = n0 + 16 * nt + i16;
+    brow[nt] = n < g.N ? (unsigned)n * (unsigned)g.S * 4u : kOOB;
+  }
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  f32x4 ra[4][2], rb[2][2];                             // raw fp32 operands of one K step
+  auto issue = [&](int step) {
+    const bool live = step < kend;
+    const int pos = step * 32, b = live ? pos / g.S : 0, s = pos - b * g.S;
+    const crn_rsrc xrs = make_rsrc(g.x + (long long)b * g.xsB);
+    const crn_rsrc drs = make_rsrc(g.dy + (long long)b * g.dsB);
+    const unsigned koff = (unsigned)(s + 8 * kk) * 4u, oob = live ? 0u : kOOB;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      crn_bload4(ra[mt][0], xrs, (arow[mt] + koff) | oob);
+      crn_bload4(ra[mt][1], xrs, (arow[mt] + koff + 16u) | oob);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      crn_bload4(rb[nt][0], drs, (brow[nt] + koff) | oob);
+      crn_bload4(rb[nt][1], drs, (brow[nt] + koff + 16u) | oob);
+    }
+  };
+  auto wait_all = [&]() {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[mt][0]), "+v"(ra[mt][1]));
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb[nt][0]), "+v"(rb[nt][1]));
+  };
+  int step = kbeg + wave;
+  issue(step);
+  for (; step < kend; step += 4) {
+    wait_all();
+    bf16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = ra[mt][j >> 2][j & 3];
+        if (has_tr) {
+          if (g.pre_relu) a = fmaxf(a, 0.f);
+          a = a * sc[mt] + sh[mt];
+          if (g.post_relu) a = fmaxf(a, 0.f);
+        }
+        v[j] = a;
+      }
+      if (has_tr && arow[mt] == kOOB) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;           // channels past C: T(0) is not 0
+      }
+      split8(v, ah[mt], al[mt]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = rb[nt][j >> 2][j & 3];
+      split8(v, bh[nt], bl[nt]);
+    }
+    issue(step + 4);                                    // the raw registers are free again: next K step of this wave
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+    }
+  }
+  wait_all();                                           // the loads issued for "the step after the last" (zeros)
+  // the four partial tiles -> LDS -> one sum per element -> dw.  D row = 4*kk + r (channel), col = i16 (column)
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) red[wave][mt * 2 + nt][lane] = acc[mt][nt];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int tile = wave * 2 + q;                      // wave w sums tiles 2w, 2w + 1
+    const f32x4 v = red[0][tile][lane] + red[1][tile][lane] + red[2][tile][lane] + red[3][tile][lane];
+    const int mt = tile >> 1, nt = tile & 1;
+    const int n = n0 + 16 * nt + i16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = c0 + 16 * mt + 4 * kk + r;
+      if (c < g.C && n < g.N) atomicAdd(g.dw + (long long)c * g.Npad + n, v[r]);
+    }
+  }
+}
+
 bool dense_2d(const crnView& v) {   // unit W stride, rows back to back, 16-byte aligned channel planes
   return v.chan_off == nullptr && v.sW == 1 && v.sH == v.W && (v.D == 1 || v.sD == v.H * v.W) && (v.sC & 3) == 0 &&
          (v.sB & 3) == 0 && (((uintptr_t)v.base) & 15) == 0;
@@ -536,5 +671,35 @@ extern "C" int crn_e2d_debug_stamps(long long* out32) {
   if (!g_stamps) return CRN_EINVAL;
   CRN_HIP(hipDeviceSynchronize());
   CRN_HIP(hipMemcpy(out32, g_stamps, 32 * sizeof(long long), hipMemcpyDeviceToHost));
+  return CRN_OK;
+}
+
+// The weight gradient of a 1x1 layer on the split-bf16 MFMA (see wgrad1x1_bf3_kernel); same contract as
+// crn_conv_wgrad with a 1x1x1 window: dw[c*Npad + n] += sum T(x)[b,c,p] * dy[b,n,p], dw zeroed by the caller or by
+// zero_first.  CRN_EINVAL for views that are not dense or positions per sample that are not a multiple of 32.
+extern "C" int crn_conv_wgrad_1x1_bf3(const crnView* x, const crnInTransform* tr, const crnView* dy, float* dw, int Npad,
+                                      int zero_first, crnStream stream) {
+  if (!x || !dy || !dw || Npad <= 0 || (Npad & 15) || x->B != dy->B || dy->C > Npad) return CRN_EINVAL;
+  if (!dense_2d(*x) || !dense_2d(*dy)) return CRN_EINVAL;
+  if (x->D != dy->D || x->H != dy->H || x->W != dy->W) return CRN_EINVAL;
+  const int64_t S = (int64_t)x->D * x->H * x->W;
+  if (S % 32 || x->sC != S || dy->sC != S) return CRN_EINVAL;
+  if (S * x->C * 4 >= ((int64_t)1 << 31) || S * dy->C * 4 >= ((int64_t)1 << 31)) return CRN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (zero_first) CRN_HIP(hipMemsetAsync(dw, 0, (size_t)x->C * Npad * 4, st));
+  Wg1Geom g{};
+  g.x = x->base; g.dy = dy->base; g.dw = dw;
+  g.scale = tr ? tr->scale : nullptr; g.shift = tr ? tr->shift : nullptr;
+  g.pre_relu = tr ? tr->pre_relu : 0; g.post_relu = tr ? tr->post_relu : 0;
+  g.xsB = x->sB; g.dsB = dy->sB; g.C = x->C; g.N = dy->C; g.Npad = Npad; g.S = (int)S;
+  g.ksteps = (int)((int64_t)x->B * S / 32);
+  const int tiles = crn_cdiv(x->C, 64) * crn_cdiv(dy->C, 32);
+  static const int kFill = getenv("CRN_WG1_FILL") ? atoi(getenv("CRN_WG1_FILL")) : 512;
+  int splits = std::max(1, std::min(g.ksteps / 8, crn_cdiv(kFill, tiles)));       // >= 2 K steps per wave
+  g.ksteps_per_block = crn_cdiv(g.ksteps, splits);
+  splits = crn_cdiv(g.ksteps, g.ksteps_per_block);
+  const dim3 grid((unsigned)crn_cdiv(x->C, 64), (unsigned)crn_cdiv(dy->C, 32), (unsigned)splits);
+  hipLaunchKernelGGL(wgrad1x1_bf3_kernel, grid, dim3(256), 0, st, g);
+  CRN_CHECK_LAUNCH();
   return CRN_OK;
 }

@@ -135,6 +135,13 @@ int crn_bf3_operands(const float* packed, const int64_t* desc, int nlayers, int6
 int crn_conv2d_bf3(const crnView* x, const crnInTransform* tr, const void* wop, int Npad, const float* bias,
                    int bias_sB, const crnView* y, int kh, int kw, int ph, int pw, int accumulate, crnStream stream);
 
+/* Weight gradient of a 1x1 layer on the split-bf16 MFMA (csrc/conv_e2d.hip: both operands straight from HBM, K =
+ * positions): dw[c*Npad + n] += sum_{b,p} T(x)[b,c,p] * dy[b,n,p], the contract of crn_conv_wgrad for a 1x1x1 window
+ * (Conv2d 1x1 of resnet50.py:62-69; dw zeroed by the caller or zero_first).  Dense NC(D)HW views with the same
+ * extent, positions per sample a multiple of 32; CRN_EINVAL otherwise.                                          */
+int crn_conv_wgrad_1x1_bf3(const crnView* x, const crnInTransform* tr, const crnView* dy, float* dw, int Npad,
+                           int zero_first, crnStream stream);
+
 /* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0        (weight packing)            */
 /* Tiled index copy between a reference-layout buffer and a packed buffer (weight pack / gradient un-pack).
  * Tile t covers packed positions desc[t][0] + r*desc[t][1] + c (r, c in 0..7); bit (r*8+c) of mask[t] says
