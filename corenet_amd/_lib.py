@@ -58,6 +58,8 @@ _SIGS = {
                        i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "crn_bf3_operands": [vp, vp, i32, i64, vp, vp],
     "crn_conv_wgrad_1x1_bf3": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32, i32, vp],
+    "crn_conv_wgrad_2d_bf3": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32, i32, i32, i32,
+                              i32, i32, vp],
     "crn_conv2d_bf3": [C.POINTER(CrnView), C.POINTER(CrnInTransform), vp, i32, vp, i32, C.POINTER(CrnView),
                        i32, i32, i32, i32, i32, vp],
     "crn_copy_tiles_f32": [vp, vp, vp, vp, vp, i64, i32, vp],

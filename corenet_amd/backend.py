@@ -119,6 +119,10 @@ class HipBackend:
       self.lib.crn_conv_wgrad_1x1_bf3(C.byref(_cview(x)), _ctr(tr), C.byref(_cview(dy)), ptr(dw), npad, int(zero_first),
                                       _lib.stream())
       return
+    if math == "bf16x3_2d":        # ... 1x1 and 3x3 layers of the encoder
+      self.lib.crn_conv_wgrad_2d_bf3(C.byref(_cview(x)), _ctr(tr), C.byref(_cview(dy)), ptr(dw), npad, window[1],
+                                     window[2], pad_lo[1], pad_lo[2], int(zero_first), _lib.stream())
+      return
     if math == "bf16x3":
       self.lib.crn_conv_wgrad_bf3(C.byref(_cview(x)), _ctr(tr), C.byref(_cview(dy)), ptr(dw), npad,
                                   window[0], window[1], window[2], pad_lo[0], pad_lo[1], pad_lo[2],

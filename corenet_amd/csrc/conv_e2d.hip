@@ -561,6 +561,156 @@ __global__ __launch_bounds__(256, 2) void wgrad1x1_bf3_kernel(Wg1Geom g) {
   }
 }
 
+// ---- weight gradient of the 3x3 layers: the same idea -----------------------------------------------------------
+// Row m = c*9 + zh*3 + zw of dw is x shifted by (zh - 1, zw - 1).  The three zw taps of one (c, zh) read the SAME
+// 8-aligned group of positions (s .. s+7 of image row h + zh - 1; W is a multiple of 8, so a group never leaves its
+// row) shifted by -1 / 0 / +1: a lane owns one q = 3*c + zh, loads the aligned group (two 16-byte loads) plus the two
+// edge elements (two dword loads, out of range at the image border), and builds three operand vectors from the same
+// registers -- rows 3*q + 0, 1, 2, i.e. lane i16 of three M tiles.  Nothing is loaded unaligned, nothing outside
+// the sample is touched, zero padding is a load that is not issued.
+struct Wg3Geom {
+  const float* x; const float* dy; float* dw;
+  const float* scale; const float* shift;
+  int pre_relu, post_relu;
+  long long xsB, dsB;
+  int C, N, Npad, S, H, W;
+  int ksteps, ksteps_per_block;
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad3x3_bf3_kernel(Wg3Geom g) {
+  crn_kernargs_now(g.x, g.dy, g.dw, g.scale, g.shift, g.pre_relu, g.post_relu, g.xsB, g.dsB, g.C, g.N, g.Npad, g.S, g.H,
+                   g.W, g.ksteps, g.ksteps_per_block);
+  __shared__ __attribute__((aligned(16))) f32x4 red[4][12][64];         // [wave][tile][lane]: 48 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, kk = lane >> 4;
+  const int q0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int kbeg = blockIdx.z * g.ksteps_per_block, kend = min(kbeg + g.ksteps_per_block, g.ksteps);
+  const bool has_tr = g.scale != nullptr;
+  // the lane's two (c, zh) pairs and two output columns
+  unsigned arow[2], brow[2];
+  int dzh[2];
+  float sc[2], sh[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = q0 + 16 * qt + i16, c = q / 3;
+    dzh[qt] = q - 3 * c - 1;                            // zh - 1
+    arow[qt] = c < g.C ? (unsigned)c * (unsigned)g.S * 4u : kOOB;
+    sc[qt] = (has_tr && c < g.C) ? g.scale[c] : 1.f;
+    sh[qt] = (has_tr && c < g.C) ? g.shift[c] : 0.f;
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = n0 + 16 * nt + i16;
+    brow[nt] = n < g.N ? (unsigned)n * (unsigned)g.S * 4u : kOOB;
+  }
+  f32x4 acc[6][2];
+#pragma unroll
+  for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  f32x4 ra[2][2], rb[2][2];
+  float el[2], er[2];                                   // edge elements left / right of the aligned group
+  unsigned vmask = 0;                                   // bits qt: group valid, 2 + qt: left edge valid, 4 + qt: right
+  auto issue = [&](int step) {
+    const bool live = step < kend;
+    const int pos = step * 32, b = live ? pos / g.S : 0, s = pos - b * g.S + 8 * kk;
+    const int h = s / g.W, w0 = s - h * g.W;
+    const crn_rsrc xrs = make_rsrc(g.x + (long long)b * g.xsB);
+    const crn_rsrc drs = make_rsrc(g.dy + (long long)b * g.dsB);
+    vmask = 0;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int hh = h + dzh[qt];
+      const bool ok = live && arow[qt] != kOOB && hh >= 0 && hh < g.H;
+      const bool okl = ok && w0 > 0, okr = ok && w0 + 8 < g.W;
+      const unsigned off = arow[qt] + (unsigned)(s + dzh[qt] * g.W) * 4u;
+      vmask |= (ok ? 1u : 0u) << qt | (okl ? 1u : 0u) << (2 + qt) | (okr ? 1u : 0u) << (4 + qt);
+      crn_bload4(ra[qt][0], xrs, ok ? off : kOOB);
+      crn_bload4(ra[qt][1], xrs, ok ? off + 16u : kOOB);
+      crn_bload(el[qt], xrs, okl ? off - 4u : kOOB);
+      crn_bload(er[qt], xrs, okr ? off + 32u : kOOB);
+    }
+    const unsigned koff = (unsigned)s * 4u, oob = live ? 0u : kOOB;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      crn_bload4(rb[nt][0], drs, (brow[nt] + koff) | oob);
+      crn_bload4(rb[nt][1], drs, (brow[nt] + koff + 16u) | oob);
+    }
+  };
+  auto wait_all = [&]() {
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[qt][0]), "+v"(ra[qt][1]), "+v"(el[qt]), "+v"(er[qt]));
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb[nt][0]), "+v"(rb[nt][1]));
+  };
+  auto tf = [&](float a, int qt, bool valid) -> float {  // transform of a loaded element; padding stays zero
+    if (!has_tr) return a;
+    if (g.pre_relu) a = fmaxf(a, 0.f);
+    a = a * sc[qt] + sh[qt];
+    if (g.post_relu) a = fmaxf(a, 0.f);
+    return valid ? a : 0.f;
+  };
+  int step = kbeg + wave;
+  issue(step);
+  for (; step < kend; step += 4) {
+    wait_all();
+    bf16x8 ah[6], al[6], bh[2], bl[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float u[10];                                      // positions s-1 .. s+8 of the lane's row
+      u[0] = tf(el[qt], qt, (vmask >> (2 + qt)) & 1u);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) u[1 + j] = tf(ra[qt][j >> 2][j & 3], qt, (vmask >> qt) & 1u);
+      u[9] = tf(er[qt], qt, (vmask >> (4 + qt)) & 1u);
+#pragma unroll
+      for (int zw = 0; zw < 3; ++zw) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = u[j + zw];
+        split8(v, ah[qt * 3 + zw], al[qt * 3 + zw]);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = rb[nt][j >> 2][j & 3];
+      split8(v, bh[nt], bl[nt]);
+    }
+    issue(step + 4);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int mt = 0; mt < 6; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 6; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 6; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+    }
+  }
+  wait_all();
+#pragma unroll
+  for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) red[wave][mt * 2 + nt][lane] = acc[mt][nt];
+  __syncthreads();
+  // D row = 4*kk + r = lane-row index iq of the M tile (qt, zw): q = q0 + 16*qt + iq, dw row 3*q + zw
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int tile = wave * 3 + j;                      // wave w sums tiles 3w .. 3w+2
+    const f32x4 v = red[0][tile][lane] + red[1][tile][lane] + red[2][tile][lane] + red[3][tile][lane];
+    const int mt = tile >> 1, nt = tile & 1, qt = mt / 3, zw = mt - 3 * qt;
+    const int n = n0 + 16 * nt + i16;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = q0 + 16 * qt + 4 * kk + r;
+      if (q < 3 * g.C && n < g.N) atomicAdd(g.dw + (long long)(3 * q + zw) * g.Npad + n, v[r]);
+    }
+  }
+}
+
 bool dense_2d(const crnView& v) {   // unit W stride, rows back to back, 16-byte aligned channel planes
   return v.chan_off == nullptr && v.sW == 1 && v.sH == v.W && (v.D == 1 || v.sD == v.H * v.W) && (v.sC & 3) == 0 &&
          (v.sB & 3) == 0 && (((uintptr_t)v.base) & 15) == 0;
@@ -679,6 +829,11 @@ extern "C" int crn_e2d_debug_stamps(long long* out32) {
 // zero_first.  CRN_EINVAL for views that are not dense or positions per sample that are not a multiple of 32.
 extern "C" int crn_conv_wgrad_1x1_bf3(const crnView* x, const crnInTransform* tr, const crnView* dy, float* dw, int Npad,
                                       int zero_first, crnStream stream) {
+  return crn_conv_wgrad_2d_bf3(x, tr, dy, dw, Npad, 1, 1, 0, 0, zero_first, stream);
+}
+
+extern "C" int crn_conv_wgrad_2d_bf3(const crnView* x, const crnInTransform* tr, const crnView* dy, float* dw, int Npad,
+                                     int kh, int kw, int ph, int pw, int zero_first, crnStream stream) {
   if (!x || !dy || !dw || Npad <= 0 || (Npad & 15) || x->B != dy->B || dy->C > Npad) return CRN_EINVAL;
   if (!dense_2d(*x) || !dense_2d(*dy)) return CRN_EINVAL;
   if (x->D != dy->D || x->H != dy->H || x->W != dy->W) return CRN_EINVAL;
@@ -686,6 +841,26 @@ extern "C" int crn_conv_wgrad_1x1_bf3(const crnView* x, const crnInTransform* tr
   if (S % 32 || x->sC != S || dy->sC != S) return CRN_EINVAL;
   if (S * x->C * 4 >= ((int64_t)1 << 31) || S * dy->C * 4 >= ((int64_t)1 << 31)) return CRN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  if (kh == 3 && kw == 3) {
+    if (ph != 1 || pw != 1 || x->D != 1 || (x->W & 7)) return CRN_EINVAL;
+    if (zero_first) CRN_HIP(hipMemsetAsync(dw, 0, (size_t)x->C * 9 * Npad * 4, st));
+    Wg3Geom g{};
+    g.x = x->base; g.dy = dy->base; g.dw = dw;
+    g.scale = tr ? tr->scale : nullptr; g.shift = tr ? tr->shift : nullptr;
+    g.pre_relu = tr ? tr->pre_relu : 0; g.post_relu = tr ? tr->post_relu : 0;
+    g.xsB = x->sB; g.dsB = dy->sB; g.C = x->C; g.N = dy->C; g.Npad = Npad; g.S = (int)S; g.H = x->H; g.W = x->W;
+    g.ksteps = (int)((int64_t)x->B * S / 32);
+    const int tiles = crn_cdiv(3 * x->C, 32) * crn_cdiv(dy->C, 32);
+    static const int kFill3 = getenv("CRN_WG3_FILL") ? atoi(getenv("CRN_WG3_FILL")) : 512;
+    int splits = std::max(1, std::min(g.ksteps / 8, crn_cdiv(kFill3, tiles)));
+    g.ksteps_per_block = crn_cdiv(g.ksteps, splits);
+    splits = crn_cdiv(g.ksteps, g.ksteps_per_block);
+    const dim3 grid((unsigned)crn_cdiv(3 * x->C, 32), (unsigned)crn_cdiv(dy->C, 32), (unsigned)splits);
+    hipLaunchKernelGGL(wgrad3x3_bf3_kernel, grid, dim3(256), 0, st, g);
+    CRN_CHECK_LAUNCH();
+    return CRN_OK;
+  }
+  if (kh != 1 || kw != 1 || ph || pw) return CRN_EINVAL;
   if (zero_first) CRN_HIP(hipMemsetAsync(dw, 0, (size_t)x->C * Npad * 4, st));
   Wg1Geom g{};
   g.x = x->base; g.dy = dy->base; g.dw = dw;

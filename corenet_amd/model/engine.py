@@ -201,7 +201,7 @@ class Engine:
     # in bf16x3 mode the encoder's stride-1 1x1 / 3x3 convs (forward and data gradient) run on the encoder
     # engine (csrc/conv_e2d.hip: the same split-bf16 products, weights pre-arranged as MFMA operand blocks)
     self.encoder_e2d = self.decoder_math == "bf16x3" and os.environ.get("CRN_E2D", "1") != "0"
-    self.wgrad_1x1 = os.environ.get("CRN_WG1", "1") != "0"
+    self.wgrad_2d = os.environ.get("CRN_WG2D", "1") != "0"
     # fp32 is the only dtype of the HIP kernels; float64 exists so that the CPU
     # contract emulator (tests/) can check the host wiring far below fp32 noise.
     assert dtype == t.float32 or getattr(backend, "name", "") == "emu"
@@ -687,8 +687,10 @@ class Plan:
     beside the data-gradient chain; most layers below 32^3 / 64^2 cannot fill 256 CUs alone."""
     g = cv.fwd
     math = self._math(cv, "wgrad")
-    if self.eng.encoder_e2d and g.window == (1, 1, 1) and cv.name.startswith("encoder.") and self.eng.wgrad_1x1:
-      math = "bf16x3_1x1"         # both operands straight from HBM, K = positions (csrc/conv_e2d.hip)
+    if (self.eng.encoder_e2d and self.eng.wgrad_2d and g.window in ((1, 1, 1), (1, 3, 3))
+        and (cv.name.startswith("encoder.stage") and not cv.name.startswith("encoder.stage1")
+             or cv.name.startswith("decoder.rt_skip"))):
+      math = "bf16x3_2d"          # both operands straight from HBM, K = positions (csrc/conv_e2d.hip)
     if self.side is None or self.trace is not None:
       self._timed("wgrad " + cv.name, lambda: self.be.conv_wgrad(
           x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes), math=math))

@@ -141,6 +141,10 @@ int crn_conv2d_bf3(const crnView* x, const crnInTransform* tr, const void* wop, 
  * extent, positions per sample a multiple of 32; CRN_EINVAL otherwise.                                          */
 int crn_conv_wgrad_1x1_bf3(const crnView* x, const crnInTransform* tr, const crnView* dy, float* dw, int Npad,
                            int zero_first, crnStream stream);
+/* ... and of a 1x1 (pads 0) or 3x3 (pads 1, W a multiple of 8, 2-D images) layer: for 3x3 the three zw taps of an
+ * input row come from one aligned 8-position load plus its two edge elements (dw row = c*9 + zh*3 + zw).        */
+int crn_conv_wgrad_2d_bf3(const crnView* x, const crnInTransform* tr, const crnView* dy, float* dw, int Npad,
+                          int kh, int kw, int ph, int pw, int zero_first, crnStream stream);
 
 /* dst[i] = idx[i] >= 0 ? src[idx[i]] : 0        (weight packing)            */
 /* Tiled index copy between a reference-layout buffer and a packed buffer (weight pack / gradient un-pack).

@@ -195,10 +195,10 @@ def test_conv2d_bf3_encoder_engine(be, name, wshape, hw, B):
   assert e <= 2e-5, (name, "dgrad", e)
 
 
-@pytest.mark.parametrize("name,wshape,hw,B", [c for c in E2D_CASES if c[1][2] == 1], ids=[c[0] for c in E2D_CASES if c[1][2] == 1])
-def test_conv_wgrad_1x1_bf3(be, name, wshape, hw, B):
-  """crn_conv_wgrad_1x1_bf3 (operands straight from HBM, K = positions) on the encoder's 1x1 shapes, with the fused
-  input transform, accumulating into a non-zero dw: against the contract emulator, 2e-5 of the gradient's range."""
+@pytest.mark.parametrize("name,wshape,hw,B", E2D_CASES, ids=[c[0] for c in E2D_CASES])
+def test_conv_wgrad_2d_bf3(be, name, wshape, hw, B):
+  """crn_conv_wgrad_2d_bf3 (operands straight from HBM, K = positions) on the encoder's 1x1 and 3x3 shapes, with the
+  fused input transform, accumulating into a non-zero dw: against the contract emulator, 2e-5 of the gradient's range."""
   if _SELF:
     return
   from corenet_amd import views as V
@@ -206,22 +206,22 @@ def test_conv_wgrad_1x1_bf3(be, name, wshape, hw, B):
   from corenet_amd.model import conv_geometry as G
   g = t.Generator().manual_seed(len(name) + 7)
   cout, cin = wshape[0], wshape[1]
-  fwd = G.conv_fwd(wshape, 0)
+  fwd = G.conv_fwd(wshape, wshape[2] // 2)
   H, W = hw
   x = t.randn((B, cin, H, W), generator=g); dy = t.randn((B, cout, H, W), generator=g)
   scale = t.rand(cin, generator=g) + 0.5; shift = t.randn(cin, generator=g) * 0.3
   trc = Transform(scale, shift, post_relu=True); trg = Transform(scale.to(DEV), shift.to(DEV), post_relu=True)
-  dw0 = t.randn(cin * fwd.npad, generator=g)
+  dw0 = t.randn(cin * fwd.taps * fwd.npad, generator=g)
   dw = dw0.clone(); dwg = dw0.to(DEV)
   EMU.conv_wgrad(V.view_of(x), trc, V.view_of(dy), dw, fwd.npad, fwd.window, fwd.pad_lo, False)
   be.conv_wgrad(V.view_of(x.to(DEV)), trg, V.view_of(dy.to(DEV)), dwg, fwd.npad, fwd.window, fwd.pad_lo, False,
-                math="bf16x3_1x1")
+                math="bf16x3_2d")
   e = float((dwg.cpu() - dw).abs().max() / (dw - dw0).abs().max())
-  print(f"wgrad 1x1 {name}: max-abs-err/max = {e:.2e}")
+  print(f"wgrad 2d {name}: max-abs-err/max = {e:.2e}")
   assert e <= 2e-5, (name, e)
   dwz = t.full_like(dwg, 7.0)
   be.conv_wgrad(V.view_of(x.to(DEV)), None, V.view_of(dy.to(DEV)), dwz, fwd.npad, fwd.window, fwd.pad_lo, True,
-                math="bf16x3_1x1")
+                math="bf16x3_2d")
   dwr = t.zeros_like(dw)
   EMU.conv_wgrad(V.view_of(x), None, V.view_of(dy), dwr, fwd.npad, fwd.window, fwd.pad_lo, True)
   assert float((dwz.cpu() - dwr).abs().max() / dwr.abs().max()) <= 2e-5
