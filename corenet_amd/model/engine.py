@@ -392,10 +392,11 @@ class Engine:
       if not self.encoder_e2d or not name.startswith("encoder.") or name.startswith("encoder.stage1"):
         continue
       self.convs[name].wop_kind = "e2d"
+      only_dgrad = kinds == "3x3+dgrad1x1" and fwd.window != (1, 3, 3)      # tuning aid
       if kinds == "3x3" and fwd.window != (1, 3, 3):
         continue
       fwd_stages = os.environ.get("CRN_E2D_FWD_STAGES", "45")
-      if G.operand_eligible(fwd) and name[len("encoder.stage")] in fwd_stages:
+      if G.operand_eligible(fwd) and name[len("encoder.stage")] in fwd_stages and not only_dgrad:
         groups["enc_early" if name.startswith("encoder.stage2") else "enc_late"].append((src_f, eo, fwd))
         slices.append((name, "wop_f", eo, G.operand_entries(fwd))); eo += G.operand_entries(fwd)
       if dgrad is not None and G.operand_eligible(dgrad):
