@@ -101,6 +101,10 @@ class HipBackend:
                           pad_lo[0], pad_lo[1], pad_lo[2], splits, int(accumulate), _ctapboxes(boxes),
                           _lib.stream())
 
+  def splitk_defer(self, on: bool = True):
+    """The next conv call may leave its split-K sum to the BatchRenorm launch that follows (crn_splitk_defer)."""
+    self.lib.crn_splitk_defer(int(on))
+
   def bf3_operands(self, packed: t.Tensor, table, out: t.Tensor):
     """table = (desc int64 [n, 6] on the device, total workgroups): conv_geometry.operand_table."""
     desc, blocks = table

@@ -190,14 +190,17 @@ __global__ __launch_bounds__(kThreads) void bn_owner_stats_kernel(
 // Register-resident owner kernels: when all of (B, S) of a channel fits in NV float4 per thread (B*S <= 1024*NV), every
 // thread issues its NV loads at once (the loops above walk them one latency after the other: these launches are
 // latency bound) and the backward kernel makes its second pass over registers instead of re-reading x and dy.
+// part != nullptr: x is the output of a split-K convolution whose `splits` partial sums are still in the scratch
+// ([split][b][c][pos], dense): they are added up here (split 0 first, the order of the reduction kernel) and the
+// sum is stored to x on the way -- one launch instead of reduction + statistics (crn_splitk_defer).
 template <int NV>
 __global__ __launch_bounds__(kThreads) void bn_owner_stats_reg_kernel(
-    const float* x, int B, int C, int S4, int64_t sB, int pre_relu, const float* gamma, const float* beta,
+    float* x, int B, int C, int S4, int64_t sB, int pre_relu, const float* gamma, const float* beta,
     float* running_mean, float* running_var, const int64_t* nbt, float eps, float momentum, float* scale,
-    float* shift, float* saved) {
+    float* shift, float* saved, const float* part, int splits) {
   __shared__ double red[2 * (kThreads / 64)];
   crn_kernargs_now(x, B, C, S4, sB, pre_relu, gamma, beta, running_mean, running_var, nbt, eps, momentum, scale, shift,
-                   saved);
+                   saved, part, splits);
   const int c = blockIdx.x, total4 = B * S4;
   const BnChannelIn cin = bn_channel_in(c, gamma, beta, running_mean, running_var, nbt);
   f32x4 v[NV];
@@ -205,8 +208,19 @@ __global__ __launch_bounds__(kThreads) void bn_owner_stats_reg_kernel(
   for (int k = 0; k < NV; ++k) {
     const int e = threadIdx.x + k * kThreads;
     const int b = e / S4, s4 = e - b * S4;
-    v[k] = e < total4 ? *reinterpret_cast<const f32x4*>(x + (int64_t)b * sB + ((int64_t)c * S4 + s4) * 4)
-                      : (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4* xp = reinterpret_cast<f32x4*>(x + (int64_t)b * sB + ((int64_t)c * S4 + s4) * 4);
+    if (part == nullptr) {
+      v[k] = e < total4 ? *xp : (f32x4){0.f, 0.f, 0.f, 0.f};
+    } else {
+      f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (e < total4) {
+        const f32x4* pp = reinterpret_cast<const f32x4*>(part) + ((int64_t)b * C + c) * S4 + s4;
+        const int64_t slab4 = (int64_t)B * C * S4;
+        for (int sp = 0; sp < splits; ++sp) sum += pp[sp * slab4];
+        *xp = sum;
+      }
+      v[k] = sum;
+    }
   }
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -225,16 +239,18 @@ __global__ __launch_bounds__(kThreads) void bn_owner_stats_reg_kernel(
                            scale, shift, saved);
 }
 
+// part != nullptr: dy is the output of a split-K convolution (a data gradient) still in `splits` partial sums in the
+// scratch: added up while they are loaded; dy itself is NOT written (its only reader is this kernel).
 template <int NV>
 __global__ __launch_bounds__(kThreads) void bn_owner_bwd_reg_kernel(
     const float* x, int64_t sBx, const float* dy, int64_t sBdy, int B, int S4, int C, int pre_relu,
     int post_relu, const float* gamma, const float* scale, const float* shift, const float* saved, float* dx,
-    int64_t sBdx, float* dgamma, float* dbeta, int accumulate, float* dsum, int ndsum) {
+    int64_t sBdx, float* dgamma, float* dbeta, int accumulate, float* dsum, int ndsum, const float* part, int splits) {
   __shared__ double red[2 * (kThreads / 64)];
   __shared__ float sm[2];
   __shared__ float redf[kThreads / 64];
   crn_kernargs_now(x, sBx, dy, sBdy, B, S4, C, pre_relu, post_relu, gamma, scale, shift, saved, dx, sBdx, dgamma, dbeta,
-                   accumulate, dsum, ndsum);
+                   accumulate, dsum, ndsum, part, splits);
   const int c = blockIdx.x, total4 = B * S4;
   // every per-channel scalar of the kernel is loaded here, next to x and dy: one round trip to memory, not three
   const float sc = scale[c], sh = shift[c], mu = saved[c], rstd = saved[C + c];
@@ -249,7 +265,17 @@ __global__ __launch_bounds__(kThreads) void bn_owner_bwd_reg_kernel(
     const int64_t o = ((int64_t)c * S4 + s4) * 4;
     const bool ok = e < total4;
     xv[k] = ok ? *reinterpret_cast<const f32x4*>(x + (int64_t)b * sBx + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    gv[k] = ok ? *reinterpret_cast<const f32x4*>(dy + (int64_t)b * sBdy + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (part == nullptr) {
+      gv[k] = ok ? *reinterpret_cast<const f32x4*>(dy + (int64_t)b * sBdy + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    } else {
+      f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        const f32x4* pp = reinterpret_cast<const f32x4*>(part) + ((int64_t)b * C + c) * S4 + s4;
+        const int64_t slab4 = (int64_t)B * C * S4;
+        for (int sp = 0; sp < splits; ++sp) sum += pp[sp * slab4];
+      }
+      gv[k] = sum;
+    }
   }
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
@@ -600,11 +626,27 @@ extern "C" int crn_batch_renorm_stats(const float* x, int B, int C, int64_t S, i
   hipStream_t st = (hipStream_t)stream;
   if (B < 1 || C < 1 || S < 1 || B > 64) return CRN_EINVAL;
   int nparts = 1;
-  if (training && owner_form(S, C, B) && vec_ok(S, {sB}, {x}) && (int64_t)B * S <= 16384) {
+  const bool reg_form = training && owner_form(S, C, B) && vec_ok(S, {sB}, {x}) && (int64_t)B * S <= 16384;
+  // a split-K convolution left the partial sums of x pending (crn_splitk_defer): the register kernel adds them up
+  const float* part = nullptr;
+  int psplits = 0;
+  {
+    CrnSplitPending& pend = crn_splitk_pending();
+    if (pend.active) {
+      const crnView& py = pend.y;
+      if (reg_form && py.base == x && py.B == B && py.C == C && (int64_t)py.D * py.H * py.W == S && sB == (int64_t)C * S) {
+        part = pend.scratch; psplits = pend.splits; pend.active = false;
+      } else {
+        const int rcf = crn_splitk_flush(st);
+        if (rcf != CRN_OK) return rcf;
+      }
+    }
+  }
+  if (reg_form) {
     const int per = (int)crn_cdiv((int64_t)B * S / 4, kThreads);       // float4 per thread
 #define CRN_BN_STATS_REG(NV)                                                                                      \
-  hipLaunchKernelGGL(bn_owner_stats_reg_kernel<NV>, dim3(C), dim3(kThreads), 0, st, x, B, C, (int)(S / 4), sB, pre_relu, \
-                     gamma, beta, running_mean, running_var, nbt, eps, momentum, scale, shift, saved)
+  hipLaunchKernelGGL(bn_owner_stats_reg_kernel<NV>, dim3(C), dim3(kThreads), 0, st, const_cast<float*>(x), B, C, (int)(S / 4), sB, pre_relu, \
+                     gamma, beta, running_mean, running_var, nbt, eps, momentum, scale, shift, saved, part, psplits)
     if (per <= 1) CRN_BN_STATS_REG(1); else if (per <= 2) CRN_BN_STATS_REG(2); else if (per <= 4) CRN_BN_STATS_REG(4);
     else if (per <= 8) CRN_BN_STATS_REG(8); else CRN_BN_STATS_REG(16);
 #undef CRN_BN_STATS_REG
@@ -658,11 +700,27 @@ extern "C" int crn_batch_renorm_bwd(const float* x, int64_t sB_x, const float* d
   hipStream_t st = (hipStream_t)stream;
   if (B < 1 || C < 1 || S < 1 || B > 64) return CRN_EINVAL;
   const bool v = vec_ok(S, {sB_x, sB_dy, sB_dx}, {x, dy, dx});
-  if (owner_form(S, C, B) && v && (int64_t)B * S <= 16384) {
+  const bool reg_form = owner_form(S, C, B) && v && (int64_t)B * S <= 16384;
+  const float* part = nullptr;
+  int psplits = 0;
+  {
+    CrnSplitPending& pend = crn_splitk_pending();
+    if (pend.active) {
+      const crnView& py = pend.y;
+      if (reg_form && py.base == dy && py.B == B && py.C == C && (int64_t)py.D * py.H * py.W == S && sB_dy == (int64_t)C * S) {
+        part = pend.scratch; psplits = pend.splits; pend.active = false;
+      } else {
+        const int rcf = crn_splitk_flush(st);
+        if (rcf != CRN_OK) return rcf;
+      }
+    }
+  }
+  if (reg_form) {
     const int per = (int)crn_cdiv((int64_t)B * S / 4, kThreads);       // float4 per thread (of x and of dy)
 #define CRN_BN_BWD_REG(NV)                                                                                          \
   hipLaunchKernelGGL(bn_owner_bwd_reg_kernel<NV>, dim3(C), dim3(kThreads), 0, st, x, sB_x, dy, sB_dy, B, (int)(S / 4), C, \
-                     pre_relu, post_relu, gamma, scale, shift, saved, dx, sB_dx, dgamma, dbeta, accumulate, dsum, ndsum)
+                     pre_relu, post_relu, gamma, scale, shift, saved, dx, sB_dx, dgamma, dbeta, accumulate, dsum, ndsum, \
+                     part, psplits)
     if (per <= 1) CRN_BN_BWD_REG(1); else if (per <= 2) CRN_BN_BWD_REG(2); else if (per <= 4) CRN_BN_BWD_REG(4);
     else if (per <= 8) CRN_BN_BWD_REG(8); else CRN_BN_BWD_REG(16);
 #undef CRN_BN_BWD_REG

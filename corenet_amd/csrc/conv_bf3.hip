@@ -800,6 +800,8 @@ int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w
   if (!x || !y || (!w && !wslab) || Npad <= 0 || (Npad & 15) || x->B != y->B || kd < 1 || kh < 1 || kw < 1) return CRN_EINVAL;
   if (y->C > Npad || x->C > kTabC) return CRN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  (void)crn_splitk_take_armed();
+  { const int rcf = crn_splitk_flush(st); if (rcf != CRN_OK) return rcf; }
   const int xmode = even_view(*x) ? 1 : ((x->sW == 2 && x->chan_off != nullptr && (x->W & 1) == 0) ? 2 : 0);
   if (!xmode) return CRN_EINVAL;
   Bf3Geom g{};

@@ -756,6 +756,8 @@ extern "C" int crn_conv2d_bf3(const crnView* x, const crnInTransform* tr, const 
   const int64_t S = (int64_t)x->D * x->H * x->W;
   if (S * x->C * 4 >= ((int64_t)1 << 31)) return CRN_EINVAL;           // one sample inside the 2 GiB buffer range
   hipStream_t st = (hipStream_t)stream;
+  const bool armed = crn_splitk_take_armed();
+  { const int rcf = crn_splitk_flush(st); if (rcf != CRN_OK) return rcf; }
   E2dGeom g{};
   g.x = *x; g.y = *y;
   if (tr) g.tr = *tr; else g.tr = crnInTransform{nullptr, nullptr, 0, 0};
@@ -812,7 +814,14 @@ extern "C" int crn_conv2d_bf3(const crnView* x, const crnInTransform* tr, const 
   if (k1) rc = launch_e2d<1, 4, 16>(g, grid, lds, st);
   else if (TW == 16) rc = launch_e2d<9, 1, 16>(g, grid, lds, st);
   else rc = launch_e2d<9, 1, 8>(g, grid, lds, st);
-  if (rc == CRN_OK && splits > 1) rc = crn_splitk_reduce(yreal, scratch, splits, accumulate, st);
+  if (rc == CRN_OK && splits > 1) {
+    if (armed && !accumulate && yreal.sB == (int64_t)yreal.C * S) {      // the next BatchRenorm launch adds them up
+      CrnSplitPending& pend = crn_splitk_pending();
+      pend.active = true; pend.y = yreal; pend.scratch = scratch; pend.splits = splits;
+      return rc;
+    }
+    rc = crn_splitk_reduce(yreal, scratch, splits, accumulate, st);
+  }
   return rc;
 }
 

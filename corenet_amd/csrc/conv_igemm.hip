@@ -469,6 +469,29 @@ bool fwd_cfg(int MSUB, int NSUB, int B, int Cin, int Npad, int D, int H, int W, 
 
 }  // namespace
 
+CrnSplitPending& crn_splitk_pending() {
+  static thread_local CrnSplitPending p;
+  return p;
+}
+bool crn_splitk_take_armed() {
+  CrnSplitPending& p = crn_splitk_pending();
+  const bool a = p.armed;
+  p.armed = false;
+  return a;
+}
+int crn_splitk_reduce_view(const crnView& y, const float* scratch, int splits, int accumulate, hipStream_t st) {
+  return crn_splitk_reduce(y, scratch, splits, accumulate, st);
+}
+int crn_splitk_flush(hipStream_t st) {
+  CrnSplitPending& p = crn_splitk_pending();
+  if (!p.active) return CRN_OK;
+  p.active = false;
+  return crn_splitk_reduce(p.y, p.scratch, p.splits, 0, st);
+}
+extern "C" int crn_splitk_defer(int on) {
+  crn_splitk_pending().armed = on != 0;
+  return CRN_OK;
+}
 float* crn_splitk_scratch(size_t floats) { return splitk_scratch(floats); }
 int* crn_splitk_counters(size_t n) { return splitk_counters(n); }
 int crn_splitk_reduce(const crnView& y, const float* scratch, int splits, int accumulate, hipStream_t st) {
@@ -496,6 +519,8 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
     return CRN_EINVAL;
   if (y->C > Npad) return CRN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  const bool armed = crn_splitk_take_armed();
+  { const int rcf = crn_splitk_flush(st); if (rcf != CRN_OK) return rcf; }
   const int64_t Sx = (int64_t)x->D * x->H * x->W;
   if (kd * kh * kw == 1 && pd == 0 && ph == 0 && pw == 0 && splits <= 1 && one_position(*x) && one_position(*y) &&
       x->B <= kDenseB) {
@@ -557,7 +582,14 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
     if (wide) hipLaunchKernelGGL(pointwise_fwd_kernel<4>, grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL(pointwise_fwd_kernel<2>, grid, dim3(256), 0, st, p);
     CRN_CHECK_LAUNCH();
-    if (p.splits > 1 && !p.counters) return crn_splitk_reduce(*y, scratch, p.splits, accumulate, st);
+    if (p.splits > 1 && !p.counters) {
+      if (armed && !accumulate && plain_view(*y) && y->sB == (int64_t)y->C * Sx) {
+        CrnSplitPending& pend = crn_splitk_pending();
+        pend.active = true; pend.y = *y; pend.scratch = scratch; pend.splits = p.splits;
+        return CRN_OK;
+      }
+      return crn_splitk_reduce(*y, scratch, p.splits, accumulate, st);
+    }
     return CRN_OK;
   }
   // Score every (MSUB, NSUB) tile: useful MFMA rows x operand reuse of the tile x how well

@@ -81,3 +81,15 @@ __device__ __forceinline__ void crn_kernarg_touch(const T& g) {
   asm volatile("" ::"s"(p[sizeof(T) / 4 - 1]));
 }
 
+// A split-K convolution whose partial sums are still in the scratch: the next BatchRenorm launch over `y` adds them up
+// itself (crn_splitk_defer); anything else that needs the scratch or y first calls crn_splitk_flush.
+struct CrnSplitPending {
+  bool armed = false, active = false;
+  crnView y{};                 // the conv's real output (dense [B][C][S])
+  const float* scratch = nullptr;
+  int splits = 0;
+};
+CrnSplitPending& crn_splitk_pending();                 // per host thread
+int crn_splitk_flush(hipStream_t st);                  // run the pending reduction now (no-op if none)
+bool crn_splitk_take_armed();                          // consumes the arming of crn_splitk_defer
+int crn_splitk_reduce_view(const crnView& y, const float* scratch, int splits, int accumulate, hipStream_t st);

@@ -202,6 +202,7 @@ class Engine:
     # engine (csrc/conv_e2d.hip: the same split-bf16 products, weights pre-arranged as MFMA operand blocks)
     self.encoder_e2d = self.decoder_math == "bf16x3" and os.environ.get("CRN_E2D", "1") != "0"
     self.wgrad_2d = os.environ.get("CRN_WG2D", "1") != "0"
+    self.defer_reduce = os.environ.get("CRN_DEFER_REDUCE", "1") != "0"
     # fp32 is the only dtype of the HIP kernels; float64 exists so that the CPU
     # contract emulator (tests/) can check the host wiring far below fp32 noise.
     assert dtype == t.float32 or getattr(backend, "name", "") == "emu"
@@ -835,11 +836,17 @@ class Plan:
     else:
       xin = self.vw(cur)
     ba, bb, bc = bn[p + "op_a.bn."], bn[p + "op_b.bn."], bn[p + "op_c.bn."]
+    # (training: every conv is followed directly by the statistics of its norm, which can add up the partial sums of
+    # a split-K conv itself: crn_splitk_defer)
+    defer = be.splitk_defer if training and self.eng.defer_reduce else (lambda: None)
+    defer()
     self._conv(cv[p + "op_a.conv."], xin, None, self.vw(blk["ya"]))
     self._stats(ba, blk["ya"], S, f1 * S, False, training)
+    defer()
     self._conv(cv[p + "op_b.conv."], self.vw(blk["ya"]), Transform(ba.scale, ba.shift, post_relu=True),
                self.vw(blk["yb"]))
     self._stats(bb, blk["yb"], S, f2 * S, False, training)
+    defer()
     self._conv(cv[p + "op_c.conv."], self.vw(blk["yb"]), Transform(bb.scale, bb.shift, post_relu=True),
                self.vw(blk["yc"]))
     self._stats(bc, blk["yc"], S, f3 * S, False, training)
@@ -849,6 +856,7 @@ class Plan:
       pre, sB_pre = None, 0
     if blk["down"]:
       bs = bn[p + "shortcut.bn."]
+      defer()
       self._conv(cv[p + "shortcut.conv."], xin, None, self.vw(blk["ys"]))
       self._stats(bs, blk["ys"], S, f3 * S, False, training)
       be.affine_add_relu(blk["yc"], bc.scale, bc.shift, blk["ys"], bs.scale, bs.shift, B, f3, S,
@@ -1003,10 +1011,14 @@ class Plan:
     trb = Transform(bb.scale, bb.shift, post_relu=True)
     tra = Transform(ba.scale, ba.shift, post_relu=True)
     self._wgrad(cc, self.vw(blk["yb"]), trb, self.vw(blk["gyc"]))
+    if self.eng.defer_reduce:
+      be.splitk_defer()                       # the norm's backward below is the only reader of gab: it adds up the splits
     self._dgrad(cc, self.vw(blk["gyc"]), self.vw(blk["gab"]))
     be.bn_bwd(blk["yb"], f2 * S, blk["gab"], f2 * S, B, f2, S, False, True, bb.gamma, bb.scale, bb.shift,
               bb.saved, blk["gyb"], f2 * S, bb.dgamma, bb.dbeta, dsum=cb.dbias, ndsum=cb.n_ref)
     self._wgrad(cb, self.vw(blk["ya"]), tra, self.vw(blk["gyb"]))
+    if self.eng.defer_reduce:
+      be.splitk_defer()
     self._dgrad(cb, self.vw(blk["gyb"]), self.vw(blk["gaa"]))
     be.bn_bwd(blk["ya"], f1 * S, blk["gaa"], f1 * S, B, f1, S, False, True, ba.gamma, ba.scale, ba.shift,
               ba.saved, blk["gya"], f1 * S, ba.dgamma, ba.dbeta, dsum=ca.dbias, ndsum=ca.n_ref)

@@ -94,6 +94,16 @@ int crn_conv_fwd_bf3_slabs(const crnView* x, const crnInTransform* tr, const voi
                            int kd, int kh, int kw, int pd, int ph, int pw,
                            int accumulate, const crnTapBoxes* boxes /* may be NULL */, crnStream stream);
 
+/* A convolution that splits its reduction writes partial sums to the library's scratch and adds them up in a
+ * second launch.  crn_splitk_defer(1) arms, for the NEXT convolution call of this host thread (crn_conv2d_bf3, or
+ * the 1x1 path of crn_conv_fwd), the following shortcut: if that call splits and does not accumulate, the sum is
+ * left pending and the next crn_batch_renorm_stats (x = the conv's output) or crn_batch_renorm_bwd (dy = the conv's
+ * output) on the same stream adds the partial sums up while it loads them (stats also stores the sum to x; bwd does
+ * not write dy: it is its only reader).  Any other use of the library in between completes the pending sum first, so
+ * arming is always safe; it only pays when the BatchRenorm call follows directly (resnet50.py:62-69: every conv of
+ * the encoder is followed by its norm; in backward every data gradient feeds the norm's backward).              */
+int crn_splitk_defer(int on);
+
 /* Weight gradient in the same packed layout:
  *   dw[(c*T+t)*Npad+n] = sum_{b,o} T(x)[b,c,o-pad_lo+t] * dy[b,n,o]
  * dw must be zeroed by the caller or zero_first!=0.  Replaces autograd of the

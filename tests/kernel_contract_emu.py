@@ -92,6 +92,9 @@ class EmuBackend:
         out = out + bias[:y.C].view(1, -1, 1, 1, 1)
     write_logical(y, out, accumulate)
 
+  def splitk_defer(self, on=True):
+    pass                                       # a scheduling hint: no effect on results
+
   # encoder engine (csrc/conv_e2d.hip): operand blocks [(cb*T + t)][ntile][kk*16 + i][hi 8 | lo 8] bf16
   def bf3_operands(self, packed, table, out):
     desc, _blocks = table
