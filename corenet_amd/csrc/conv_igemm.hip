@@ -49,10 +49,12 @@ struct PwGeom {
                                    // of 32); partial sums go to the dense scratch y (mode 0), split*B + b as batch
   // fused reduction (counters != nullptr): the last workgroup of a tile adds the splits up and writes yr
   float* yr; int64_t yr_sB, yr_sC, yr_sP; int yr_accumulate; int* counters;
+  long long* stamps;               // tuning aid (CRN_PW_STAMPS=1): shader-clock stamps of workgroup 0
 };
 
 // NS = 16-column blocks per workgroup (2: 64 x 32 tiles; 4: 64 x 64 tiles -- half the workgroups and half the
 // re-reads of x for the wide layers)
+constexpr int kPwTab = 2048;        // channels of one workgroup (its split's range) whose scale / shift are staged in LDS
 template <int NS>
 __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
   constexpr int BM = 64, BN = NS * 16, KC = 64, SA = BM + 16, SB = BN + 16;   // KC 64: half the barriers of KC 32
@@ -61,9 +63,14 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
   __shared__ __attribute__((aligned(16))) float ldsB[KC * SB];
   crn_kernargs_now(g.x, g.y, g.w, g.bias, g.tr.scale, g.tr.shift, g.tr.pre_relu, g.tr.post_relu, g.B, g.C, g.N, g.Npad,
                    g.S, g.xsB, g.ysB, g.ysC, g.ysP, g.bias_sB, g.mode, g.splits, g.cps, g.counters);
+  const long long t_entry = (long long)__builtin_amdgcn_s_memtime();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kk = lane >> 4;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const bool stamp = g.stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+  int nmark = 0;
+  auto mark = [&]() { if (stamp && nmark < 31) g.stamps[nmark] = (long long)__builtin_amdgcn_s_memtime() - t_entry; ++nmark; };
+  mark();
   const int split = blockIdx.z / g.B, b = blockIdx.z - split * g.B;
   const int cbeg = split * g.cps, cend = min(g.C, cbeg + g.cps);
   const float* xb = g.x + (int64_t)b * g.xsB;
@@ -73,23 +80,41 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
   const int kb = tid / BQ, cb = (tid % BQ) * 4;       // B row / column
   const bool a_ok = (m0 + ca) < g.S;                  // S % 4 == 0 (checked on the host)
   const bool b_ok = (n0 + cb) < g.Npad;
-  f32x4 ra[NRA], rb[NRB];
-  auto issue = [&](int c0) {
-    const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // Two chunks of loads are in flight (a chunk's MFMAs take 0.45 us, a load 1-2 us: with one chunk in flight every
+  // iteration waited out most of a memory latency), hand-tracked like in conv_e2d.hip: asm buffer loads, s_waitcnt
+  // vmcnt(N) with the N the issue order implies, out-of-range offsets (zeros, no traffic) past the end.  The
+  // BatchRenorm scale / shift of the workgroup's channels are staged into LDS once, next to the first loads (read from
+  // global inside the loop they cost another exposed latency per chunk).
+  __shared__ float tsc[kPwTab], tsh[kPwTab];
+  const bool has_tr = g.tr.scale != nullptr;
+  constexpr unsigned kOOBo = 0x80000000u;
+  constexpr int NL = NRA + NRB;                      // loads per thread and chunk
+  const crn_rsrc xrs = crnk::make_rsrc(xb);
+  const crn_rsrc wrs = crnk::make_rsrc(g.w);
+  f32x4 ra[2][NRA], rb[2][NRB];
+  auto issue = [&](int c0, f32x4 (&pa_)[NRA], f32x4 (&pb_)[NRB]) {
 #pragma unroll
     for (int q = 0; q < NRA; ++q) {
       const int c_a = c0 + ka + q * 16;
-      ra[q] = (a_ok && c_a < cend) ? *reinterpret_cast<const f32x4*>(xb + (int64_t)c_a * g.S + m0 + ca) : z;
+      const unsigned off = (a_ok && c_a < cend) ? (unsigned)(c_a * g.S + m0 + ca) * 4u : kOOBo;
+      crnk::crn_bload4(pa_[q], xrs, off);
     }
 #pragma unroll
     for (int q = 0; q < NRB; ++q) {
       const int c_b = c0 + kb + q * BROWS;
-      rb[q] = (b_ok && c_b < cend) ? *reinterpret_cast<const f32x4*>(g.w + (int64_t)c_b * g.Npad + n0 + cb) : z;
+      const unsigned off = (b_ok && c_b < cend) ? (unsigned)(c_b * g.Npad + n0 + cb) * 4u : kOOBo;
+      crnk::crn_bload4(pb_[q], wrs, off);
     }
   };
+  auto wait_slot = [&](f32x4 (&pa_)[NRA], f32x4 (&pb_)[NRB]) {   // the other slot's NL loads were issued later
+#pragma unroll
+    for (int q = 0; q < NRA; ++q) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pa_[q]) : "n"(NL));
+#pragma unroll
+    for (int q = 0; q < NRB; ++q) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pb_[q]) : "n"(NL));
+  };
   auto xform = [&](f32x4 v, int c) -> f32x4 {
-    if (g.tr.scale && a_ok && c < cend) {
-      const float sc = g.tr.scale[c], sh = g.tr.shift[c];
+    if (has_tr && a_ok && c < cend) {
+      const float sc = tsc[c - cbeg], sh = tsh[c - cbeg];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float t = v[i];
@@ -104,15 +129,22 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
   f32x4 acc[NS];
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) acc[ns] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  issue(cbeg);
-  for (int c0 = cbeg; c0 < cend; c0 += KC) {
-    __syncthreads();
+  issue(cbeg, ra[0], rb[0]);
+  issue(cbeg + KC, ra[1], rb[1]);
+  mark();
+  if (has_tr)
+    for (int c = tid; c < cend - cbeg; c += 256) { tsc[c] = g.tr.scale[cbeg + c]; tsh[c] = g.tr.shift[cbeg + c]; }
+  auto step = [&](int c0, f32x4 (&pa_)[NRA], f32x4 (&pb_)[NRB]) {
+    wait_slot(pa_, pb_);
+    mark();
+    __syncthreads();                                   // (first step: the tables; later: the previous chunk's MFMA reads)
 #pragma unroll
-    for (int q = 0; q < NRA; ++q) *reinterpret_cast<f32x4*>(ldsA + (ka + q * 16) * SA + ca) = xform(ra[q], c0 + ka + q * 16);
+    for (int q = 0; q < NRA; ++q) *reinterpret_cast<f32x4*>(ldsA + (ka + q * 16) * SA + ca) = xform(pa_[q], c0 + ka + q * 16);
 #pragma unroll
-    for (int q = 0; q < NRB; ++q) *reinterpret_cast<f32x4*>(ldsB + (kb + q * BROWS) * SB + cb) = rb[q];
+    for (int q = 0; q < NRB; ++q) *reinterpret_cast<f32x4*>(ldsB + (kb + q * BROWS) * SB + cb) = pb_[q];
     __syncthreads();
-    if (c0 + KC < cend) issue(c0 + KC);
+    mark();
+    issue(c0 + 2 * KC, pa_, pb_);                      // this slot's registers are free: the chunk after the next
     const float* pa = ldsA + kk * SA + wave * 16 + i16;
     const float* pb = ldsB + kk * SB + i16;
 #pragma unroll
@@ -124,6 +156,19 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
 #pragma unroll
       for (int ns = 0; ns < NS; ++ns) acc[ns] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[ns], acc[ns], 0, 0, 0);
     }
+    mark();
+  };
+  for (int c0 = cbeg; c0 < cend; c0 += 2 * KC) {
+    step(c0, ra[0], rb[0]);
+    if (c0 + KC < cend) step(c0 + KC, ra[1], rb[1]);
+  }
+  // the loads issued past the end (zeros) still target the staging registers: keep them allocated until they landed
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+#pragma unroll
+    for (int q = 0; q < NRA; ++q) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[sl][q]));
+#pragma unroll
+    for (int q = 0; q < NRB; ++q) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rb[sl][q]));
   }
   // D: rows kk*4..kk*4+3 = 4 consecutive positions, col i16 = channel -> one float4 per lane
   const int m = m0 + wave * 16 + kk * 4;
@@ -145,6 +190,7 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
       }
     }
   }
+  if (stamp) g.stamps[31] = (long long)__builtin_amdgcn_s_memtime() - t_entry;
   if (g.counters) {       // fused split-K reduction: see conv_fwd_kernel (mode 4)
     __threadfence();
     __shared__ int s_last;
@@ -510,6 +556,13 @@ int crn_splitk_reduce(const crnView& y, const float* scratch, int splits, int ac
   return CRN_OK;
 }
 
+static long long* g_pw_stamps = nullptr;
+extern "C" int crn_pw_debug_stamps(long long* out32) {       // tuning aid (CRN_PW_STAMPS=1)
+  if (!g_pw_stamps) return CRN_EINVAL;
+  CRN_HIP(hipDeviceSynchronize());
+  CRN_HIP(hipMemcpy(out32, g_pw_stamps, 32 * sizeof(long long), hipMemcpyDeviceToHost));
+  return CRN_OK;
+}
 extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const float* w, int Npad,
                             const float* bias, int bias_sB, const crnView* y,
                             int kd, int kh, int kw, int pd, int ph, int pw,
@@ -544,7 +597,9 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
     }
   }
   if (kd * kh * kw == 1 && pd == 0 && ph == 0 && pw == 0 && splits <= 1 && plain_view(*x) && flat_out_view(*y) &&
-      Sx == (int64_t)y->D * y->H * y->W && (Sx & 3) == 0 && (((uintptr_t)w) & 15) == 0) {
+      Sx == (int64_t)y->D * y->H * y->W && (Sx & 3) == 0 && (((uintptr_t)w) & 15) == 0 &&
+      (int64_t)x->C * Sx * 4 < ((int64_t)1 << 31) && (int64_t)x->C * Npad * 4 < ((int64_t)1 << 31) &&
+      (!tr || !tr->scale || x->C <= kPwTab)) {           // (buffer offsets of the hand-tracked loads; the LDS tables)
     PwGeom p{};
     p.x = x->base; p.y = y->base; p.w = w; p.bias = bias;
     p.tr = tr ? *tr : crnInTransform{nullptr, nullptr, 0, 0};
@@ -577,6 +632,14 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
           p.cps = (x->C + 31) & ~31;
         }
       }
+    }
+    static const bool want_stamps = getenv("CRN_PW_STAMPS") != nullptr;
+    static long long* pw_stamps = nullptr;
+    if (want_stamps) {
+      if (!pw_stamps) CRN_HIP(hipMalloc(&pw_stamps, 32 * sizeof(long long)));
+      CRN_HIP(hipMemsetAsync(pw_stamps, 0, 32 * sizeof(long long), st));
+      p.stamps = pw_stamps;
+      g_pw_stamps = pw_stamps;
     }
     dim3 grid((unsigned)crn_cdiv(Sx, 64), (unsigned)crn_cdiv(y->C, BNh), (unsigned)(x->B * p.splits));
     if (wide) hipLaunchKernelGGL(pointwise_fwd_kernel<4>, grid, dim3(256), 0, st, p);
