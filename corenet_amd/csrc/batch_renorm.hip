@@ -600,10 +600,12 @@ __global__ __launch_bounds__(kThreads) void bias_grad_owner_kernel(const float* 
 }
 
 __global__ void bias_grad_final_kernel(const double* ws, int nparts, int C, float* db, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // a wave per channel
   if (c >= C) return;
   double s = 0.0;
-  for (int i = 0; i < nparts; ++i) s += ws[(int64_t)c * nparts + i];
+  for (int i = lane; i < nparts; i += 64) s += ws[(int64_t)c * nparts + i];
+  s = crn_wave_sum(s);
+  if (lane) return;
   if (accumulate) db[c] += (float)s; else db[c] = (float)s;
 }
 
@@ -823,7 +825,7 @@ extern "C" int crn_bias_grad(const float* dy, int B, int C, int64_t S, int64_t s
   else
     hipLaunchKernelGGL(bias_grad_partial_kernel<false>, grid, dim3(kThreads), 0, st, dy, S, sB, ws);
   CRN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(bias_grad_final_kernel, dim3(crn_cdiv(C, 128)), dim3(128), 0, st, ws, nparts, C, db,
+  hipLaunchKernelGGL(bias_grad_final_kernel, dim3(crn_cdiv(C, 4)), dim3(256), 0, st, ws, nparts, C, db,
                      accumulate);
   CRN_CHECK_LAUNCH();
   return CRN_OK;

@@ -97,6 +97,7 @@ __global__ void linear_fwd_kernel(const float* x, const float* w, const float* b
   if (wid >= B * N) return;
   const int b = wid / N, n = wid % N;
   float s = 0.f;
+#pragma unroll 8                                         // (the loads of 8 steps in flight: the loop is a latency chain)
   for (int k = lane; k < K; k += 64) s += x[(int64_t)b * K + k] * w[(int64_t)n * K + k];
   s = crn_wave_sum(s);
   if (lane == 0) y[(int64_t)b * ldy + n] = s + (bias ? bias[n] : 0.f);
@@ -106,6 +107,7 @@ __global__ void linear_bwd_dx_kernel(const float* w, const float* dy, int lddy, 
   if (e >= B * K) return;
   const int b = e / K, k = e % K;
   float s = 0.f;
+#pragma unroll 16
   for (int n = 0; n < N; ++n) s += dy[(int64_t)b * lddy + n] * w[(int64_t)n * K + k];
   dx[e] = s;
 }
