@@ -505,7 +505,12 @@ __global__ __launch_bounds__(kThreads) void bn_owner_bwd_kernel(
 }
 
 // many channels, little data per channel: the channel-owner kernels (bench.py: 17.15 -> 16.95 ms per step)
-inline bool owner_form(int64_t S, int C, int B) { return C >= 64 && (int64_t)B * S <= 65536; }
+// one workgroup per channel pays when there are enough channels to fill the chip or the channel fits the register
+// kernels; a 64-channel map of 65536 values per channel (the stem) keeps 64 CUs busy with 1 MB each (75 us for the
+// backward pass against 2 x ~15 us for the partial + apply pair on all CUs)
+inline bool owner_form(int64_t S, int C, int B) {
+  return C >= 64 && (int64_t)B * S <= 65536 && ((int64_t)B * S <= 16384 || C >= 256);
+}
 
 // ---- block tails ---------------------------------------------------------------
 template <bool VEC>
