@@ -32,17 +32,22 @@ __global__ void bn_relu_maxpool_fwd_kernel(const float* x, const float* scale, c
   const float* p = x + bc * (int64_t)H * W;
   float best = -INFINITY;
   int bi = -1;
-  for (int dh = 0; dh < 3; ++dh)
-    for (int dw = 0; dw < 3; ++dw) {
-      const int ih = 2 * oh - 1 + dh, iw = 2 * ow - 1 + dw;
-      float v = 0.f;           // the zero pad
-      int idx = -1;
-      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-        idx = ih * W + iw;
-        v = fmaxf(p[idx] * sc + sh, 0.f);
-      }
-      if (v > best) { best = v; bi = idx; }
-    }
+  // all nine loads are issued up front from clamped addresses (inside the bounds check they were nine memory
+  // latencies one after the other); padding positions then take the value 0 like before
+  float raw[9];
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9) {
+    const int ih = min(max(2 * oh - 1 + t9 / 3, 0), H - 1), iw = min(max(2 * ow - 1 + t9 % 3, 0), W - 1);
+    raw[t9] = p[ih * W + iw];
+  }
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9) {
+    const int ih = 2 * oh - 1 + t9 / 3, iw = 2 * ow - 1 + t9 % 3;
+    const bool in = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    const float v = in ? fmaxf(raw[t9] * sc + sh, 0.f) : 0.f;           // the zero pad
+    const int idx = in ? ih * W + iw : -1;
+    if (v > best) { best = v; bi = idx; }
+  }
   y[e] = best;
   argmax[e] = (best > 0.f) ? bi : -1;   // zero-valued maxima carry no gradient through the ReLU
 }
@@ -59,10 +64,21 @@ __global__ void bn_relu_maxpool_bwd_kernel(const float* dy, const int32_t* argma
   const float* g = dy + bc * (int64_t)Ho * Wo;
   const int32_t* am = argmax + bc * (int64_t)Ho * Wo;
   float s = 0.f;
-  // windows covering row ih: 2*oh-1 <= ih <= 2*oh+1
-  for (int oh = ih / 2; oh <= (ih + 1) / 2; ++oh)
-    for (int ow = iw / 2; ow <= (iw + 1) / 2; ++ow)
-      if (oh < Ho && ow < Wo && am[oh * Wo + ow] == idx) s += g[oh * Wo + ow];
+  // windows covering row ih: 2*oh-1 <= ih <= 2*oh+1 (at most 2 x 2; loaded from clamped addresses up front)
+  int amv[4];
+  float gv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int oh = min(ih / 2 + (q >> 1), Ho - 1), ow = min(iw / 2 + (q & 1), Wo - 1);
+    amv[q] = am[oh * Wo + ow];
+    gv[q] = g[oh * Wo + ow];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int oh = ih / 2 + (q >> 1), ow = iw / 2 + (q & 1);
+    const bool in = oh <= (ih + 1) / 2 && ow <= (iw + 1) / 2 && oh < Ho && ow < Wo;
+    if (in && amv[q] == idx) s += gv[q];
+  }
   dx[e] = s;
 }
 
