@@ -170,9 +170,35 @@ def ptr(x: Optional[t.Tensor]) -> Optional[int]:
   return x.data_ptr()
 
 
+_pinned_stream: Optional[int] = None
+
+
 def stream() -> int:
-  """The current torch HIP stream as a hipStream_t value."""
+  """The current torch HIP stream as a hipStream_t value.  Inside pinned_stream() blocks it is the pinned handle:
+  torch.cuda.current_stream() costs ~1.2 us per call, 0.7 ms of the host's 6 ms per training step."""
+  if _pinned_stream is not None:
+    return _pinned_stream
   return t.cuda.current_stream().cuda_stream
+
+
+class pinned_stream:
+  """with pinned_stream(): every library call of the block goes to the torch stream that is current at entry
+  (or to `s`), without asking torch each time.  Blocks nest; code that switches torch streams inside must enter a
+  new block (Plan does, around its side-stream sections)."""
+
+  def __init__(self, s: Optional[t.cuda.Stream] = None):
+    self.s = s
+
+  def __enter__(self):
+    global _pinned_stream
+    self.prev = _pinned_stream
+    _pinned_stream = (self.s if self.s is not None else t.cuda.current_stream()).cuda_stream
+    return self
+
+  def __exit__(self, *exc):
+    global _pinned_stream
+    _pinned_stream = self.prev
+    return False
 
 
 def require_gpu(x: t.Tensor, what: str = "tensor"):

@@ -20,6 +20,7 @@ from typing import Any, Dict, Optional, Tuple
 import torch as t
 from torch import nn
 
+from corenet_amd import _lib
 from corenet_amd.model.engine import Engine
 
 
@@ -146,9 +147,15 @@ class CoreNet(nn.Module):
     self.engine.weights_dirty = True
 
   def _on_device(self):
-    """Kernels go to the current stream of the CURRENT device: make that the model's device for the call."""
+    """Kernels go to the current stream of the CURRENT device: make that the model's device for the call, and pin
+    that stream's handle for the library calls of the block (_lib.pinned_stream)."""
     d = self.engine.device
-    return t.cuda.device(d) if d.type == "cuda" else contextlib.nullcontext()
+    if d.type != "cuda":
+      return contextlib.nullcontext()
+    stack = contextlib.ExitStack()
+    stack.enter_context(t.cuda.device(d))
+    stack.enter_context(_lib.pinned_stream())
+    return stack
 
   def reset_parameters(self, seed: int = 0):
     """resnet50.py:40-47 (kaiming-normal convs, BN gamma=1 beta=0) and torch's
@@ -322,7 +329,7 @@ class CoreNet(nn.Module):
       g = t.cuda.CUDAGraph()
       cap = t.cuda.Stream(device=eng.device)
       cap.wait_stream(t.cuda.current_stream())
-      with t.cuda.graph(g, stream=cap):
+      with t.cuda.graph(g, stream=cap), _lib.pinned_stream(cap):      # (the library calls follow the capture stream)
         self._step_body(plan, loss)
       t.cuda.current_stream().wait_stream(cap)
       plan.graphs[loss] = g

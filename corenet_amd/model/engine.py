@@ -29,6 +29,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch as t
 
+from corenet_amd import _lib
 from corenet_amd import views as V
 from corenet_amd.backend import Transform
 from corenet_amd.model import conv_geometry as G
@@ -701,7 +702,7 @@ class Plan:
       self._side_ev.append(t.cuda.Event())
     ev = self._side_ev[self._side_i]; self._side_i += 1
     ev.record()                                   # dy (and the zeroed slab) are ready on the main stream
-    with t.cuda.stream(self.side):
+    with t.cuda.stream(self.side), _lib.pinned_stream(self.side):
       self.side.wait_event(ev)
       self.be.conv_wgrad(x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes), math=math)
 
@@ -735,7 +736,7 @@ class Plan:
       if dec_later:
         eng.pack_weights("enc_early")             # stem + stage2 (0.2 M weights): needed at once
       self._pack_ev.record()                      # the parameters are final on the main stream
-      with t.cuda.stream(self.side):
+      with t.cuda.stream(self.side), _lib.pinned_stream(self.side):
         self.side.wait_event(self._pack_ev)
         if dec_later:
           eng.pack_weights("enc_late")            # stage3-5 (23 M): needed ~0.5 ms into the encoder
@@ -885,7 +886,7 @@ class Plan:
     if self.side is None or self.trace is not None:
       return run()
     self._bucket_ev[i].record()                  # bias / norm gradients of the bucket are written on the main stream
-    with t.cuda.stream(self.side):
+    with t.cuda.stream(self.side), _lib.pinned_stream(self.side):
       self.side.wait_event(self._bucket_ev[i])
       run()
 
