@@ -836,15 +836,18 @@ int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w
   const int KD = g.NG == 7 ? 5 : 4;                   // window depth of the instantiated whole-window slabs
   g.ctab = (x->C + 15) & ~15;
   auto lds_of = [&](int nsub, int zs) { return (size_t)(3 * g.ctab * 4) + (size_t)2 * g.NP * 16 + (size_t)2 * zs * g.NG * 4 * nsub * 16 * 16; };
-  // N block: wide blocks re-use the staged patch; with per-output-group tap boxes (transposed convolutions) a
-  // 16-column block belongs to one parity and skips that parity's structural zeros instead.  When the tiles
-  // alone cannot fill the chip, narrower N blocks (more workgroups) come first, then split-K over the chunks.
-  int NSUB = (Npad % 64 == 0) ? 4 : ((Npad % 32 == 0) ? 2 : 1);
-  if (have_nbox && (y->C / g.n_groups) % 16 == 0) NSUB = 1;
-  // 32 columns: two 16-column workgroups per tile instead of one 32-column one keep the launch under 80 KiB of LDS
-  // and 128 VGPRs, i.e. two workgroups per CU (stage_6.c1 data gradient 374 vs 408 us, stage_5.c1 forward unchanged)
-  if (Npad <= 32) NSUB = 1;
-  while (NSUB > 1 && (lds_of(NSUB, 1) > kLdsMax || tiles * crn_cdiv(Npad, NSUB * 16) < 192)) NSUB >>= 1;
+  // N block (NSUB x 16 columns per workgroup), measured per layer with the pre-arranged weight slabs (tools/bf3bench.sh
+  // with CRN_BF3_NSUB = 1 / 2 / 4, profiles/r02_bf3_nsub_sweep.txt): wide blocks re-use the staged patch, narrow ones
+  // keep two workgroups on a CU and (transposed convolutions) skip more structural zeros.  32 columns is within 10 %
+  // of the best everywhere; 64 wins on the 16^3 maps (32 tiles: one big workgroup per tile and split-K over the
+  // channels beat four narrow ones: stage_4 -18 ... -33 %) and for few input channels without tap boxes (stage_5.c1
+  // data gradient), and loses badly on the 64^3 maps.  (Before the slabs, 16-column blocks were the default for
+  // every transposed convolution and for Npad <= 32: stage_5.t1 forward 255 us against 189 us now.)
+  int NSUB;
+  if (Npad <= 16) NSUB = 1;
+  else if (Npad <= 32) NSUB = 2;
+  else NSUB = ((g.mw == 16 && tiles <= 64) || (!have_nbox && x->C <= 32)) ? 4 : 2;
+  while (NSUB > 1 && lds_of(NSUB, 1) > kLdsMax) NSUB >>= 1;
   if (const char* f = getenv("CRN_BF3_NSUB")) NSUB = atoi(f);
   if (NSUB != 1 && NSUB != 2 && NSUB != 4) return CRN_EINVAL;
   // Whole-window slabs (ZS = kd: one staging step per chunk instead of one per window plane) were measured
