@@ -618,8 +618,11 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
     const int64_t ytot = (int64_t)y->B * y->C * Sx;
     static const bool pw_nosplit = getenv("CRN_PW_NOSPLIT") != nullptr;
     float* scratch = nullptr;
-    if (splits < 1 && !pw_nosplit && blocks < 256 && x->C >= 256) {
-      int sp = (int)std::min<int64_t>(std::min<int64_t>(x->C / 128, 16), crn_cdiv(512, blocks));
+    static const int pw_blocks = getenv("CRN_PW_BLOCKS") ? atoi(getenv("CRN_PW_BLOCKS")) : 256;   // tuning aids
+    static const int pw_fill = getenv("CRN_PW_FILL") ? atoi(getenv("CRN_PW_FILL")) : 512;
+    static const int pw_minc = getenv("CRN_PW_MINC") ? atoi(getenv("CRN_PW_MINC")) : 128;
+    if (splits < 1 && !pw_nosplit && blocks < pw_blocks && x->C >= 2 * pw_minc) {
+      int sp = (int)std::min<int64_t>(std::min<int64_t>(x->C / pw_minc, 16), crn_cdiv(pw_fill, blocks));
       if (sp > 1) {
         p.cps = (crn_cdiv(x->C, sp) + 31) & ~31;
         sp = crn_cdiv(x->C, p.cps);
