@@ -3,6 +3,7 @@
 // pass per tensor, fp64 accumulation of the per-channel sums.
 // Reference: model/batch_renorm.py:33-62, model/resnet50.py:72-82,109-115.
 #include "crn_common.h"
+#include <cstdlib>
 #include <algorithm>
 
 namespace {
@@ -623,7 +624,8 @@ inline bool vec_ok(int64_t S, std::initializer_list<int64_t> strides, std::initi
 
 inline int nsplit_for(int64_t S, int C, int B) {
   // enough blocks to fill 256 CUs x 8, >= 4096 elements per block
-  int64_t want = std::max<int64_t>(1, 2048 / std::max(1, C * B));
+  static const int kWant = getenv("CRN_BN_WANT") ? atoi(getenv("CRN_BN_WANT")) : 2048;       // tuning aid
+  int64_t want = std::max<int64_t>(1, kWant / std::max(1, C * B));
   int64_t maxs = std::max<int64_t>(1, S / 4096);
   return (int)std::min<int64_t>(std::min(want, maxs), 64);
 }

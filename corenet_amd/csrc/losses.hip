@@ -76,11 +76,11 @@ __global__ __launch_bounds__(kThreads) void loss_pass1_kernel(const float* logit
 // One workgroup of 256 threads: wave w reduces the (sample, quantity) pairs w, w+4, ... (the per-block partials of
 // a pair are summed in a fixed order: lane-strided, then the wave tree), thread 0 combines them.  (A single wave
 // walking all B*5 pairs one after the other took 25 us of the step's critical path.)
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const double* part, int nblk, int B, int64_t S, int kind,
+__global__ __launch_bounds__(1024) void loss_finalize_kernel(const double* part, int nblk, int B, int64_t S, int kind,
                                                             float grad_scale, float* loss, float* coef) {
   __shared__ double sums[64 * kNQ];                      // B <= 64
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int pair = wave; pair < B * kNQ; pair += 4) {
+  for (int pair = wave; pair < B * kNQ; pair += (int)(blockDim.x >> 6)) {     // 16 waves: 20 sums in two rounds
     const int b = pair / kNQ, k = pair - b * kNQ;
     double s = 0.0;
     for (int i = lane; i < nblk; i += 64) s += part[((int64_t)b * nblk + i) * kNQ + k];
@@ -221,7 +221,7 @@ extern "C" int crn_loss_fwd_bwd(int kind, const float* logits, const int32_t* gt
 #undef CRN_LOSS_P1
   CRN_CHECK_LAUNCH();
   if (B > 64) return CRN_EINVAL;
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, part, nblk, B, S, kind, grad_scale, loss, coef);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nblk, B, S, kind, grad_scale, loss, coef);
   CRN_CHECK_LAUNCH();
   if (dlogits) {
 #define CRN_LOSS_P2(CT) hipLaunchKernelGGL(loss_pass2_kernel<CT>, grid, dim3(kThreads), 0, st, logits, gt, weights, C, S, coef, dlogits)
