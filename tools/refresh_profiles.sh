@@ -14,6 +14,8 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r02 -- python $R/tools/prof_step.py bf16x3 10 > /dev/null 2>&1
 cp /tmp/prof/r02_kernel_stats.csv $O/r02_step_kernel_stats.csv
 python $R/tools/trace_summary.py /tmp/prof/r02_kernel_trace.csv 13 > $O/r02_step_trace_summary.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o b -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-side > $O/r02_bench_under_rocprof.json 2>/dev/null
+cp /tmp/pb/b_kernel_stats.csv $O/r02_bench_kernel_stats.csv
 rocprofv3 --kernel-trace --output-format csv -d /tmp/pe -o e -- python $R/tools/bench_e2d.py 20 > /dev/null 2>&1
 python $R/tools/bench_e2d_trace.py /tmp/pe/e_kernel_trace.csv 20 > $O/r02_e2d_kernel_times.txt
 cd $R
