@@ -340,3 +340,57 @@ def test_checkpoint_interop_and_fused_adam():
     assert int(d["optimizer_state"]["state"][i]["step"]) == 3
   st2 = S.decode_state(raw, "cpu", backend=EMU)
   assert st2.model.engine.adam_t == 3 and all(t.equal(st2.model.state_dict()[k], st.model.state_dict()[k]) for k in keys)
+
+
+def test_bf3_operand_layouts_round_trip():
+  """The two pre-arranged weight formats of crn_bf3_operands as include/corenet_hip.h describes them, on the CPU:
+  an entry = 8 bf16 hi + 8 bf16 lo of 8 consecutive input channels (w = hi + lo, hi = bf16(w));  encoder operand
+  blocks: entry ((cb*T + t)*(Npad/16) + ntile)*64 + kk*16 + i = column 16*ntile + i, tap t, channels 32*cb + 8*kk..;
+  decoder slabs: entry ((chunk*kd + zd)*TP + tp)*Npad + n = column n, tap zd*KHW + tp, channels 8*chunk...
+  The emulator writes them element by element from that text, reads them back, and a convolution on the read-back
+  weights equals the convolution on the fp32 weights to the 2^-17 of the split."""
+  g = t.Generator().manual_seed(3)
+  # encoder engine: 3x3, 64 -> 64
+  wshape = (64, 64, 3, 3)
+  w = t.randn(wshape, generator=g) * 0.1
+  fwd = G.conv_fwd(wshape, 1)
+  wf = pack(w, fwd.index)
+  assert G.operand_eligible(fwd) and G.operand_entries(fwd) == 2 * 9 * 4 * 64
+  desc, blocks = G.operand_table([(0, 0, fwd)])
+  assert desc.shape == (1, 7) and blocks == (G.operand_entries(fwd) + 255) // 256
+  wop = t.zeros(G.operand_entries(fwd) * 32, dtype=t.uint8)
+  EMU.bf3_operands(wf, (t.as_tensor(desc), blocks), wop)
+  ent = wop.view(t.int16).view(t.bfloat16).view(-1, 2, 8).float()
+  cb, tap, ntile, kk, i = 1, 5, 2, 3, 7                    # one entry, straight from the header's formula
+  e = ((cb * 9 + tap) * 4 + ntile) * 64 + kk * 16 + i
+  ref = wf.view(64, 9, 64)[32 * cb + 8 * kk:32 * cb + 8 * kk + 8, tap, 16 * ntile + i]
+  assert t.equal(ent[e, 0], ref.to(t.bfloat16).float())
+  assert float((ent[e, 0] + ent[e, 1] - ref).abs().max()) <= float(ref.abs().max()) * 2.0 ** -16
+  x = t.randn(2, 64, 8, 8, generator=g)
+  y0, y1 = t.zeros(2, 64, 8, 8), t.zeros(2, 64, 8, 8)
+  EMU.conv_fwd(V.view_of(x), None, wf, fwd.npad, None, 0, V.view_of(y0), fwd.window, fwd.pad_lo)
+  EMU.conv2d_bf3(V.view_of(x), None, wop, fwd.npad, None, 0, V.view_of(y1), fwd.window, fwd.pad_lo)
+  assert err(y1, y0) < 2e-5
+  # decoder slabs: Conv3d k5, 12 -> 16 channels (a partial chunk: zeros past Cin, 3 empty tap slots per plane)
+  wshape = (16, 12, 5, 5, 5)
+  w = t.randn(wshape, generator=g) * 0.05
+  fwd = G.conv_fwd(wshape, 2)
+  wf = pack(w, fwd.index)
+  assert G.slab_entries(fwd) == 2 * 5 * 28 * 16
+  desc, blocks = G.operand_table([(0, 0, fwd, True)])
+  assert int(desc[0, 6]) == 25
+  slabs = t.zeros(G.slab_entries(fwd) * 32, dtype=t.uint8)
+  EMU.bf3_operands(wf, (t.as_tensor(desc), blocks), slabs)
+  ent = slabs.view(t.int16).view(t.bfloat16).view(-1, 2, 8).float()
+  chunk, zd, tp, n = 1, 3, 17, 9
+  e = ((chunk * 5 + zd) * 28 + tp) * 16 + n
+  ref = t.zeros(8)
+  ref[:4] = wf.view(12, 125, 16)[8:12, zd * 25 + tp, n]    # channels 8..11 exist, 12..15 are zeros
+  assert t.equal(ent[e, 0], ref.to(t.bfloat16).float())
+  assert float(ent[((0 * 5 + 0) * 28 + 26) * 16].abs().max()) == 0.0        # tap slot 26 of a 25-tap plane
+  x = t.randn(1, 12, 4, 8, 16, generator=g)
+  y0, y1 = t.zeros(1, 16, 4, 8, 16), t.zeros(1, 16, 4, 8, 16)
+  EMU.conv_fwd(V.view_of(x), None, wf, fwd.npad, None, 0, V.view_of(y0), fwd.window, fwd.pad_lo)
+  EMU.conv_fwd(V.view_of(x), None, None, fwd.npad, None, 0, V.view_of(y1), fwd.window, fwd.pad_lo, wslab=slabs)
+  assert err(y1, y0) < 2e-5
+
