@@ -4,8 +4,14 @@
 One "step" = the reference's training hot loop body (pipeline.py:224-233) on one
 synthetic batch already resident in HBM: CoReNet forward -> iou_fgbg loss ->
 backward -> gradient all-reduce (RCCL, N>1) -> Adam, B=4 samples of 256x256 RGB
--> 128^3 voxels per GPU (configs/models/h7.json5:42,62-67), fp32 like the
-reference.  value = global_batch * 128^3 * steps / time.
+-> 128^3 voxels per GPU (configs/models/h7.json5:42,62-67).  value = global_batch * 128^3 * steps / time.
+
+Arithmetic: the headline line is the product's default math mode, decoder_math="bf16x3" (fp32 tensors everywhere;
+the convolutions of decoder stages 3-6 and the encoder's 3x3 layers multiply operands split into two bf16 terms,
+three bf16 MFMAs per product, fp32 accumulation -- wider than the "bf16" BASELINE.json names for h7, narrower than
+the reference's fp32; inside north_star's 1e-3 on every reference fixture).  The same step with every convolution
+on the fp32 MFMA engine is timed in the same run and printed under "fp32_math"; "parity" holds the eval-mode logits
+error of BOTH modes against the oracle on the bench's own weights and inputs (rank 0, after the timed region).
 
   python bench.py --gpus 1 --steps 10 --warmup 3
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -29,6 +35,10 @@ RAY64_BYTES = 64 ** 3 * 12 * 4 + 64 * 64 * 12 * 4  # ray-sample 64^3 x 12ch: out
 PEAK_F32_MFMA = 157.3e12                           # MI355X_MICROARCH.md: fp32 matrix peak
 PEAK_BF16_MFMA = 2500e12                           # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM = 8.0e12                                  # HBM3E spec peak
+# HBM bytes per launch come from separate rocprofv3 --pmc passes of this command (tools/pmc_traffic.sh); the record is
+# keyed by kernel name + grid, so both are named here, next to the kernel they describe
+TRAFFIC_FILES = {"bf16x3": "r02_pmc_traffic.json", "fp32": "r01_pmc_traffic.json"}
+CONV_BF3_TRAFFIC_KERNEL, CONV_BF3_THREADS = "conv_bf3_kernel<1, 1, 7, 1", 512
 
 
 def canonical_camera():
@@ -98,6 +108,25 @@ def cpu_baseline(state, batch, loss_name, seconds_budget=25.0):
           "host_cores": os.cpu_count(), "host_cores_available": avail, "kind": "port", "batch": B,
           "sample": f"{n} steps of B={B} fwd+loss+bwd (oracle/corenet_oracle.py, torch-CPU fp32, the bench's own "
                     f"weights and inputs)"}
+
+
+def parity_check(state, batch, classes, dev, headline_math):
+  """Eval-mode logits of both math modes of the library against the oracle, on the bench's own weights and inputs,
+  every voxel of the bench batch (the oracle is the checker here, never the thing measured)."""
+  from oracle import corenet_oracle as O
+  from corenet_amd.model.core_net import CoreNet, CoreNetConfig, DecoderConfig
+  image, v2s, off, _ = batch
+  with t.no_grad():
+    want = O.corenet_forward({k: v.detach().cpu().clone() for k, v in state.items()}, image, v2s, off, training=False)
+    out = {}
+    for math in dict.fromkeys((headline_math, "fp32")):
+      m = CoreNet(CoreNetConfig(DecoderConfig((128, 128, 128), classes, 2, 64, 0.75)), device=dev, decoder_math=math)
+      m.load_state_dict(state); m.eval()
+      got = m(image.to(dev), v2s.to(dev), off.to(dev)).cpu()
+      out[math] = float((got.double() - want.double()).abs().max() / want.double().abs().max())
+      del m
+  return {"eval_logits_max_rel_err_vs_oracle": out, "voxels_compared": int(want.numel()), "tolerance": 1e-3,
+          "note": "north_star: logits within 1e-3 relative; eval mode (running statistics), B = the bench batch"}
 
 
 def cpu_baseline_fill(shells_cpu, seconds_budget=5.0):
@@ -206,14 +235,18 @@ def main():
   # HBM bytes per launch from the PMC passes of this same command (profiles/*_pmc_traffic.json;
   # FETCH_SIZE / WRITE_SIZE need their own rocprofv3 runs and cannot be read from inside the process)
   traffic = {}
-  traffic_file = os.path.join("profiles", "r02_pmc_traffic.json" if args.math == "bf16x3" else "r01_pmc_traffic.json")
+  traffic_file = os.path.join("profiles", TRAFFIC_FILES[args.math])
   try:
     tj = json.load(open(os.path.join(ROOT, traffic_file)))
+  except (OSError, ValueError) as e:
+    tj = None
+    print(f"bench.py: no HBM-traffic record ({traffic_file}: {e}); roofline.traffic = null", file=sys.stderr)
+  if tj is not None:
     if B == 4 and C == 2:
       for k, v in tj.get("kernels", {}).items():
         if args.math == "bf16x3":
           # stage_6.c1 fwd is the only launch of conv_bf3_kernel<NSUB 1, unit-stride x, 5x5 plane> on 2048 tiles
-          if "conv_bf3_kernel<1, 1, 7, 1" in k and k.endswith(f"grid {2048 * 512}"):
+          if CONV_BF3_TRAFFIC_KERNEL in k and k.endswith(f"grid {2048 * CONV_BF3_THREADS}"):
             traffic["conv"] = v["hbm_bytes"]
         # stage_6.c1 fwd (fp32 engine): conv_fwd_kernel<8,1,xvec>, 2048 tiles x 1 N-block.  stage_5.t1 and stage_6.t1 fwd
         # share that (kernel, grid); per step the dispatch order is s5.t1, s6.c1, s6.t1 -> every 3rd from 1
@@ -226,10 +259,14 @@ def main():
           traffic["ray"] = v["hbm_bytes"]
         if "fill_fused_kernel" in k:
           traffic["fill"] = v["hbm_bytes"]
-  except Exception:
-    pass
-  # ground-truth side: fill_voxels on 3 hollow shells per sample, whole call (memset + the
-  # single-launch kernel + status read-back) timed with HIP events; the kernel-only time is in profiles/
+      missing = [k for k in ("conv", "ray", "fill") if k not in traffic]
+      if missing:
+        # a kernel was renamed / re-gridded since the PMC passes were taken: say so instead of printing a stale or
+        # silently empty number (tools/pmc_traffic.sh regenerates the file)
+        print(f"bench.py: {traffic_file} has no record for {missing} (kernel names / grids changed?) -- "
+              f"re-run tools/pmc_traffic.sh; roofline.traffic = null for those", file=sys.stderr)
+  # ground-truth side: fill_voxels on 3 hollow shells per sample, whole call (the single-launch kernel +
+  # the conditional rescue kernel) timed with HIP events; the kernel-only time is in profiles/
   ax = t.arange(128, device=dev, dtype=t.float32) - 63.5
   dist3 = (ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :] ** 2).sqrt()
   shells = t.stack([((dist3 <= r) & (dist3 > r - 1.5)).float() for r in (10, 30, 50)] * B)
@@ -238,8 +275,8 @@ def main():
   for _ in range(2):
     be.fill_voxels(shells, filled)
   e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
-  # every call ends in a blocking status read-back; on a shared host such a wait occasionally takes tens of
-  # milliseconds whatever was launched (seen around any synchronising call), so: median of 9 timed calls
+  # the call is asynchronous (kernel + a rescue kernel that returns at once); a host-side synchronize on this shared
+  # host occasionally takes tens of milliseconds whatever was launched, so: median of 9 timed calls
   fill_times = []
   for _ in range(9):
     e0.record()
@@ -329,6 +366,8 @@ def main():
                    "exposed_exchange_ms": probes.get("grad_exchange_wait", 0.0) * 1e3}
   if not args.no_cpu_baseline and world == 1:
     out["cpu_baseline"] = cpu_baseline(state0, batch_cpu, loss_name)
+    del model, plan
+    out["parity"] = parity_check(state0, batch_cpu, C, dev, args.math)
     out["cpu_baseline_fill_voxels"] = cpu_baseline_fill(shells.cpu())
   print(json.dumps(out))
 

@@ -170,34 +170,37 @@ def ptr(x: Optional[t.Tensor]) -> Optional[int]:
   return x.data_ptr()
 
 
-_pinned_stream: Optional[int] = None
+import threading
+
+_tls = threading.local()       # the pinned handle is per host thread: autograd runs backward on a worker thread, a
+                               # data-loader thread may call the voxelizer on another stream / device at the same time
 
 
 def stream() -> int:
-  """The current torch HIP stream as a hipStream_t value.  Inside pinned_stream() blocks it is the pinned handle:
-  torch.cuda.current_stream() costs ~1.2 us per call, 0.7 ms of the host's 6 ms per training step."""
-  if _pinned_stream is not None:
-    return _pinned_stream
+  """The current torch HIP stream as a hipStream_t value.  Inside pinned_stream() blocks (of THIS thread) it is the
+  pinned handle: torch.cuda.current_stream() costs ~1.2 us per call, 0.7 ms of the host's 6 ms per training step."""
+  s = getattr(_tls, "stream", None)
+  if s is not None:
+    return s
   return t.cuda.current_stream().cuda_stream
 
 
 class pinned_stream:
-  """with pinned_stream(): every library call of the block goes to the torch stream that is current at entry
-  (or to `s`), without asking torch each time.  Blocks nest; code that switches torch streams inside must enter a
-  new block (Plan does, around its side-stream sections)."""
+  """with pinned_stream(): every library call this thread makes inside the block goes to the torch stream that is
+  current at entry (or to `s`), without asking torch each time.  Blocks nest; code that switches torch streams inside
+  must enter a new block (Plan does, around its side-stream sections).  Other threads are not affected: they keep
+  resolving torch.cuda.current_stream() (or their own pin)."""
 
   def __init__(self, s: Optional[t.cuda.Stream] = None):
     self.s = s
 
   def __enter__(self):
-    global _pinned_stream
-    self.prev = _pinned_stream
-    _pinned_stream = (self.s if self.s is not None else t.cuda.current_stream()).cuda_stream
+    self.prev = getattr(_tls, "stream", None)
+    _tls.stream = (self.s if self.s is not None else t.cuda.current_stream()).cuda_stream
     return self
 
   def __exit__(self, *exc):
-    global _pinned_stream
-    _pinned_stream = self.prev
+    _tls.stream = self.prev
     return False
 
 

@@ -654,7 +654,7 @@ extern "C" int crn_batch_renorm_stats(const float* x, int B, int C, int64_t S, i
     CrnSplitPending& pend = crn_splitk_pending();
     if (pend.active) {
       const crnView& py = pend.y;
-      if (reg_form && py.base == x && py.B == B && py.C == C && (int64_t)py.D * py.H * py.W == S && sB == (int64_t)C * S) {
+      if (reg_form && pend.stream == st && py.base == x && py.B == B && py.C == C && (int64_t)py.D * py.H * py.W == S && sB == (int64_t)C * S) {
         part = pend.scratch; psplits = pend.splits; pend.active = false;
       } else {
         const int rcf = crn_splitk_flush(st);
@@ -703,6 +703,7 @@ extern "C" int crn_batch_renorm_stats(const float* x, int B, int C, int64_t S, i
 
 extern "C" int crn_batch_renorm_eval_affine(const float* params, const float* buffers, const int32_t* table,
                                             int n, float eps, float* scale, float* shift, crnStream stream) {
+  CRN_ENTRY(stream);
   if (n < 0 || (n > 0 && (!params || !buffers || !table || !scale || !shift))) return CRN_EINVAL;
   if (n == 0) return CRN_OK;
   hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(crn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, params,
@@ -727,7 +728,7 @@ extern "C" int crn_batch_renorm_bwd(const float* x, int64_t sB_x, const float* d
     CrnSplitPending& pend = crn_splitk_pending();
     if (pend.active) {
       const crnView& py = pend.y;
-      if (reg_form && py.base == dy && py.B == B && py.C == C && (int64_t)py.D * py.H * py.W == S && sB_dy == (int64_t)C * S) {
+      if (reg_form && pend.stream == st && py.base == dy && py.B == B && py.C == C && (int64_t)py.D * py.H * py.W == S && sB_dy == (int64_t)C * S) {
         part = pend.scratch; psplits = pend.splits; pend.active = false;
       } else {
         const int rcf = crn_splitk_flush(st);
@@ -785,6 +786,7 @@ extern "C" int crn_affine_add_relu(const float* x, const float* scale, const flo
                                    int B, int C, int64_t S, int64_t sB_x, int64_t sB_r,
                                    float* y_pre, int64_t sB_pre, float* y, int64_t sB_y, int relu,
                                    crnStream stream) {
+  CRN_ENTRY(stream);
   hipStream_t st = (hipStream_t)stream;
   if (B < 1 || C < 1 || S < 1 || (!y && !y_pre)) return CRN_EINVAL;
   dim3 grid(nsplit_for(S, C, B), C, B);
@@ -801,6 +803,7 @@ extern "C" int crn_affine_add_relu(const float* x, const float* scale, const flo
 extern "C" int crn_relu_bwd_add(const float* dy, const float* y_pre, const float* dy2, int B, int C,
                                 int64_t S, int64_t sB_dy, int64_t sB_pre, int64_t sB_dy2, float* dx,
                                 int64_t sB_dx, crnStream stream) {
+  CRN_ENTRY(stream);
   hipStream_t st = (hipStream_t)stream;
   if (B < 1 || C < 1 || S < 1 || !y_pre || !dx) return CRN_EINVAL;
   dim3 grid(nsplit_for(S, C, B), C, B);
@@ -816,6 +819,7 @@ extern "C" int crn_relu_bwd_add(const float* dy, const float* y_pre, const float
 
 extern "C" int crn_bias_grad(const float* dy, int B, int C, int64_t S, int64_t sB, float* db,
                              int accumulate, double* ws, size_t ws_bytes, crnStream stream) {
+  CRN_ENTRY(stream);
   hipStream_t st = (hipStream_t)stream;
   if (B < 1 || C < 1 || S < 1 || B > 64) return CRN_EINVAL;
   if ((int64_t)B * S <= 65536) {

@@ -917,6 +917,7 @@ int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w
 // zero_first).  Returns CRN_EINVAL for shapes it does not cover.
 extern "C" int crn_conv_wgrad_bf3(const crnView* x, const crnInTransform* tr, const crnView* dy, float* dw, int Npad,
                                   int kd, int kh, int kw, int pd, int ph, int pw, int zero_first, crnStream stream) {
+  CRN_ENTRY(stream);
   if (!x || !dy || !dw || Npad <= 0 || (Npad & 15) || x->B != dy->B || kd < 1 || kh < 1 || kw < 1) return CRN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (!even_view(*x)) return CRN_EINVAL;

@@ -720,6 +720,7 @@ bool dense_2d(const crnView& v) {   // unit W stride, rows back to back, 16-byte
 
 extern "C" int crn_bf3_operands(const float* packed, const int64_t* desc, int nlayers, int64_t total_blocks, void* out,
                                 crnStream stream) {
+  CRN_ENTRY(stream);
   if (!packed || !desc || !out || nlayers < 1 || total_blocks < 1 || total_blocks > 0x7fffffff) return CRN_EINVAL;
   hipLaunchKernelGGL(bf3_operands_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, packed,
                      reinterpret_cast<const long long*>(desc), nlayers, reinterpret_cast<char*>(out));
@@ -816,8 +817,7 @@ extern "C" int crn_conv2d_bf3(const crnView* x, const crnInTransform* tr, const 
   else rc = launch_e2d<9, 1, 8>(g, grid, lds, st);
   if (rc == CRN_OK && splits > 1) {
     if (armed && !accumulate && yreal.sB == (int64_t)yreal.C * S) {      // the next BatchRenorm launch adds them up
-      CrnSplitPending& pend = crn_splitk_pending();
-      pend.active = true; pend.y = yreal; pend.scratch = scratch; pend.splits = splits;
+      crn_splitk_set_pending(yreal, scratch, splits, st);
       return rc;
     }
     rc = crn_splitk_reduce(yreal, scratch, splits, accumulate, st);
@@ -838,11 +838,13 @@ extern "C" int crn_e2d_debug_stamps(long long* out32) {
 // zero_first.  CRN_EINVAL for views that are not dense or positions per sample that are not a multiple of 32.
 extern "C" int crn_conv_wgrad_1x1_bf3(const crnView* x, const crnInTransform* tr, const crnView* dy, float* dw, int Npad,
                                       int zero_first, crnStream stream) {
+  CRN_ENTRY(stream);
   return crn_conv_wgrad_2d_bf3(x, tr, dy, dw, Npad, 1, 1, 0, 0, zero_first, stream);
 }
 
 extern "C" int crn_conv_wgrad_2d_bf3(const crnView* x, const crnInTransform* tr, const crnView* dy, float* dw, int Npad,
                                      int kh, int kw, int ph, int pw, int zero_first, crnStream stream) {
+  CRN_ENTRY(stream);
   if (!x || !dy || !dw || Npad <= 0 || (Npad & 15) || x->B != dy->B || dy->C > Npad) return CRN_EINVAL;
   if (!dense_2d(*x) || !dense_2d(*dy)) return CRN_EINVAL;
   if (x->D != dy->D || x->H != dy->H || x->W != dy->W) return CRN_EINVAL;

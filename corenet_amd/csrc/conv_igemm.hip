@@ -532,7 +532,18 @@ int crn_splitk_flush(hipStream_t st) {
   CrnSplitPending& p = crn_splitk_pending();
   if (!p.active) return CRN_OK;
   p.active = false;
-  return crn_splitk_reduce(p.y, p.scratch, p.splits, 0, st);
+  (void)st;                       // the sum is ordered behind the convolution: it runs on the conv's own stream / device
+  int cur = -1;
+  CRN_HIP(hipGetDevice(&cur));
+  if (cur != p.device) CRN_HIP(hipSetDevice(p.device));
+  const int rc = crn_splitk_reduce(p.y, p.scratch, p.splits, 0, p.stream);
+  if (cur != p.device) CRN_HIP(hipSetDevice(cur));
+  return rc;
+}
+void crn_splitk_set_pending(const crnView& y, const float* scratch, int splits, hipStream_t st) {
+  CrnSplitPending& p = crn_splitk_pending();
+  p.active = true; p.y = y; p.scratch = scratch; p.splits = splits; p.stream = st;
+  if (hipGetDevice(&p.device) != hipSuccess) p.device = 0;
 }
 extern "C" int crn_splitk_defer(int on) {
   crn_splitk_pending().armed = on != 0;
@@ -650,8 +661,7 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
     CRN_CHECK_LAUNCH();
     if (p.splits > 1 && !p.counters) {
       if (armed && !accumulate && plain_view(*y) && y->sB == (int64_t)y->C * Sx) {
-        CrnSplitPending& pend = crn_splitk_pending();
-        pend.active = true; pend.y = *y; pend.scratch = scratch; pend.splits = p.splits;
+        crn_splitk_set_pending(*y, scratch, p.splits, st);
         return CRN_OK;
       }
       return crn_splitk_reduce(*y, scratch, p.splits, accumulate, st);
@@ -957,6 +967,7 @@ int wgrad_launch(const crnView* x, const crnInTransform* tr, const crnView* dy, 
 extern "C" int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const crnView* dy,
                               float* dw, int Npad, int kd, int kh, int kw, int pd, int ph, int pw,
                               int zero_first, const crnTapBoxes* boxes, crnStream stream) {
+  CRN_ENTRY(stream);
   if (!x || !dy || !dw || Npad <= 0 || (Npad & 15) || x->B != dy->B) return CRN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int T = kd * kh * kw;

@@ -88,8 +88,18 @@ struct CrnSplitPending {
   crnView y{};                 // the conv's real output (dense [B][C][S])
   const float* scratch = nullptr;
   int splits = 0;
+  hipStream_t stream = nullptr;  // the stream (and its device) the convolution ran on: only a BatchRenorm call on the SAME
+  int device = -1;               // stream may take the sum over; a flush always runs on this stream, behind the conv
 };
 CrnSplitPending& crn_splitk_pending();                 // per host thread
-int crn_splitk_flush(hipStream_t st);                  // run the pending reduction now (no-op if none)
+// Run the pending reduction now, on the stream of the convolution that left it (no-op if none).  EVERY entry point of
+// the library calls this first (CRN_ENTRY(stream)), except the BatchRenorm calls that can take the sum over.
+int crn_splitk_flush(hipStream_t st);
+void crn_splitk_set_pending(const crnView& y, const float* scratch, int splits, hipStream_t st);
+#define CRN_ENTRY(stream_arg)                                                          \
+  do {                                                                                 \
+    const int crn_rcf_ = crn_splitk_flush((hipStream_t)(stream_arg));                  \
+    if (crn_rcf_ != CRN_OK) return crn_rcf_;                                           \
+  } while (0)
 bool crn_splitk_take_armed();                          // consumes the arming of crn_splitk_defer
 int crn_splitk_reduce_view(const crnView& y, const float* scratch, int splits, int accumulate, hipStream_t st);

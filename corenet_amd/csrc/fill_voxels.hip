@@ -708,6 +708,7 @@ extern "C" size_t crn_fill_voxels_workspace_bytes(int N, int D, int H, int W) {
 
 extern "C" int crn_fill_voxels(const void* grid, void* out, int dtype, int N, int D, int H, int W,
                                void* workspace, size_t workspace_bytes, crnStream stream) {
+  CRN_ENTRY(stream);
   hipStream_t st = (hipStream_t)stream;
   if (!grid || !out || N < 1 || D < 1 || H < 1 || W < 1) return CRN_EINVAL;
   if (workspace_bytes < crn_fill_voxels_workspace_bytes(N, D, H, W)) return CRN_ENOMEM;

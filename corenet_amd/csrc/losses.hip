@@ -206,6 +206,7 @@ extern "C" size_t crn_loss_workspace_bytes(int B, int C) {
 extern "C" int crn_loss_fwd_bwd(int kind, const float* logits, const int32_t* gt, const float* weights, int B, int C,
                                 int64_t S, float* loss, float* dlogits, float grad_scale, void* workspace,
                                 size_t workspace_bytes, crnStream stream) {
+  CRN_ENTRY(stream);
   hipStream_t st = (hipStream_t)stream;
   if (kind < 0 || kind > 4 || B < 1 || C < 2 || C > 32 || S < 1 || !logits || !gt || !loss) return CRN_EINVAL;
   if (workspace_bytes < crn_loss_workspace_bytes(B, C)) return CRN_ENOMEM;
@@ -243,6 +244,7 @@ extern "C" const int* crn_loss_status_ptr(void* workspace, int B) {
 
 extern "C" int crn_argmax_confusion(const float* logits, const int32_t* gt, int B, int C, int64_t S,
                                     int32_t* labels, int64_t* cm, crnStream stream) {
+  CRN_ENTRY(stream);
   hipStream_t st = (hipStream_t)stream;
   if (B < 1 || C < 1 || C > 32 || S < 1 || !logits || (gt && !cm)) return CRN_EINVAL;
   dim3 grid(loss_nblk(S), B);
@@ -287,6 +289,7 @@ __global__ __launch_bounds__(256) void softmax_superres_kernel(const float* __re
 
 extern "C" int crn_softmax_superres(const float* logits, int m, int B, int C, int D, int H, int W, float* out,
                                     crnStream stream) {
+  CRN_ENTRY(stream);
   hipStream_t st = (hipStream_t)stream;
   if (!logits || !out || m < 1 || B < 1 || C < 1 || C > 32 || D < 1 || H < 1 || W < 1) return CRN_EINVAL;
   const int64_t So = (int64_t)D * H * W * m * m * m;

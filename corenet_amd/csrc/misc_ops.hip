@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256) void preprocess4_kernel(const uint8_t* img, in
 }
 
 extern "C" int crn_preprocess_caffe(const uint8_t* img, int B, int H, int W, float* out, crnStream s) {
+  CRN_ENTRY(s);
   const int64_t total = (int64_t)B * 3 * H * W;
   if (((int64_t)H * W) % 4 == 0 && total / 4 < (1 << 30) && (((uintptr_t)img) & 3) == 0 && (((uintptr_t)out) & 15) == 0) {
     hipLaunchKernelGGL(preprocess4_kernel, dim3(nblk(total / 4)), dim3(256), 0, (hipStream_t)s, img, (int)((int64_t)H * W / 4),
@@ -297,6 +298,7 @@ extern "C" int crn_preprocess_caffe(const uint8_t* img, int B, int H, int W, flo
 
 extern "C" int crn_bn_relu_maxpool_fwd(const float* x, const float* scale, const float* shift, int B, int C,
                                        int H, int W, float* y, int32_t* argmax, crnStream s) {
+  CRN_ENTRY(s);
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const int64_t total = (int64_t)B * C * Ho * Wo;
   hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)s, x, scale, shift,
@@ -307,6 +309,7 @@ extern "C" int crn_bn_relu_maxpool_fwd(const float* x, const float* scale, const
 
 extern "C" int crn_bn_relu_maxpool_bwd(const float* dy, const int32_t* argmax, int B, int C, int H, int W,
                                        float* dx_bn, crnStream s) {
+  CRN_ENTRY(s);
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   const int64_t total = (int64_t)B * C * H * W;
   hipLaunchKernelGGL(bn_relu_maxpool_bwd_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)s, dy, argmax, H, W,
@@ -316,6 +319,7 @@ extern "C" int crn_bn_relu_maxpool_bwd(const float* dy, const int32_t* argmax, i
 }
 
 extern "C" int crn_relu_mean_fwd(const float* x_pre, int B, int C, int64_t S, int64_t sB, float* avg, crnStream s) {
+  CRN_ENTRY(s);
   const int BC = B * C;
   hipLaunchKernelGGL(relu_mean_fwd_kernel, dim3(nblk((int64_t)BC * 64)), dim3(256), 0, (hipStream_t)s, x_pre, C, S,
                      sB, avg, BC);
@@ -325,6 +329,7 @@ extern "C" int crn_relu_mean_fwd(const float* x_pre, int B, int C, int64_t S, in
 
 extern "C" int crn_relu_mean_bwd(const float* x_pre, const float* davg, int B, int C, int64_t S, int64_t sB,
                                  float* dx, int64_t sB_dx, int accumulate, crnStream s) {
+  CRN_ENTRY(s);
   const int64_t total = (int64_t)B * C * S;
   hipLaunchKernelGGL(relu_mean_bwd_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)s, x_pre, davg, C, S, sB,
                      dx, sB_dx, accumulate, total);
@@ -334,6 +339,7 @@ extern "C" int crn_relu_mean_bwd(const float* x_pre, const float* davg, int B, i
 
 extern "C" int crn_linear_fwd(const float* x, const float* w, const float* bias, int B, int K, int N, float* y,
                               int ldy, crnStream s) {
+  CRN_ENTRY(s);
   hipLaunchKernelGGL(linear_fwd_kernel, dim3(nblk((int64_t)B * N * 64)), dim3(256), 0, (hipStream_t)s, x, w, bias, B,
                      K, N, y, ldy);
   CRN_CHECK_LAUNCH();
@@ -342,6 +348,7 @@ extern "C" int crn_linear_fwd(const float* x, const float* w, const float* bias,
 
 extern "C" int crn_linear_bwd(const float* x, const float* w, const float* dy, int lddy, int B, int K, int N,
                               float* dx, float* dw, float* db, crnStream s) {
+  CRN_ENTRY(s);
   if (dx) {
     hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(nblk((int64_t)B * K)), dim3(256), 0, (hipStream_t)s, w, dy, lddy, B,
                        K, N, dx);
@@ -357,6 +364,7 @@ extern "C" int crn_linear_bwd(const float* x, const float* w, const float* dy, i
 
 extern "C" int crn_fill_offset_channels(float* x, int B, int64_t sB, int64_t S, int c0, const float* offset,
                                         crnStream s) {
+  CRN_ENTRY(s);
   const int64_t total = (int64_t)B * 3 * S;
   hipLaunchKernelGGL(fill_offset_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)s, x, sB, S, c0, offset, total);
   CRN_CHECK_LAUNCH();
@@ -364,6 +372,7 @@ extern "C" int crn_fill_offset_channels(float* x, int B, int64_t sB, int64_t S, 
 }
 
 extern "C" int crn_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, crnStream s) {
+  CRN_ENTRY(s);
   hipLaunchKernelGGL(gather_kernel, dim3(std::min(nblk(n), 4096u)), dim3(256), 0, (hipStream_t)s, src, idx, dst, n);
   CRN_CHECK_LAUNCH();
   return CRN_OK;
@@ -371,6 +380,7 @@ extern "C" int crn_gather_f32(const float* src, const int32_t* idx, float* dst, 
 
 extern "C" int crn_scatter_f32(const float* src, const int32_t* idx, float* dst, int64_t n, int accumulate,
                                crnStream s) {
+  CRN_ENTRY(s);
   hipLaunchKernelGGL(scatter_kernel, dim3(std::min(nblk(n), 4096u)), dim3(256), 0, (hipStream_t)s, src, idx, dst, n,
                      accumulate);
   CRN_CHECK_LAUNCH();
@@ -379,6 +389,7 @@ extern "C" int crn_scatter_f32(const float* src, const int32_t* idx, float* dst,
 
 extern "C" int crn_copy_tiles_f32(const float* src, float* dst, const int32_t* desc, const uint64_t* mask,
                                   const int32_t* explicit_idx, int64_t ntiles, int reverse, crnStream s) {
+  CRN_ENTRY(s);
   if (!src || !dst || !desc || !mask || ntiles < 0) return CRN_EINVAL;
   if (ntiles == 0) return CRN_OK;
   const unsigned blocks = (unsigned)std::min<int64_t>(crn_cdiv(ntiles, 4), 16384);
@@ -393,11 +404,13 @@ extern "C" int crn_copy_tiles_f32(const float* src, float* dst, const int32_t* d
 }
 
 extern "C" int crn_zero_f32(float* p, int64_t n, crnStream s) {
+  CRN_ENTRY(s);
   CRN_HIP(hipMemsetAsync(p, 0, (size_t)n * 4, (hipStream_t)s));
   return CRN_OK;
 }
 
 extern "C" int crn_add_i64(int64_t* p, int n, int64_t v, crnStream s) {
+  CRN_ENTRY(s);
   hipLaunchKernelGGL(add_i64_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)s, p, n, v);
   CRN_CHECK_LAUNCH();
   return CRN_OK;
@@ -406,6 +419,7 @@ extern "C" int crn_add_i64(int64_t* p, int n, int64_t v, crnStream s) {
 extern "C" int crn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                              float lr, float beta1, float beta2, float eps, float grad_scale, int step,
                              crnStream s) {
+  CRN_ENTRY(s);
   if (step < 1 || n < 1) return CRN_EINVAL;
   if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return CRN_EINVAL;
   const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
@@ -418,6 +432,7 @@ extern "C" int crn_adam_step(float* param, const float* grad, float* exp_avg, fl
 
 extern "C" int crn_adam_set_hyper(float* hyper, float lr, float beta1, float beta2, float eps, float grad_scale,
                                   int step, crnStream s) {
+  CRN_ENTRY(s);
   if (!hyper || step < 1) return CRN_EINVAL;
   const double bc1 = 1.0 - std::pow((double)beta1, step), bc2 = 1.0 - std::pow((double)beta2, step);
   hipLaunchKernelGGL(set_hyper_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, hyper, lr, beta1, beta2, eps, grad_scale,
@@ -428,6 +443,7 @@ extern "C" int crn_adam_set_hyper(float* hyper, float lr, float beta1, float bet
 
 extern "C" int crn_adam_step_hyper(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                                    const float* hyper, crnStream s) {
+  CRN_ENTRY(s);
   if (n < 1 || !hyper) return CRN_EINVAL;
   if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return CRN_EINVAL;
   const int64_t n4 = n / 4;
@@ -478,6 +494,7 @@ __global__ __launch_bounds__(256) void stride2_scatter_kernel(const float* __res
 }  // namespace
 
 extern "C" int crn_stride2_gather(const float* x, float* y, int B, int C, int h, int w, crnStream s) {
+  CRN_ENTRY(s);
   if (!x || !y || B < 1 || C < 1 || h < 1 || w < 2 || (w & 1) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 7)) return CRN_EINVAL;
   const int64_t planes = (int64_t)B * C, n = planes * h * (w >> 1);
   hipLaunchKernelGGL(stride2_gather_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)s, x, y, h, w, planes);
@@ -486,6 +503,7 @@ extern "C" int crn_stride2_gather(const float* x, float* y, int B, int C, int h,
 }
 
 extern "C" int crn_stride2_scatter(const float* dy, float* dx, int B, int C, int h, int w, crnStream s) {
+  CRN_ENTRY(s);
   if (!dy || !dx || B < 1 || C < 1 || h < 1 || w < 2 || (w & 1) || (((uintptr_t)dx) & 15)) return CRN_EINVAL;
   const int64_t planes = (int64_t)B * C, n = planes * (2 * h) * (w >> 1);
   hipLaunchKernelGGL(stride2_scatter_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)s, dy, dx, h, w, planes);

@@ -272,6 +272,7 @@ __global__ __launch_bounds__(kTMax * kTMax) void ray_sample_bwd_kernel(
 extern "C" int crn_ray_sample_fwd(const float* map, int64_t map_sB, int64_t map_sC, int64_t map_sP, int B, int C,
                                   int h, int w, const float* matrix, const float* offset, float* out,
                                   int64_t out_sB, int D, int H, int W, crnStream stream) {
+  CRN_ENTRY(stream);
   hipStream_t st = (hipStream_t)stream;
   if (!map || !out || B < 1 || C < 1 || h < 1 || w < 1 || D < 1 || H < 1 || W < 1 || map_sC < 1 || map_sP < 1)
     return CRN_EINVAL;
@@ -295,6 +296,7 @@ extern "C" int crn_ray_sample_fwd(const float* map, int64_t map_sB, int64_t map_
 extern "C" int crn_ray_sample_bwd(const float* dout, int64_t dout_sB, int B, int C, int D, int H, int W,
                                   const float* matrix, const float* offset, float* dmap,
                                   int64_t dmap_sB, int h, int w, int zero_first, crnStream stream) {
+  CRN_ENTRY(stream);
   hipStream_t st = (hipStream_t)stream;
   if (!dout || !dmap || B < 1 || C < 1) return CRN_EINVAL;
   if (zero_first) {

@@ -162,6 +162,7 @@ __global__ void transform_meshes_kernel(const float* __restrict__ tri, const int
 
 extern "C" int crn_transform_meshes(const float* triangles, const int32_t* tri_mesh, int T, const float* mesh_matrix,
                                     int M, float* out, crnStream stream) {
+  CRN_ENTRY(stream);
   hipStream_t st = (hipStream_t)stream;
   if (T < 0 || M < 0 || (T > 0 && (!triangles || !tri_mesh || !mesh_matrix || !out))) return CRN_EINVAL;
   if (T == 0) return CRN_OK;
@@ -175,6 +176,7 @@ extern "C" int crn_transform_meshes(const float* triangles, const int32_t* tri_m
 extern "C" int crn_voxelize_mesh(const float* triangles, const int32_t* tri_mesh, int T, const float* view2voxel,
                                  int M, int D, int H, int W, int sub_grid_side, float image_resolution_multiplier,
                                  int conservative, int depth_multiplier, float* grid, crnStream stream) {
+  CRN_ENTRY(stream);
   hipStream_t st = (hipStream_t)stream;
   if (!grid || M < 1 || D < 1 || H < 1 || W < 1 || T < 0) return CRN_EINVAL;
   if (sub_grid_side > 0 && (sub_grid_side % 2 == 0)) return CRN_EINVAL;   // voxelization.py:107-109
@@ -195,6 +197,7 @@ extern "C" int crn_voxelize_mesh(const float* triangles, const int32_t* tri_mesh
 
 extern "C" int crn_merge_labels(const float* meshes_grid, const int32_t* scene_mesh_start, const int32_t* mesh_label,
                                 int B, int D, int H, int W, int sub_grid, int32_t* out, crnStream stream) {
+  CRN_ENTRY(stream);
   hipStream_t st = (hipStream_t)stream;
   if (!meshes_grid || !out || B < 1) return CRN_EINVAL;
   const int64_t S = (int64_t)D * H * W;

@@ -118,8 +118,10 @@ class CoreNet(nn.Module):
   """Image to 3D reconstruction with CoReNet (MI355X-native)."""
 
   def __init__(self, config, device: Optional[str] = None, backend=None, decoder_math: Optional[str] = None):
-    """decoder_math: "fp32" (default; also env CRN_DECODER_MATH) or "bf16x3" -- the big decoder convolutions on
-    the split-bf16 MFMA engine (engine.BF16X3_LAUNCHES), a throughput mode with ~3e-6 relative error per layer."""
+    """decoder_math: "bf16x3" (default on the GPU; also env CRN_DECODER_MATH) -- the big decoder convolutions and the
+    encoder's 3x3 layers on the split-bf16 MFMA engines (engine.BF16X3_LAUNCHES), ~3e-6 relative error per layer,
+    inside the 1e-3 logits tolerance on every reference fixture -- or "fp32": every convolution on the fp32 MFMA
+    engine, the reference's own arithmetic, at half the speed."""
     super().__init__()
     self.config = config
     dc = config.decoder

@@ -194,9 +194,14 @@ class Engine:
       from corenet_amd.backend import default_backend
       backend = default_backend()
     self.be = backend
-    # "fp32": v_mfma_f32_16x16x4_f32 everywhere (the parity default, the reference is fp32 end to end);
-    # "bf16x3": BF16X3_LAUNCHES run as three bf16 MFMAs per product with fp32 accumulation (throughput mode)
-    self.decoder_math = decoder_math or os.environ.get("CRN_DECODER_MATH", "fp32")
+    # "bf16x3" (default on the GPU): BF16X3_LAUNCHES and the encoder's 3x3 layers multiply operands split into two bf16
+    #   terms -- three bf16 MFMAs per product, fp32 accumulation, ~2^-16 relative per product.  Signed off as the product
+    #   default in round 3: eval logits 1e-4 against the oracle on every voxel at the bench batch for
+    #   C=2 and C=14, train logits within north_star's 1e-3 on every reference fixture, every parameter gradient of the
+    #   well-conditioned fixture element by element (tests/test_model_gpu.py) -- and it is what bench.py measures.
+    # "fp32": v_mfma_f32_16x16x4_f32 everywhere, the reference's own arithmetic (it is fp32 end to end); half the speed.
+    default_math = "bf16x3" if getattr(backend, "name", "") == "hip" else "fp32"
+    self.decoder_math = decoder_math or os.environ.get("CRN_DECODER_MATH", default_math)
     if self.decoder_math not in ("fp32", "bf16x3"):
       raise ValueError(f"decoder_math must be 'fp32' or 'bf16x3', not {self.decoder_math!r}")
     # in bf16x3 mode the encoder's stride-1 1x1 / 3x3 convs (forward and data gradient) run on the encoder
@@ -226,6 +231,23 @@ class Engine:
     self.adam_hyper: Optional[t.Tensor] = None
     self.dgrad_dirty = True
     self.weights_dirty = True
+    self._side = False             # created on first use (side_stream)
+    self._pack_ev = self._dgrad_packed = self._dec_packed = self._enc_late_packed = None
+    self._enc_late_pending = False     # the side stream still owes the main stream: encoder stage 3-5 weights,
+    self._dec_pack_pending = False     # ... the decoder's forward weights,
+    self._dgrad_pack_pending = False   # ... the data-gradient weights;
+    self._gpacked_zeroed = False       # the packed gradient slab was zeroed (on the side stream) for the next backward
+
+  def side_stream(self):
+    """The engine's second HIP stream (weight gradients, weight packs, gradient buckets) or None (CPU emulator,
+    CRN_SIDE_STREAM=0); one per engine, shared by the plans of all batch sizes."""
+    if self._side is False:
+      use = self.device.type == "cuda" and os.environ.get("CRN_SIDE_STREAM", "1") != "0"
+      self._side = t.cuda.Stream(device=self.device) if use else None
+      if use:
+        self._pack_ev, self._dgrad_packed = t.cuda.Event(), t.cuda.Event()
+        self._dec_packed, self._enc_late_packed = t.cuda.Event(), t.cuda.Event()
+    return self._side
 
   # ------------------------------------------------------------------ layers
   def _bn(self, prefix: str) -> BN:
@@ -591,19 +613,14 @@ class Plan:
     self.offset = f(B, 3)
     self.loss = f(1)
     self.gt = t.zeros(B, 128, 128, 128, dtype=t.int32, device=dev)
-    use_side = t.device(dev).type == "cuda" and os.environ.get("CRN_SIDE_STREAM", "1") != "0"
-    self.side = t.cuda.Stream(device=dev) if use_side else None
+    # the side stream, the events of the weight packs and their "pending" flags belong to the ENGINE: packed weights
+    # and the packed gradient slab are shared by the plans of all batch sizes (forward(B=4), forward+backward(B=2),
+    # backward(B=4) must see one consistent state)
+    self.side = eng.side_stream()
+    use_side = self.side is not None
     self._side_ev, self._side_i = [], 0
     self._side_done = t.cuda.Event() if use_side else None
     self._bucket_ev = [t.cuda.Event() for _ in GRAD_BUCKET_LABELS] if use_side else None
-    self._pack_ev = t.cuda.Event() if use_side else None
-    self._dgrad_packed = t.cuda.Event() if use_side else None
-    self._dec_packed = t.cuda.Event() if use_side else None
-    self._enc_late_packed = t.cuda.Event() if use_side else None
-    self._enc_late_pending = False
-    self._dgrad_pack_pending = False
-    self._dec_pack_pending = False
-    self._gpacked_zeroed = False
 
   # ------------------------------------------------------------------ cached views
   def _cached(self, key, fn):
@@ -735,22 +752,22 @@ class Plan:
       dec_later = eng.weights_dirty
       if dec_later:
         eng.pack_weights("enc_early")             # stem + stage2 (0.2 M weights): needed at once
-      self._pack_ev.record()                      # the parameters are final on the main stream
+      eng._pack_ev.record()                      # the parameters are final on the main stream
       with t.cuda.stream(self.side), _lib.pinned_stream(self.side):
-        self.side.wait_event(self._pack_ev)
+        self.side.wait_event(eng._pack_ev)
         if dec_later:
           eng.pack_weights("enc_late")            # stage3-5 (23 M): needed ~0.5 ms into the encoder
-          self._enc_late_packed.record(self.side)
+          eng._enc_late_packed.record(self.side)
           eng.pack_weights("dec")
-          self._dec_packed.record(self.side)
+          eng._dec_packed.record(self.side)
         if eng.dgrad_dirty:
           eng.pack_dgrad_weights()
         be.zero(eng.gpacked)
-        self._dgrad_packed.record(self.side)
-      self._dgrad_pack_pending = True
-      self._dec_pack_pending = dec_later
-      self._enc_late_pending = dec_later
-      self._gpacked_zeroed = True
+        eng._dgrad_packed.record(self.side)
+      eng._dgrad_pack_pending = True
+      eng._dec_pack_pending = dec_later
+      eng._enc_late_pending = dec_later
+      eng._gpacked_zeroed = True
     elif eng.weights_dirty:
       eng.pack_weights()
     cv, bn = eng.convs, eng.bns
@@ -766,9 +783,9 @@ class Plan:
     be.maxpool_fwd(self.y1, b1.scale, b1.shift, B, 64, 128, 128, self.p1, self.p1_arg)
     cur = self.p1
     for blk in self.blocks:
-      if self._enc_late_pending and blk["stage"] != "stage2":
-        t.cuda.current_stream().wait_event(self._enc_late_packed)
-        self._enc_late_pending = False
+      if eng._enc_late_pending and blk["stage"] != "stage2":
+        t.cuda.current_stream().wait_event(eng._enc_late_packed)
+        eng._enc_late_pending = False
       cur = self._block_fwd(blk, cur, training)
     f5 = self.feat["stage5"]
     be.relu_mean_fwd(f5, B, 2048, 64, f5.stride(0), self.avg)
@@ -778,9 +795,9 @@ class Plan:
     eng, be, B = self.eng, self.be, self.B
     cv, bn = eng.convs, eng.bns
     self.generation += 1
-    if self._dec_pack_pending:
-      t.cuda.current_stream().wait_event(self._dec_packed)
-      self._dec_pack_pending = False
+    if eng._dec_pack_pending:
+      t.cuda.current_stream().wait_event(eng._dec_packed)
+      eng._dec_pack_pending = False
     self.offset.copy_(offset)
     # layer matrices v2s @ scale(128 / r) for the four skip grids (reconstruction_decoder.py:111-116)
     v = v2s.to(self.layer_mats.dtype).reshape(1, B, 4, 4)
@@ -896,14 +913,14 @@ class Plan:
     eng, be, B = self.eng, self.be, self.B
     cv, bn = eng.convs, eng.bns
     assert self.training, "backward needs a training-mode forward"
-    if self._dgrad_pack_pending:
-      t.cuda.current_stream().wait_event(self._dgrad_packed)
-      self._dgrad_pack_pending = False
+    if eng._dgrad_pack_pending:
+      t.cuda.current_stream().wait_event(eng._dgrad_packed)
+      eng._dgrad_pack_pending = False
     elif eng.dgrad_dirty:
       eng.pack_dgrad_weights()
-    if not self._gpacked_zeroed:
+    if not eng._gpacked_zeroed:
       be.zero(eng.gpacked)
-    self._gpacked_zeroed = False
+    eng._gpacked_zeroed = False
     be.zero(self.gsmap_slab)                       # the four skip-map gradients: one launch instead of four memsets
     if grad_hook is None and self.side is not None and self.trace is None:
       grad_hook = _no_exchange                     # un-pack the finished buckets on the side stream all the same

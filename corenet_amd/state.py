@@ -24,25 +24,54 @@ class FusedAdam:
     self.model = model
     self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False,
                               params=list(range(len(model._param_keys))))]
+    self.gather_copies = 0
+
+  # -- torch.optim.Optimizer surface used by the reference's train loop (pipeline.py:224-230) --
+  def _shared_grad_slab(self, params):
+    """The ONE tensor all `.grad`s are slices of, laid out like the engine's slab -- or None.  After loss.backward()
+    the gradients are per-parameter views of one slab-shaped clone (core_net._CoreNetFn._backward); AccumulateGrad
+    stores `new_grad.detach()`, which drops `._base`, so the views are recognised by their storage: same
+    untyped storage, contiguous, and storage offsets that differ from the slab offsets by one constant."""
+    store = self.model.engine.store
+    g0 = params[0].grad
+    if g0 is None or g0.dtype != store.grads.dtype or g0.device != store.grads.device:
+      return None
+    st = g0.untyped_storage()
+    c0 = g0.storage_offset() - store.offset(self.model._param_keys[0])
+    n = store.grads.numel()
+    if c0 < 0 or (c0 + n) * g0.element_size() > st.nbytes():
+      return None
+    sp = st.data_ptr()
+    for p, k in zip(params, self.model._param_keys):
+      g = p.grad
+      if (g is None or g.dtype != g0.dtype or not g.is_contiguous() or g.untyped_storage().data_ptr() != sp
+          or g.storage_offset() - store.offset(k) != c0):
+        return None
+    return t.empty(0, dtype=g0.dtype, device=g0.device).set_(st, c0, (n,))
 
   # -- torch.optim.Optimizer surface used by the reference's train loop (pipeline.py:224-230) --
   def zero_grad(self, set_to_none: bool = False):
     """torch 1.7 semantics by default (zero in place, pipeline.py:225); like torch.optim, the gradients are the
     parameters' `.grad` tensors -- the engine's slab is only the staging area of step()."""
-    for p in self.model.parameters():
-      if p.grad is not None:
-        if set_to_none:
-          p.grad = None
-        else:
-          p.grad.detach_()
-          p.grad.requires_grad_(False)
-          p.grad.zero_()
+    params = [self.model.get_parameter(k) for k in self.model._param_keys]
+    flat = None if set_to_none else self._shared_grad_slab(params)
+    if flat is not None:
+      flat.zero_()                                  # one launch instead of ~270
+    else:
+      for p in params:
+        if p.grad is not None:
+          if set_to_none:
+            p.grad = None
+          else:
+            p.grad.detach_()
+            p.grad.requires_grad_(False)
+            p.grad.zero_()
     self.model.engine.store.grads.zero_()
 
   def _gather_grads(self):
     """`.grad` of the model's parameters -> the engine's flat gradient slab.  After loss.backward() the
-    gradients are views of one slab-shaped tensor (core_net._CoreNetFn.backward): one copy; anything else
-    (gradients replaced by the user, DistributedDataParallel buckets with gradient_as_bucket_view, ...) is
+    gradients are views of one slab-shaped tensor (_shared_grad_slab): one copy; anything else (gradients
+    replaced by the user, DistributedDataParallel buckets with gradient_as_bucket_view, ...) is
     copied per parameter.  Parameters without a gradient are skipped by torch.optim.Adam; the fused kernel
     steps the whole slab, so they get a zero gradient (their moments decay like Adam's would not -- the
     reference never trains with frozen parameters)."""
@@ -51,20 +80,19 @@ class FusedAdam:
     params = [self.model.get_parameter(k) for k in self.model._param_keys]
     if all(p.grad is None for p in params):
       return                                        # the fused path (CoreNet.train_step) wrote the slab itself
-    base = params[0].grad._base if params[0].grad is not None else None
-    if base is not None and base.shape == slab.shape and base.dtype == slab.dtype and all(
-        p.grad is not None and p.grad._base is base and p.grad.is_contiguous()
-        and p.grad.storage_offset() - base.storage_offset() == store.offset(k)
-        for p, k in zip(params, self.model._param_keys)):
-      if base.data_ptr() != slab.data_ptr():
-        slab.copy_(base)
+    flat = self._shared_grad_slab(params)
+    if flat is not None:
+      if flat.data_ptr() != slab.data_ptr():
+        slab.copy_(flat)
+      self.gather_copies = 1                        # (observable by tests)
       return
+    self.gather_copies = 0
     for p, k in zip(params, self.model._param_keys):
       v = store.view(k, grad=True)
       if p.grad is None:
         v.zero_()
       elif p.grad.data_ptr() != v.data_ptr():
-        v.copy_(p.grad)
+        v.copy_(p.grad); self.gather_copies += 1
 
   def step(self, grad_scale: float = 1.0):
     g = self.param_groups[0]

@@ -97,11 +97,15 @@ int crn_conv_fwd_bf3_slabs(const crnView* x, const crnInTransform* tr, const voi
 /* A convolution that splits its reduction writes partial sums to the library's scratch and adds them up in a
  * second launch.  crn_splitk_defer(1) arms, for the NEXT convolution call of this host thread (crn_conv2d_bf3, or
  * the 1x1 path of crn_conv_fwd), the following shortcut: if that call splits and does not accumulate, the sum is
- * left pending and the next crn_batch_renorm_stats (x = the conv's output) or crn_batch_renorm_bwd (dy = the conv's
- * output) on the same stream adds the partial sums up while it loads them (stats also stores the sum to x; bwd does
- * not write dy: it is its only reader).  Any other use of the library in between completes the pending sum first, so
- * arming is always safe; it only pays when the BatchRenorm call follows directly (resnet50.py:62-69: every conv of
- * the encoder is followed by its norm; in backward every data gradient feeds the norm's backward).              */
+ * left pending (recorded per host thread, together with the stream and device the convolution ran on) and a
+ * crn_batch_renorm_stats (x = the conv's output) or crn_batch_renorm_bwd (dy = the conv's output) that follows ON THE
+ * SAME STREAM adds the partial sums up while it loads them (stats also stores the sum to x; bwd does not write dy: it
+ * is its only reader).  EVERY other entry point of this library that takes a stream -- and a BatchRenorm call on
+ * another tensor or another stream -- first completes a pending sum with an ordinary reduction launch on the
+ * convolution's own stream, so arming is always safe for callers that reach the tensor through this library on that
+ * host thread; it only pays when the BatchRenorm call follows directly (resnet50.py:62-69: every conv of the encoder is
+ * followed by its norm; in backward every data gradient feeds the norm's backward).  A caller that hands y to code
+ * OUTSIDE the library (a torch op, a memcpy) or to another host thread while a sum may be pending must not arm.   */
 int crn_splitk_defer(int on);
 
 /* Weight gradient in the same packed layout:

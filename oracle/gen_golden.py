@@ -50,7 +50,7 @@ def ref_model(num_classes, sd):
   return net
 
 
-def gen_model(tag, num_classes, nbt, batch, loss_name, training=True):
+def gen_model(tag, num_classes, nbt, batch, loss_name, training=True, store_all_grads=False):
   sd = O.make_state(seed=0, num_classes=num_classes, nbt=nbt)
   image, v2s, off, grid = O.synthetic_batch(batch, seed=0, num_classes=num_classes)
   net = ref_model(num_classes, sd)
@@ -76,11 +76,24 @@ def gen_model(tag, num_classes, nbt, batch, loss_name, training=True):
     lo_loss = getattr(O, loss_name)(grid, lo)
     lo_loss.backward()
     gn, worst = {}, 0.0
+    # A conv bias in front of a train-mode BatchRenorm has a true gradient of exactly 0; what either side holds
+    # there is summation-order noise (it depends on how many threads the machine gives torch), so the error of
+    # every parameter is taken relative to max(its own gradient scale, 1e-3 of the largest gradient of the model)
+    gmax = max(float(p.grad.abs().max()) for _, p in net.named_parameters())
     for name, p in net.named_parameters():
       gn[name] = np.float64(p.grad.double().norm().item())
-      worst = max(worst, maxrel(sd_o[name].grad, p.grad))
-    print(f"[{tag}] oracle vs reference worst param-grad max-rel = {worst:.3e}")
+      den = max(float(p.grad.abs().max()), 1e-3 * gmax)
+      worst = max(worst, float((sd_o[name].grad.double() - p.grad.double()).abs().max()) / den)
+    print(f"[{tag}] oracle vs reference worst param-grad error (of the tensor's scale) = {worst:.3e}")
     assert worst < 2e-3
+    if store_all_grads:
+      # element-wise vectors of EVERY parameter gradient (a fixed strided subsample of <= 512 elements per tensor):
+      # this fixture (B=2, num_batches_tracked=30000: r/d clamps live, statistics over two samples) is the
+      # well-conditioned one, so the whole backward pass can be pinned element by element
+      for name, p in net.named_parameters():
+        g = p.grad.reshape(-1)
+        out["gsub::" + name] = g[::max(1, -(-g.numel() // 512))].numpy().copy()
+        out["gmax::" + name] = np.float32(g.abs().max().item())
     out["grad_names"] = np.array(list(gn.keys()))
     out["grad_norms"] = np.array(list(gn.values()))
     # a few full gradients (small tensors) for direct comparison
@@ -400,6 +413,9 @@ def gen_data_path():
 
 
 if __name__ == "__main__":
+  if "--only-nbt30k" in sys.argv:
+    gen_model("h7_train_b2_nbt30k", 2, 30000, 2, "iou_fgbg", store_all_grads=True)
+    sys.exit(0)
   if "--only-super-resolution" in sys.argv:
     gen_super_resolution()
     sys.exit(0)
@@ -415,7 +431,7 @@ if __name__ == "__main__":
   gen_losses()
   gen_metrics()
   gen_model("h7_train_b1", 2, 0, 1, "iou_fgbg")
-  gen_model("h7_train_b2_nbt30k", 2, 30000, 2, "iou_fgbg")
+  gen_model("h7_train_b2_nbt30k", 2, 30000, 2, "iou_fgbg", store_all_grads=True)
   gen_model("h7_eval_b1", 2, 100, 1, "iou_fgbg", training=False)
   gen_model("m9_train_b1", 14, 0, 1, "xent_times_iou_agnostic")
   gen_super_resolution()

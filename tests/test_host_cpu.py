@@ -166,6 +166,9 @@ def test_autograd_path_with_fused_adam_two_steps():
     loss = O.iou_fgbg(grid, ma(image, v2s, off))
     loss.backward()
     opt.step()
+    # the gradients are views of ONE slab-shaped tensor: step() moves them with a single copy (the test on
+    # `._base` never fired, AccumulateGrad detaches), and zero_grad() of the second iteration zeroes that tensor once
+    assert opt.gather_copies == 1
     lb = mb.train_step(image, v2s, off, grid.to(t.int32), "iou_fgbg", lr=4e-4, adam_eps=1e-4)
     assert abs(float(loss) - float(lb)) < 1e-5 * abs(float(lb)), (step, float(loss), float(lb))
   pa, pb = ma.engine.store.params, mb.engine.store.params

@@ -321,6 +321,19 @@ def test_conv_bf16x3_fwd_dgrad(be, name, kind, wshape, pad, dims, B):
   e = float((got - want).abs().max() / want.abs().max())
   print(f"bf16x3 {name} wgrad: max-abs-err/max = {e:.2e}")
   assert e <= 2e-5, (name, "wgrad", e)
+  # ... un-packed (the scatter of corenet_amd/model/conv_geometry index), against autograd of torch's own op on
+  # the transformed input: the contract emulator is not in this comparison
+  xt = x.relu() * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)
+  wref = w.clone().requires_grad_(True)
+  if kind == "conv":
+    t.nn.functional.conv3d(xt, wref, None, padding=pad).backward(dy)
+  else:
+    t.nn.functional.conv_transpose3d(xt, wref, None, stride=2, padding=pad, output_padding=1).backward(dy)
+  gw = t.zeros(w.numel())
+  EMU.scatter(dwg.cpu(), t.as_tensor(fwd.index), gw)
+  e = float((gw.view(wshape) - wref.grad).abs().max() / wref.grad.abs().max())
+  print(f"bf16x3 {name} wgrad vs torch autograd: max-abs-err/max = {e:.2e}")
+  assert e <= 5e-5, (name, "wgrad-vs-autograd", e)
   # accumulate into an existing gradient (zero_first = False)
   dwg2 = dwg.clone()
   be.conv_wgrad(V.view_of(xg), trg, yview(dyg), dwg2, fwd.npad, fwd.window, fwd.pad_lo, False,

@@ -119,6 +119,58 @@ def test_forward_eval_b4_matches_oracle():
   assert float((logits[0] - logits[1]).abs().max()) > 0           # different images, not one sample four times
 
 
+@pytest.mark.parametrize("nc", [2, 14])
+def test_bf16x3_eval_b4_matches_oracle(nc):
+  """The HEADLINE mode of bench.py (decoder_math="bf16x3": split-bf16 MFMA in decoder stages 3-6 and the encoder's 3x3
+  layers) at the bench batch, against the oracle and not against this library's own fp32 mode: eval-mode logits, every
+  voxel, 1e-4 relative, for the h7 (C=2) and the m7 / m9 (C=14) heads.  The fp32 mode is measured beside it."""
+  sd = O.make_state(0, nc, nbt=100)
+  image, v2s, off, grid = O.synthetic_batch(4, 0, nc)
+  with t.no_grad():
+    want = O.corenet_forward({k: v.clone() for k, v in sd.items()}, image, v2s, off, training=False)
+    errs = {}
+    for math in ("bf16x3", "fp32"):
+      m = _model(nc, sd, math).eval()
+      logits = m(image.cuda(), v2s.cuda(), off.cuda())
+      assert logits.shape == (4, nc, 128, 128, 128)
+      errs[math] = max(relerr(logits[b], want[b]) for b in range(4))
+      del m
+  print(f"B=4 C={nc} eval logits vs oracle, every voxel: bf16x3 {errs['bf16x3']:.2e}, fp32 {errs['fp32']:.2e}")
+  assert errs["bf16x3"] < 1e-4 and errs["fp32"] < 1e-4, errs
+
+
+@pytest.mark.parametrize("math", ["fp32", "bf16x3"])
+def test_all_parameter_gradients_well_conditioned_fixture(math):
+  """EVERY parameter gradient, element by element, on the well-conditioned fixture (h7, B=2, num_batches_tracked =
+  30000: the r/d clamps are live and the statistics run over two samples; the reference's own fp32-vs-fp64 noise is
+  ~1e-5 here, against 3e-4 ... 5e-2 on the B=1 / nbt=0 fixtures).  The fixture stores a fixed strided subsample (<= 512
+  elements) of each of the 266 gradient tensors of the reference's backward pass (oracle/gen_golden.py) plus each
+  tensor's max; the error of a tensor is max |got - want| over the stored elements relative to max(the tensor's own
+  scale, 1e-3 of the model's largest gradient) -- conv biases in front of a train-mode norm have a true gradient of 0."""
+  from corenet_amd.model import losses
+  z = np.load(os.path.join(G, "model_h7_train_b2_nbt30k.npz"))
+  m = _model(2, O.make_state(0, 2, nbt=30000), math).train()
+  image, v2s, off, grid = O.synthetic_batch(2, 0, 2)
+  loss = losses.iou_fgbg(grid.cuda(), m(image.cuda(), v2s.cuda(), off.cuda()))
+  loss.backward()
+  gmax = max(float(z[k]) for k in z.files if k.startswith("gmax::"))
+  errs = {}
+  for name, p in m.named_parameters():
+    want = t.as_tensor(z["gsub::" + name]).double()
+    g = p.grad.reshape(-1)
+    got = g[::max(1, -(-g.numel() // 512))].double().cpu()
+    assert got.shape == want.shape, name
+    errs[name] = float((got - want).abs().max()) / max(float(z["gmax::" + name]), 1e-3 * gmax)
+  worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+  print(f"[{math}] all {len(errs)} parameter gradients, worst element-wise errors (of the tensor's scale): " +
+        ", ".join(f"{k} {v:.2e}" for k, v in worst))
+  # measured on MI355X (round 3): see the printed line; the bar leaves ~4x head room over the worst tensor
+  assert len(errs) == 266 and worst[0][1] < ALL_GRAD_TOL[math], worst
+
+
+ALL_GRAD_TOL = {"fp32": 2e-3, "bf16x3": 2e-3}
+
+
 # element-wise bars of the five full gradients the fixtures store (oracle/gen_golden.py:87-90), by depth of the
 # tensor below the loss: last layer / its norm / the 64^3 skip compression (through stage_6) / the latent bias
 # (through the whole decoder; BatchRenorm over B=1 has zero gradient there).  The reference itself moves by
