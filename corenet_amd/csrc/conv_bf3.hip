@@ -29,12 +29,14 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 using namespace crnk;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 512, kMSUB = 4, kCK = 8;
 constexpr int kNUX = 2;          // patch units (2 positions x 8 channels) per thread
@@ -65,6 +67,8 @@ struct Bf3Geom {
   signed char n_box[8][6], c_box[8][6];
   unsigned magic_pw2, magic_PH, magic_kw;
   const void* wslab;       // weights pre-arranged as slab images (crn_bf3_operands, slab order), or nullptr: w is staged
+  int UP;                  // wave-specialised kernel: staging units per patch plane (PH * pw2)
+  unsigned magic_UP;
   int dbg;
   long long* stamps;       // tuning aid (CRN_BF3_STAMPS=1): shader-clock stamps of workgroup 0, 4 per staging step
 };
@@ -78,6 +82,20 @@ __device__ __forceinline__ void wait_loads2d(VT (&v)[A][B]) {
   for (int i = 0; i < A; ++i)
 #pragma unroll
     for (int j = 0; j < B; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[i][j]));
+}
+
+template <int N, typename VT, int A, int B>
+__device__ __forceinline__ void wait_loads2d_n(VT (&v)[A][B]) {      // ... until at most N (newer) loads are outstanding
+#pragma unroll
+  for (int i = 0; i < A; ++i)
+#pragma unroll
+    for (int j = 0; j < B; ++j) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v[i][j]) : "n"(N));
+}
+
+template <int N, typename VT, int A>
+__device__ __forceinline__ void wait_loads1d_n(VT (&v)[A]) {
+#pragma unroll
+  for (int i = 0; i < A; ++i) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v[i]) : "n"(N));
 }
 
 // x = hi + lo with hi = bf16(x) (round to nearest even), lo = bf16(x - hi)
@@ -469,6 +487,355 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
   }
 }
 
+template <typename G>
+__host__ __device__ __forceinline__ void bf3_chunk_zrange(const G& g, const TapBox& nbox, int c0, int& z0, int& z1) {
+  const int chi = (c0 + kCK < g.x.C ? c0 + kCK : g.x.C) - 1;
+  const TapBox tb = box_intersect(nbox, box_union(g.c_box, g.c_groups, g.x.C, c0, chi, g.kd, g.kh, g.kw));
+  z0 = tb.d0; z1 = tb.d1;
+  if (tb.h1 <= tb.h0 || tb.w1 <= tb.w0) z1 = z0;
+}
+
+// ------------------------------------ wave-specialised forward / data gradient --------------------------------
+// The kernel above spends ~55 % of a staging step outside its MFMA phase, and what it waits for is not work but the
+// ~2 us (4-5 k cycles) a global load takes to come back on a busy chip: every wave issues its loads, multiplies for
+// ~2.9 k cycles, waits for the rest of the latency, commits, and sits in two barriers (T ~ T_mfma + T_staging even with
+// two workgroups per CU; ablations of a first role-split version: producer chain alone 4.9 k cycles per step,
+// consumers alone 5.4 k with compiler-scheduled LDS reads -- profiles/r03_ws_ablate.txt).  Here:
+//   * ONE workgroup of 12 waves per CU.  Waves 0-7 ("consumers") only multiply: one (chunk, window plane) step after
+//     the other, ONE barrier per step, operand fragments of the next tap group read from LDS before the MFMAs of the
+//     current one issue (two waves per SIMD cannot hide an LDS round trip per MFMA triple the way four did).  They also
+//     own the weights: while it multiplies step n, a wave copies its share of step n+1's slab from the pre-arranged
+//     slab image (L2-resident) into the idle one of two slab buffers by LDS-DMA (buffer_load ... lds: no registers,
+//     no VALU), and waits for it at the end of the step.
+//   * Waves 8-11 ("producers", one per SIMD) own the activations.  The input patch is a RING of 8 window planes
+//     ([position][8 ch] bf16 hi / lo images like above); step n = (chunk c, plane zd) reads planes zd .. zd+3 of the
+//     chunk's PD = kd + 3.  Plane p of chunk c is written the moment the plane it replaces is dead, on a fixed
+//     timetable: during the step f(p) - 3 steps away from the chunk's first, f = 0,1,2,2,3,3,4,5 -- at most two
+//     planes = 240 staging units per step, one unit (2 positions x 8 channels) per producer lane.  Its global loads
+//     are issued TWO steps before that into one of three register sets, so a load has two whole steps (~6 k cycles)
+//     to come back and a producer never waits: wait (counted vmcnt: the two younger sets stay in flight) ->
+//     BatchRenorm-apply + ReLU + split -> LDS, ~1 k cycles of a 2.9 k cycle step.
+//     Ring slot of plane p of the c-th chunk: (PD * c + p) mod 8 -- p itself for the 5^3 windows (PD = 8), a rotating
+//     slot for the 4^3 windows (PD = 7).  That no step reads a slot a concurrent write touches follows from the
+//     timetable (bf3_ws_timetable_ok runs it on the host for every launch geometry).
+//   * Tap boxes (transposed convolutions): the timetable ignores them -- every chunk stages all its planes -- and the
+//     consumers skip the MFMAs of steps whose window plane holds only structural zeros.
+// Same products, same summation order as the kernel above: bit-identical results.
+constexpr int kWsConsumers = 8, kWsProducers = 4;
+constexpr int kWsThreads = (kWsConsumers + kWsProducers) * 64, kWsPL = kWsProducers * 64;
+constexpr int kWsR = 8;                                        // planes of the patch ring
+
+// planes whose ring write (commit) happens in iteration T (T = kd*c + f(p)): up to two (chunk-in-split, plane) pairs
+struct Bf3WsPlanes { int n, c0, p0, c1, p1; };
+template <int KD>
+__host__ __device__ __forceinline__ Bf3WsPlanes bf3_ws_planes_at(int T, int nch) {
+  Bf3WsPlanes w{0, 0, 0, 0, 0};
+  if (T < 0) return w;
+  const int q = T / KD, r = T - q * KD;
+  int ca = q, pa = 6, cb = -1, pb = 0;                         // (r == 4, KD == 5 only: plane 6)
+  if (r == 0) { pa = 0; cb = q - 1; pb = KD + 2; }
+  else if (r == 1) pa = 1;
+  else if (r == 2) { pa = 2; cb = q; pb = 3; }
+  else if (r == 3) { pa = 4; cb = q; pb = 5; }
+  const bool va = ca >= 0 && ca < nch, vb = cb >= 0 && cb < nch;
+  if (va) { w.c0 = ca; w.p0 = pa; w.n = 1; if (vb) { w.c1 = cb; w.p1 = pb; w.n = 2; } }
+  else if (vb) { w.c0 = cb; w.p0 = pb; w.n = 1; }
+  return w;
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int NSUB, int XM, int NG>
+__global__ __launch_bounds__(kWsThreads) void conv_bf3_ws_kernel(Bf3Geom g) {
+  crn_kernarg_touch(g);
+  constexpr int NB = NSUB * 16;
+  constexpr int KD = NG == 7 ? 5 : 4, PD = KD + 3;             // 5^3 / 4^3 windows on 4 x 8 x 16 tiles
+  constexpr int kSlab = NG * 4 * NB;                           // weight items (hi 16 B + lo 16 B) per slab
+  static_assert(kSlab % 64 == 0, "a slab is a whole number of 64-lane DMA instructions");
+  constexpr int kSlabI = kSlab / 64;                           // LDS-DMA instructions per slab half (hi / lo)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned* choff = reinterpret_cast<unsigned*>(smem);                    // [ctab]
+  float* tscale = reinterpret_cast<float*>(smem + g.ctab * 4);            // [ctab]
+  float* tshift = reinterpret_cast<float*>(smem + 2 * g.ctab * 4);        // [ctab]
+  int* zrtab = reinterpret_cast<int*>(smem + 3 * g.ctab * 4);              // [64] z range (z0 | z1 << 8) of a chunk
+  bf16x8* Ahi = reinterpret_cast<bf16x8*>(smem + 3 * g.ctab * 4 + 256);   // [8][PHW]
+  bf16x8* Alo = Ahi + kWsR * g.PHW;
+  bf16x8* Bhi = Alo + kWsR * g.PHW;                                       // [2][NG*4][NB]
+  bf16x8* Blo = Bhi + 2 * kSlab;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kk = lane >> 4;
+  const bool producer = wave >= kWsConsumers;
+  typedef typename XLoad<XM>::T XT;
+
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int twi = tile % g.tilesW; tile /= g.tilesW;
+  const int thi = tile % g.tilesH; tile /= g.tilesH;
+  const int tdi = tile % g.tilesD; tile /= g.tilesD;
+  const int b = tile;
+  const int d0 = tdi * g.TD, h0 = thi * g.TH, w0 = twi * g.TW;
+  const int n0 = blockIdx.y * NB;
+  const int split = blockIdx.z;
+  const int cbeg = split * g.chunks_per_split, cend = min(cbeg + g.chunks_per_split, g.nchunks);
+  const int nch = cend - cbeg, nsteps = nch * KD;
+  const int niter = (nsteps + 3 + 2) / 3 * 3;        // iterations (= barriers) of both roles: a multiple of three
+
+  for (int c = tid; c < g.ctab; c += kWsThreads) {
+    const int cc = min(c, g.x.C - 1);
+    choff[c] = g.x.chan_off ? (unsigned)g.x.chan_off[cc] : (unsigned)cc * (unsigned)g.x.sC;
+    tscale[c] = g.tr.scale ? (c < g.x.C ? g.tr.scale[cc] : 0.f) : 1.f;      // (channels past C are loaded as 0 and stay 0)
+    tshift[c] = g.tr.scale && c < g.x.C ? g.tr.shift[cc] : 0.f;
+  }
+
+  if (tid < nch) {       // window planes of each chunk that can hold non-zero weights (tap boxes of transposed convs)
+    const TapBox nbox = box_union(g.n_box, g.n_groups, g.y.C, n0, min(n0 + NB, g.y.C) - 1, g.kd, g.kh, g.kw);
+    int z0, z1;
+    bf3_chunk_zrange(g, nbox, (cbeg + tid) * kCK, z0, z1);
+    zrtab[tid] = z0 | (z1 << 8);
+  }
+  __syncthreads();       // the tables are in LDS (the producers read them before the first barrier of the loops)
+
+  if (producer) {
+    // ------------------------------------------------ producers ------------------------------------------------
+    // (the producer is the youngest wave of its SIMD and would lose every issue arbitration against the two consumers:
+    // its ~300 VALU / LDS / VMEM instructions per step took 4-5 k cycles that way -- more than the step; with priority
+    // they slot in between the MFMAs, which issue from their own pipe)
+    if (g.dbg != 6) __builtin_amdgcn_s_setprio(3);
+    const int ptid = tid - kWsConsumers * 64;
+    const crn_rsrc xrs = make_rsrc(g.x.base + (int64_t)b * g.x.sB);
+    XT pv[3][kCK];
+    unsigned inm[3] = {0, 0, 0};
+    // this lane's unit of an iteration's (up to two) planes: plane pz = ptid / UP, patch row, position pair
+    const int pz = ptid >= g.UP ? 1 : 0, ru = ptid - pz * g.UP;
+    const int row = mdiv(ru, g.magic_pw2), pr = ru - row * g.pw2;
+    const int gh = h0 + row - g.ph, gw = w0 + 2 * pr - g.pw;
+    const bool in_hw = ru < g.UP && (unsigned)gh < (unsigned)g.x.H && (unsigned)gw < (unsigned)g.x.W;
+    const unsigned sp_hw = (unsigned)gh * (unsigned)g.x.sH + (unsigned)gw * (unsigned)(XM == 2 ? 2 : 1);
+    const int lpos_hw = row * g.PW + 2 * pr;
+    auto issue = [&](int T, XT (&pvs)[kCK], unsigned& msk) {                // loads of the planes committed at T
+      const Bf3WsPlanes w = bf3_ws_planes_at<KD>(T, nch);
+      const int c = pz ? w.c1 : w.c0, p = pz ? w.p1 : w.p0;
+      const int gd = d0 + p - g.pd;
+      const bool ld = pz < w.n && in_hw && (unsigned)gd < (unsigned)g.x.D && g.dbg != 5;
+      msk = ld ? 1u : 0u;
+      const int c0 = (cbeg + c) * kCK;
+      const unsigned sp = (unsigned)gd * (unsigned)g.x.sD + sp_hw;
+      // the chunk's eight channel offsets: two 16-byte LDS reads (one address for the whole plane)
+      const u32x4 co0 = *reinterpret_cast<const u32x4*>(choff + c0), co1 = *reinterpret_cast<const u32x4*>(choff + c0 + 4);
+      unsigned off[kCK];
+#pragma unroll
+      for (int cl = 0; cl < kCK; ++cl)
+        off[cl] = (ld && c0 + cl < g.x.C) ? ((cl < 4 ? co0[cl & 3] : co1[cl & 3]) + sp) * 4u : 0x80000000u;
+#pragma unroll
+      for (int cl = 0; cl < kCK; ++cl) XLoad<XM>::load(pvs[cl], xrs, off[cl]);
+    };
+    auto commit = [&](int T, XT (&pvs)[kCK], unsigned msk) {
+      const Bf3WsPlanes w = bf3_ws_planes_at<KD>(T, nch);
+      if (pz < w.n && ru < g.UP) {
+        const int c = pz ? w.c1 : w.c0, p = pz ? w.p1 : w.p0;
+        const int c0 = (cbeg + c) * kCK;
+        float v0[kCK], v1[kCK];
+#pragma unroll
+        for (int cl = 0; cl < kCK; ++cl) { v0[cl] = XLoad<XM>::e0(pvs[cl]); v1[cl] = XLoad<XM>::e1(pvs[cl]); }
+        if (g.tr.scale && msk) {                                            // zero padding stays zero
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(tscale + c0), s1 = *reinterpret_cast<const f32x4*>(tscale + c0 + 4);
+          const f32x4 h0 = *reinterpret_cast<const f32x4*>(tshift + c0), h1 = *reinterpret_cast<const f32x4*>(tshift + c0 + 4);
+#pragma unroll
+          for (int cl = 0; cl < kCK; ++cl) {
+            const float sc = cl < 4 ? s0[cl & 3] : s1[cl & 3], sh = cl < 4 ? h0[cl & 3] : h1[cl & 3];
+            float a = v0[cl], e = v1[cl];
+            if (g.tr.pre_relu) { a = fmaxf(a, 0.f); e = fmaxf(e, 0.f); }
+            a = a * sc + sh; e = e * sc + sh;
+            if (g.tr.post_relu) { a = fmaxf(a, 0.f); e = fmaxf(e, 0.f); }
+            v0[cl] = a; v1[cl] = e;
+          }
+        }
+        bf16x8 h0v, l0v, h1v, l1v;
+        split8(v0, h0v, l0v);
+        split8(v1, h1v, l1v);
+        const int lpos = ((PD * c + p) & (kWsR - 1)) * g.PHW + lpos_hw;
+        Ahi[lpos] = h0v; Ahi[lpos + 1] = h1v;
+        Alo[lpos] = l0v; Alo[lpos + 1] = l1v;
+      }
+    };
+    // iteration t: issue the loads of the planes committed at t + 2 into set (t + 2) % 3, then commit the planes of
+    // t from set t % 3 once only the two younger sets are still outstanding (every set is always issued in full --
+    // lanes without a unit use the out-of-range offset -- so the count is a constant)
+    const bool pstamp = g.stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && ptid == 0;
+    auto pmark = [&](int t, int i) { if (pstamp && t < 24) g.stamps[t * 8 + i] = (long long)__builtin_amdgcn_s_memtime(); };
+    auto stage = [&](int t, auto S_) {
+      constexpr int S = decltype(S_)::value;                   // = t mod 3
+      pmark(t, 4);
+      issue(t + 2, pv[(S + 2) % 3], inm[(S + 2) % 3]);
+      pmark(t, 5);
+      wait_loads1d_n<2 * kCK>(pv[S]);
+      pmark(t, 6);
+      if (g.dbg != 4) commit(t, pv[S], inm[S]);
+      pmark(t, 7);
+    };
+    issue(0, pv[0], inm[0]);                                   // the pipeline is two iterations deep before the loop
+    issue(1, pv[1], inm[1]);
+    // three iterations per trip, straight-line: registers with loads in flight must never meet a control-flow merge
+    // (the compiler would be free to copy them there, before the data has landed)
+    for (int t = 0; t < niter; t += 3) {
+      __syncthreads();
+      stage(t, std::integral_constant<int, 0>());
+      __syncthreads();
+      stage(t + 1, std::integral_constant<int, 1>());
+      __syncthreads();
+      stage(t + 2, std::integral_constant<int, 2>());
+    }
+    return;
+  }
+
+  // -------------------------------------------------- consumers --------------------------------------------------
+  int toff[NG];
+  int pa[kMSUB];
+  int sd_w = 0;
+  f32x4 acc[kMSUB][NSUB];
+#pragma unroll
+  for (int gq = 0; gq < NG; ++gq) {
+    const int t = gq * 4 + kk < g.KHW ? gq * 4 + kk : 0;       // slots past the window carry zero weights
+    const int zh = mdiv(t, g.magic_kw), zw = t - zh * g.kw;
+    toff[gq] = zh * g.PW + zw;
+  }
+  {
+    const int ri = i16 / g.mw, rj = i16 - ri * g.mw;
+#pragma unroll
+    for (int ms = 0; ms < kMSUB; ++ms) {
+      int s_ = wave * kMSUB + ms;
+      const int sw = s_ % g.nsw; s_ /= g.nsw;
+      const int sh = s_ % g.nsh;
+      sd_w = s_ / g.nsh;                                       // (nsw * nsh is a multiple of kMSUB: the same for all ms)
+      pa[ms] = (sh * g.mh + ri) * g.PW + sw * g.mw + rj + g.lead;
+    }
+  }
+#pragma unroll
+  for (int ms = 0; ms < kMSUB; ++ms)
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) acc[ms][ns] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // (inline asm: hipcc does not know these loads write LDS, so it neither drains them before the ds_reads of the
+  // current step -- which read the OTHER slab buffer -- nor before the barrier; the wait is the explicit vmcnt(0) at
+  // the end of the step.  M0 = LDS byte address of the 1 KiB piece; lane l lands at +16*l.)
+  const crn_rsrc wsrs = make_rsrc(reinterpret_cast<const float*>(g.wslab));
+  const unsigned lds_bhi = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(Bhi);
+  const unsigned lds_blo = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(Blo);
+  auto slab_dma = [&](int n) {                                 // the slab of step n -> slab buffer n & 1
+    const int c = n / KD, zd = n - c * KD;
+    const unsigned sbase = (unsigned)((cbeg + c) * g.kd + zd) * (unsigned)(NG * 4);
+    const unsigned bufo = (unsigned)((n & 1) * kSlab * 16);
+#pragma unroll
+    for (int j = 0; j < (kSlabI + kWsConsumers - 1) / kWsConsumers; ++j) {
+      const int piece = wave + j * kWsConsumers;               // wave-uniform
+      if (piece < kSlabI) {
+        const int it = piece * 64 + lane;
+        const int nn = it & (NB - 1), tp = it / NB;
+        const unsigned off = n0 + nn < g.Npad ? ((sbase + (unsigned)tp) * (unsigned)g.Npad + (unsigned)(n0 + nn)) * 32u : 0x80000000u;
+        const unsigned mh = __builtin_amdgcn_readfirstlane(lds_bhi + bufo + (unsigned)piece * 1024u);
+        const unsigned ml = __builtin_amdgcn_readfirstlane(lds_blo + bufo + (unsigned)piece * 1024u);
+        const unsigned off_lo = off + 16u;                     // (bit 31 survives: out-of-range lanes stay out of range)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, 0 offen lds\n\t"
+                     "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, 0 offen lds"
+                     :: "s"(mh), "s"(ml), "v"(off), "v"(off_lo), "s"(wsrs) : "memory", "m0");
+      }
+    }
+  };
+  const bool cstamp = g.stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+  auto cmark = [&](int t, int i) { if (cstamp && t < 24) g.stamps[t * 8 + i] = (long long)__builtin_amdgcn_s_memtime(); };
+  for (int t = 0; t < niter; ++t) {
+    __syncthreads();             // step t-3's planes and slab are in LDS; nobody reads the step before it any more
+    const int n = t - 3;
+    cmark(t, 0);
+    if (n + 1 >= 0 && n + 1 < nsteps) slab_dma(n + 1);
+    cmark(t, 1);
+    if (n >= 0 && n < nsteps) {
+      const int c = n / KD, zd = n - c * KD;
+      const int zr = __builtin_amdgcn_readfirstlane(zrtab[c]);
+      if (zd >= (zr & 255) && zd < (zr >> 8) && g.dbg != 1) {  // (outside: only structural zeros)
+        const int abase = ((PD * c + zd + sd_w) & (kWsR - 1)) * g.PHW;
+        const bf16x8* bh0 = Bhi + (n & 1) * kSlab;
+        const bf16x8* bl0 = Blo + (n & 1) * kSlab;
+        // software pipeline over "units" u = (tap group gq, half of the wave's sub-tiles): the A fragments of unit
+        // u + 1 (and, at a group boundary, the B fragments of the next group) are read before the MFMAs of unit u
+        // issue.  NSUB 1: a unit is a whole group (4 sub-tiles, 12 MFMAs); NSUB 2: half a group (2 sub-tiles, 12 MFMAs),
+        // which keeps the double-buffered fragments at 64 registers.
+        constexpr int MH = NSUB == 1 ? kMSUB : kMSUB / 2, HPG = kMSUB / MH, NU = NG * HPG;
+        bf16x8 bh[2][NSUB], bl[2][NSUB], ah[2][MH], al[2][MH];
+        auto fragsB = [&](int gq, int q) {
+#pragma unroll
+          for (int ns = 0; ns < NSUB; ++ns) {
+            bh[q][ns] = bh0[(gq * 4 + kk) * NB + ns * 16 + i16];
+            bl[q][ns] = bl0[(gq * 4 + kk) * NB + ns * 16 + i16];
+          }
+        };
+        auto fragsA = [&](int u, int q) {
+          const int gq = u / HPG, hf = u - gq * HPG;
+          const int off = toff[gq] + abase;
+#pragma unroll
+          for (int m = 0; m < MH; ++m) { ah[q][m] = Ahi[pa[hf * MH + m] + off]; al[q][m] = Alo[pa[hf * MH + m] + off]; }
+        };
+        fragsB(0, 0);
+        fragsA(0, 0);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const int gq = u / HPG, hf = u - gq * HPG, q = u & 1, qb = gq & 1;
+          if (u + 1 < NU) {
+            if (hf == HPG - 1) fragsB(gq + 1, qb ^ 1);
+            fragsA(u + 1, q ^ 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int m = 0; m < MH; ++m)
+#pragma unroll
+            for (int ns = 0; ns < NSUB; ++ns) {
+              f32x4& a = acc[hf * MH + m][ns];
+              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q][m], bh[qb][ns], a, 0, 0, 0);
+              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q][m], bl[qb][ns], a, 0, 0, 0);
+              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[q][m], bh[qb][ns], a, 0, 0, 0);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    cmark(t, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next step's slab has landed
+    cmark(t, 3);
+  }
+
+  // epilogue: D row = kk*4 + r = position (kk*4 + r) of the mh x mw sub-tile, col = i16 = channel
+  float* yb = g.y.base + (int64_t)(g.mode >= 3 ? split * g.x.B + b : b) * g.y.sB;
+#pragma unroll
+  for (int ns = 0; ns < NSUB; ++ns) {
+    const int n = n0 + ns * 16 + i16;
+    if (n >= g.y.C) continue;
+    const int64_t co = view_chan(g.y, n);
+    const float bsv = (g.bias && split == 0) ? g.bias[(int64_t)b * g.bias_sB + n] : 0.f;
+#pragma unroll
+    for (int ms = 0; ms < kMSUB; ++ms) {
+      int s_ = wave * kMSUB + ms;
+      const int sw = s_ % g.nsw; s_ /= g.nsw;
+      const int sh = s_ % g.nsh, sd = s_ / g.nsh;
+      const int p0 = kk * 4;
+      const int od = d0 + sd, oh = h0 + sh * g.mh + p0 / g.mw, ow = w0 + sw * g.mw + p0 % g.mw;
+      if (od >= g.y.D || oh >= g.y.H || ow >= g.y.W) continue;
+      float* dst = yb + co + (int64_t)od * g.y.sD + (int64_t)oh * g.y.sH + (int64_t)ow * g.y.sW;
+      if (g.vec_store) {
+        f32x4 v = acc[ms][ns] + bsv;
+        if (g.mode == 1) v += *reinterpret_cast<const f32x4*>(dst);
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (ow + r < g.y.W) {
+            float* d = dst + (int64_t)r * g.y.sW;
+            const float v = acc[ms][ns][r] + bsv;
+            *d = g.mode == 1 ? *d + v : v;
+          }
+        }
+      }
+    }
+  }
+}
+
 // MEASURED AND REMOVED: a "sliding" variant of the kernel above (K = 4 (zd, zw) tap pairs x 8 channels, the zh taps
 // in time, so that the KH + 3 patch rows of a wave's four H-consecutive sub-tiles are read once per group: 1.9x
 // fewer LDS bytes per MFMA).  Bit-identical results, 0-10 % SLOWER on every decoder layer: the MFMA phase of a
@@ -753,6 +1120,45 @@ int launch_bf3(const Bf3Geom& g, dim3 grid, size_t lds, hipStream_t st) {
   return CRN_OK;
 }
 
+template <int NSUB, int XM, int NG>
+int launch_bf3_ws(const Bf3Geom& g, dim3 grid, size_t lds, hipStream_t st) {
+  auto k = conv_bf3_ws_kernel<NSUB, XM, NG>;
+  if (lds > 65536) CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, grid, dim3(kWsThreads), lds, st, g);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+// The producers' timetable, run on the host: every plane a step reads was written (by an earlier iteration) and still
+// holds that chunk's data, and no iteration writes a ring slot that the step multiplying at the same time reads.
+template <int KD>
+bool bf3_ws_timetable_ok(int nch) {
+  constexpr int PD = KD + 3;
+  int owner_c[kWsR], owner_p[kWsR];
+  for (int i = 0; i < kWsR; ++i) owner_c[i] = owner_p[i] = -1;
+  const int nsteps = nch * KD;
+  for (int t = 0; t <= nsteps + 2; ++t) {
+    const int n = t - 3;
+    bool reads[kWsR] = {};
+    if (n >= 0) {
+      const int c = n / KD, zd = n % KD;
+      for (int sd = 0; sd < 4; ++sd) {
+        const int slot = (PD * c + zd + sd) & (kWsR - 1);
+        if (owner_c[slot] != c || owner_p[slot] != zd + sd) return false;
+        reads[slot] = true;
+      }
+    }
+    const Bf3WsPlanes w = bf3_ws_planes_at<KD>(t, nch);
+    for (int i = 0; i < w.n; ++i) {
+      const int wc = i ? w.c1 : w.c0, wp = i ? w.p1 : w.p0;
+      const int slot = (PD * wc + wp) & (kWsR - 1);
+      if (reads[slot] || wp >= PD) return false;
+      owner_c[slot] = wc; owner_p[slot] = wp;
+    }
+  }
+  return true;
+}
+
 bool even_view(const crnView& v) {       // 8-byte staging of position pairs on a unit-stride view
   return v.chan_off == nullptr && v.sW == 1 && (v.W & 1) == 0 && (v.sH & 1) == 0 && (v.sD & 1) == 0 && (v.sC & 1) == 0 &&
          (v.sB & 1) == 0 && (((uintptr_t)v.base) & 7) == 0;
@@ -903,6 +1309,27 @@ int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w
             "%dx%dx%d units %d NG %d grid %ux%ux%u lds %zu\n", x->C, x->D, x->H, x->W, y->C, y->D, y->H, y->W, kd, kh, kw, NSUB,
             ZS, xmode, g.TD, g.TH, g.TW, g.PD, g.PH, g.PW, g.nunits, g.NG, grid.x, grid.y, grid.z, lds);
   int rc = CRN_EINVAL;
+  // the wave-specialised kernel (conv_bf3_ws_kernel): pre-arranged slabs, 4 x 8 x 16 tiles, N blocks of 16 / 32
+  // columns, cubic 5^3 / 4^3 windows
+  static const bool ws_on = !(getenv("CRN_BF3_WS") && atoi(getenv("CRN_BF3_WS")) == 0);
+  if (ws_on && wslab && xmode == 1 && g.mw == 16 && NSUB <= 2 && g.mode != 4 && kd == (g.NG == 7 ? 5 : 4)) {
+    Bf3Geom gw = g;
+    gw.UP = gw.PH * gw.pw2; gw.magic_UP = magic20b(gw.UP);
+    const int NB = NSUB * 16;
+    const size_t lds_ws = (size_t)(3 * gw.ctab * 4) + 256 + (size_t)2 * kWsR * gw.PHW * 16 + (size_t)4 * gw.NG * 4 * NB * 16;
+    const int nch = std::min(g.chunks_per_split, g.nchunks);
+    const bool ok = 2 * gw.UP <= kWsPL && lds_ws <= kLdsMax && nch <= 64 &&
+                    (kd == 5 ? bf3_ws_timetable_ok<5>(nch) : bf3_ws_timetable_ok<4>(nch));
+    if (ok) {
+      if (dbg) fprintf(stderr, "[crn_conv_fwd_bf3] wave-specialised: %d chunks x %d planes, lds %zu\n", nch, kd, lds_ws);
+#define CRN_BF3_WS_CASE(N, X, G) if (NSUB == N && xmode == X && gw.NG == G) rc = launch_bf3_ws<N, X, G>(gw, grid, lds_ws, st);
+      CRN_BF3_WS_CASE(1, 1, 7) CRN_BF3_WS_CASE(2, 1, 7)
+      CRN_BF3_WS_CASE(1, 1, 4) CRN_BF3_WS_CASE(2, 1, 4)
+#undef CRN_BF3_WS_CASE
+      if (rc == CRN_OK && g.mode == 3) rc = crn_splitk_reduce(yreal, scratch, splits, accumulate, st);
+      return rc;
+    }
+  }
 #define CRN_BF3_CASE(N, X, G, Z) if (NSUB == N && xmode == X && g.NG == G && ZS == Z) rc = launch_bf3<N, X, G, Z>(g, grid, lds, st);
   CRN_BF3_CASE(1, 1, 7, 1) CRN_BF3_CASE(2, 1, 7, 1) CRN_BF3_CASE(4, 1, 7, 1)
   CRN_BF3_CASE(1, 1, 4, 1) CRN_BF3_CASE(2, 1, 4, 1) CRN_BF3_CASE(4, 1, 4, 1)

@@ -382,7 +382,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
 // nzw > 1 (with KW == 1): window widths without an unrolled variant walk the taps one by one.
 // tap box (half open) of the window that can hold non-zero weights
 struct TapBox { int d0, d1, h0, h1, w0, w1; };
-__device__ __forceinline__ TapBox box_union(const signed char (*box)[6], int groups, int nchan, int lo, int hi,
+__host__ __device__ __forceinline__ TapBox box_union(const signed char (*box)[6], int groups, int nchan, int lo, int hi,
                                             int kd, int kh, int kw) {
   TapBox b{0, kd, 0, kh, 0, kw};
   if (groups <= 0) return b;
@@ -396,7 +396,7 @@ __device__ __forceinline__ TapBox box_union(const signed char (*box)[6], int gro
   }
   return b;
 }
-__device__ __forceinline__ TapBox box_intersect(const TapBox& a, const TapBox& b) {
+__host__ __device__ __forceinline__ TapBox box_intersect(const TapBox& a, const TapBox& b) {
   return TapBox{max(a.d0, b.d0), min(a.d1, b.d1), max(a.h0, b.h0), min(a.h1, b.h1), max(a.w0, b.w0), min(a.w1, b.w1)};
 }
 

@@ -90,10 +90,30 @@ def gen_model(tag, num_classes, nbt, batch, loss_name, training=True, store_all_
       # element-wise vectors of EVERY parameter gradient (a fixed strided subsample of <= 512 elements per tensor):
       # this fixture (B=2, num_batches_tracked=30000: r/d clamps live, statistics over two samples) is the
       # well-conditioned one, so the whole backward pass can be pinned element by element
+      # ... and the SAME arithmetic in fp64 (the oracle, which equals the reference bit for bit in fp32 above; the
+      # camera stays fp32 so that the gather indices are the same): what the gradients would be without rounding.
+      # gnoise = the error of the reference's own fp32 gradients against it, per tensor over all elements, on the
+      # scale used everywhere here (the tensor's own max, floored at 1e-3 of the model's largest gradient) -- the
+      # conditioning of each tensor, measured: up to 1e-1 in encoder stage 5 although the logits move by 2e-6.
+      sd64 = {k: (v.double() if v.dtype == t.float32 else v.clone()) for k, v in sd.items()}
+      for k in sd64:
+        if sd64[k].dtype == t.float64 and "running" not in k:
+          sd64[k].requires_grad_(True)
+      feats, avg = O.resnet50_features(O.preprocess_image_caffe(image).double(), sd64, True)
+      l64 = O.decoder_forward(feats, avg, sd64, v2s, off, (128, 128, 128), True)
+      getattr(O, loss_name)(grid, l64).backward()
+      print(f"[{tag}] fp32 vs fp64 logits max-rel = {maxrel(logits.detach(), l64.detach()):.3e}")
+      worst_noise = 0.0
       for name, p in net.named_parameters():
-        g = p.grad.reshape(-1)
-        out["gsub::" + name] = g[::max(1, -(-g.numel() // 512))].numpy().copy()
-        out["gmax::" + name] = np.float32(g.abs().max().item())
+        g, g64 = p.grad.reshape(-1), sd64[name].grad.reshape(-1)
+        st = max(1, -(-g.numel() // 512))
+        out["gsub::" + name] = g[::st].numpy().copy()
+        out["g64sub::" + name] = g64[::st].float().numpy().copy()
+        out["gmax::" + name] = np.float32(g64.abs().max().item())
+        den = max(float(g64.abs().max()), 1e-3 * gmax)
+        out["gnoise::" + name] = np.float32(float((g.double() - g64).abs().max()) / den)
+        worst_noise = max(worst_noise, float(out["gnoise::" + name]))
+      print(f"[{tag}] reference fp32 vs fp64 gradients: worst tensor {worst_noise:.3e} of its scale")
     out["grad_names"] = np.array(list(gn.keys()))
     out["grad_norms"] = np.array(list(gn.values()))
     # a few full gradients (small tensors) for direct comparison

@@ -140,13 +140,16 @@ def test_bf16x3_eval_b4_matches_oracle(nc):
 
 
 @pytest.mark.parametrize("math", ["fp32", "bf16x3"])
-def test_all_parameter_gradients_well_conditioned_fixture(math):
-  """EVERY parameter gradient, element by element, on the well-conditioned fixture (h7, B=2, num_batches_tracked =
-  30000: the r/d clamps are live and the statistics run over two samples; the reference's own fp32-vs-fp64 noise is
-  ~1e-5 here, against 3e-4 ... 5e-2 on the B=1 / nbt=0 fixtures).  The fixture stores a fixed strided subsample (<= 512
-  elements) of each of the 266 gradient tensors of the reference's backward pass (oracle/gen_golden.py) plus each
-  tensor's max; the error of a tensor is max |got - want| over the stored elements relative to max(the tensor's own
-  scale, 1e-3 of the model's largest gradient) -- conv biases in front of a train-mode norm have a true gradient of 0."""
+def test_all_parameter_gradients_against_fp64_truth(math):
+  """EVERY parameter gradient, element by element, on the h7 B=2 fixture with num_batches_tracked = 30000 (r/d clamps
+  live, statistics over two samples).  The logits of this fixture are well conditioned (the reference moves by 2e-6
+  between fp32 and fp64) but its gradients are not: the reference's OWN fp32 gradients sit up to 1e-1 of a tensor's
+  scale away from the same arithmetic in fp64 (encoder stage 5; oracle/gen_golden.py measures it per tensor and stores
+  it as gnoise).  So the bar is conditioning-aware and against the truth, not against another fp32 run: the fixture
+  holds a fixed strided subsample (<= 512 elements) of each of the 266 gradient tensors in fp64 arithmetic, and the HIP
+  path must be as close to it as the reference's fp32 run is -- within 4x the reference's own error for that tensor, or
+  1e-3 of the tensor's scale where the reference is more exact than that (scale = max(the tensor's own max, 1e-3 of
+  the model's largest gradient): conv biases in front of a train-mode norm have a true gradient of 0)."""
   from corenet_amd.model import losses
   z = np.load(os.path.join(G, "model_h7_train_b2_nbt30k.npz"))
   m = _model(2, O.make_state(0, 2, nbt=30000), math).train()
@@ -154,21 +157,20 @@ def test_all_parameter_gradients_well_conditioned_fixture(math):
   loss = losses.iou_fgbg(grid.cuda(), m(image.cuda(), v2s.cuda(), off.cuda()))
   loss.backward()
   gmax = max(float(z[k]) for k in z.files if k.startswith("gmax::"))
-  errs = {}
+  rows = []
   for name, p in m.named_parameters():
-    want = t.as_tensor(z["gsub::" + name]).double()
+    want = t.as_tensor(z["g64sub::" + name]).double()
     g = p.grad.reshape(-1)
     got = g[::max(1, -(-g.numel() // 512))].double().cpu()
     assert got.shape == want.shape, name
-    errs[name] = float((got - want).abs().max()) / max(float(z["gmax::" + name]), 1e-3 * gmax)
-  worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
-  print(f"[{math}] all {len(errs)} parameter gradients, worst element-wise errors (of the tensor's scale): " +
-        ", ".join(f"{k} {v:.2e}" for k, v in worst))
-  # measured on MI355X (round 3): see the printed line; the bar leaves ~4x head room over the worst tensor
-  assert len(errs) == 266 and worst[0][1] < ALL_GRAD_TOL[math], worst
-
-
-ALL_GRAD_TOL = {"fp32": 2e-3, "bf16x3": 2e-3}
+    err = float((got - want).abs().max()) / max(float(z["gmax::" + name]), 1e-3 * gmax)
+    bar = max(4.0 * float(z["gnoise::" + name]), 1e-3)
+    rows.append((err / bar, err, float(z["gnoise::" + name]), name))
+  rows.sort(reverse=True)
+  print(f"[{math}] {len(rows)} parameter gradients vs fp64 truth; closest to their bars (error / reference's own fp32 error): " +
+        ", ".join(f"{n} {e:.1e}/{ns:.1e}" for _, e, ns, n in rows[:5]) +
+        f"; tensors above the reference's own error: {sum(1 for _, e, ns, _ in rows if e > max(ns, 1e-4))}")
+  assert len(rows) == 266 and rows[0][0] <= 1.0, rows[:5]
 
 
 # element-wise bars of the five full gradients the fixtures store (oracle/gen_golden.py:87-90), by depth of the

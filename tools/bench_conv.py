@@ -67,7 +67,19 @@ import numpy as np
 flop = 2.0 * B * np.prod(dims) * cin * cout * np.prod(wshape[2:])
 print(f"{mode} {key} B={B} {MATH}: {ms*1e3:.1f} us  {flop/ms/1e9:.1f} TFLOP/s (real flops)")
 
-if os.environ.get("CRN_BF3_STAMPS"):        # per-step phases of workgroup 0 (conv_bf3.hip, crn_bf3_debug_stamps)
+if os.environ.get("CRN_BF3_STAMPS") == "ws":  # wave-specialised kernel: consumer wave 0 / producer wave 8 of workgroup 0
+  import ctypes
+  st = (ctypes.c_longlong * 192)()
+  be.lib.cdll.crn_bf3_debug_stamps(st)
+  base = min(v for v in st if v > 0)
+  print("iter | consumer: barrier-exit  +dma-issue  +mfma  +vmcnt0 | producer: barrier-exit  +issue  +wait  +commit   (cycles; exits relative to the first stamp)")
+  for i in range(24):
+    r = st[i * 8:i * 8 + 8]
+    if r[0] == 0 and r[4] == 0: break
+    c = f"{r[0]-base:8d} {r[1]-r[0]:6d} {r[2]-r[1]:6d} {r[3]-r[2]:6d}" if r[0] else " " * 29
+    q = f"{r[4]-base:8d} {r[5]-r[4]:6d} {r[6]-r[5]:6d} {r[7]-r[6]:6d}" if r[4] else ""
+    print(f"{i:4d} | {c} | {q}")
+elif os.environ.get("CRN_BF3_STAMPS"):        # per-step phases of workgroup 0 (conv_bf3.hip, crn_bf3_debug_stamps)
   import ctypes
   st = (ctypes.c_longlong * 192)()
   be.lib.cdll.crn_bf3_debug_stamps(st)
