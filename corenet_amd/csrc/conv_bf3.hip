@@ -884,7 +884,7 @@ typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 // TWT: tile width: 16 (tile 4 x 8 x 16, a K block of 32 positions = 2 H rows x 16 W) or 8 (tile 8 x 8 x 8 -- the 8^3
 // maps of decoder stage 3 --, a K block = 4 H rows x 8 W)
-template <int NSUB, int DM, int TPW, int TWT>
+template <int NSUB, int DM, int TPW, int TWT, bool PIPE>
 __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
   crn_kernarg_touch(g);
   constexpr int TDT = TWT == 16 ? 4 : 8;
@@ -942,6 +942,8 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
 
   XLoad<1>::T pv[kNUX][kCK];
   DT dv[NSUB][kCK];
+  unsigned xco[kCK], dco[NSUB][kCK];
+  float tsc[kCK], tsh[kCK];
   unsigned inmask = 0;
   int b = 0, d0 = 0, h0 = 0, w0 = 0;
   auto tile_origin = [&](int tl) {
@@ -983,7 +985,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
       if (ld) inmask |= 1u << jx;
 #pragma unroll
       for (int cl = 0; cl < kCK; ++cl) {
-        const unsigned off = (ld && c0 + cl < g.x.C) ? (choff[cl] + sp) * 4u : 0x80000000u;
+        const unsigned off = (ld && c0 + cl < g.x.C) ? (xco[cl] + sp) * 4u : 0x80000000u;
         XLoad<1>::load(pv[jx][cl], xrs, off);
       }
     }
@@ -994,7 +996,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
 #pragma unroll
       for (int cl = 0; cl < kCK; ++cl) {
         const int n = oct * 8 + cl;
-        const unsigned off = (in && n0 + n < g.ncols && n0 + n < g.dy.C) ? (dchoff[n] + sp) * 4u : 0x80000000u;
+        const unsigned off = (in && n0 + n < g.ncols && n0 + n < g.dy.C) ? (dco[jd][cl] + sp) * 4u : 0x80000000u;
         XLoad<DM>::load(dv[jd][cl], drs, off);
       }
     }
@@ -1012,7 +1014,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
 #pragma unroll
             for (int cl = 0; cl < kCK; ++cl) {
               if (c0 + cl < g.x.C) {
-                const float sc = tscale[cl], sh = tshift[cl];
+                const float sc = tsc[cl], sh = tsh[cl];
                 float a = v0[cl], c = v1[cl];
                 if (g.tr.pre_relu) { a = fmaxf(a, 0.f); c = fmaxf(c, 0.f); }
                 a = a * sc + sh; c = c * sc + sh;
@@ -1050,6 +1052,14 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
   auto cat = [](bf16x4 a, bf16x4 c) -> bf16x8 { return __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7); };
 
   __syncthreads();
+  // the workgroup's 8 input channels and this thread's dy columns never change: their offsets and the BatchRenorm
+  // scale / shift live in registers (read from LDS per load, every staged load waited for an LDS round trip first)
+#pragma unroll
+  for (int cl = 0; cl < kCK; ++cl) { xco[cl] = choff[cl]; tsc[cl] = tscale[cl]; tsh[cl] = tshift[cl]; }
+#pragma unroll
+  for (int jd = 0; jd < NSUB; ++jd)
+#pragma unroll
+    for (int cl = 0; cl < kCK; ++cl) dco[jd][cl] = dchoff[((tid >> 8) + 2 * jd) * 8 + cl];
   if (tbeg < tend) { tile_origin(tbeg); stage_issue(); }
   for (int tl = tbeg; tl < tend; ++tl) {
     wait_loads2d(pv);
@@ -1059,28 +1069,79 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
     __syncthreads();
     if (tl + 1 < tend) { tile_origin(tl + 1); stage_issue(); }
     if (g.dbg == 1) continue;
-    for (int kb = 0; kb < 16; ++kb) {
-      const int kbx = TWT == 16 ? (((kb >> 2) * g.PH + (kb & 3) * 2) * g.PW) << 4      // K block kb = (d, H row pair)
-                                : (((kb >> 1) * g.PH + (kb & 1) * 4) * g.PW) << 4;     //            = (d, H row quad)
-      const char* yb = Yhi + ybase + kb * (32 * NB * 2);
-      bf16x8 bh[NSUB], bl[NSUB];
-#pragma unroll
-      for (int ns = 0; ns < NSUB; ++ns) {
-        bh[ns] = cat(trd(yb + ns * 32), trd(yb + ns * 32 + 4 * NB * 2));
-        bl[ns] = cat(trd(yb + ylo + ns * 32), trd(yb + ylo + ns * 32 + 4 * NB * 2));
-      }
-#pragma unroll
-      for (int ti = 0; ti < TPW; ++ti) {
-        const char* xa = Xhi + abase + toffL[ti] + kbx;
-        const bf16x8 ah = cat(trd(xa), trd(xa + 64));
-        const bf16x8 al = cat(trd(xa + xlo), trd(xa + xlo + 64));
+    if constexpr (!PIPE) {
+      // the compiler's own schedule of the reads (measured faster for the 4^3 windows, TPW 4)
+      for (int kb = 0; kb < 16; ++kb) {
+        const int kbx = TWT == 16 ? (((kb >> 2) * g.PH + (kb & 3) * 2) * g.PW) << 4
+                                  : (((kb >> 1) * g.PH + (kb & 1) * 4) * g.PW) << 4;
+        const char* yb = Yhi + ybase + kb * (32 * NB * 2);
+        bf16x8 bh[NSUB], bl[NSUB];
 #pragma unroll
         for (int ns = 0; ns < NSUB; ++ns) {
-          acc[ti][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ns], acc[ti][ns], 0, 0, 0);
-          acc[ti][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ns], acc[ti][ns], 0, 0, 0);
-          acc[ti][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ns], acc[ti][ns], 0, 0, 0);
+          bh[ns] = cat(trd(yb + ns * 32), trd(yb + ns * 32 + 4 * NB * 2));
+          bl[ns] = cat(trd(yb + ylo + ns * 32), trd(yb + ylo + ns * 32 + 4 * NB * 2));
+        }
+#pragma unroll
+        for (int ti = 0; ti < TPW; ++ti) {
+          const char* xa = Xhi + abase + toffL[ti] + kbx;
+          const bf16x8 ah = cat(trd(xa), trd(xa + 64));
+          const bf16x8 al = cat(trd(xa + xlo), trd(xa + xlo + 64));
+#pragma unroll
+          for (int ns = 0; ns < NSUB; ++ns) {
+            acc[ti][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ns], acc[ti][ns], 0, 0, 0);
+            acc[ti][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ns], acc[ti][ns], 0, 0, 0);
+            acc[ti][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ns], acc[ti][ns], 0, 0, 0);
+          }
         }
       }
+      continue;
+    }
+    // Software-pipelined over (K block kb, tap pair ti): the transposing reads of the NEXT unit's A fragments (and, at
+    // the last tap pair of a K block, of the next block's B fragments) are issued before the MFMAs of the current one.
+    // The workgroup is alone on its CU (95 KB of LDS), two waves per SIMD: with the compiler's own schedule (read,
+    // wait lgkmcnt(0), multiply) every MFMA triple paid an LDS round trip (MfmaUtil 40 %, profiles/r02_conv_mfma_pmc_bf16x3_wgrad.txt).
+    auto kbx_of = [&](int kb) {
+      return TWT == 16 ? (((kb >> 2) * g.PH + (kb & 3) * 2) * g.PW) << 4      // K block kb = (d, H row pair)
+                       : (((kb >> 1) * g.PH + (kb & 1) * 4) * g.PW) << 4;     //            = (d, H row quad)
+    };
+    bf16x8 bh[2][NSUB], bl[2][NSUB], ah[2], al[2];
+    auto ldB = [&](int kb, int qb) {
+      const char* yb = Yhi + ybase + kb * (32 * NB * 2);
+#pragma unroll
+      for (int ns = 0; ns < NSUB; ++ns) {
+        bh[qb][ns] = cat(trd(yb + ns * 32), trd(yb + ns * 32 + 4 * NB * 2));
+        bl[qb][ns] = cat(trd(yb + ylo + ns * 32), trd(yb + ylo + ns * 32 + 4 * NB * 2));
+      }
+    };
+    auto ldA = [&](int kbx, int ti, int q) {
+      const char* xa = Xhi + abase + toffL[ti] + kbx;
+      ah[q] = cat(trd(xa), trd(xa + 64));
+      al[q] = cat(trd(xa + xlo), trd(xa + xlo + 64));
+    };
+    auto block = [&](int kb, auto QB_) {
+      constexpr int qb = decltype(QB_)::value;
+      const int kbx = kbx_of(kb);
+#pragma unroll
+      for (int ti = 0; ti < TPW; ++ti) {
+        const int q = ti & 1;                                  // (TPW is even: every K block starts on buffer 0)
+        if (ti + 1 < TPW) ldA(kbx, ti + 1, q ^ 1);
+        else { const int kn = min(kb + 1, 15); ldB(kn, qb ^ 1); ldA(kbx_of(kn), 0, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ns = 0; ns < NSUB; ++ns) {
+          acc[ti][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q], bh[qb][ns], acc[ti][ns], 0, 0, 0);
+          acc[ti][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q], bl[qb][ns], acc[ti][ns], 0, 0, 0);
+          acc[ti][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[q], bh[qb][ns], acc[ti][ns], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    static_assert(TPW % 2 == 0, "");
+    ldB(0, 0);
+    ldA(kbx_of(0), 0, 0);
+    for (int kb = 0; kb < 16; kb += 2) {
+      block(kb, std::integral_constant<int, 0>());
+      block(kb + 1, std::integral_constant<int, 1>());
     }
   }
 
@@ -1102,7 +1163,10 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
 
 template <int NSUB, int DM, int TPW, int TWT>
 int launch_bf3_wgrad(const Bf3WgGeom& g, dim3 grid, size_t lds, hipStream_t st) {
-  auto k = conv_bf3_wgrad_kernel<NSUB, DM, TPW, TWT>;
+  // software-pipelined LDS reads: measured per variant (profiles/r03_wgrad_pipe_ab.txt); CRN_BF3_WG_PIPE = 0 / 1 forces
+  static const int force = getenv("CRN_BF3_WG_PIPE") ? atoi(getenv("CRN_BF3_WG_PIPE")) : -1;
+  const bool pipe = force >= 0 ? force != 0 : (NSUB == 1 || (TPW == 8 && TWT == 16));
+  auto k = pipe ? conv_bf3_wgrad_kernel<NSUB, DM, TPW, TWT, true> : conv_bf3_wgrad_kernel<NSUB, DM, TPW, TWT, false>;
   if (lds > 65536) CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, st, g);
   CRN_CHECK_LAUNCH();
@@ -1311,7 +1375,14 @@ int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w
   int rc = CRN_EINVAL;
   // the wave-specialised kernel (conv_bf3_ws_kernel): pre-arranged slabs, 4 x 8 x 16 tiles, N blocks of 16 / 32
   // columns, cubic 5^3 / 4^3 windows
-  static const bool ws_on = !(getenv("CRN_BF3_WS") && atoi(getenv("CRN_BF3_WS")) == 0);
+  // Where it is used is measured (tools/ws_ab.sh, profiles/r03_ws_ab.txt, B = 4): it wins where a step is long -- N blocks
+  // of 32 columns on 5^3 windows (stage_6.c1 data gradient 359 -> 336 us, stage_5.c1 forward 181 -> 161 us) -- and loses
+  // on the 16-column blocks (stage_6.c1 forward 426 -> 486 us, stage_6.t1 160 -> 190 us): there a step is 2.7 k cycles of
+  // MFMA fed by 2.2 k cycles of LDS reads (one A fragment pair per three MFMAs), and the ~0.9 k cycles of DMA issue, slab
+  // wait and barrier per step cost more than two co-resident workgroups of the kernel above lose.  CRN_BF3_WS = 0 / 1:
+  // never / wherever it applies.
+  static const int ws_force = getenv("CRN_BF3_WS") ? atoi(getenv("CRN_BF3_WS")) : -1;
+  const bool ws_on = ws_force >= 0 ? ws_force != 0 : (NSUB == 2 && g.NG == 7);
   if (ws_on && wslab && xmode == 1 && g.mw == 16 && NSUB <= 2 && g.mode != 4 && kd == (g.NG == 7 ? 5 : 4)) {
     Bf3Geom gw = g;
     gw.UP = gw.PH * gw.pw2; gw.magic_UP = magic20b(gw.UP);
