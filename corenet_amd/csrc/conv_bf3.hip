@@ -213,20 +213,40 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
   };
   auto patch_issue = [&](int c0) {
     inmask = 0;
+    // the chunk's eight channel offsets with two 16-byte LDS reads (one dword read per load made every load wait for
+    // its own LDS round trip: 16 of them in a row per staging step)
+    // (NSUB 1 only: in the wider variants the 16 extra live registers cross 128 and cost the second workgroup per CU --
+    // stage_5.t1 forward 200 -> 232 us)
+    u32x4 co0, co1;
+    if constexpr (NSUB == 1) { co0 = *reinterpret_cast<const u32x4*>(choff + c0); co1 = *reinterpret_cast<const u32x4*>(choff + c0 + 4); }
 #pragma unroll
     for (int j = 0; j < kNUX; ++j) {
       int pos; unsigned sp; bool in;
       const bool valid = unit_of(j, pos, sp, in);
       const bool ld = valid && in;
       if (ld) inmask |= 1u << j;
+      if constexpr (NSUB == 1) {
+        unsigned off[kCK];
 #pragma unroll
-      for (int cl = 0; cl < kCK; ++cl) {
-        const unsigned off = (ld && c0 + cl < g.x.C) ? (choff[c0 + cl] + sp) * 4u : 0x80000000u;
-        XLoad<XM>::load(pv[j][cl], xrs, off);
+        for (int cl = 0; cl < kCK; ++cl)
+          off[cl] = (ld && c0 + cl < g.x.C) ? ((cl < 4 ? co0[cl & 3] : co1[cl & 3]) + sp) * 4u : 0x80000000u;
+#pragma unroll
+        for (int cl = 0; cl < kCK; ++cl) XLoad<XM>::load(pv[j][cl], xrs, off[cl]);
+      } else {
+#pragma unroll
+        for (int cl = 0; cl < kCK; ++cl) {
+          const unsigned off = (ld && c0 + cl < g.x.C) ? (choff[c0 + cl] + sp) * 4u : 0x80000000u;
+          XLoad<XM>::load(pv[j][cl], xrs, off);
+        }
       }
     }
   };
   auto patch_commit = [&](int c0) {
+    f32x4 s0, s1, h0, h1;
+    if (NSUB == 1 && g.tr.scale) {
+      s0 = *reinterpret_cast<const f32x4*>(tscale + c0); s1 = *reinterpret_cast<const f32x4*>(tscale + c0 + 4);
+      h0 = *reinterpret_cast<const f32x4*>(tshift + c0); h1 = *reinterpret_cast<const f32x4*>(tshift + c0 + 4);
+    }
 #pragma unroll
     for (int j = 0; j < kNUX; ++j) {
       if (j * kThreads < g.nunits) {                     // block-uniform
@@ -240,7 +260,8 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
 #pragma unroll
             for (int cl = 0; cl < kCK; ++cl) {
               if (c0 + cl < g.x.C) {
-                const float sc = tscale[c0 + cl], sh = tshift[c0 + cl];
+                const float sc = NSUB == 1 ? (cl < 4 ? s0[cl & 3] : s1[cl & 3]) : tscale[c0 + cl];
+                const float sh = NSUB == 1 ? (cl < 4 ? h0[cl & 3] : h1[cl & 3]) : tshift[c0 + cl];
                 float a = v0[cl], c = v1[cl];
                 if (g.tr.pre_relu) { a = fmaxf(a, 0.f); c = fmaxf(c, 0.f); }
                 a = a * sc + sh; c = c * sc + sh;
