@@ -58,6 +58,7 @@ _SIGS = {
                        i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "crn_bf3_operands": [vp, vp, i32, i64, vp, vp],
     "crn_splitk_defer": [i32],
+    "crn_set_deterministic": [i32],
     "crn_conv_wgrad_1x1_bf3": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32, i32, vp],
     "crn_conv_wgrad_2d_bf3": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32, i32, i32, i32,
                               i32, i32, vp],

@@ -110,6 +110,10 @@ class HipBackend:
     """The next conv call may leave its split-K sum to the BatchRenorm launch that follows (crn_splitk_defer)."""
     self.lib.crn_splitk_defer(int(on))
 
+  def set_deterministic(self, on: bool = True):
+    """Order-independent sums everywhere (crn_set_deterministic): two runs from the same state are bit-identical."""
+    self.lib.crn_set_deterministic(int(on))
+
   def bf3_operands(self, packed: t.Tensor, table, out: t.Tensor):
     """table = (desc int64 [n, 6] on the device, total workgroups): conv_geometry.operand_table."""
     desc, blocks = table

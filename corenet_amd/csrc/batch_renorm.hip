@@ -762,6 +762,10 @@ extern "C" int crn_batch_renorm_bwd(const float* x, int64_t sB_x, const float* d
   const int nparts = ns * B;
   if (ws_bytes < (size_t)C * nparts * 2 * sizeof(double)) return CRN_ENOMEM;
   dim3 grid(ns, C, B);
+  // deterministic mode: the ns * B workgroups of a channel add their share of sum(dx) atomically below; instead the
+  // sum is taken afterwards by the ordered two-level reduction of crn_bias_grad over dx
+  float* const dsum_det = (dsum && ndsum > 0 && crn_deterministic()) ? dsum : nullptr;
+  if (dsum_det) dsum = nullptr;
   if (v)
     hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, grid, dim3(kThreads), 0, st, x, sB_x, dy, sB_dy, S, C,
                        pre_relu, post_relu, scale, shift, saved, ws, dsum, ndsum);
@@ -778,6 +782,16 @@ extern "C" int crn_batch_renorm_bwd(const float* x, int64_t sB_x, const float* d
                        pre_relu, post_relu, gamma, scale, shift, saved, ws, nparts,
                        (double)B * (double)S, dx, sB_dx, dgamma, dbeta, accumulate, dsum, ndsum);
   CRN_CHECK_LAUNCH();
+  if (dsum_det) {
+    dim3 gridb(ns, ndsum, B);
+    if (vec_ok(S, {sB_dx}, {dx}))
+      hipLaunchKernelGGL(bias_grad_partial_kernel<true>, gridb, dim3(kThreads), 0, st, dx, S, sB_dx, ws);
+    else
+      hipLaunchKernelGGL(bias_grad_partial_kernel<false>, gridb, dim3(kThreads), 0, st, dx, S, sB_dx, ws);
+    CRN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bias_grad_final_kernel, dim3(crn_cdiv(ndsum, 4)), dim3(256), 0, st, ws, nparts, ndsum, dsum_det, 0);
+    CRN_CHECK_LAUNCH();
+  }
   return CRN_OK;
 }
 

@@ -1470,6 +1470,7 @@ extern "C" int crn_conv_wgrad_bf3(const crnView* x, const crnInTransform* tr, co
   const int cblocks = crn_cdiv(x->C, kCK), nblocks = crn_cdiv(Npad, NB);
   static const int kBlocks = getenv("CRN_BF3_WG_BLOCKS") ? atoi(getenv("CRN_BF3_WG_BLOCKS")) : 256;
   int splits = std::max(1, std::min(g.ntiles, kBlocks / std::max(1, cblocks * nblocks)));
+  if (crn_deterministic()) splits = 1;                       // one workgroup per dw element: one add, no order to vary
   g.tiles_per_split = crn_cdiv(g.ntiles, splits);
   splits = crn_cdiv(g.ntiles, g.tiles_per_split);
   g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;

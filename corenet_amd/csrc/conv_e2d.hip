@@ -864,6 +864,7 @@ extern "C" int crn_conv_wgrad_2d_bf3(const crnView* x, const crnInTransform* tr,
     const int tiles = crn_cdiv(3 * x->C, 32) * crn_cdiv(dy->C, 32);
     static const int kFill3 = getenv("CRN_WG3_FILL") ? atoi(getenv("CRN_WG3_FILL")) : 512;
     int splits = std::max(1, std::min(g.ksteps / 8, crn_cdiv(kFill3, tiles)));
+    if (crn_deterministic()) splits = 1;
     g.ksteps_per_block = crn_cdiv(g.ksteps, splits);
     splits = crn_cdiv(g.ksteps, g.ksteps_per_block);
     const dim3 grid((unsigned)crn_cdiv(3 * x->C, 32), (unsigned)crn_cdiv(dy->C, 32), (unsigned)splits);
@@ -882,6 +883,7 @@ extern "C" int crn_conv_wgrad_2d_bf3(const crnView* x, const crnInTransform* tr,
   const int tiles = crn_cdiv(x->C, 64) * crn_cdiv(dy->C, 32);
   static const int kFill = getenv("CRN_WG1_FILL") ? atoi(getenv("CRN_WG1_FILL")) : 512;
   int splits = std::max(1, std::min(g.ksteps / 8, crn_cdiv(kFill, tiles)));       // >= 2 K steps per wave
+  if (crn_deterministic()) splits = 1;
   g.ksteps_per_block = crn_cdiv(g.ksteps, splits);
   splits = crn_cdiv(g.ksteps, g.ksteps_per_block);
   const dim3 grid((unsigned)crn_cdiv(x->C, 64), (unsigned)crn_cdiv(dy->C, 32), (unsigned)splits);

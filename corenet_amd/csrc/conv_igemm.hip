@@ -228,6 +228,128 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
   }
 }
 
+// --------------------------- pointwise convolutions, operands straight from HBM -------------------------------
+// The kernel above stages K chunks of 64 channels through LDS, two barriers per chunk, and every chunk waits out most
+// of a memory latency (~2 us on a busy chip): 11-19 us per launch for layers whose FLOPs and bytes are worth 3-5 us
+// -- 80 launches, 1.1 ms of a 8 ms training step (profiles/r02_bench_kernel_stats.csv, its top line).  This one has no
+// staging at all:
+//   * NCHW activations are K-major for the A operand and the packed weights [Cin][Npad] for the B operand once the
+//     16 rows / 16 columns of an MFMA tile are taken with stride 4: lane (i16, kk) loads ONE float4 = positions
+//     p0 + 4*i16 .. +3 of channel c + kk, and element j of it is row i16 of M tile j (positions p0 + 4*i + j); the
+//     same for the weights (columns n0 + 4*i + jn).  One A float4 and one B float4 per lane feed 16
+//     v_mfma_f32_16x16x4_f32 (4 M tiles x 4 N tiles, K = 4 channels): a wave owns a 64 position x 64 column tile, all
+//     loads are full 256-byte rows, and nothing goes through LDS on the way in.
+//   * Work split: a workgroup = NW waves on one 64 x 64 tile, wave w takes the 16-channel groups w, w + NW, ... of
+//     the workgroup's K slice (GPW groups per wave, all their loads issued at once: one memory latency per
+//     workgroup), then the NW partial tiles are added up through LDS (one barrier) and stored as float4 rows.
+//     Layers with few tiles split K over workgroups as well (partial sums to the split-K scratch, summed by the
+//     BatchRenorm launch that follows -- crn_splitk_defer -- or by the reduction launch).
+//   * The BatchRenorm-apply + ReLU of the producer is applied to the A registers (scale / shift of the lane's channel).
+// fp32 MFMA like the kernel above: same products, different summation order (2e-5 of the output range in the tests).
+struct Pw2Geom {
+  const float* x; const float* w; const float* bias; float* y;
+  crnInTransform tr;
+  int B, C, N, Npad, S, tilesS;
+  int64_t xsB, ysB, ysC;
+  int bias_sB, mode;           // mode 1: y += result
+  int ksl, ksplits;            // channels per workgroup slice (multiple of 16), slices; slices > 1: y is the scratch,
+};                             // batch index split * B + b, no bias except slice 0
+
+template <int NW, int GPW>
+__global__ __launch_bounds__(NW * 64) void pw2_kernel(Pw2Geom g) {
+  crn_kernargs_now(g.x, g.w, g.bias, g.y, g.tr.scale, g.tr.shift, g.tr.pre_relu, g.tr.post_relu, g.B, g.C, g.N, g.Npad,
+                   g.S, g.tilesS, g.xsB, g.ysB, g.ysC, g.bias_sB, g.mode, g.ksl, g.ksplits);
+  extern __shared__ __attribute__((aligned(16))) f32x4 red[];        // [NW][16][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, kk = lane >> 4;
+  const int b = blockIdx.x / g.tilesS, p0 = (blockIdx.x - b * g.tilesS) * 64;
+  const int n0 = blockIdx.y * 64;
+  const int split = blockIdx.z;
+  const int cbeg = split * g.ksl, cend = min(g.C, cbeg + g.ksl);
+  const __amdgpu_buffer_rsrc_t xrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x + (int64_t)b * g.xsB), 0, g.C * g.S * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w), 0, g.C * g.Npad * 4, 0x00020000);
+  const bool p_ok = p0 + 4 * i16 < g.S, n_ok = n0 + 4 * i16 < g.Npad;
+  const bool has_tr = g.tr.scale != nullptr;
+  f32x4 av[GPW][4], bv[GPW][4];
+  float sc[GPW][4], sh[GPW][4];
+  constexpr unsigned kOut = 0x80000000u;                             // past the buffer: reads 0
+#pragma unroll
+  for (int t = 0; t < GPW; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = cbeg + 16 * (wave + NW * t) + 4 * q + kk;
+      const bool ok = c < cend;
+      av[t][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+          xrs, (ok && p_ok) ? (unsigned)(c * g.S + p0 + 4 * i16) * 4u : kOut, 0, 0));
+      bv[t][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+          wrs, (ok && n_ok) ? (unsigned)(c * g.Npad + n0 + 4 * i16) * 4u : kOut, 0, 0));
+      sc[t][q] = (has_tr && ok) ? g.tr.scale[c] : 1.f;
+      sh[t][q] = (has_tr && ok) ? g.tr.shift[c] : 0.f;
+    }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn) acc[j][jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < GPW; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 a = av[t][q];
+      if (has_tr) {
+        const int c = cbeg + 16 * (wave + NW * t) + 4 * q + kk;
+        if (c < cend && p_ok) {                                      // (channels / positions past the end stay 0)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v = a[j];
+            if (g.tr.pre_relu) v = fmaxf(v, 0.f);
+            v = v * sc[t][q] + sh[t][q];
+            if (g.tr.post_relu) v = fmaxf(v, 0.f);
+            a[j] = v;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) acc[j][jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], bv[t][q][jn], acc[j][jn], 0, 0, 0);
+    }
+  // D row kk*4 + r of M tile j = position p0 + 4*(kk*4 + r) + j, col i16 of N tile jn = column n0 + 4*i16 + jn: the four
+  // M tiles of one (jn, r) are four consecutive positions -> one float4 per (jn, r) and lane, in output order
+#pragma unroll
+  for (int jn = 0; jn < 4; ++jn)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      red[(wave * 16 + jn * 4 + r) * 64 + lane] = (f32x4){acc[0][jn][r], acc[1][jn][r], acc[2][jn][r], acc[3][jn][r]};
+  __syncthreads();
+  constexpr int EPW = 16 / NW;                                       // (jn, r) pairs summed and stored by each wave
+#pragma unroll
+  for (int e = 0; e < EPW; ++e) {
+    const int pr = wave * EPW + e, jn = pr >> 2, r = pr & 3;
+    f32x4 v = red[pr * 64 + lane];
+#pragma unroll
+    for (int w2 = 1; w2 < NW; ++w2) v += red[(w2 * 16 + pr) * 64 + lane];
+    const int n = n0 + 4 * i16 + jn, p = p0 + 16 * kk + 4 * r;
+    if (n < g.N && p < g.S) {
+      if (g.bias && split == 0) v += g.bias[(int64_t)b * g.bias_sB + n];
+      float* dst = g.y + (int64_t)(split * g.B + b) * g.ysB + (int64_t)n * g.ysC + p;
+      if (g.mode == 1) v += *reinterpret_cast<const f32x4*>(dst);
+      *reinterpret_cast<f32x4*>(dst) = v;
+    }
+  }
+}
+
+template <int NW, int GPW>
+int launch_pw2(const Pw2Geom& g, dim3 grid, hipStream_t st) {
+  auto k = pw2_kernel<NW, GPW>;
+  const size_t lds = (size_t)NW * 16 * 64 * 16;
+  if (lds > 65536) CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, grid, dim3(NW * 64), lds, st, g);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
 // --------------------------- dense layers on 1^3 grids ------------------------------------------------------
 // decoder stage_1 (reconstruction_decoder.py:52-54): ConvTranspose3d(k=4) from a 1^3 grid = a dense layer from
 // 67 channels onto 16384 logical channels, i.e. ONE position per sample.  The tile engine needs 16 positions per
@@ -597,7 +719,7 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
       return CRN_OK;
     }
     if (y->C <= 256 && !trv.scale && x->C >= 1024) {   // long reduction onto few columns
-      const int zs = (y->sC == 1 && y->sB >= y->C) ? std::max(1, std::min(16, x->C / 2048)) : 1;   // slices of >= 2048 rows
+      const int zs = (y->sC == 1 && y->sB >= y->C && !crn_deterministic()) ? std::max(1, std::min(16, x->C / 2048)) : 1;   // slices of >= 2048 rows
       if (zs > 1 && !accumulate)
         CRN_HIP(hipMemset2DAsync(y->base, (size_t)y->sB * 4, 0, (size_t)y->C * 4, (size_t)x->B, st));
       hipLaunchKernelGGL(dense_rows_kernel, dim3((unsigned)crn_cdiv(y->C, 8), (unsigned)x->B, (unsigned)zs), dim3(256), 0, st,
@@ -611,6 +733,45 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
       Sx == (int64_t)y->D * y->H * y->W && (Sx & 3) == 0 && (((uintptr_t)w) & 15) == 0 &&
       (int64_t)x->C * Sx * 4 < ((int64_t)1 << 31) && (int64_t)x->C * Npad * 4 < ((int64_t)1 << 31) &&
       (!tr || !tr->scale || x->C <= kPwTab)) {           // (buffer offsets of the hand-tracked loads; the LDS tables)
+    static const bool pw2_on = getenv("CRN_PW2") && atoi(getenv("CRN_PW2")) != 0;   // measured (tools/pw_trace.sh, profiles/r03_pw_trace.txt): 13-15 us per layer like the staged kernel -- both sit at ~38 TF/s on these 0.5 GFLOP launches -- plus a split-K reduction where it splits: off by default
+    if (pw2_on && plain_view(*y) && (x->C & 15) == 0 && x->C >= 64 && (y->sB & 3) == 0 && (y->sC & 3) == 0) {
+      // operands straight from HBM (pw2_kernel).  Decomposition: 64 x 64 tiles; 8 waves per workgroup (4 for 64 input
+      // channels), one or two 16-channel groups per wave; K slices of NW * GPW * 16 channels over blockIdx.z
+      Pw2Geom q{};
+      q.x = x->base; q.w = w; q.bias = bias; q.y = y->base;
+      q.tr = tr ? *tr : crnInTransform{nullptr, nullptr, 0, 0};
+      q.B = x->B; q.C = x->C; q.N = y->C; q.Npad = Npad; q.S = (int)Sx; q.tilesS = (int)crn_cdiv(Sx, 64);
+      q.xsB = x->sB; q.ysB = y->sB; q.ysC = y->sC; q.bias_sB = bias_sB; q.mode = accumulate ? 1 : 0;
+      const int groups = x->C / 16;
+      const int NW = groups >= 8 ? 8 : 4;
+      const int64_t tiles = (int64_t)q.tilesS * x->B * crn_cdiv(y->C, 64);
+      static const int pw2_fill = getenv("CRN_PW2_FILL") ? atoi(getenv("CRN_PW2_FILL")) : 384;
+      int GPW = (groups >= 2 * NW && tiles * crn_cdiv(groups, 2 * NW) >= pw2_fill) ? 2 : 1;
+      if (const char* f = getenv("CRN_PW2_GPW")) GPW = atoi(f) == 2 ? 2 : 1;
+      q.ksl = NW * GPW * 16;
+      q.ksplits = crn_cdiv(x->C, q.ksl);
+      float* scratch2 = nullptr;
+      if (q.ksplits > 1) {
+        const int64_t ytot2 = (int64_t)y->B * y->C * Sx;
+        scratch2 = splitk_scratch((size_t)q.ksplits * ytot2);
+        if (scratch2) { q.y = scratch2; q.ysB = (int64_t)y->C * Sx; q.ysC = Sx; q.mode = 0; }
+      }
+      if (q.ksplits == 1 || scratch2) {
+        const dim3 grid((unsigned)(q.tilesS * x->B), (unsigned)crn_cdiv(y->C, 64), (unsigned)q.ksplits);
+        int rc2;
+        if (NW == 8) rc2 = GPW == 2 ? launch_pw2<8, 2>(q, grid, st) : launch_pw2<8, 1>(q, grid, st);
+        else rc2 = launch_pw2<4, 1>(q, grid, st);
+        if (rc2 != CRN_OK) return rc2;
+        if (q.ksplits > 1) {
+          if (armed && !accumulate && y->sB == (int64_t)y->C * Sx) {
+            crn_splitk_set_pending(*y, scratch2, q.ksplits, st);
+            return CRN_OK;
+          }
+          return crn_splitk_reduce(*y, scratch2, q.ksplits, accumulate, st);
+        }
+        return CRN_OK;
+      }
+    }
     PwGeom p{};
     p.x = x->base; p.y = y->base; p.w = w; p.bias = bias;
     p.tr = tr ? *tr : crnInTransform{nullptr, nullptr, 0, 0};
@@ -911,6 +1072,7 @@ int wgrad_launch(const crnView* x, const crnInTransform* tr, const crnView* dy, 
   // one resident round: at most kWgBlocks (= 2 per CU) workgroups, or the stragglers double the time
   const int budget = max_blocks > 0 ? std::min(max_blocks, kWgBlocks) : kWgBlocks;
   int splits = std::max(1, std::min(g.ntiles, budget / (cblocks * nblocks)));
+  if (crn_deterministic()) splits = 1;                       // (the per-group splits below follow: min(ntiles, ~splits))
   g.tiles_per_split = crn_cdiv(g.ntiles, splits);
   splits = crn_cdiv(g.ntiles, g.tiles_per_split);
   bool balanced = false;
@@ -929,7 +1091,7 @@ int wgrad_launch(const crnView* x, const crnInTransform* tr, const crnView* dy, 
     g.balanced = 1; g.nbpg = (dy->C / boxes->n_groups) / NB;
     g.zoff[0] = 0;
     for (int gi = 0; gi < g.n_groups; ++gi) {
-      const int sgi = std::max(1, std::min(g.ntiles, (int)(splits * w[gi] * g.n_groups / wsum + 0.5)));
+      const int sgi = crn_deterministic() ? 1 : std::max(1, std::min(g.ntiles, (int)(splits * w[gi] * g.n_groups / wsum + 0.5)));
       g.tps[gi] = crn_cdiv(g.ntiles, sgi);
       g.sg[gi] = crn_cdiv(g.ntiles, g.tps[gi]);
       g.zoff[gi + 1] = g.zoff[gi] + g.nbpg * g.sg[gi];

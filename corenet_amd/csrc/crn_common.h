@@ -81,6 +81,13 @@ __device__ __forceinline__ void crn_kernarg_touch(const T& g) {
   asm volatile("" ::"s"(p[sizeof(T) / 4 - 1]));
 }
 
+// Deterministic mode (env CRN_DETERMINISTIC=1 or crn_set_deterministic(1)): every floating-point sum of the library is
+// taken in an order that does not depend on how workgroups are scheduled, so two runs from the same state are
+// bit-identical (debugging aid: a loss regression can be told from atomic-order noise).  Weight gradients give each
+// dw element to ONE workgroup (no split over the positions: slow), the bias gradient fused into the BatchRenorm
+// backward becomes its own ordered reduction, and the ray-sample scatter accumulates in 64-bit fixed point.
+bool crn_deterministic();
+
 // A split-K convolution whose partial sums are still in the scratch: the next BatchRenorm launch over `y` adds them up
 // itself (crn_splitk_defer); anything else that needs the scratch or y first calls crn_splitk_flush.
 struct CrnSplitPending {

@@ -2,6 +2,7 @@
 // stem's BN+ReLU+maxpool, global average, the latent Linear layer, weight
 // (un)packing gathers, Adam.  References cited per kernel.
 #include "crn_common.h"
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 
@@ -510,5 +511,12 @@ extern "C" int crn_stride2_scatter(const float* dy, float* dx, int B, int C, int
   CRN_CHECK_LAUNCH();
   return CRN_OK;
 }
+
+static int g_crn_det = -1;
+bool crn_deterministic() {
+  if (g_crn_det < 0) { const char* e = getenv("CRN_DETERMINISTIC"); g_crn_det = (e && atoi(e) != 0) ? 1 : 0; }
+  return g_crn_det != 0;
+}
+extern "C" int crn_set_deterministic(int on) { g_crn_det = on ? 1 : 0; return CRN_OK; }
 
 extern "C" const char* crn_version(void) { return "corenet_hip 0.1 (gfx950)"; }

@@ -154,10 +154,15 @@ __device__ __forceinline__ void project_uv(const Cam& c, float x, float y, float
 // still need this kernel as a second launch.
 constexpr int kTMax = 16;                      // tile: 32x8 columns (full 128-B rows) for grids >= 64, else 8x8
 constexpr int kWinFloats = 12 * 1024;          // 48 KiB of LDS
-template <int CN>
+// DET (deterministic mode, crn_common.h): the sums are taken in 64-bit fixed point -- integer adds commute, so the
+// result does not depend on the order in which threads reach a pixel.  scale_p[0] = 2^k chosen from max |dout| so
+// that a pixel's sum cannot overflow; detmap = int64 image of dmap ([B][C][h][w], zeroed), converted by
+// ray_det_finish_kernel.  The LDS window is not used (its float adds are the order-dependent part).
+template <int CN, bool DET>
 __global__ __launch_bounds__(kTMax * kTMax) void ray_sample_bwd_kernel(
     const float* __restrict__ dout, int64_t dout_sB, int C, int D, int H, int W, const float* matrix,
-    const float* offset, float* dmap, int64_t dmap_sB, int h, int w, int zseg, int tilesX, int tilesY, int kTX, int kTY) {
+    const float* offset, float* dmap, int64_t dmap_sB, int h, int w, int zseg, int tilesX, int tilesY, int kTX, int kTY,
+    unsigned long long* detmap, const float* scale_p) {
   __shared__ float win[kWinFloats];
   __shared__ int wbox[4];
   crn_kernargs_now(dout, dout_sB, C, D, H, W, matrix, offset, dmap, dmap_sB, h, w, zseg, tilesX, tilesY, kTX, kTY);
@@ -187,6 +192,7 @@ __global__ __launch_bounds__(kTMax * kTMax) void ray_sample_bwd_kernel(
       iy0 = max(0, (int)floorf(vmin) - 1); iy1 = min(h - 1, (int)ceilf(vmax) + 1);
       if (ix1 < ix0 || iy1 < iy0 || (int64_t)(ix1 - ix0 + 1) * (iy1 - iy0 + 1) * CN > kWinFloats) { ix1 = -1; iy1 = -1; ix0 = iy0 = 0; }
     }
+    if (DET) { ix0 = iy0 = 0; ix1 = iy1 = -1; }              // no LDS window: every run goes to the fixed-point image
     wbox[0] = ix0; wbox[1] = ix1; wbox[2] = iy0; wbox[3] = iy1;
   }
   __syncthreads();
@@ -210,6 +216,12 @@ __global__ __launch_bounds__(kTMax * kTMax) void ray_sample_bwd_kernel(
 #pragma unroll
           for (int k = 0; k < CN; ++k)
             if (cbase + k < C) atomicAdd(wp + k * wn, acc[k]);          // ds_add_f32
+        } else if (DET) {
+          const float sc = scale_p[0];
+          unsigned long long* ib = detmap + ((int64_t)b * C + cbase) * hw;
+#pragma unroll
+          for (int k = 0; k < CN; ++k)
+            if (cbase + k < C) atomicAdd(ib + k * hw + cur, (unsigned long long)(long long)__float2ll_rn(acc[k] * sc));
         } else {
 #pragma unroll
           for (int k = 0; k < CN; ++k)
@@ -267,6 +279,32 @@ __global__ __launch_bounds__(kTMax * kTMax) void ray_sample_bwd_kernel(
   }
 }
 
+// deterministic mode: max |dout| (integer max of the float bit patterns), then the power-of-two scale
+__global__ void ray_det_maxabs_kernel(const float* dout, int64_t dout_sB, int64_t per_b, int B, unsigned* maxbits) {
+  unsigned m = 0;
+  for (int b = 0; b < B; ++b)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per_b; i += (int64_t)gridDim.x * blockDim.x)
+      m = max(m, __float_as_uint(fabsf(dout[b * dout_sB + i])));
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(maxbits, m);
+}
+__global__ void ray_det_scale_kernel(const unsigned* maxbits, float* scale, int log2_terms) {
+  // |sum| <= 2^log2_terms * max: scale = 2^(61 - log2_terms - exponent(max) - 1) keeps it below 2^62
+  const float mx = __uint_as_float(maxbits[0]);
+  int e = 0;
+  if (mx > 0.f) frexpf(mx, &e);                                 // mx = f * 2^e, 0.5 <= f < 1
+  scale[0] = mx > 0.f ? ldexpf(1.f, 61 - log2_terms - e) : 1.f;
+}
+__global__ void ray_det_finish_kernel(const unsigned long long* detmap, const float* scale, float* dmap, int64_t dmap_sB,
+                                      int64_t per_b, int B) {
+  const double inv = 1.0 / (double)scale[0];
+  for (int b = 0; b < B; ++b)
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < per_b; i += (int64_t)gridDim.x * blockDim.x)
+      dmap[b * dmap_sB + i] += (float)((double)(long long)detmap[b * per_b + i] * inv);
+}
+void* g_ray_det_buf = nullptr;
+size_t g_ray_det_bytes = 0;
+
 }  // namespace
 
 extern "C" int crn_ray_sample_fwd(const float* map, int64_t map_sB, int64_t map_sC, int64_t map_sP, int B, int C,
@@ -312,14 +350,45 @@ extern "C" int crn_ray_sample_bwd(const float* dout, int64_t dout_sB, int B, int
   const bool big = W >= 64 && H >= 64;
   const int kTX = big ? 32 : 8, kTY = 8;
   const int tilesX = crn_cdiv(W, kTX), tilesY = crn_cdiv(H, kTY);
+  if (crn_deterministic()) {
+    // 64-bit fixed-point accumulation (see ray_sample_bwd_kernel<.., DET>): scratch = int64 image + max bits + scale
+    const int64_t per_b = (int64_t)C * h * w;
+    const size_t need = (size_t)B * per_b * 8 + 256;
+    if (need > g_ray_det_bytes) {
+      if (g_ray_det_buf) CRN_HIP(hipFree(g_ray_det_buf));
+      CRN_HIP(hipMalloc(&g_ray_det_buf, need));
+      g_ray_det_bytes = need;
+    }
+    unsigned long long* detmap = reinterpret_cast<unsigned long long*>(g_ray_det_buf);
+    unsigned* maxbits = reinterpret_cast<unsigned*>(detmap + (size_t)B * per_b);
+    float* scale = reinterpret_cast<float*>(maxbits + 16);
+    CRN_HIP(hipMemsetAsync(g_ray_det_buf, 0, need, st));
+    const int64_t dper_b = (int64_t)C * D * H * W;
+    hipLaunchKernelGGL(ray_det_maxabs_kernel, dim3(1024), dim3(256), 0, st, dout, dout_sB, dper_b, B, maxbits);
+    int lg = 0;
+    while (((int64_t)1 << lg) < (int64_t)D * H * W) ++lg;
+    hipLaunchKernelGGL(ray_det_scale_kernel, dim3(1), dim3(1), 0, st, maxbits, scale, lg);
+    if (C % 12 == 0) {
+      dim3 grid((unsigned)(tilesX * tilesY * nseg), (unsigned)(C / 12), (unsigned)B);
+      hipLaunchKernelGGL((ray_sample_bwd_kernel<12, true>), grid, dim3(kTX * kTY), 0, st, dout, dout_sB, C, D, H, W, matrix,
+                         offset, dmap, dmap_sB, h, w, zseg, tilesX, tilesY, kTX, kTY, detmap, scale);
+    } else {
+      dim3 grid((unsigned)(tilesX * tilesY * nseg), (unsigned)crn_cdiv(C, 4), (unsigned)B);
+      hipLaunchKernelGGL((ray_sample_bwd_kernel<4, true>), grid, dim3(kTX * kTY), 0, st, dout, dout_sB, C, D, H, W, matrix,
+                         offset, dmap, dmap_sB, h, w, zseg, tilesX, tilesY, kTX, kTY, detmap, scale);
+    }
+    hipLaunchKernelGGL(ray_det_finish_kernel, dim3(256), dim3(256), 0, st, detmap, scale, dmap, dmap_sB, per_b, B);
+    CRN_CHECK_LAUNCH();
+    return CRN_OK;
+  }
   if (C % 12 == 0) {
     dim3 grid((unsigned)(tilesX * tilesY * nseg), (unsigned)(C / 12), (unsigned)B);
-    hipLaunchKernelGGL(ray_sample_bwd_kernel<12>, grid, dim3(kTX * kTY), 0, st, dout, dout_sB, C, D, H, W, matrix,
-                       offset, dmap, dmap_sB, h, w, zseg, tilesX, tilesY, kTX, kTY);
+    hipLaunchKernelGGL((ray_sample_bwd_kernel<12, false>), grid, dim3(kTX * kTY), 0, st, dout, dout_sB, C, D, H, W, matrix,
+                       offset, dmap, dmap_sB, h, w, zseg, tilesX, tilesY, kTX, kTY, (unsigned long long*)nullptr, (const float*)nullptr);
   } else {
     dim3 grid((unsigned)(tilesX * tilesY * nseg), (unsigned)crn_cdiv(C, 4), (unsigned)B);
-    hipLaunchKernelGGL(ray_sample_bwd_kernel<4>, grid, dim3(kTX * kTY), 0, st, dout, dout_sB, C, D, H, W, matrix,
-                       offset, dmap, dmap_sB, h, w, zseg, tilesX, tilesY, kTX, kTY);
+    hipLaunchKernelGGL((ray_sample_bwd_kernel<4, false>), grid, dim3(kTX * kTY), 0, st, dout, dout_sB, C, D, H, W, matrix,
+                       offset, dmap, dmap_sB, h, w, zseg, tilesX, tilesY, kTX, kTY, (unsigned long long*)nullptr, (const float*)nullptr);
   }
   CRN_CHECK_LAUNCH();
   return CRN_OK;

@@ -367,6 +367,15 @@ int crn_merge_labels(const float* meshes_grid, const int32_t* scene_mesh_start,
                      const int32_t* mesh_label, int B, int D, int H, int W, int sub_grid,
                      int32_t* out, crnStream s);
 
+/* Deterministic mode (also env CRN_DETERMINISTIC=1): every floating-point sum of the library is taken in an order that
+ * does not depend on how workgroups are scheduled, so two runs from the same state are bit-identical -- a debugging
+ * aid (the reference gets the same from torch.use_deterministic_algorithms; its index_put_(accumulate=True) and cuDNN
+ * weight gradients are atomic-order dependent too).  Default mode: weight gradients, the bias gradient fused into the
+ * BatchRenorm backward and the ray-sample scatter add partial sums with fire-and-forget atomics.  Deterministic mode:
+ * one workgroup per weight-gradient element (slow: 10-50x for those launches), an ordered two-level reduction for the
+ * bias gradient, 64-bit fixed-point accumulation (scale from max |dout|) for the scatter.  Process-wide.           */
+int crn_set_deterministic(int on);
+
 /* misc */
 int crn_zero_f32(float* p, int64_t n, crnStream s);
 /* p[i] += v, i < n : steps every BatchRenorm's num_batches_tracked (batch_renorm.py:57) */

@@ -321,6 +321,42 @@ def test_mean_iou_parity_on_trained_weights():
   assert abs(iou_h - iou_o) < 1e-4, (iou_h, iou_o)
 
 
+@pytest.mark.parametrize("math", ["bf16x3", "fp32"])
+def test_deterministic_mode_two_runs_bit_identical(math):
+  """CRN_DETERMINISTIC / crn_set_deterministic: five training steps (forward, iou_fgbg, backward, Adam, running
+  statistics) run twice from the same state give bit-identical parameters, Adam moments, buffers and losses -- weight
+  gradients without position splits, ordered bias-gradient sums, fixed-point ray-sample scatter.  The default mode is
+  run beside it (its atomics make the two runs differ in the last bits; printed, not asserted) and must stay within
+  1e-4 of the deterministic trajectory: the switch changes the ORDER of the sums, nothing else."""
+  from corenet_amd.backend import default_backend
+  be = default_backend()
+  sd = O.make_state(0, 2, nbt=0)
+  image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(2, 0, 2)]
+  gi = grid.to(t.int32)
+
+  def run():
+    m = _model(2, sd, math).train()
+    ls = [float(m.train_step(image, v2s, off, gi, "iou_fgbg", lr=4e-4, adam_eps=1e-4)) for _ in range(5)]
+    t.cuda.synchronize()
+    e = m.engine
+    return ls, [x.clone() for x in (e.store.params, e.store.buffers, e.adam_m, e.adam_v, e.store.grads)]
+
+  try:
+    be.set_deterministic(True)
+    la, ta = run()
+    lb, tb = run()
+  finally:
+    be.set_deterministic(False)
+  assert la == lb, (la, lb)
+  for name, a, b in zip(("params", "buffers", "adam_m", "adam_v", "grads"), ta, tb):
+    assert t.equal(a, b), (name, float((a - b).abs().max()))
+  lc, tc = run()
+  ld, td = run()
+  print(f"[{math}] deterministic: 5 steps twice, bit-identical (loss {la[-1]:.6f}); default mode: run-to-run max |d param| "
+        f"{float((tc[0] - td[0]).abs().max()):.2e}, vs deterministic {float((tc[0] - ta[0]).abs().max()):.2e}")
+  assert abs(lc[-1] - la[-1]) < 1e-3 * abs(la[-1]) + 1e-6
+
+
 def _sync_state(dst, src):
   """dst becomes an exact replica of src (parameters, buffers, step counters, Adam moments)."""
   de, se = dst.engine, src.engine

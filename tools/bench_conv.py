@@ -15,6 +15,10 @@ LAYERS = {  # name: (kind, wshape, pad, in dims)
     "s5t1": ("convT", (32, 16, 7, 7, 7), 3, (32, 32, 32)),
     "s6t1c14": ("convT", (16, 14, 7, 7, 7), 3, (64, 64, 64)),     # m7/m9: 14 classes
     "e2c": ("conv", (256, 64, 1, 1), 0, (1, 64, 64)),
+    "e2a": ("conv", (64, 256, 1, 1), 0, (1, 64, 64)), "e2a0": ("conv", (64, 64, 1, 1), 0, (1, 64, 64)),
+    "e3c": ("conv", (512, 128, 1, 1), 0, (1, 32, 32)), "e3a": ("conv", (128, 512, 1, 1), 0, (1, 32, 32)),
+    "e4c": ("conv", (1024, 256, 1, 1), 0, (1, 16, 16)), "e4a": ("conv", (256, 1024, 1, 1), 0, (1, 16, 16)),
+    "e5c": ("conv", (2048, 512, 1, 1), 0, (1, 8, 8)), "e5a": ("conv", (512, 2048, 1, 1), 0, (1, 8, 8)),
     "e3b": ("conv", (128, 128, 3, 3), 1, (1, 32, 32)),
     "e2b": ("conv", (64, 64, 3, 3), 1, (1, 64, 64)),
     "e4b": ("conv", (256, 256, 3, 3), 1, (1, 16, 16)),
