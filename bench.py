@@ -178,13 +178,16 @@ def main():
   batch_cpu = synthetic_batch(B, seed=rank, num_classes=C)
   image, v2s, off, grid = [x.to(dev) for x in batch_cpu]
   grid = grid.to(t.int32)
-  sync = D.GradientSync(world)
+  # gradient exchange: overlapped buckets; rank 0's BatchRenorm buffers ride on the first bucket (what DDP's per-forward
+  # buffer broadcast delivers, without the blocking collective in front of every step); one broadcast up front
+  sync = D.GradientSync(world).attach(model.engine)
+  sync.probe = world > 1
+  D.broadcast_buffers(model.engine.store)
   plan = model.engine.plan(B)
 
   def timed(mdl, pl):
     """W warm-up steps, then K steps timed between barrier + synchronize on both sides, max over ranks."""
     def step():
-      D.broadcast_buffers(mdl.engine.store)
       return mdl.train_step(image, v2s, off, grid, loss_name, lr=4e-4, adam_eps=1e-4, world_size=world,
                             all_reduce=sync if world > 1 else None)
     for _ in range(args.warmup):
@@ -359,11 +362,10 @@ def main():
   if fp32_side is not None:
     out["fp32_math"] = fp32_side
   if world > 1:
-    out["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
-                   "version": ".".join(str(v) for v in t.cuda.nccl.version()) if dist.get_backend() == "nccl" else None,
-                   "NCCL_ALGO": os.environ.get("NCCL_ALGO"), "NCCL_PROTO": os.environ.get("NCCL_PROTO"),
-                   "overlap": bool(sync.overlap), "buckets_mb": [round((hi - lo) * 4 / 1e6, 1) for _, lo, hi in model.engine.grad_buckets],
-                   "exposed_exchange_ms": probes.get("grad_exchange_wait", 0.0) * 1e3}
+    out["rccl"] = dict(sync.describe(), backend=dist.get_backend(),
+                       buckets_mb=[round((hi - lo) * 4 / 1e6, 1) for _, lo, hi in model.engine.grad_buckets],
+                       exposed_ms_per_bucket=[round(v, 4) for v in sync.exposed_ms_per_bucket()],
+                       exposed_exchange_ms=probes.get("grad_exchange_wait", 0.0) * 1e3)
   if not args.no_cpu_baseline and world == 1:
     out["cpu_baseline"] = cpu_baseline(state0, batch_cpu, loss_name)
     del model, plan

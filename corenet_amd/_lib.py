@@ -59,6 +59,12 @@ _SIGS = {
     "crn_bf3_operands": [vp, vp, i32, i64, vp, vp],
     "crn_splitk_defer": [i32],
     "crn_set_deterministic": [i32],
+    "crn_comm_unique_id": [vp],
+    "crn_comm_init": [vp, i32, i32, C.POINTER(vp)],
+    "crn_comm_destroy": [vp],
+    "crn_comm_info": [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)],
+    "crn_allreduce_f32": [vp, vp, i64, vp],
+    "crn_broadcast_f32": [vp, vp, i64, i32, vp],
     "crn_conv_wgrad_1x1_bf3": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32, i32, vp],
     "crn_conv_wgrad_2d_bf3": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32, i32, i32, i32,
                               i32, i32, vp],

@@ -756,7 +756,7 @@ __global__ __launch_bounds__(kWsThreads) void conv_bf3_ws_kernel(Bf3Geom g) {
         const unsigned off_lo = off + 16u;                     // (bit 31 survives: out-of-range lanes stay out of range)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %4, 0 offen lds\n\t"
                      "s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %3, %4, 0 offen lds"
-                     :: "s"(mh), "s"(ml), "v"(off), "v"(off_lo), "s"(wsrs) : "memory", "m0");
+                     :: "s"(mh), "s"(ml), "v"(off), "v"(off_lo), "s"(wsrs) : "memory");   // (m0 is not an allocatable register: nothing of the compiler's lives in it here)
       }
     }
   };

@@ -35,6 +35,45 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
   return rank, local, world
 
 
+class NativeComm:
+  """RCCL communicator owned by libcorenet_hip.so (crn_comm_*, include/corenet_hip.h): rank 0 draws the unique id,
+  the torch.distributed store that init_from_env already set up hands the 128 bytes to the other ranks, every rank
+  creates its communicator on its own GPU.  all_reduce(x) enqueues an in-place sum on the CURRENT library stream
+  (corenet_amd._lib.stream(): inside the engine's bucket hook that is the side stream, right behind the un-pack)."""
+
+  def __init__(self, rank: Optional[int] = None, world: Optional[int] = None, group=None):
+    import ctypes as C
+    from corenet_amd import _lib
+    self._lib = _lib
+    L = _lib.lib()
+    if rank is None:
+      rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world is None:
+      world = dist.get_world_size(group) if dist.is_initialized() else 1
+    buf = (C.c_char * 128)()
+    if rank == 0:
+      L.crn_comm_unique_id(C.cast(buf, C.c_void_p))
+    if world > 1:
+      box = [bytes(buf)]
+      dist.broadcast_object_list(box, src=0, group=group)       # through the store / the existing process group
+      buf = (C.c_char * 128).from_buffer_copy(box[0])
+    comm = C.c_void_p()
+    L.crn_comm_init(C.cast(buf, C.c_void_p), rank, world, C.byref(comm))
+    self.comm, self.rank, self.world = comm, rank, world
+    ver = C.c_int(0)
+    L.crn_comm_info(self.comm, C.byref(ver), None, None)
+    self.version = ver.value
+
+  def all_reduce(self, x: t.Tensor):
+    assert x.is_cuda and x.dtype == t.float32 and x.is_contiguous()
+    self._lib.lib().crn_allreduce_f32(self.comm, x.data_ptr(), x.numel(), self._lib.stream())
+
+  def close(self):
+    if self.comm is not None:
+      self._lib.lib().crn_comm_destroy(self.comm)
+      self.comm = None
+
+
 class GradientSync:
   """Gradient exchange of the data-parallel step: all-reduce(sum) over RCCL, the division by world_size is
   folded into the Adam kernel's grad_scale.
@@ -42,11 +81,21 @@ class GradientSync:
   Two ways to drive it.  `sync(grads)` reduces the whole flat slab after backward in `chunks` pieces.
   With `overlap` (default, env CRN_OVERLAP_ALLREDUCE=0 turns it off) `CoreNet.train_step` passes `push` to
   `Plan.backward` as the bucket hook: every finished range of the slab (engine.GRAD_BUCKET_LABELS, reverse
-  layer order like DDP's buckets, pipeline.py:199) is reduced on RCCL's own stream while the rest of
-  backward still runs, and `wait` joins them before Adam."""
+  layer order like DDP's buckets, pipeline.py:199) is reduced while the rest of backward still runs, and `wait`
+  joins them before Adam.
+
+  Transport: torch.distributed (RCCL on GPUs, gloo in the CPU tests), or -- `native=True` / env CRN_NATIVE_RCCL=1 --
+  the library's own RCCL communicator (NativeComm): the all-reduce is then enqueued on the side stream itself.
+
+  BatchRenorm buffers (`attach(engine)`): DDP broadcasts rank 0's buffers before every forward (broadcast_buffers=True,
+  pipeline.py:199-200; the r/d clamps read them, batch_renorm.py:46-49) -- a blocking collective in front of a 8 ms
+  step.  Here the 0.22 MB ride on the first gradient bucket of the step BEFORE: the slab has a staging tail that rank 0
+  fills with its buffers (already stepped by this step's forward) and every other rank with zeros, the bucket's
+  sum-all-reduce covers the tail, and `wait` copies it back into the buffers on every rank: the same values the
+  broadcast would deliver, no extra collective.  (num_batches_tracked advances identically on every rank.)"""
 
   def __init__(self, world_size: int, chunks: int = 4, group=None, overlap: Optional[bool] = None,
-               force: bool = False):
+               force: bool = False, native: Optional[bool] = None):
     self.world, self.chunks, self.group = world_size, max(1, chunks), group
     if overlap is None:
       overlap = os.environ.get("CRN_OVERLAP_ALLREDUCE", "1") != "0"
@@ -54,34 +103,115 @@ class GradientSync:
     self.force = force          # exchange even at world_size 1 (tests: exercises the stream wiring on one GPU)
     self._works = []
     self.pushed = []            # (offset-free) element counts of the buckets of the last step, for tests
+    if native is None:
+      native = os.environ.get("CRN_NATIVE_RCCL", "0") == "1"
+    self.native: Optional[NativeComm] = None
+    if native and t.cuda.is_available() and (world_size > 1 or force):
+      self.native = NativeComm(group=group) if dist.is_initialized() else NativeComm(0, 1)
+    self.engine = None
+    self._staged = False
+    self.probe = False          # bench.py: HIP-event pairs around the wait for every bucket ...
+    self.bucket_log = []        # ... one list of (start, end) per step, buckets in push order
+
+  def attach(self, engine):
+    """Carry the BatchRenorm buffers of `engine` on the first gradient bucket (see the class docstring)."""
+    self.engine = engine
+    return self
 
   def _active(self) -> bool:
-    return self.world > 1 or (self.force and dist.is_initialized())
+    return self.world > 1 or (self.force and (dist.is_initialized() or self.native is not None))
+
+  def _rank(self) -> int:
+    if self.native is not None:
+      return self.native.rank
+    return dist.get_rank(self.group) if dist.is_initialized() else 0
+
+  def _with_buffers(self, grads: t.Tensor) -> t.Tensor:
+    """The slice `grads` extended by the staging tail when it is the top of the gradient slab."""
+    if self.engine is None or not self._active():
+      return grads
+    st = self.engine.store
+    np_ = st.grads.numel()
+    if grads.data_ptr() + 4 * grads.numel() != st.grads.data_ptr() + 4 * np_ or self._staged:
+      return grads
+    if self._rank() == 0:
+      st.buf_stage.copy_(st.buffers)
+    else:
+      st.buf_stage.zero_()
+    self._staged = True
+    lo = (grads.data_ptr() - st.gslab.data_ptr()) // 4
+    return st.gslab[lo:]
+
+  def _reduce(self, x: t.Tensor):
+    if self.native is not None:
+      self.native.all_reduce(x)
+      return None
+    return dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
   def __call__(self, grads: t.Tensor):
     if not self._active():
       return
+    grads = self._with_buffers(grads)
     n = grads.numel()
     step = (n + self.chunks - 1) // self.chunks
     step = (step + 1023) // 1024 * 1024
-    works = []
-    for o in range(0, n, step):
-      works.append(dist.all_reduce(grads[o:o + step], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+    works = [self._reduce(grads[o:o + step]) for o in range(0, n, step)]
     for w in works:
-      w.wait()
+      if w is not None:
+        w.wait()
+    self._unstage()
 
   def push(self, grads: t.Tensor):
     """Bucket hook: start the all-reduce of one finished slice of the slab (ordered after the work already
     queued on the current stream) and return immediately."""
     self.pushed.append(grads.numel())
     if self._active():
-      self._works.append(dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+      self._works.append(self._reduce(self._with_buffers(grads)))
 
   def wait(self):
     """The current stream waits for every pushed bucket."""
+    evs = []
     for w in self._works:
-      w.wait()
+      if self.probe and t.cuda.is_available():
+        a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        a.record()
+        if w is not None:
+          w.wait()
+        b.record()
+        evs.append((a, b))
+      elif w is not None:
+        w.wait()
     self._works.clear()
+    if evs:
+      self.bucket_log.append(evs)
+    self._unstage()
+
+  def exposed_ms_per_bucket(self):
+    """Mean time the main stream spent waiting for each bucket (push order) over the probed steps; synchronises."""
+    if not self.bucket_log:
+      return []
+    t.cuda.synchronize()
+    n = min(len(e) for e in self.bucket_log)
+    return [sum(e[i][0].elapsed_time(e[i][1]) for e in self.bucket_log) / len(self.bucket_log) for i in range(n)]
+
+  def describe(self) -> dict:
+    """What the N > 1 bench line reports about the exchange."""
+    be = "native RCCL (crn_allreduce_f32 on the side stream)" if self.native is not None else (
+        f"torch.distributed/{dist.get_backend(self.group)}" if dist.is_initialized() else "none")
+    ver = None
+    if self.native is not None:
+      ver = self.native.version
+    elif dist.is_initialized() and dist.get_backend(self.group) == "nccl":
+      ver = ".".join(str(v) for v in t.cuda.nccl.version())
+    return {"transport": be, "ranks": self.world, "version": ver, "overlap": bool(self.overlap),
+            "buffers_on_first_bucket": self.engine is not None,
+            "NCCL_ALGO": os.environ.get("NCCL_ALGO"), "NCCL_PROTO": os.environ.get("NCCL_PROTO")}
+
+  def _unstage(self):
+    if self._staged:
+      st = self.engine.store
+      st.buffers.copy_(st.buf_stage)       # (native transport: ordered by Plan._join_side, which ran before wait)
+      self._staged = False
 
 
 def broadcast_buffers(store, src: int = 0, group=None):

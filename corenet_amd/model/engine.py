@@ -124,7 +124,11 @@ class ParamStore:
         self.off[key] = (nn, shape); nn += 1
     self.kind = {k: kd for k, _, kd in specs}
     self.params = t.zeros(np_, dtype=dtype, device=device)
-    self.grads = t.zeros(np_, dtype=dtype, device=device)
+    # gradient slab + a staging tail of the size of the buffer slab: the data-parallel exchange carries rank 0's
+    # BatchRenorm buffers on the first (top-of-slab) gradient bucket (distributed.GradientSync)
+    self.gslab = t.zeros(np_ + nb, dtype=dtype, device=device)
+    self.grads = self.gslab[:np_]
+    self.buf_stage = self.gslab[np_:]
     self.buffers = t.zeros(nb, dtype=dtype, device=device)
     self.nbt = t.zeros(nn, dtype=t.int64, device=device)
 

@@ -367,6 +367,23 @@ int crn_merge_labels(const float* meshes_grid, const int32_t* scene_mesh_start,
                      const int32_t* mesh_label, int B, int D, int H, int W, int sub_grid,
                      int32_t* out, crnStream s);
 
+/* ---------------- data parallelism: RCCL from the library ------------------------
+ * The reference exchanges gradients through torch's DistributedDataParallel over NCCL (pipeline.py:199-200,229) and
+ * broadcasts the BatchRenorm buffers from rank 0 (DDP broadcast_buffers).  Here the exchange can be enqueued by the
+ * library itself on the caller's stream (the engine's side stream, behind the un-pack of a gradient bucket):
+ *   rank 0: crn_comm_unique_id(id)  ->  the host hands the 128 bytes to every rank (torch.distributed store, MPI, ...)
+ *   every rank (its GPU current): crn_comm_init(id, rank, nranks, &comm)
+ *   crn_allreduce_f32(comm, buf, n, stream): in-place sum over the ranks, asynchronous, stream-ordered.
+ * librccl.so is opened on first use; without it these calls return CRN_EINVAL and the rest of the library works.
+ * RCCL picks ring / tree / direct by message size and topology; NCCL_ALGO / NCCL_PROTO (read by RCCL at communicator
+ * creation) override it -- tools/scale_probe.sh times the engine's bucket sizes under each.                        */
+int crn_comm_unique_id(void* id128 /* 128 bytes, host */);
+int crn_comm_init(const void* id128, int rank, int nranks, void** comm);
+int crn_comm_destroy(void* comm);
+int crn_comm_info(void* comm /* may be NULL */, int* rccl_version, int* rank, int* nranks);
+int crn_allreduce_f32(void* comm, float* buf, int64_t n, crnStream s);
+int crn_broadcast_f32(void* comm, float* buf, int64_t n, int root, crnStream s);
+
 /* Deterministic mode (also env CRN_DETERMINISTIC=1): every floating-point sum of the library is taken in an order that
  * does not depend on how workgroups are scheduled, so two runs from the same state are bit-identical -- a debugging
  * aid (the reference gets the same from torch.use_deterministic_algorithms; its index_put_(accumulate=True) and cuDNN

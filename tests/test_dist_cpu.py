@@ -77,10 +77,14 @@ def _train_worker(rank, world, port, out):
     model.engine.store.buffers.add_(1.0)
   D.broadcast_buffers(model.engine.store)
   image, v2s, off, grid = O.synthetic_batch(1, seed=rank, num_classes=2)       # a different sample per rank
-  sync = D.GradientSync(world)
+  # rank 0's BatchRenorm buffers ride on the first gradient bucket (GradientSync.attach): after the step every rank holds
+  # the running statistics rank 0 computed from ITS sample, as DDP's broadcast before the next forward would deliver
+  sync = D.GradientSync(world).attach(model.engine)
   before = model.engine.store.params.clone()
+  buf0 = model.engine.store.buffers.clone()
   loss = model.train_step(image, v2s, off, grid.to(t.int32), "iou_fgbg", world_size=world, all_reduce=sync)
   t.save({"p": model.engine.store.params.clone(), "g": model.engine.store.grads.clone(), "before": before,
+          "buf": model.engine.store.buffers.clone(), "buf_before": buf0,
           "loss": float(loss), "pushed": list(sync.pushed), "buckets": [(lo, hi) for _, lo, hi in model.engine.grad_buckets]},
          os.path.join(out, f"t{rank}.pt"))
   dist.barrier(); dist.destroy_process_group()
@@ -97,6 +101,7 @@ def test_two_rank_overlapped_train_step(tmp_path):
   assert a["loss"] != b["loss"] and all(map(lambda v: v == v, (a["loss"], b["loss"])))     # different samples, finite
   assert t.equal(a["g"], b["g"]) and t.equal(a["p"], b["p"])
   assert a["pushed"] == [hi - lo for lo, hi in a["buckets"]] and sum(a["pushed"]) == a["g"].numel()
+  assert t.equal(a["buf"], b["buf"]) and not t.equal(a["buf"], a["buf_before"])         # rank 0's stepped statistics everywhere
   moved = (a["p"] - a["before"]).abs()
   assert float(moved.max()) > 1e-5 and float(moved.max()) <= 4e-4 * 1.01      # one Adam step of lr 4e-4
 

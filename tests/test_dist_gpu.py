@@ -26,14 +26,15 @@ def _worker(rank, world, port, out):
   model.load_state_dict(O.make_state(0, 2, nbt=0)); model.train()
   image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(1, seed=rank, num_classes=2)]
   grid = grid.to(t.int32)
-  sync = D.GradientSync(world)
+  sync = D.GradientSync(world).attach(model.engine)      # rank 0's BatchRenorm buffers ride on the first bucket
   assert sync.overlap and model.engine.plan(1).side is not None
+  D.broadcast_buffers(model.engine.store)
   losses = []
   for _ in range(3):
-    D.broadcast_buffers(model.engine.store)
     losses.append(float(model.train_step(image, v2s, off, grid, "iou_fgbg", world_size=world, all_reduce=sync)))
   t.cuda.synchronize()
   t.save({"p": model.engine.store.params.cpu(), "g": model.engine.store.grads.cpu(), "losses": losses,
+          "buf": model.engine.store.buffers.cpu(),
           "pushed": list(sync.pushed), "n": model.engine.store.grads.numel()}, os.path.join(out, f"g{rank}.pt"))
   dist.barrier(); dist.destroy_process_group()
 
@@ -44,6 +45,7 @@ def test_two_ranks_one_gpu_overlapped_train_steps(tmp_path):
   a, b = t.load(tmp_path / "g0.pt"), t.load(tmp_path / "g1.pt")
   assert t.equal(a["g"], b["g"]) and t.equal(a["p"], b["p"])          # same summed gradients, same parameters
   assert sum(a["pushed"]) == a["n"] and len(a["pushed"]) == 7
+  assert t.equal(a["buf"], b["buf"])                                   # ... and the same running statistics (rank 0's)
   assert a["losses"][0] != b["losses"][0]                              # different samples per rank
   assert a["losses"][-1] < a["losses"][0] and b["losses"][-1] < b["losses"][0]
 
@@ -69,4 +71,7 @@ def test_bench_two_rank_launch_path_dry_run():
   assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
   assert abs(d["value"] - 8 * 128 ** 3 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
   assert d["rccl"]["ranks"] == 2 and d["rccl"]["backend"] == "gloo" and len(d["rccl"]["buckets_mb"]) == 7
+  assert d["rccl"]["transport"] == "torch.distributed/gloo" and d["rccl"]["buffers_on_first_bucket"] is True
+  assert len(d["rccl"]["exposed_ms_per_bucket"]) == 7 and all(v >= 0 for v in d["rccl"]["exposed_ms_per_bucket"])
+  assert "NCCL_ALGO" in d["rccl"] and d["rccl"]["exposed_exchange_ms"] >= 0
   assert "cpu_baseline" not in d

@@ -359,6 +359,40 @@ def test_deterministic_mode_two_runs_bit_identical(math):
   assert abs(lc[-1] - la[-1]) < 2e-2 * abs(la[-1]), (lc, la)
 
 
+def test_native_rccl_from_the_library_single_rank():
+  """crn_comm_* / crn_allreduce_f32 (include/corenet_hip.h): the library's own RCCL communicator, bootstrapped from a
+  unique id, on ONE rank (all this box can host): the in-place all-reduce is the identity and stream-ordered, and the
+  fused train step driven through GradientSync(native=True) -- all-reduces enqueued on the engine's side stream
+  behind each bucket's un-pack, rank 0's BatchRenorm buffers riding on the first bucket -- lands bit for bit on the
+  parameters and buffers of the step without an exchange."""
+  from corenet_amd import distributed as D
+  comm = D.NativeComm(0, 1)
+  assert comm.version > 0
+  x = t.randn(1 << 20, device="cuda"); y = x.clone()
+  comm.all_reduce(x)
+  t.cuda.synchronize()
+  assert t.equal(x, y)
+  comm.close()
+  sd = O.make_state(0, 2, nbt=0)
+  image, v2s, off, grid = [v.cuda() for v in O.synthetic_batch(1, 0, 2)]
+  gi = grid.to(t.int32)
+  ma, mb = _model(2, sd, "bf16x3").train(), _model(2, sd, "bf16x3").train()
+  be = ma.engine.be
+  sync = D.GradientSync(1, force=True, native=True).attach(ma.engine)
+  assert sync.native is not None and sync.describe()["transport"].startswith("native RCCL")
+  try:
+    be.set_deterministic(True)                     # (so that the two replicas can be compared bit for bit)
+    for _ in range(2):
+      la = ma.train_step(image, v2s, off, gi, "iou_fgbg", lr=4e-4, adam_eps=1e-4, all_reduce=sync)
+      lb = mb.train_step(image, v2s, off, gi, "iou_fgbg", lr=4e-4, adam_eps=1e-4)
+    t.cuda.synchronize()
+  finally:
+    be.set_deterministic(False)
+  assert len(sync.pushed) == 7 and float(la) == float(lb)
+  assert t.equal(ma.engine.store.params, mb.engine.store.params) and t.equal(ma.engine.store.buffers, mb.engine.store.buffers)
+  sync.native.close()
+
+
 def _sync_state(dst, src):
   """dst becomes an exact replica of src (parameters, buffers, step counters, Adam moments)."""
   de, se = dst.engine, src.engine
