@@ -59,6 +59,8 @@ _SIGS = {
     "crn_bf3_operands": [vp, vp, i32, i64, vp, vp],
     "crn_splitk_defer": [i32],
     "crn_set_deterministic": [i32],
+    "crn_roctx_push": [C.c_char_p],
+    "crn_roctx_pop": [],
     "crn_comm_unique_id": [vp],
     "crn_comm_init": [vp, i32, i32, C.POINTER(vp)],
     "crn_comm_destroy": [vp],
@@ -208,6 +210,34 @@ class pinned_stream:
 
   def __exit__(self, *exc):
     _tls.stream = self.prev
+    return False
+
+
+ROCTX = os.environ.get("CRN_ROCTX", "0") == "1"
+
+
+class roctx_range:
+  """with roctx_range("fwd encoder.stage2.a.op_a.conv."): a rocprofv3 marker range around the library calls of the
+  block (crn_roctx_push / crn_roctx_pop); does nothing unless CRN_ROCTX=1 (or force) and a roctx library is present."""
+  __slots__ = ("label", "on")
+
+  def __init__(self, label: str, force: bool = False):
+    self.label, self.on = label, (ROCTX or force)
+
+  def __enter__(self):
+    if self.on:
+      try:
+        lib().crn_roctx_push(self.label.encode())
+      except HipError:
+        self.on = False
+    return self
+
+  def __exit__(self, *exc):
+    if self.on:
+      try:
+        lib().crn_roctx_pop()
+      except HipError:
+        pass
     return False
 
 

@@ -125,3 +125,44 @@ extern "C" int crn_broadcast_f32(void* comm, float* buf, int64_t n, int root, cr
   const int rc = r.broadcast(buf, buf, (size_t)n, kNcclFloat32, root, c->comm, (hipStream_t)stream);
   return rc ? fail(rc, "ncclBroadcast") : CRN_OK;
 }
+
+// ---------------- rocprofv3 markers --------------------------------------------------------------------------------
+// roctx ranges around the library calls of one layer (the reference has no tracing hooks at all):
+// with CRN_ROCTX=1 the Python engine brackets every layer's launches with crn_roctx_push(label) / crn_roctx_pop(), and
+//   rocprofv3 --kernel-trace --marker-trace -- python ...
+// attributes kernels to layers without the event-probe tools.  The marker library is opened on first use
+// (librocprofiler-sdk-roctx.so, else libroctx64.so); without it the calls are no-ops that return CRN_EINVAL.
+namespace {
+typedef int (*RoctxPushFn)(const char*);
+typedef int (*RoctxPopFn)();
+struct Roctx { RoctxPushFn push = nullptr; RoctxPopFn pop = nullptr; };
+Roctx& roctx() {
+  static Roctx r;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    const char* names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
+    for (const char* n : names) {
+      void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      r.push = (RoctxPushFn)dlsym(h, "roctxRangePushA");
+      r.pop = (RoctxPopFn)dlsym(h, "roctxRangePop");
+      if (r.push && r.pop) break;
+      r.push = nullptr; r.pop = nullptr;
+    }
+  }
+  return r;
+}
+}  // namespace
+extern "C" int crn_roctx_push(const char* label) {
+  Roctx& r = roctx();
+  if (!r.push || !label) return CRN_EINVAL;
+  r.push(label);
+  return CRN_OK;
+}
+extern "C" int crn_roctx_pop(void) {
+  Roctx& r = roctx();
+  if (!r.pop) return CRN_EINVAL;
+  r.pop();
+  return CRN_OK;
+}

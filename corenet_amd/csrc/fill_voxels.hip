@@ -60,6 +60,70 @@ __global__ __launch_bounds__(256) void fill_unpack_kernel(const u64* E, const u6
 // bits of r (subset of e) spread towards higher bit positions through runs of 1s in e
 __device__ __forceinline__ u64 fill_up(u64 e, u64 r) { return (((e + r) ^ e) & e) | r; }
 
+// Grids of ANY size (the reference op has no size limit, fill_voxels_gpu.cu:136-171): rows wider than 512 voxels, or
+// planes whose bitmaps do not fit the LDS budget of the kernels below.  One workgroup per grid, bitmaps in the global
+// workspace (words of 64 voxels, WX words per row, WX unbounded): pack, then relax rows in place -- neighbours in y / z
+// are ORed in, the closure along x is the same carry arithmetic, a forward and a backward pass over the row's words --
+// until a whole sweep changes nothing, then unpack.  Every update only sets bits (monotone closure), words are written
+// with single 8-byte stores, and the workgroup barrier between sweeps orders them: any interleaving inside a sweep
+// reads valid lower bounds and the fixed point is the reference's connected components.  No host round trip.
+template <typename T>
+__global__ __launch_bounds__(1024) void fill_global_kernel(const T* grid, T* out, u64* E, u64* R, int D, int H, int W, int WX) {
+  const int n = blockIdx.x;
+  const int64_t rows = (int64_t)D * H, nw = rows * WX;
+  const T* g = grid + (int64_t)n * rows * W;
+  T* o = out + (int64_t)n * rows * W;
+  u64* e = E + (int64_t)n * nw;
+  u64* r = R + (int64_t)n * nw;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  for (int64_t wi = wave; wi < nw; wi += nwaves) {             // pack: one wave per word
+    const int k = (int)(wi % WX);
+    const int64_t row = wi / WX;
+    const int y = (int)(row % H), z = (int)(row / H);
+    const int x = k * 64 + lane;
+    const bool empty = x < W && !(g[row * W + x] > (T)0);
+    const u64 eb = __ballot(empty);
+    if (lane == 0) { e[wi] = eb; r[wi] = (y == 0 || z == 0) ? eb : (k == 0 ? (eb & 1ull) : 0ull); }
+  }
+  __syncthreads();
+  for (int sweep = 0; sweep < (1 << 24); ++sweep) {
+    int changed = 0;
+    for (int64_t row = threadIdx.x; row < rows; row += blockDim.x) {
+      const int y = (int)(row % H), z = (int)(row / H);
+      u64* rr = r + row * WX;
+      const u64* er = e + row * WX;
+      u64 carry = 0;
+      for (int k = 0; k < WX; ++k) {                           // neighbours + closure towards +x
+        const u64 ek = er[k], old = rr[k];
+        u64 nb = carry & 1ull;
+        if (y > 0) nb |= rr[k - WX];
+        if (y + 1 < H) nb |= rr[k + WX];
+        if (z > 0) nb |= rr[k - (int64_t)H * WX];
+        if (z + 1 < D) nb |= rr[k + (int64_t)H * WX];
+        u64 v = fill_up(ek, old | (nb & ek));
+        carry = v >> 63;
+        if (v != old) { rr[k] = v; changed = 1; }
+      }
+      carry = 0;
+      for (int k = WX - 1; k >= 0; --k) {                      // closure towards -x
+        const u64 eb = __brevll(er[k]), old = rr[k];
+        u64 v = fill_up(eb, __brevll(old) | (carry & eb & 1ull));
+        carry = v >> 63;
+        v = __brevll(v);
+        if (v != old) { rr[k] = v; changed = 1; }
+      }
+    }
+    if (!__syncthreads_or(changed)) break;
+  }
+  for (int64_t wi = wave; wi < nw; wi += nwaves) {             // unpack
+    const int k = (int)(wi % WX);
+    const int64_t row = wi / WX;
+    const int x = k * 64 + lane;
+    const u64 outside = e[wi] & r[wi];
+    if (x < W) o[row * W + x] = ((outside >> lane) & 1ull) ? (T)0 : (T)1;
+  }
+}
+
 template <int WX>
 __device__ __forceinline__ bool relax_row(const u64* e, u64* r) {
   // r |= x-closure of r inside e, both directions, with carries across the row's words
@@ -153,31 +217,6 @@ __device__ int relax_slab(const u64* El, u64* Rl, int nz, int H) {
     any = 1;
   }
   return any;
-}
-
-template <int WX>
-__global__ __launch_bounds__(512) void fill_sweep_kernel(const u64* E, u64* R, int D, int H, int zs,
-                                                         int nslabs, int* flags, int round) {
-  extern __shared__ __attribute__((aligned(16))) u64 sm[];
-  if (round > 0 && flags[round - 1] == 0) return;      // converged in an earlier round
-  const int slab = blockIdx.x % nslabs, n = blockIdx.x / nslabs;
-  const int z0 = slab * zs, nz = min(zs, D - z0);
-  const int rowsz = H * WX;
-  u64* El = sm;                          // [nz][H][WX]
-  u64* Rl = sm + (size_t)zs * rowsz;     // [nz+2][H][WX], plane 0 / nz+1 = halos
-  const u64* Eg = E + ((int64_t)n * D + z0) * rowsz;
-  u64* Rg = R + ((int64_t)n * D + z0) * rowsz;
-  for (int i = threadIdx.x; i < nz * rowsz; i += blockDim.x) { El[i] = Eg[i]; Rl[rowsz + i] = Rg[i]; }
-  for (int i = threadIdx.x; i < rowsz; i += blockDim.x) {
-    Rl[i] = z0 > 0 ? Rg[i - rowsz] : 0ull;
-    Rl[(nz + 1) * rowsz + i] = (z0 + nz < D) ? Rg[nz * rowsz + i] : 0ull;
-  }
-  __syncthreads();
-  const int any = relax_slab<WX>(El, Rl, nz, H);
-  if (any) {
-    for (int i = threadIdx.x; i < nz * rowsz; i += blockDim.x) Rg[i] = Rl[rowsz + i];
-    if (threadIdx.x == 0) atomicOr(&flags[round], 1);
-  }
 }
 
 // ---- device-side rescue path ---------------------------------------------------------------------
@@ -555,7 +594,7 @@ __global__ __launch_bounds__(1024) void fill_fused_kernel(const T* grid, T* out,
   store_slab();
 }
 
-constexpr int kMaxRounds = 4096;
+
 
 constexpr int CRN_EAGAIN = -1000;     // internal: use the multi-launch path
 constexpr size_t kSweepLds = 144 * 1024;
@@ -643,54 +682,16 @@ int run_fill_fused(const T* grid, T* out, int N, int D, int H, int W, int WX, vo
 template <typename T>
 int run_fill(const T* grid, T* out, int N, int D, int H, int W, void* ws, hipStream_t st) {
   const int WX = (W + 63) / 64;
-  if (WX > 8) return CRN_EINVAL;
   const int64_t nwords = (int64_t)N * D * H * WX;
-  {
+  if (WX <= 8) {
     const int rc = run_fill_fused<T>(grid, out, N, D, H, W, WX, ws, st);
     if (rc != CRN_EAGAIN) return rc;
   }
+  // any other size (rows wider than 512 voxels, planes beyond the LDS budget, CRN_FILL_MULTI=1): one persistent
+  // workgroup per grid on bitmaps in the workspace -- still a single asynchronous launch, no host wait
   u64* E = reinterpret_cast<u64*>(ws);
   u64* R = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + align256((size_t)nwords * 8));
-  int* flags = reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + 2 * align256((size_t)nwords * 8));
-  CRN_HIP(hipMemsetAsync(flags, 0, kMaxRounds * sizeof(int), st));
-  const unsigned pk_blocks = (unsigned)std::min<int64_t>(std::max<int64_t>(1, (nwords + 3) / 4), 8192);
-  hipLaunchKernelGGL(fill_pack_kernel<T>, dim3(pk_blocks), dim3(256), 0, st, grid, E, R, D, H, W, WX, nwords);
-  CRN_CHECK_LAUNCH();
-  const size_t plane = (size_t)H * WX * 8;
-  int zs = (int)std::min<size_t>((size_t)D, (kSweepLds / plane - 2) / 2);
-  if (zs < 1) return CRN_EINVAL;
-  const int nslabs = (D + zs - 1) / zs;
-  zs = (D + nslabs - 1) / nslabs;                       // balance the slabs
-  const size_t lds = (size_t)(2 * zs + 2) * plane;
-  auto launch = [&](int round) -> int {
-    dim3 grid_(nslabs * N);
-#define CRN_SWEEP(K)                                                                                           \
-  case K: {                                                                                                    \
-    if (lds > 65536)                                                                                           \
-      CRN_HIP(hipFuncSetAttribute((const void*)fill_sweep_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  (int)lds));                                                                  \
-    hipLaunchKernelGGL(fill_sweep_kernel<K>, grid_, dim3(512), lds, st, E, R, D, H, zs, nslabs, flags, round);  \
-  } break;
-    switch (WX) { CRN_SWEEP(1) CRN_SWEEP(2) CRN_SWEEP(3) CRN_SWEEP(4) CRN_SWEEP(5) CRN_SWEEP(6) CRN_SWEEP(7) CRN_SWEEP(8) }
-#undef CRN_SWEEP
-    CRN_CHECK_LAUNCH();
-    return CRN_OK;
-  };
-  int round = 0;
-  const int batch = nslabs == 1 ? 1 : 4;
-  for (;;) {
-    for (int i = 0; i < batch && round < kMaxRounds; ++i, ++round) {
-      const int rc = launch(round);
-      if (rc != CRN_OK) return rc;
-    }
-    if (nslabs == 1) break;                 // a single slab converges inside one launch
-    int last = 1;
-    CRN_HIP(hipMemcpyAsync(&last, flags + round - 1, sizeof(int), hipMemcpyDeviceToHost, st));
-    CRN_HIP(hipStreamSynchronize(st));
-    if (last == 0) break;
-    if (round >= kMaxRounds) return CRN_ENOCONV;
-  }
-  hipLaunchKernelGGL(fill_unpack_kernel<T>, dim3(pk_blocks), dim3(256), 0, st, E, R, out, W, WX, nwords);
+  hipLaunchKernelGGL(fill_global_kernel<T>, dim3(N), dim3(1024), 0, st, grid, out, E, R, D, H, W, WX);
   CRN_CHECK_LAUNCH();
   return CRN_OK;
 }
@@ -700,7 +701,7 @@ int run_fill(const T* grid, T* out, int N, int D, int H, int W, void* ws, hipStr
 extern "C" size_t crn_fill_voxels_workspace_bytes(int N, int D, int H, int W) {
   const int WX = (W + 63) / 64;
   const size_t nwords = (size_t)N * D * H * WX;
-  const size_t multi = 2 * align256(nwords * 8) + kMaxRounds * sizeof(int) + 256;
+  const size_t multi = fused_offset((int64_t)nwords);      // the two bitmaps (any-size and rescue kernels) + slack
   // single-launch path: control blocks + status + halo planes (2 parities x 2 planes per slab, <= D slabs)
   const size_t fused = align256((size_t)N * sizeof(FusedCtl)) + 256 + (size_t)N * D * 4 * H * WX * 8 + 256;
   return multi + fused;

@@ -663,12 +663,19 @@ class Plan:
   def _stats(self, bn: BN, x: t.Tensor, S: int, sB: int, pre_relu: bool, training: bool):
     if not training:
       return            # eval mode: forward_encoder filled every scale / shift already (Engine.bn_eval_affine)
+    with _lib.roctx_range("bn_stats C%d S%d" % (bn.C, S)):
+      self._bn_stats(bn, x, S, sB, pre_relu, training)
+
+  def _bn_stats(self, bn: BN, x: t.Tensor, S: int, sB: int, pre_relu: bool, training: bool):
     self.be.bn_stats(x, self.B, bn.C, S, sB, pre_relu, bn.gamma, bn.beta, bn.rmean, bn.rvar, bn.nbt,
                      BN_EPS, BN_MOMENTUM, training, bn.scale, bn.shift, bn.saved)
 
   trace = None      # tools/layer_times.py: list of (label, start_event, end_event) for every conv launch
 
   def _timed(self, label, fn):
+    if _lib.ROCTX:                 # CRN_ROCTX=1: a rocprofv3 marker range per layer and direction
+      with _lib.roctx_range(label):
+        return fn()
     if self.trace is None:
       return fn()
     a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
@@ -723,7 +730,7 @@ class Plan:
       self._side_ev.append(t.cuda.Event())
     ev = self._side_ev[self._side_i]; self._side_i += 1
     ev.record()                                   # dy (and the zeroed slab) are ready on the main stream
-    with t.cuda.stream(self.side), _lib.pinned_stream(self.side):
+    with t.cuda.stream(self.side), _lib.pinned_stream(self.side), _lib.roctx_range("wgrad " + cv.name):
       self.side.wait_event(ev)
       self.be.conv_wgrad(x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes), math=math)
 

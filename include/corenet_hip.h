@@ -384,6 +384,12 @@ int crn_comm_info(void* comm /* may be NULL */, int* rccl_version, int* rank, in
 int crn_allreduce_f32(void* comm, float* buf, int64_t n, crnStream s);
 int crn_broadcast_f32(void* comm, float* buf, int64_t n, int root, crnStream s);
 
+/* rocprofv3 markers: a roctx range around the calls that follow (one per layer and direction when the Python engine
+ * runs with CRN_ROCTX=1); `rocprofv3 --kernel-trace --marker-trace` then attributes kernels to layers.  No-ops
+ * (CRN_EINVAL) when no roctx library can be opened.                                                                 */
+int crn_roctx_push(const char* label);
+int crn_roctx_pop(void);
+
 /* Deterministic mode (also env CRN_DETERMINISTIC=1): every floating-point sum of the library is taken in an order that
  * does not depend on how workgroups are scheduled, so two runs from the same state are bit-identical -- a debugging
  * aid (the reference gets the same from torch.use_deterministic_algorithms; its index_put_(accumulate=True) and cuDNN

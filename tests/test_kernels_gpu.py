@@ -856,8 +856,9 @@ def test_fill_serpentine_rescue_and_multi_launch_paths(be):
   """A corridor that snakes up and down z behind every wall needs far more slab exchanges than the
   single-launch kernel allows: it raises its device-side status word and the rescue kernel enqueued behind
   it (one workgroup per grid, no host involvement) must deliver the bit-exact answer, also in place.
-  The rescue path and the multi-launch path are also run on their own (CRN_FILL_RESCUE / CRN_FILL_MULTI)
-  in fresh processes, on random grids of three dtypes."""
+  The rescue path and the any-size path (one persistent workgroup per grid on global bitmaps, which replaced the
+  multi-launch sweeps and their host-side convergence check) are also run on their own (CRN_FILL_RESCUE /
+  CRN_FILL_MULTI) in fresh processes, on random grids of three dtypes."""
   import fill_oracle_c, subprocess, sys, os
   D, H, W = 64, 6, 64
   g = np.zeros((2, D, H, W), np.float32)
@@ -891,6 +892,31 @@ def test_fill_serpentine_rescue_and_multi_launch_paths(be):
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{var: "1"}), capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "path ok" in r.stdout, (var, r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 9, 640), (1, 3, 600, 600), (1, 2, 70, 1100), (3, 20, 20, 513)])
+def test_fill_any_size_bit_exact(be, shape):
+  """The reference op has no size limit (fill_voxels_gpu.cu:136-171): rows wider than 512 voxels and planes whose
+  bitmaps exceed the LDS budget go to the one-workgroup-per-grid kernel on bitmaps in the workspace (round 2 returned
+  CRN_EINVAL for W > 512).  Random grids at three densities plus a serpentine corridor across the wide axis, in place
+  and out of place, two dtypes: bit-exact against the C oracle."""
+  import fill_oracle_c
+  rng = np.random.RandomState(sum(shape))
+  N, D, H, W = shape
+  grids = [(rng.rand(*shape) < d).astype(np.float32) for d in (0.25, 0.45, 0.65)]
+  snake = np.zeros(shape, np.float32)
+  snake[:, 0] = 1; snake[:, :, 0] = 1                      # seeds only on x = 0
+  for i, x in enumerate(range(2, W - 1, 2)):
+    snake[:, :, :, x] = 1
+    snake[:, :, (H - 1) if i % 2 == 0 else 1, x] = 0       # the gap alternates between the two ends of y
+  for g in grids + [snake]:
+    want = fill_oracle_c.fill(g)
+    out = t.empty(shape, device=DEV)
+    be.fill_voxels(t.tensor(g).to(DEV), out)
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    gi = t.tensor(g).to(t.uint8).to(DEV)
+    be.fill_voxels(gi, gi)
+    np.testing.assert_array_equal(gi.cpu().numpy(), want.astype(np.uint8))
 
 
 def test_fill_is_asynchronous_graph_capturable(be):
