@@ -538,7 +538,7 @@ def test_checkpoint_interop_on_gpu():
   for k, p in zip(pkeys, params):
     assert float((st.model.state_dict()[k].cpu() - p.detach()).abs().max()) < 1e-6, k
   # (ii) our own checkpoint, written from the GPU
-  m = _model(2, O.make_state(0, 2, nbt=0)).train()
+  m = _model(2, O.make_state(0, 2, nbt=0), "bf16x3").train()      # (the product default, which decode_state builds too)
   o1 = S.FusedAdam(m, lr=4e-4, eps=1e-4)
   gi = [x.cuda() for x in (image, v2s, off)]; gg = grid.cuda().to(t.int32)
   for _ in range(2):
