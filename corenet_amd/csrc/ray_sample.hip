@@ -345,7 +345,11 @@ extern "C" int crn_ray_sample_bwd(const float* dout, int64_t dout_sB, int B, int
     }
   }
   static const int zseg_env = getenv("CRN_RAY_ZSEG") ? atoi(getenv("CRN_RAY_ZSEG")) : 0;
-  const int zseg = zseg_env > 0 ? std::min(zseg_env, D) : (D >= 32 ? 16 : (D >= 16 ? 8 : D));
+  // z segment and channels per thread, measured at the four decoder scales (tools/ray_bwd_sweep.sh,
+  // profiles/r03_ray_bwd_sweep.txt): 4 channels per thread (three times the waves of the 12-channel variant: the kernel is
+  // latency bound, one workgroup of four waves per CU at 64^3) and z segments of 8 (16 at 32^3):
+  // 64^3 48.7 -> 44.4 us, 32^3 24.0 -> 17.3 us, 16^3 19.0 -> 11.7 us, 8^3 13.2 -> 11.5 us
+  const int zseg = zseg_env > 0 ? std::min(zseg_env, D) : (D == 32 ? 16 : std::min(D, 8));
   const int nseg = (D + zseg - 1) / zseg;
   const bool big = W >= 64 && H >= 64;
   const int kTX = big ? 32 : 8, kTY = 8;
@@ -381,7 +385,8 @@ extern "C" int crn_ray_sample_bwd(const float* dout, int64_t dout_sB, int B, int
     CRN_CHECK_LAUNCH();
     return CRN_OK;
   }
-  if (C % 12 == 0) {
+  static const bool cn4 = !(getenv("CRN_RAY_CN") && atoi(getenv("CRN_RAY_CN")) == 12);
+  if (C % 12 == 0 && !cn4) {
     dim3 grid((unsigned)(tilesX * tilesY * nseg), (unsigned)(C / 12), (unsigned)B);
     hipLaunchKernelGGL((ray_sample_bwd_kernel<12, false>), grid, dim3(kTX * kTY), 0, st, dout, dout_sB, C, D, H, W, matrix,
                        offset, dmap, dmap_sB, h, w, zseg, tilesX, tilesY, kTX, kTY, (unsigned long long*)nullptr, (const float*)nullptr);
