@@ -58,6 +58,7 @@ _SIGS = {
                        i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "crn_bf3_operands": [vp, vp, i32, i64, vp, vp],
     "crn_splitk_defer": [i32],
+    "crn_splitk_reserve": [i64, vp],
     "crn_set_deterministic": [i32],
     "crn_roctx_push": [C.c_char_p],
     "crn_roctx_pop": [],

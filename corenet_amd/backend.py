@@ -82,7 +82,9 @@ class HipBackend:
 
   def _bn_ws(self, Cn: int, device):
     n = self.lib.crn_batch_renorm_workspace_bytes(Cn)
-    return self.workspace("bn", n, device), n
+    # one workspace per stream: the engine runs the skip path's bias gradients on its side stream next to the
+    # BatchRenorm backward of the main chain
+    return self.workspace("bn@%x" % _lib.stream(), n, device), n
 
   # -- convolution engine -----------------------------------------------------
   def conv_fwd(self, x: View, tr: Optional[Transform], w: t.Tensor, npad: int,
@@ -113,6 +115,10 @@ class HipBackend:
   def set_deterministic(self, on: bool = True):
     """Order-independent sums everywhere (crn_set_deterministic): two runs from the same state are bit-identical."""
     self.lib.crn_set_deterministic(int(on))
+
+  def splitk_reserve(self, stream: t.cuda.Stream, floats: int = 0):
+    """Give `stream` its split-K scratch ahead of a HIP-graph capture (crn_splitk_reserve)."""
+    self.lib.crn_splitk_reserve(int(floats), stream.cuda_stream)
 
   def bf3_operands(self, packed: t.Tensor, table, out: t.Tensor):
     """table = (desc int64 [n, 6] on the device, total workgroups): conv_geometry.operand_table."""

@@ -1366,7 +1366,7 @@ int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w
   float* scratch = nullptr;
   if (splits > 1) {
     const int64_t S = (int64_t)y->D * y->H * y->W, ytot = (int64_t)y->B * y->C * S;
-    scratch = crn_splitk_scratch((size_t)splits * ytot);
+    scratch = crn_splitk_scratch((size_t)splits * ytot, st);
     if (!scratch) { splits = 1; g.chunks_per_split = g.nchunks; }
     else {
       g.mode = 3;

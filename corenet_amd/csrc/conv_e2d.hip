@@ -799,7 +799,7 @@ extern "C" int crn_conv2d_bf3(const crnView* x, const crnInTransform* tr, const 
   crnView yreal = *y;
   const float* scratch = nullptr;
   if (splits > 1) {
-    float* sc = crn_splitk_scratch((size_t)splits * x->B * y->C * S);
+    float* sc = crn_splitk_scratch((size_t)splits * x->B * y->C * S, st);
     if (!sc) return CRN_ENOMEM;
     scratch = sc;
     g.y.base = sc; g.y.sC = S; g.y.sB = (int64_t)y->C * S; g.y.sH = x->W; g.y.sD = x->H * x->W;

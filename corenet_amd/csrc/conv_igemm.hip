@@ -536,19 +536,31 @@ __global__ __launch_bounds__(256) void splitk_reduce_plain_kernel(float* y, int6
 
 // per-device scratch for split-K partial sums (one process drives one GPU; calls that use it on different
 // streams of the same device must not overlap)
-float* splitk_scratch(size_t floats) {
-  constexpr int kMaxDev = 16;
-  static float* buf[kMaxDev] = {};
-  static size_t cap[kMaxDev] = {};
+// One scratch per (device, stream): convolutions that split their reduction on DIFFERENT streams (the engine runs the
+// ray-traced skip path beside the encoder / decoder chain) must not share partial-sum storage.  Grown on demand;
+// hipFree synchronises the device, so a buffer is never released under a kernel that still uses it.
+constexpr int kSkSlots = 64;
+struct SkSlot { int dev; hipStream_t st; float* buf; size_t cap; bool used; };
+SkSlot g_sk_slots[kSkSlots] = {};
+float* splitk_scratch(size_t floats, hipStream_t st) {
+  constexpr int kSlots = kSkSlots;
+  SkSlot* const slots = g_sk_slots;
+  typedef SkSlot Slot;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
-  if (floats > cap[dev]) {
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  Slot* sl = nullptr;
+  for (int i = 0; i < kSlots && !sl; ++i)
+    if (slots[i].used && slots[i].dev == dev && slots[i].st == st) sl = &slots[i];
+  for (int i = 0; i < kSlots && !sl; ++i)
+    if (!slots[i].used) { slots[i] = Slot{dev, st, nullptr, 0, true}; sl = &slots[i]; }
+  if (!sl) return nullptr;
+  if (floats > sl->cap) {
     if (floats > ((size_t)256 << 20) / 4) return nullptr;       // larger outputs keep the atomic path
-    if (buf[dev]) (void)hipFree(buf[dev]);
-    cap[dev] = std::max(floats, ((size_t)16 << 20) / 4);
-    if (hipMalloc(&buf[dev], cap[dev] * 4) != hipSuccess) { buf[dev] = nullptr; cap[dev] = 0; }
+    if (sl->buf) (void)hipFree(sl->buf);
+    sl->cap = std::max(floats, ((size_t)16 << 20) / 4);
+    if (hipMalloc(&sl->buf, sl->cap * 4) != hipSuccess) { sl->buf = nullptr; sl->cap = 0; }
   }
-  return buf[dev];
+  return sl->buf;
 }
 
 // arrival counters of the fused split-K reduction (mode 4): zero at allocation, every call leaves them zero
@@ -671,7 +683,19 @@ extern "C" int crn_splitk_defer(int on) {
   crn_splitk_pending().armed = on != 0;
   return CRN_OK;
 }
-float* crn_splitk_scratch(size_t floats) { return splitk_scratch(floats); }
+float* crn_splitk_scratch(size_t floats, hipStream_t st) { return splitk_scratch(floats, st); }
+// A stream that is about to be CAPTURED into a HIP graph cannot allocate: give it, ahead of the capture, a scratch as
+// large as the largest one any stream of this device has needed so far (floats == 0) or `floats`.
+extern "C" int crn_splitk_reserve(int64_t floats, crnStream stream) {
+  int dev = 0;
+  CRN_HIP(hipGetDevice(&dev));
+  size_t want = floats > 0 ? (size_t)floats : 0;
+  if (!want)
+    for (int i = 0; i < kSkSlots; ++i)
+      if (g_sk_slots[i].used && g_sk_slots[i].dev == dev) want = std::max(want, g_sk_slots[i].cap);
+  if (!want) return CRN_OK;
+  return splitk_scratch(want, (hipStream_t)stream) ? CRN_OK : CRN_ENOMEM;
+}
 int* crn_splitk_counters(size_t n) { return splitk_counters(n); }
 int crn_splitk_reduce(const crnView& y, const float* scratch, int splits, int accumulate, hipStream_t st) {
   const int64_t ytot = (int64_t)y.B * y.C * y.D * y.H * y.W;
@@ -753,7 +777,7 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
       float* scratch2 = nullptr;
       if (q.ksplits > 1) {
         const int64_t ytot2 = (int64_t)y->B * y->C * Sx;
-        scratch2 = splitk_scratch((size_t)q.ksplits * ytot2);
+        scratch2 = splitk_scratch((size_t)q.ksplits * ytot2, st);
         if (scratch2) { q.y = scratch2; q.ysB = (int64_t)y->C * Sx; q.ysC = Sx; q.mode = 0; }
       }
       if (q.ksplits == 1 || scratch2) {
@@ -798,7 +822,7 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
       if (sp > 1) {
         p.cps = (crn_cdiv(x->C, sp) + 31) & ~31;
         sp = crn_cdiv(x->C, p.cps);
-        if (sp > 1 && (scratch = splitk_scratch((size_t)sp * ytot)) != nullptr) {
+        if (sp > 1 && (scratch = splitk_scratch((size_t)sp * ytot, st)) != nullptr) {
           p.yr = y->base; p.yr_sB = y->sB; p.yr_sC = y->sC; p.yr_sP = y->sW; p.yr_accumulate = accumulate ? 1 : 0;
           p.splits = sp; p.y = scratch; p.ysB = (int64_t)y->C * Sx; p.ysC = Sx; p.ysP = 1; p.mode = 0;
           static const bool sk_launch_pw = getenv("CRN_SPLITK_FUSED") == nullptr;
@@ -916,7 +940,7 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
   const crnView yreal = *y;
   const int64_t ytot = (int64_t)y->B * y->C * y->D * y->H * y->W;
   static const bool sk_atomic = getenv("CRN_SPLITK_ATOMIC") != nullptr;
-  float* scratch = (g.mode == 2 && !sk_atomic) ? splitk_scratch((size_t)splits * ytot) : nullptr;
+  float* scratch = (g.mode == 2 && !sk_atomic) ? splitk_scratch((size_t)splits * ytot, st) : nullptr;
   static const bool sk_launch = getenv("CRN_SPLITK_FUSED") == nullptr;   // default: the separate reduction launch (see conv_kernels.h, mode 4)
   if (scratch) {
     g.mode = 3;

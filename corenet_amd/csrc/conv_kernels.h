@@ -1087,7 +1087,7 @@ inline int launch_wgrad(const WgradGeom& g, dim3 grid, size_t lds_bytes, hipStre
 }  // namespace crnk
 
 // split-K scratch + reduction shared by the fp32 and the bf16x3 engine (defined in conv_igemm.hip)
-float* crn_splitk_scratch(size_t floats);
+float* crn_splitk_scratch(size_t floats, hipStream_t st);      // per (device, stream)
 int* crn_splitk_counters(size_t n);          // n zero-initialised arrival counters (self-resetting), or nullptr
 int crn_splitk_reduce(const crnView& y, const float* scratch, int splits, int accumulate, hipStream_t st);
 

@@ -330,6 +330,7 @@ class CoreNet(nn.Module):
     if g is None:
       g = t.cuda.CUDAGraph()
       cap = t.cuda.Stream(device=eng.device)
+      eng.be.splitk_reserve(cap)                   # (the split-K scratch is per stream and cannot grow inside a capture)
       cap.wait_stream(t.cuda.current_stream())
       with t.cuda.graph(g, stream=cap), _lib.pinned_stream(cap):      # (the library calls follow the capture stream)
         self._step_body(plan, loss)

@@ -624,6 +624,14 @@ class Plan:
     use_side = self.side is not None
     self._side_ev, self._side_i = [], 0
     self._side_done = t.cuda.Event() if use_side else None
+    # the ray-traced skip path (offset channels -> 1x1 compress -> ray sample; backward: scatter -> compress gradients)
+    # hangs off the encoder's stage outputs and joins the main chain only at the consuming decoder stage (backward: at the
+    # start of the encoder's backward pass): it runs on the side stream beside the encoder / decoder chain
+    self.async_skip = use_side and os.environ.get("CRN_ASYNC_SKIP", "1") != "0"
+    self._skip_ev = {k: (t.cuda.Event(), t.cuda.Event()) for k in (2, 3, 4, 5)} if use_side else None
+    self._skip_bwd_ev = {k: t.cuda.Event() for k in (2, 3, 4, 5)} if use_side else None
+    self._skip_bwd_done = t.cuda.Event() if use_side else None
+    self._skip_async_live = False
     self._bucket_ev = [t.cuda.Event() for _ in GRAD_BUCKET_LABELS] if use_side else None
 
   # ------------------------------------------------------------------ cached views
@@ -746,8 +754,46 @@ class Plan:
 
   # ------------------------------------------------------------------ forward
   def forward(self, image_u8: t.Tensor, v2s: t.Tensor, offset: t.Tensor, training: bool) -> t.Tensor:
+    self._skip_async_live = bool(training and self.async_skip and self.trace is None)
+    if self._skip_async_live:
+      self._decoder_inputs(v2s, offset)            # the skip path starts inside the encoder: it needs them now
     self.forward_encoder(image_u8, training)
-    return self.forward_decoder(v2s, offset, training)
+    try:
+      return self.forward_decoder(v2s, offset, training)
+    finally:
+      self._skip_async_live = False
+
+  def _decoder_inputs(self, v2s: t.Tensor, offset: t.Tensor):
+    """Sampling offset and the layer matrices v2s @ scale(128 / r) of the four skip grids (reconstruction_decoder.py:111-116)."""
+    B = self.B
+    self.offset.copy_(offset)
+    v = v2s.to(self.layer_mats.dtype).reshape(1, B, 4, 4)
+    self.layer_mats.copy_((v * self.layer_scales).reshape(4, B, 16))    # exact: column scaling
+
+  def _skip_fwd(self, k: int):
+    """Skip connection into decoder stage k+1 (reconstruction_decoder.py:97-117): offset channels, 1x1 compress, ray sample
+    straight into the skip channels of the stage's concat buffer."""
+    eng, be, B = self.eng, self.be, self.B
+    d = self.dec[k]
+    out = self.dec[k + 1]["u"]
+    ft = self.feat[self.skip_src[k]]
+    hw, ro = self.skip_hw[k], 2 * d["r"]
+    be.fill_offset_channels(ft, B, ft.stride(0), ft.shape[2] * ft.shape[3], ft.shape[1] - 3, self.offset)
+    self._conv(eng.convs[f"decoder.rt_skip_{k}.compress_channels."], self.vw(ft), None,
+               self.vw(self.smap[k].permute(0, 3, 1, 2)))
+    self._probe(f"ray_sample_fwd_{ro}", lambda: be.ray_sample_fwd(
+        self.smap[k], self.smap[k].stride(0), B, eng.skip_ch[k], hw, hw, self.layer_mats[k - 2],
+        self.offset, out[:, d["cout"]:], out.stride(0), ro, ro, ro, map_sC=1, map_sP=eng.skip_ch[k]))
+
+  def _skip_fwd_async(self, stage: str):
+    """The stage's pre-ReLU feature map is final on the main stream: its skip path goes to the side stream."""
+    k = {v: kk for kk, v in self.skip_src.items()}[stage]
+    ready, done = self._skip_ev[k]
+    ready.record()
+    with t.cuda.stream(self.side), _lib.pinned_stream(self.side):
+      self.side.wait_event(ready)
+      self._skip_fwd(k)
+      done.record(self.side)
 
   def forward_encoder(self, image_u8: t.Tensor, training: bool):
     """ResNet-50 features + global average (resnet50.py:176-186).  In eval mode the result does not depend
@@ -798,6 +844,8 @@ class Plan:
         t.cuda.current_stream().wait_event(eng._enc_late_packed)
         eng._enc_late_pending = False
       cur = self._block_fwd(blk, cur, training)
+      if blk["final"] and self._skip_async_live:
+        self._skip_fwd_async(blk["stage"])
     f5 = self.feat["stage5"]
     be.relu_mean_fwd(f5, B, 2048, 64, f5.stride(0), self.avg)
 
@@ -809,13 +857,9 @@ class Plan:
     if eng._dec_pack_pending:
       t.cuda.current_stream().wait_event(eng._dec_packed)
       eng._dec_pack_pending = False
-    self.offset.copy_(offset)
-    # layer matrices v2s @ scale(128 / r) for the four skip grids (reconstruction_decoder.py:111-116)
-    v = v2s.to(self.layer_mats.dtype).reshape(1, B, 4, 4)
-    self.layer_mats.copy_((v * self.layer_scales).reshape(4, B, 16))    # exact: column scaling
-    for k in ("stage2", "stage3", "stage4", "stage5"):
-      ft = self.feat[k]
-      be.fill_offset_channels(ft, B, ft.stride(0), ft.shape[2] * ft.shape[3], ft.shape[1] - 3, self.offset)
+    skip_async = self._skip_async_live
+    if not skip_async:
+      self._decoder_inputs(v2s, offset)
     # decoder (reconstruction_decoder.py:136-151)
     L = eng.latent
     s = eng.store
@@ -833,6 +877,8 @@ class Plan:
       r, S = d["r"], d["r"] ** 3
       p = f"decoder.stage_{k}."
       b1_, b2_ = bn[p + "b1."], bn[p + "b2."]
+      if skip_async and k > 2:
+        t.cuda.current_stream().wait_event(self._skip_ev[k - 1][1])      # the skip channels of this stage's input
       self._stats(b1_, d["u"], S, d["cin"] * S, True, training)
       self._probe(f"conv3d_stage{k}_c1_fwd", lambda: self._conv(
           cv[p + "c1."], self.vw(d["u"]), Transform(b1_.scale, b1_.shift, pre_relu=True), self.vw(d["w"])))
@@ -840,15 +886,8 @@ class Plan:
       out = self.dec[k + 1]["u"] if k < 6 else self.logits
       ov = self.s2d(out, d["cout"], (2, 2, 2))
       self._conv(cv[p + "t1."], self.vw(d["w"]), Transform(b2_.scale, b2_.shift, pre_relu=True), ov)
-      if k < 6:
-        ft = self.feat[self.skip_src[k]]
-        hw = self.skip_hw[k]
-        self._conv(cv[f"decoder.rt_skip_{k}.compress_channels."], self.vw(ft), None,
-                   self.vw(self.smap[k].permute(0, 3, 1, 2)))
-        ro = 2 * r
-        self._probe(f"ray_sample_fwd_{ro}", lambda: be.ray_sample_fwd(
-            self.smap[k], self.smap[k].stride(0), B, eng.skip_ch[k], hw, hw, self.layer_mats[k - 2],
-            self.offset, out[:, d["cout"]:], out.stride(0), ro, ro, ro, map_sC=1, map_sP=eng.skip_ch[k]))
+      if k < 6 and not skip_async:
+        self._skip_fwd(k)
     if training:
       be.add_i64(eng.store.nbt, eng.store.nbt.numel(), 1)     # batch_renorm.py:57
     return self.logits
@@ -945,16 +984,17 @@ class Plan:
       b1_, b2_ = bn[p + "b1."], bn[p + "b2."]
       ctot = g_out.shape[1]
       if k < 6:    # ray-traced skip: scatter-add, compress conv grads
-        hw = self.skip_hw[k]
-        ns = eng.skip_ch[k]
-        be.ray_sample_bwd(g_out[:, d["cout"]:], g_out.stride(0), B, ns, ro, ro, ro,
-                          self.layer_mats[k - 2], self.offset, self.gsmap[k], self.gsmap[k].stride(0),
-                          hw, hw, False)
-        cs = cv[f"decoder.rt_skip_{k}.compress_channels."]
-        ft = self.feat[self.skip_src[k]]
-        self._wgrad(cs, self.vw(ft), None, self.vw(self.gsmap[k]))
-        self._bias_grad(cs, self.gsmap[k], hw * hw, ns * hw * hw)
-        self._dgrad(cs, self.vw(self.gsmap[k]), self.vw(self.gfeat[self.skip_src[k]]))
+        skip_bwd_async = self.async_skip and self.side is not None and self.trace is None
+        if skip_bwd_async:
+          # off the data-gradient chain: the feature-map gradients are only needed when the encoder's backward starts
+          self._skip_bwd_ev[k].record()
+          with t.cuda.stream(self.side), _lib.pinned_stream(self.side):
+            self.side.wait_event(self._skip_bwd_ev[k])
+            self._skip_bwd(k, g_out, on_side=True)
+            if k == 2:
+              self._skip_bwd_done.record(self.side)
+        else:
+          self._skip_bwd(k, g_out, on_side=False)
       ct = cv[p + "t1."]
       gv = self.s2d(g_out, d["cout"], (2, 2, 2))
       tr2 = Transform(b2_.scale, b2_.shift, pre_relu=True)
@@ -992,6 +1032,8 @@ class Plan:
                   s.view("decoder.stage_0.weight", grad=True), s.view("decoder.stage_0.bias", grad=True))
     self._grads_ready("decoder.stage_0.", grad_hook)
     # encoder
+    if self.async_skip and self.side is not None and self.trace is None:
+      t.cuda.current_stream().wait_event(self._skip_bwd_done)          # gfeat of all four stages
     f5, g5 = self.feat["stage5"], self.gfeat["stage5"]
     last = self.blocks[-1]
     be.relu_mean_bwd(f5, self.gavg, B, 2048, 64, f5.stride(0), last["gpre"], 2048 * 64, False)
@@ -1017,6 +1059,27 @@ class Plan:
       return
     self._join_side()
     be.copy_tiles(eng.gpacked, eng.store.grads, eng.unpack_tiles, reverse=True)
+
+  def _skip_bwd(self, k: int, g_out: t.Tensor, on_side: bool):
+    """Backward of the skip connection into decoder stage k+1 (g_out = gradient of that stage's concat buffer)."""
+    eng, be, B = self.eng, self.be, self.B
+    d = self.dec[k]
+    ro, hw, ns = 2 * d["r"], self.skip_hw[k], eng.skip_ch[k]
+    be.ray_sample_bwd(g_out[:, d["cout"]:], g_out.stride(0), B, ns, ro, ro, ro,
+                      self.layer_mats[k - 2], self.offset, self.gsmap[k], self.gsmap[k].stride(0),
+                      hw, hw, False)
+    cs = eng.convs[f"decoder.rt_skip_{k}.compress_channels."]
+    ft = self.feat[self.skip_src[k]]
+    if on_side:                                 # already on the weight-gradient stream: no hand-over event
+      g = cs.fwd
+      math = "bf16x3_2d" if (eng.encoder_e2d and eng.wgrad_2d) else self._math(cs, "wgrad")
+      with _lib.roctx_range("wgrad " + cs.name):
+        be.conv_wgrad(self.vw(ft), None, self.vw(self.gsmap[k]), cs.gwf, g.npad, g.window, g.pad_lo, False,
+                      boxes=(g.n_boxes, g.c_boxes), math=math)
+    else:
+      self._wgrad(cs, self.vw(ft), None, self.vw(self.gsmap[k]))
+    self._bias_grad(cs, self.gsmap[k], hw * hw, ns * hw * hw)
+    self._dgrad(cs, self.vw(self.gsmap[k]), self.vw(self.gfeat[self.skip_src[k]]))
 
   def _block_bwd(self, blk, g_out: Optional[t.Tensor]) -> t.Tensor:
     eng, be, B = self.eng, self.be, self.B

@@ -107,6 +107,9 @@ int crn_conv_fwd_bf3_slabs(const crnView* x, const crnInTransform* tr, const voi
  * followed by its norm; in backward every data gradient feeds the norm's backward).  A caller that hands y to code
  * OUTSIDE the library (a torch op, a memcpy) or to another host thread while a sum may be pending must not arm.   */
 int crn_splitk_defer(int on);
+/* Split-K scratch is kept per (device, stream) and grown on demand -- which a stream under HIP-graph capture cannot do.
+ * Call this BEFORE the capture: reserves `floats` (or, with 0, as much as any stream of the device has needed so far).  */
+int crn_splitk_reserve(int64_t floats, crnStream stream);
 
 /* Weight gradient in the same packed layout:
  *   dw[(c*T+t)*Npad+n] = sum_{b,o} T(x)[b,c,o-pad_lo+t] * dy[b,n,o]
@@ -145,7 +148,7 @@ int crn_bf3_operands(const float* packed, const int64_t* desc, int nlayers, int6
  * Covers: window 1x1 (pads 0) or 3x3, dense NC(D)HW views (unit W stride, rows and planes back to back), x and y of
  * the same extent, Cin % 32 == 0, Cout % 64 == 0 (= Npad), H*W a multiple of 64 (3x3: W % 8 == 0 and tiles of
  * 4x16 / 8x8 positions divide the image); CRN_EINVAL otherwise (callers keep such layers on crn_conv_fwd).
- * Split-K partial sums use the scratch shared with crn_conv_fwd: calls on different streams must not overlap.    */
+ * Split-K partial sums use the per-stream scratch shared with crn_conv_fwd (crn_splitk_reserve).                */
 int crn_conv2d_bf3(const crnView* x, const crnInTransform* tr, const void* wop, int Npad, const float* bias,
                    int bias_sB, const crnView* y, int kh, int kw, int ph, int pw, int accumulate, crnStream stream);
 
