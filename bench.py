@@ -158,6 +158,7 @@ def main():
                   help="decoder stage 4-6 convolutions: fp32 MFMA, or split-bf16 (3 bf16 MFMAs per product, fp32 accumulate)")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-fp32-side", action="store_true", help="skip the fp32-math run printed beside the headline (profiling)")
+  ap.add_argument("--no-m9-side", action="store_true", help="skip the 14-class (m7 / m9) step printed beside the headline")
   args = ap.parse_args()
 
   from corenet_amd import distributed as D
@@ -232,6 +233,27 @@ def main():
                               "bound": "mfma", "achieved": CONV6_FLOP * B / c32 / 1e12, "peak": PEAK_F32_MFMA / 1e12,
                               "unit": "TFLOP/s", "frac": CONV6_FLOP * B / c32 / PEAK_F32_MFMA, "avg_launch_ms": c32 * 1e3}}
     del m32
+  m9_side = None
+  if world == 1 and C == 2 and not args.no_m9_side:
+    # the m7 / m9 head (BASELINE configs: 14 classes incl. void, xent_times_iou_agnostic): the same step, same batch
+    # and steps, timed in the same run so that the driver's clock covers it too
+    m14 = CoreNet(CoreNetConfig(DecoderConfig((128, 128, 128), 14, 2, 64, 0.75)), device=dev, decoder_math=args.math)
+    m14.reset_parameters(seed=0); m14.train()
+    b14 = synthetic_batch(B, seed=rank, num_classes=14)
+    i14, v14, o14, g14 = [x.to(dev) for x in b14]
+    g14 = g14.to(t.int32)
+    def step14():
+      return m14.train_step(i14, v14, o14, g14, "xent_times_iou_agnostic", lr=4e-4, adam_eps=1e-4)
+    for _ in range(args.warmup):
+      step14()
+    t.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+      l14 = step14()
+    t.cuda.synchronize(); dt14 = time.perf_counter() - t0
+    m9_side = {"config": "m7/m9: C=14, xent_times_iou_agnostic, B=%d/GPU, decoder_math=%s" % (B, args.math),
+               "ms_per_step": dt14 / args.steps * 1e3, "value": B * 128 ** 3 * args.steps / dt14, "unit": "voxels/s",
+               "loss": float(l14)}
+    del m14
   if rank != 0:
     return
   conv_s, ray_s = probes["conv3d_stage6_c1_fwd"], probes["ray_sample_fwd_64"]
@@ -361,6 +383,8 @@ def main():
     out[k]["traffic_source"] = out["roofline"]["traffic_source"]
   if fp32_side is not None:
     out["fp32_math"] = fp32_side
+  if m9_side is not None:
+    out["m7_m9"] = m9_side
   if world > 1:
     out["rccl"] = dict(sync.describe(), backend=dist.get_backend(),
                        buckets_mb=[round((hi - lo) * 4 / 1e6, 1) for _, lo, hi in model.engine.grad_buckets],

@@ -8,7 +8,7 @@ OUT=${1:-$R/gpurun_out/pmc_traffic.json}
 MATH=${2:-bf16x3}
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pt_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pt_$c -o a -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-side --math $MATH > /tmp/pt_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pt_$c -o a -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-side --no-m9-side --math $MATH > /tmp/pt_$c.log 2>&1
 done
 python - "$OUT" "$MATH" <<'PY'
 import csv, glob, json, sys

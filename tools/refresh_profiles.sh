@@ -1,23 +1,24 @@
+# Regenerates the profiles/r03_* files in one gpurun call (every step under its own timeout):
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh'   then copy gpurun_out/prof/r03_* to profiles/
 set -x
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof; mkdir -p $O
 cd $R
-python bench.py --steps 20 --warmup 3 > $O/r02_bench.json 2> $O/bench.err
-python bench.py --steps 10 --warmup 3 --classes 14 --no-cpu-baseline > $O/r02_bench_m9.json 2>> $O/bench.err
-python tools/layer_times.py 2 70 bf16x3 > $O/r02_layer_times_bf16x3.txt 2>/dev/null
-python tools/layer_times.py 2 70 fp32 > $O/r02_layer_times_fp32.txt 2>/dev/null
-python tools/phase_times.py 12 > $O/r02_phase_times.txt 2>/dev/null
-bash tools/pmc_traffic.sh $O/r02_pmc_traffic.json bf16x3 > /dev/null 2>&1
-bash tools/pmc_mfma.sh fwd s6c1 $O/r02_conv_mfma_pmc_bf16x3_fwd.txt bf16x3 > /dev/null 2>&1
-bash tools/pmc_mfma.sh dgrad s6c1 $O/r02_conv_mfma_pmc_bf16x3_dgrad.txt bf16x3 > /dev/null 2>&1
-bash tools/pmc_mfma.sh wgrad s6c1 $O/r02_conv_mfma_pmc_bf16x3_wgrad.txt bf16x3 > /dev/null 2>&1
+timeout 600 python bench.py --steps 20 --warmup 5 > $O/r03_bench.json 2> $O/bench.err
+timeout 300 python bench.py --steps 10 --warmup 3 --classes 14 --no-cpu-baseline > $O/r03_bench_m9.json 2>> $O/bench.err
+timeout 300 python tools/layer_times.py 2 70 bf16x3 > $O/r03_layer_times_bf16x3.txt 2>/dev/null
+timeout 300 python tools/layer_times.py 2 70 fp32 > $O/r03_layer_times_fp32.txt 2>/dev/null
+timeout 300 python tools/phase_times.py 12 > $O/r03_phase_times.txt 2>/dev/null
+timeout 900 bash tools/pmc_traffic.sh $O/r03_pmc_traffic.json bf16x3 > /dev/null 2>&1
+timeout 300 bash tools/pmc_mfma.sh fwd s6c1 $O/r03_conv_mfma_pmc_bf16x3_fwd.txt bf16x3 > /dev/null 2>&1
+timeout 300 bash tools/pmc_mfma.sh dgrad s6c1 $O/r03_conv_mfma_pmc_bf16x3_dgrad.txt bf16x3 > /dev/null 2>&1
+timeout 300 bash tools/pmc_mfma.sh wgrad s6c1 $O/r03_conv_mfma_pmc_bf16x3_wgrad.txt bf16x3 > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r02 -- python $R/tools/prof_step.py bf16x3 10 > /dev/null 2>&1
-cp /tmp/prof/r02_kernel_stats.csv $O/r02_step_kernel_stats.csv
-python $R/tools/trace_summary.py /tmp/prof/r02_kernel_trace.csv 13 > $O/r02_step_trace_summary.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o b -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-side > $O/r02_bench_under_rocprof.json 2>/dev/null
-cp /tmp/pb/b_kernel_stats.csv $O/r02_bench_kernel_stats.csv
-rocprofv3 --kernel-trace --output-format csv -d /tmp/pe -o e -- python $R/tools/bench_e2d.py 20 > /dev/null 2>&1
-python $R/tools/bench_e2d_trace.py /tmp/pe/e_kernel_trace.csv 20 > $O/r02_e2d_kernel_times.txt
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r03 -- python $R/tools/prof_step.py bf16x3 10 > /dev/null 2>&1
+cp /tmp/prof/r03_kernel_stats.csv $O/r03_step_kernel_stats.csv
+python $R/tools/trace_summary.py /tmp/prof/r03_kernel_trace.csv 13 > $O/r03_step_trace_summary.txt
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -o b -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fp32-side --no-m9-side > $O/r03_bench_under_rocprof.json 2>/dev/null
+cp /tmp/pb/b_kernel_stats.csv $O/r03_bench_kernel_stats.csv
 cd $R
-python tools/cpu_enqueue.py > $O/r02_graph_vs_eager.txt 2>/dev/null
-(for k in 3x3 all; do for st in "" 2 23 45 345 2345; do CRN_E2D_KINDS=$k CRN_E2D_FWD_STAGES=$st python tools/e2d_parity.py 2>/dev/null; done; done; CRN_E2D=0 python tools/e2d_parity.py 2>/dev/null) > $O/r02_e2d_parity.txt
+timeout 200 python tools/bench_small.py > $O/r03_small_kernels.txt 2>/dev/null
+timeout 200 python tools/train_synthetic.py 300 2 > $O/r03_train_synthetic.txt 2>/dev/null
+ls -la $O

@@ -4,6 +4,13 @@ step, and how busy each HIP stream (queue) was.  usage: trace_summary.py <kernel
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 13
+# steady state only: from the 4th step's first kernel (crn_preprocess_caffe) to the last step's -- the first step also
+# creates the plan (hundreds of torch zero-fills that round 2's summary counted as 49 "memset" launches per step)
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+pre = [i for i, r in enumerate(rows) if "preprocess" in r["Kernel_Name"]]
+if len(pre) >= 6:
+  rows = rows[pre[3]:pre[-1]]
+  nsteps = len(pre) - 4
 def cat(n):
   for key, c in (("conv_e2d", "encoder bf16x3 fwd/dgrad"), ("wgrad1x1_bf3", "encoder bf16x3 wgrad"), ("wgrad3x3_bf3", "encoder bf16x3 wgrad"),
                  ("bf3_operands", "weight pack / grad un-pack"), ("conv_bf3_wgrad", "conv bf16x3 wgrad"), ("conv_bf3", "conv bf16x3 fwd/dgrad"), ("conv_wgrad", "conv fp32 wgrad"),
