@@ -37,7 +37,7 @@ PEAK_BF16_MFMA = 2500e12                           # MI355X_MICROARCH.md: dense 
 PEAK_HBM = 8.0e12                                  # HBM3E spec peak
 # HBM bytes per launch come from separate rocprofv3 --pmc passes of this command (tools/pmc_traffic.sh); the record is
 # keyed by kernel name + grid, so both are named here, next to the kernel they describe
-TRAFFIC_FILES = {"bf16x3": "r02_pmc_traffic.json", "fp32": "r01_pmc_traffic.json"}
+TRAFFIC_FILES = {"bf16x3": "r03_pmc_traffic.json", "fp32": "r01_pmc_traffic.json"}
 CONV_BF3_TRAFFIC_KERNEL, CONV_BF3_THREADS = "conv_bf3_kernel<1, 1, 7, 1", 512
 
 
