@@ -74,6 +74,7 @@ _SIGS = {
     "crn_conv2d_bf3": [C.POINTER(CrnView), C.POINTER(CrnInTransform), vp, i32, vp, i32, C.POINTER(CrnView),
                        i32, i32, i32, i32, i32, vp],
     "crn_copy_tiles_f32": [vp, vp, vp, vp, vp, i64, i32, vp],
+    "crn_copy_mats_f32": [vp, vp, vp, i64, i32, vp],
     "crn_gather_f32": [vp, vp, vp, i64, vp],
     "crn_scatter_f32": [vp, vp, vp, i64, i32, vp],
     "crn_bias_grad": [vp, i32, i32, i64, i64, vp, i32, vp, sz, vp],

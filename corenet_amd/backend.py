@@ -152,10 +152,14 @@ class HipBackend:
                             int(zero_first), _ctapboxes(boxes), _lib.stream())
 
   def copy_tiles(self, src: t.Tensor, dst: t.Tensor, tiles, reverse: bool = False):
-    """tiles: (desc int32 [n,6], mask int64 [n], explicit int32 [m]) from conv_geometry.tile_index."""
-    desc, mask, ex = tiles
-    self.lib.crn_copy_tiles_f32(ptr(src), ptr(dst), ptr(desc), ptr(mask), ptr(ex), desc.shape[0], int(reverse),
-                                _lib.stream())
+    """tiles: (desc int32 [n,6], mask int64 [n], explicit int32 [m]) from conv_geometry.tile_index, optionally followed
+    by the LDS-transposed blocks (int32 [k,16], conv_geometry.mat_index) of the parts that are plain transposes."""
+    desc, mask, ex = tiles[:3]
+    if desc.shape[0]:
+      self.lib.crn_copy_tiles_f32(ptr(src), ptr(dst), ptr(desc), ptr(mask), ptr(ex), desc.shape[0], int(reverse),
+                                  _lib.stream())
+    if len(tiles) > 3 and tiles[3].shape[0]:
+      self.lib.crn_copy_mats_f32(ptr(src), ptr(dst), ptr(tiles[3]), tiles[3].shape[0], int(reverse), _lib.stream())
 
   def gather(self, src: t.Tensor, idx: t.Tensor, dst: t.Tensor):
     self.lib.crn_gather_f32(ptr(src), ptr(idx), ptr(dst), idx.numel(), _lib.stream())

@@ -265,6 +265,71 @@ def tile_index(parts):
   return desc.astype(np.int32), (np.concatenate(masks) if masks else np.zeros((0,), np.uint64)), ex.astype(np.int32)
 
 
+MAT_LDS = 8448      # floats of LDS per block of crn_copy_mats_f32 (csrc/misc_ops.hip)
+
+
+def mat_index(parts):
+  """Blocks for crn_copy_mats_f32 out of the same `parts` as tile_index: a part whose index map is one affine
+  rectangle per row group -- idx[g*grows + r][c] = base + g*gs + r*rs + c*cs on r < R, c < N, -1 elsewhere -- with
+  rs = +-1 (forward layouts: the packed matrix is the transpose of the reference one; data-gradient layouts: one small
+  flipped transpose per output channel) or cs = 1 (1x1 data gradients: a strided copy) is cut into G x A x B blocks,
+  b along the reference layout's contiguous axis.  Returns (desc int32 [k, 16] incl. the kernel's three reciprocals, the parts that do not fit: transposed
+  convolutions, the stem, repeated biases -- they stay on the 8x8 tiles)."""
+  descs, rest = [], []
+  for part in parts:
+    off, idx, cols, grows = part
+    idx2 = np.asarray(idx, np.int64).reshape(-1, cols)
+    rows = idx2.shape[0]
+    gr = grows or rows
+    ng = rows // gr
+    idx3 = idx2.reshape(ng, gr, cols)
+    v = idx3 >= 0
+    R, N = int(v[0, :, 0].sum()), int(v[0, 0, :].sum())
+    ok = R > 0 and N > 0 and R * N > 1 and bool(v[:, :R, :N].all()) and int(v.sum()) == ng * R * N
+    if ok:
+      base = int(idx3[0, 0, 0])
+      rs = int(idx3[0, 1, 0]) - base if R > 1 else 0
+      cs = int(idx3[0, 0, 1]) - base if N > 1 else 0
+      gs = int(idx3[1, 0, 0]) - base if ng > 1 else 0
+      pred = (base + np.arange(ng)[:, None, None] * gs + np.arange(R)[None, :, None] * rs + np.arange(N)[None, None, :] * cs)
+      ok = bool((pred == idx3[:, :R, :N]).all()) and (abs(rs) == 1 or cs == 1)
+    if not ok:
+      rest.append(part)
+      continue
+    if abs(rs) == 1 and R > 1:
+      # b = row (reversed when rs == -1), a = column
+      nb, na = R, N
+      f0 = base if rs == 1 else base - (R - 1)
+      p0 = off if rs == 1 else off + (R - 1) * cols
+      fa, pa, pb = cs, 1, (cols if rs == 1 else -cols)
+    else:
+      # b = column, a = row: both sides contiguous along b
+      nb, na = N, R
+      f0, p0 = base, off
+      fa, pa, pb = rs, cols, 1
+    fg, pg = gs, gr * cols
+    bstep = nb if nb <= 128 else 64
+    for b0 in range(0, nb, bstep):
+      B = min(bstep, nb - b0)
+      for a0 in range(0, na, 64):
+        A = min(64, na - a0)
+        gstep = max(1, MAT_LDS // (A * (B | 1))) if (B == nb and ng > 1) else 1
+        g0 = np.arange(0, ng, gstep)
+        G_ = np.minimum(gstep, ng - g0)
+        d = np.zeros((len(g0), 16), np.int64)
+        d[:, 0], d[:, 1], d[:, 2] = A, B, G_
+        d[:, 3] = f0 + g0 * fg + a0 * fa + b0
+        d[:, 4], d[:, 5] = fa, fg
+        d[:, 6] = p0 + g0 * pg + a0 * pa + b0 * pb
+        d[:, 7], d[:, 8], d[:, 9] = pa, pb, pg
+        magic = lambda q: 0 if q == 1 else ((1 << 32) + q - 1) // q
+        d[:, 10], d[:, 11], d[:, 12] = magic(A * B), magic(B), magic(A)
+        descs.append(d)
+  desc = np.concatenate(descs) if descs else np.zeros((0, 16), np.int64)
+  assert np.abs(desc[:, :10]).max(initial=0) < 2 ** 31 and (desc[:, 2] * desc[:, 0] * (desc[:, 1] | 1) <= MAT_LDS).all()
+  return desc.astype(np.uint32).view(np.int32), rest
+
+
 # ---- operand blocks of the encoder engine (csrc/conv_e2d.hip, include/corenet_hip.h crn_bf3_operands) ----
 def operand_eligible(g: Geom) -> bool:
   """Layers crn_conv2d_bf3 covers: 1x1 / 3x3 windows over 2-D images, Cin % 32 == 0, Cout % 64 == 0 == Npad."""

@@ -345,22 +345,21 @@ class Engine:
         pack_parts.append((po, parts[2], dgrad.npad, dgrad.taps if dgrad.taps > 1 else 0)); po += len(parts[2])
         pack_is_bwd.append(True)
       unpack_parts.append((go, parts[0], fwd.npad, 0)); go += len(parts[0])
-    dev = lambda tl: (t.as_tensor(tl[0], device=self.device), t.as_tensor(tl[1].view(np.int64), device=self.device),
-                      t.as_tensor(tl[2] if tl[2].size else np.zeros(1, np.int32), device=self.device))
+    dev = self._tiles_dev
     # two packs: what forward reads (forward weights + biases) and what only backward reads (data-gradient
     # weights) -- the second one runs on the side stream under the forward pass, and never in eval mode
-    self.pack_tiles = dev(G.tile_index([pp for pp, bwd in zip(pack_parts, pack_is_bwd) if not bwd]))
+    self.pack_tiles = dev([pp for pp, bwd in zip(pack_parts, pack_is_bwd) if not bwd])
     # ... and the forward pack once more in two pieces: the encoder's weights are needed at once, the decoder's
     # ~1.4 ms later, so in training the decoder piece is packed on the side stream under the encoder
     pack_names = [name for (name, *_rest) in reg for _ in range(3 if _rest[1] is not None else 2)]
     sel = lambda pred: [pp for pp, bwd, nm in zip(pack_parts, pack_is_bwd, pack_names) if not bwd and pred(nm)]
     early = lambda nm: nm.startswith("encoder.stage1") or nm.startswith("encoder.stage2")
-    self.pack_tiles_enc = dev(G.tile_index(sel(lambda nm: nm.startswith("encoder."))))
-    self.pack_tiles_enc_early = dev(G.tile_index(sel(early)))                                   # stem + stage2: 0.2 M
-    self.pack_tiles_enc_late = dev(G.tile_index(sel(lambda nm: nm.startswith("encoder.") and not early(nm))))  # 23 M
-    self.pack_tiles_dec = dev(G.tile_index(sel(lambda nm: not nm.startswith("encoder."))))
-    self.pack_tiles_bwd = dev(G.tile_index([pp for pp, bwd in zip(pack_parts, pack_is_bwd) if bwd]))
-    self.unpack_tiles = dev(G.tile_index(unpack_parts))
+    self.pack_tiles_enc = dev(sel(lambda nm: nm.startswith("encoder.")))
+    self.pack_tiles_enc_early = dev(sel(early))                                   # stem + stage2: 0.2 M
+    self.pack_tiles_enc_late = dev(sel(lambda nm: nm.startswith("encoder.") and not early(nm)))  # 23 M
+    self.pack_tiles_dec = dev(sel(lambda nm: not nm.startswith("encoder.")))
+    self.pack_tiles_bwd = dev([pp for pp, bwd in zip(pack_parts, pack_is_bwd) if bwd])
+    self.unpack_tiles = dev(unpack_parts)
     # gradient buckets for the overlapped exchange (corenet_amd/distributed.py): contiguous ranges of the
     # grad slab in the order backward completes them, each with the tile descriptors of its own convs
     los = [min(o for k, (o, _) in s.off.items() if s.kind[k] == "param" and k.startswith(lb))
@@ -445,11 +444,20 @@ class Engine:
       if k in self.op_tables:
         self.be.bf3_operands(self.packed, self.op_tables[k], self.wop)
 
+  def _tiles_dev(self, parts):
+    """Device tables of one pack / un-pack: the parts that are plain transposes as LDS blocks (conv_geometry.mat_index,
+    crn_copy_mats_f32: runs of 64+ floats on both sides), the rest as 8x8 tiles (tile_index).  CRN_COPY_MATS=0: tiles
+    only (the round-2 copies)."""
+    mats, rest = (G.mat_index(parts) if os.environ.get("CRN_COPY_MATS", "1") != "0" else
+                  (np.zeros((0, 16), np.int32), parts))
+    tl = G.tile_index(rest)
+    return (t.as_tensor(tl[0], device=self.device), t.as_tensor(tl[1].view(np.int64), device=self.device),
+            t.as_tensor(tl[2] if tl[2].size else np.zeros(1, np.int32), device=self.device),
+            t.as_tensor(mats, device=self.device))
+
   def bucket_unpack_tiles(self, i: int):
     if self._bucket_dev is None:
-      dev = lambda tl: (t.as_tensor(tl[0], device=self.device), t.as_tensor(tl[1].view(np.int64), device=self.device),
-                        t.as_tensor(tl[2] if tl[2].size else np.zeros(1, np.int32), device=self.device))
-      self._bucket_dev = [dev(G.tile_index(sel)) for sel in self._bucket_tiles]
+      self._bucket_dev = [self._tiles_dev(sel) for sel in self._bucket_tiles]
     return self._bucket_dev[i]
 
   @property
@@ -463,7 +471,7 @@ class Engine:
       self.dgrad_dirty = True
 
   def pack_weights(self, part: str = "all"):
-    """flat parameter slab -> packed forward weights and biases (1 launch; "enc" / "dec": one of the two pieces)."""
+    """flat parameter slab -> packed forward weights and biases ("enc" / "dec": one of the two pieces)."""
     tiles = {"all": self.pack_tiles, "enc": self.pack_tiles_enc, "dec": self.pack_tiles_dec,
              "enc_early": self.pack_tiles_enc_early, "enc_late": self.pack_tiles_enc_late}[part]
     self.be.copy_tiles(self.store.params, self.packed, tiles)
@@ -947,7 +955,7 @@ class Plan:
     _, lo, hi = eng.grad_buckets[i]
     tiles = eng.bucket_unpack_tiles(i)
     def run():
-      if tiles[0].numel():
+      if tiles[0].numel() or tiles[3].numel():
         self.be.copy_tiles(eng.gpacked, eng.store.grads, tiles, reverse=True)
       hook(eng.store.grads[lo:hi])
     if self.side is None or self.trace is not None:

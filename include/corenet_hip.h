@@ -172,6 +172,14 @@ int crn_conv_wgrad_2d_bf3(const crnView* x, const crnInTransform* tr, const crnV
 int crn_copy_tiles_f32(const float* src, float* dst, const int32_t* desc /* [ntiles][6] */,
                        const uint64_t* mask /* [ntiles] */, const int32_t* explicit_idx, int64_t ntiles,
                        int reverse, crnStream s);
+/* The same copy for index maps that are (batches of) 2-D transposes -- every plain convolution's forward and
+ * data-gradient layout -- staged through LDS so that both sides move in runs of 64+ floats.  Block t holds
+ * G x A x B elements (g, a, b) with  reference index = fbase + g*fg + a*fa + b,  packed position = pbase + g*pg + a*pa
+ * + b*pb  (pa == 1 or pb == 1);  desc[t] = {A, B, G, fbase, fa, fg, pbase, pa, pb, pg, ceil(2^32/(A*B)), ceil(2^32/B),
+ * ceil(2^32/A), 0, 0, 0} (the reciprocals as uint32; unused where the divisor is 1),  G*A*(B|1) <= 8448.
+ * conv_geometry.mat_index derives the blocks from the same index arrays as the tiles and proves them equal.      */
+int crn_copy_mats_f32(const float* src, float* dst, const int32_t* desc /* [nblocks][16] */, int64_t nblocks,
+                      int reverse, crnStream s);
 int crn_gather_f32(const float* src, const int32_t* idx, float* dst, int64_t n, crnStream s);
 /* dst[idx[i]] (+)= src[i] for idx[i] >= 0      (gradient un-packing)        */
 int crn_scatter_f32(const float* src, const int32_t* idx, float* dst, int64_t n,

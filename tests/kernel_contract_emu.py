@@ -139,9 +139,23 @@ class EmuBackend:
     if zero_first: dw.zero_()
     dw += full.reshape(-1)
 
+  def copy_mats(self, src, dst, desc, reverse=False):
+    """crn_copy_mats_f32 as include/corenet_hip.h words it: block (g, a, b) <-> reference fbase + g*fg + a*fa + b,
+    packed pbase + g*pg + a*pa + b*pb."""
+    for A, B, Gn, fbase, fa, fg, pbase, pa, pb, pg in desc.cpu().long()[:, :10].tolist():
+      g = t.arange(Gn).view(-1, 1, 1); a = t.arange(A).view(1, -1, 1); b = t.arange(B).view(1, 1, -1)
+      ref = (fbase + g * fg + a * fa + b).reshape(-1)
+      pk = (pbase + g * pg + a * pa + b * pb).reshape(-1)
+      if reverse: dst[ref] = src[pk]
+      else: dst[pk] = src[ref]
+
   def copy_tiles(self, src, dst, tiles, reverse=False):
-    desc, mask, ex = [x.cpu() for x in tiles]
+    if len(tiles) > 3 and tiles[3].shape[0]:
+      self.copy_mats(src, dst, tiles[3], reverse)
+    desc, mask, ex = [x.cpu() for x in tiles[:3]]
     n = desc.shape[0]
+    if not n:
+      return
     r = t.arange(8).view(1, 8, 1); c = t.arange(8).view(1, 1, 8)
     d = desc.long()
     pos = (d[:, 0].view(n, 1, 1) + r * d[:, 1].view(n, 1, 1) + c).reshape(-1)

@@ -397,3 +397,41 @@ def test_bf3_operand_layouts_round_trip():
   EMU.conv_fwd(V.view_of(x), None, None, fwd.npad, None, 0, V.view_of(y1), fwd.window, fwd.pad_lo, wslab=slabs)
   assert err(y1, y0) < 2e-5
 
+
+def test_mat_index_blocks_equal_tiles():
+  """conv_geometry.mat_index (the LDS block copies of crn_copy_mats_f32) against tile_index on the emulator of both
+  contracts: forward + data-gradient packs and the gradient un-pack of 1x1 / 3x3 / 3x3x3 / 5x5x5 layers (ragged channel
+  counts included) move exactly the same elements; transposed convolutions, the stem and repeated biases are left to the
+  tiles; the kernel's multiply-high reciprocals divide every element count of a block exactly."""
+  def both(parts, nflat, npacked, reverse):
+    d, m, ex = G.tile_index(parts)
+    full = (t.as_tensor(d), t.as_tensor(m.view(np.int64)), t.as_tensor(ex if ex.size else np.zeros(1, np.int32)))
+    mats, rest = G.mat_index(parts)
+    d2, m2, ex2 = G.tile_index(rest)
+    new = (t.as_tensor(d2), t.as_tensor(m2.view(np.int64)), t.as_tensor(ex2 if ex2.size else np.zeros(1, np.int32)),
+           t.as_tensor(mats))
+    g = t.Generator().manual_seed(1)
+    if not reverse:
+      src = t.randn(nflat, generator=g, dtype=DT)
+      a, b = t.zeros(npacked, dtype=DT), t.zeros(npacked, dtype=DT)
+    else:
+      src = t.randn(npacked, generator=g, dtype=DT)
+      a, b = t.zeros(nflat, dtype=DT), t.zeros(nflat, dtype=DT)
+    EMU.copy_tiles(src, a, full, reverse); EMU.copy_tiles(src, b, new, reverse)
+    assert t.equal(a, b)
+    return mats, d2.shape[0]
+  for shape, p in (((64, 64, 3, 3), 1), ((256, 64, 1, 1), 0), ((16, 28, 5, 5, 5), 2), ((67, 130, 3, 3), 1), ((64, 96, 3, 3, 3), 1)):
+    fw, dg = G.conv_fwd(shape, p), G.conv_dgrad(shape, p)
+    n = int(np.prod(shape))
+    parts = [(0, fw.index, fw.npad, 0), (fw.index.size + 5, dg.index, dg.npad, dg.taps if dg.taps > 1 else 0)]
+    mats, left = both(parts, n, parts[1][0] + dg.index.size, False)
+    assert mats.shape[0] and not left
+    both(parts[:1], n, fw.index.size, True)
+    for r in mats.view(np.uint32).astype(np.int64):
+      xs = np.arange(int(r[2] * r[0] * r[1]) + 1)
+      for q, magic in ((r[0] * r[1], r[10]), (r[1], r[11]), (r[0], r[12])):
+        assert q == 1 or np.array_equal((xs * magic) >> 32, xs // q)
+  ct = G.convt_fwd((32, 16, 7, 7, 7), 3)
+  for part in ((0, ct.index, ct.npad, 0), (0, G.stem_fwd().index, G.stem_fwd().npad, 0),
+               (0, G.bias_index(16, 8, 128, True).astype(np.int64), 128, 0)):
+    assert G.mat_index([part])[0].shape[0] == 0 and len(G.mat_index([part])[1]) == 1

@@ -1161,3 +1161,46 @@ def test_copy_tiles_pack_unpack(be):
   be.copy_tiles(packed.to(DEV), back, tl_dev, reverse=True)
   ref = t.full((int(gi.max()) + 1,), -5.0); ref[gi[gi >= 0]] = packed[gi >= 0]
   assert t.equal(back.cpu(), ref)
+
+
+def test_copy_mats_pack_unpack(be):
+  """crn_copy_mats_f32 (LDS-staged block copies of the plain convolutions' packs, conv_geometry.mat_index) + the 8x8
+  tiles of what is left, against the flat-index gather: forward / data-gradient layouts of 1x1, 3x3, 3x3x3 and 5x5x5
+  layers incl. ragged channel counts, plain biases; transposed convolutions, the stem and repeated biases must stay on
+  the tiles.  Bit-exact both ways."""
+  from corenet_amd.model import conv_geometry as G
+  g = t.Generator().manual_seed(5)
+  layers = [((64, 32, 3, 3), 1), ((24, 515, 1, 1), 0), ((16, 28, 5, 5, 5), 2), ((128, 224, 5, 5, 5), 2), ((256, 256, 3, 3, 3), 1),
+            ((2048, 512, 1, 1), 0), ((67, 130, 3, 3), 1)]
+  for shape, p in layers:
+    fw, dg = G.conv_fwd(shape, p), G.conv_dgrad(shape, p)
+    n = int(np.prod(shape))
+    src = t.randn(n, generator=g)
+    parts = [(3, fw.index, fw.npad, 0), (3 + fw.index.size + 8, dg.index, dg.npad, dg.taps if dg.taps > 1 else 0)]
+    total = parts[1][0] + dg.index.size
+    mats, rest = G.mat_index(parts)
+    assert mats.shape[0] and not rest, shape
+    tl = G.tile_index(rest)
+    dev = (t.as_tensor(tl[0]).to(DEV), t.as_tensor(tl[1].view(np.int64)).to(DEV), t.zeros(1, dtype=t.int32, device=DEV),
+           t.as_tensor(mats).to(DEV))
+    flat = t.full((total,), -1, dtype=t.int64)
+    flat[3:3 + fw.index.size] = t.as_tensor(fw.index.astype(np.int64))
+    flat[parts[1][0]:] = t.as_tensor(dg.index.astype(np.int64))
+    want = t.where(flat >= 0, src[flat.clamp(min=0)], t.zeros(()))
+    got = t.zeros(total, device=DEV)
+    be.copy_tiles(src.to(DEV), got, dev)
+    assert t.equal(got.cpu(), want), shape
+    # un-pack of the forward layout (the gradient's): every parameter exactly once
+    m1, r1 = G.mat_index(parts[:1])
+    dev1 = (t.zeros((0, 6), dtype=t.int32, device=DEV), t.zeros(0, dtype=t.int64, device=DEV), t.zeros(1, dtype=t.int32, device=DEV),
+            t.as_tensor(m1).to(DEV))
+    packed = t.randn(3 + fw.index.size, generator=g)
+    back = t.full((n,), -5.0, device=DEV)
+    be.copy_tiles(packed.to(DEV), back, dev1, reverse=True)
+    gi = t.as_tensor(fw.index.astype(np.int64))
+    ref = t.full((n,), -5.0); ref[gi[gi >= 0]] = packed[3:][gi >= 0]
+    assert t.equal(back.cpu(), ref), shape
+  for part in ((0, G.convt_fwd((16, 14, 7, 7, 7), 3).index, G.convt_fwd((16, 14, 7, 7, 7), 3).npad, 0),
+               (0, G.stem_fwd().index, G.stem_fwd().npad, 0), (0, G.bias_index(16, 8, 128, True).astype(np.int64), 128, 0)):
+    assert G.mat_index([part])[0].shape[0] == 0
+  assert G.mat_index([(0, G.bias_index(64, 1, 64).astype(np.int64), 64, 0)])[0].shape[0] == 1
