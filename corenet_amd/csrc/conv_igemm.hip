@@ -50,6 +50,7 @@ struct PwGeom {
   // fused reduction (counters != nullptr): the last workgroup of a tile adds the splits up and writes yr
   float* yr; int64_t yr_sB, yr_sC, yr_sP; int yr_accumulate; int* counters;
   long long* stamps;               // tuning aid (CRN_PW_STAMPS=1): shader-clock stamps of workgroup 0
+  int ablate;                      // tuning aid (CRN_PW_ABLATE bits): 1 no MFMAs, 2 no global loads, 4 no stores, 8 no LDS commit
 };
 
 // NS = 16-column blocks per workgroup (2: 64 x 32 tiles; 4: 64 x 64 tiles -- half the workgroups and half the
@@ -64,12 +65,13 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
   crn_kernargs_now(g.x, g.y, g.w, g.bias, g.tr.scale, g.tr.shift, g.tr.pre_relu, g.tr.post_relu, g.B, g.C, g.N, g.Npad,
                    g.S, g.xsB, g.ysB, g.ysC, g.ysP, g.bias_sB, g.mode, g.splits, g.cps, g.counters);
   const long long t_entry = (long long)__builtin_amdgcn_s_memtime();
+  const long long r_entry = (long long)__builtin_amdgcn_s_memrealtime();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, kk = lane >> 4;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const bool stamp = g.stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
   int nmark = 0;
-  auto mark = [&]() { if (stamp && nmark < 31) g.stamps[nmark] = (long long)__builtin_amdgcn_s_memtime() - t_entry; ++nmark; };
+  auto mark = [&]() { if (stamp && nmark < 30) g.stamps[nmark] = (long long)__builtin_amdgcn_s_memtime() - t_entry; ++nmark; };
   mark();
   const int split = blockIdx.z / g.B, b = blockIdx.z - split * g.B;
   const int cbeg = split * g.cps, cend = min(g.C, cbeg + g.cps);
@@ -85,8 +87,11 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
   // vmcnt(N) with the N the issue order implies, out-of-range offsets (zeros, no traffic) past the end.  The
   // BatchRenorm scale / shift of the workgroup's channels are staged into LDS once, next to the first loads (read from
   // global inside the loop they cost another exposed latency per chunk).
-  __shared__ float tsc[kPwTab], tsh[kPwTab];
+  // (dynamic LDS, 2 * cps floats: static tables for 2048 channels took a third of the kernel's LDS and with it the
+  // fourth and fifth resident workgroup -- and residency is what these latency chains are short of, see the host side)
+  extern __shared__ float pw_tables[];
   const bool has_tr = g.tr.scale != nullptr;
+  float* tsc = pw_tables; float* tsh = pw_tables + g.cps;
   constexpr unsigned kOOBo = 0x80000000u;
   constexpr int NL = NRA + NRB;                      // loads per thread and chunk
   const crn_rsrc xrs = crnk::make_rsrc(xb);
@@ -96,13 +101,13 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
 #pragma unroll
     for (int q = 0; q < NRA; ++q) {
       const int c_a = c0 + ka + q * 16;
-      const unsigned off = (a_ok && c_a < cend) ? (unsigned)(c_a * g.S + m0 + ca) * 4u : kOOBo;
+      const unsigned off = (a_ok && c_a < cend && !(g.ablate & 2)) ? (unsigned)(c_a * g.S + m0 + ca) * 4u : kOOBo;
       crnk::crn_bload4(pa_[q], xrs, off);
     }
 #pragma unroll
     for (int q = 0; q < NRB; ++q) {
       const int c_b = c0 + kb + q * BROWS;
-      const unsigned off = (b_ok && c_b < cend) ? (unsigned)(c_b * g.Npad + n0 + cb) * 4u : kOOBo;
+      const unsigned off = (b_ok && c_b < cend && !(g.ablate & 2)) ? (unsigned)(c_b * g.Npad + n0 + cb) * 4u : kOOBo;
       crnk::crn_bload4(pb_[q], wrs, off);
     }
   };
@@ -137,14 +142,17 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
   auto step = [&](int c0, f32x4 (&pa_)[NRA], f32x4 (&pb_)[NRB]) {
     wait_slot(pa_, pb_);
     mark();
+    if (!(g.ablate & 8)) {
     __syncthreads();                                   // (first step: the tables; later: the previous chunk's MFMA reads)
 #pragma unroll
     for (int q = 0; q < NRA; ++q) *reinterpret_cast<f32x4*>(ldsA + (ka + q * 16) * SA + ca) = xform(pa_[q], c0 + ka + q * 16);
 #pragma unroll
     for (int q = 0; q < NRB; ++q) *reinterpret_cast<f32x4*>(ldsB + (kb + q * BROWS) * SB + cb) = pb_[q];
     __syncthreads();
+    }
     mark();
     issue(c0 + 2 * KC, pa_, pb_);                      // this slot's registers are free: the chunk after the next
+    if (g.ablate & 1) { mark(); return; }
     const float* pa = ldsA + kk * SA + wave * 16 + i16;
     const float* pb = ldsB + kk * SB + i16;
 #pragma unroll
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
   }
   // D: rows kk*4..kk*4+3 = 4 consecutive positions, col i16 = channel -> one float4 per lane
   const int m = m0 + wave * 16 + kk * 4;
-  if (m < g.S) {
+  if (m < g.S && !(g.ablate & 4)) {
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) {
       const int n = n0 + ns * 16 + i16;
@@ -190,7 +198,10 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PwGeom g) {
       }
     }
   }
-  if (stamp) g.stamps[31] = (long long)__builtin_amdgcn_s_memtime() - t_entry;
+  if (stamp) {
+    g.stamps[31] = (long long)__builtin_amdgcn_s_memtime() - t_entry;
+    g.stamps[30] = (long long)__builtin_amdgcn_s_memrealtime() - r_entry;      // 100 MHz: cycles / this = shader clock
+  }
   if (g.counters) {       // fused split-K reduction: see conv_fwd_kernel (mode 4)
     __threadfence();
     __shared__ int s_last;
@@ -832,6 +843,8 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
         }
       }
     }
+    static const int pw_ablate = getenv("CRN_PW_ABLATE") ? atoi(getenv("CRN_PW_ABLATE")) : 0;
+    p.ablate = pw_ablate;
     static const bool want_stamps = getenv("CRN_PW_STAMPS") != nullptr;
     static long long* pw_stamps = nullptr;
     if (want_stamps) {
@@ -841,8 +854,9 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
       g_pw_stamps = pw_stamps;
     }
     dim3 grid((unsigned)crn_cdiv(Sx, 64), (unsigned)crn_cdiv(y->C, BNh), (unsigned)(x->B * p.splits));
-    if (wide) hipLaunchKernelGGL(pointwise_fwd_kernel<4>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(pointwise_fwd_kernel<2>, grid, dim3(256), 0, st, p);
+    const size_t tab_bytes = p.tr.scale ? (size_t)2 * p.cps * sizeof(float) : 0;
+    if (wide) hipLaunchKernelGGL(pointwise_fwd_kernel<4>, grid, dim3(256), tab_bytes, st, p);
+    else hipLaunchKernelGGL(pointwise_fwd_kernel<2>, grid, dim3(256), tab_bytes, st, p);
     CRN_CHECK_LAUNCH();
     if (p.splits > 1 && !p.counters) {
       if (armed && !accumulate && plain_view(*y) && y->sB == (int64_t)y->C * Sx) {

@@ -48,6 +48,10 @@ CONV_CASES = [
     ("conv3x3", "conv", (128, 128, 3, 3), 1, (1, 32, 32), 2),
     ("conv3x3_small", "conv", (512, 512, 3, 3), 1, (1, 8, 8), 2),
     ("conv1x1_odd", "conv", (24, 515, 1, 1), 0, (1, 32, 32), 2),
+    ("conv1x1_expand", "conv", (256, 64, 1, 1), 0, (1, 64, 64), 4),      # one K chunk per tile: many units per workgroup
+    ("conv1x1_splitk", "conv", (256, 1024, 1, 1), 0, (1, 16, 16), 4),     # long K, few positions: K splits
+    ("conv1x1_wide", "conv", (2048, 512, 1, 1), 0, (1, 8, 8), 4),
+    ("conv1x1_ragged", "conv", (40, 72, 1, 1), 0, (1, 12, 12), 3),        # partial tiles in every dimension
     ("conv3d_k3", "conv", (256, 256, 3, 3, 3), 1, (4, 4, 4), 2),
     ("conv3d_k5_8", "conv", (128, 224, 5, 5, 5), 2, (8, 8, 8), 1),
     ("conv3d_k5_32", "conv", (32, 56, 5, 5, 5), 2, (32, 32, 32), 1),

@@ -98,3 +98,12 @@ elif os.environ.get("CRN_BF3_STAMPS"):        # per-step phases of workgroup 0 (
     prev = r[6]; n += 1
     for j in range(6): tot[j] += d[j]
   if n: print("mean   : " + "  ".join(f"{nm} {v // n:6d}" for nm, v in zip(names, tot)))
+if os.environ.get("CRN_PW_STAMPS"):            # pointwise kernel (1x1 layers, fp32): workgroup (0,0,0), thread 0
+  import ctypes
+  st = (ctypes.c_longlong * 32)()
+  if be.lib.cdll.crn_pw_debug_stamps(st) == 0:
+    marks = [v for v in st[:30] if v > 0]
+    if st[30] > 0: print("  shader clock during workgroup 0: %.2f GHz (%d cycles in %d ticks of 10 ns)" % (st[31] / st[30] / 10.0, st[31], st[30]))
+    print("pointwise stamps (shader cycles from kernel entry): setup %d, loads issued %d; per chunk (wait, commit, mfma): %s; end %d"
+          % (st[0], st[1], " ".join("(%d %d %d)" % (marks[i] - marks[i - 1], marks[i + 1] - marks[i], marks[i + 2] - marks[i + 1])
+                                    for i in range(2, len(marks) - 2, 3)), st[31]))
