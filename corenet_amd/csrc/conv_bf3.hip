@@ -1291,7 +1291,7 @@ int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w
   if (!x || !y || (!w && !wslab) || Npad <= 0 || (Npad & 15) || x->B != y->B || kd < 1 || kh < 1 || kw < 1) return CRN_EINVAL;
   if (y->C > Npad || x->C > kTabC) return CRN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  (void)crn_splitk_take_armed();
+  const bool armed = crn_splitk_take_armed();
   { const int rcf = crn_splitk_flush(st); if (rcf != CRN_OK) return rcf; }
   const int xmode = even_view(*x) ? 1 : ((x->sW == 2 && x->chan_off != nullptr && (x->W & 1) == 0) ? 2 : 0);
   if (!xmode) return CRN_EINVAL;
@@ -1364,6 +1364,17 @@ int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w
   g.mode = accumulate ? 1 : 0;
   const crnView yreal = *y;
   float* scratch = nullptr;
+  // the partial sums: added up by a reduction launch -- or, after crn_splitk_defer, by the BatchRenorm launch that reads
+  // this (dense) output next (decoder stages 2-4: statistics after c1, the norms' backward after both data gradients)
+  auto finish_splits = [&]() -> int {
+    const int64_t S = (int64_t)yreal.D * yreal.H * yreal.W;
+    if (armed && !accumulate && yreal.chan_off == nullptr && yreal.sW == 1 && yreal.sH == yreal.W &&
+        yreal.sD == (int64_t)yreal.H * yreal.W && yreal.sC == S && yreal.sB == (int64_t)yreal.C * S) {
+      crn_splitk_set_pending(yreal, scratch, splits, st);
+      return CRN_OK;
+    }
+    return crn_splitk_reduce(yreal, scratch, splits, accumulate, st);
+  };
   if (splits > 1) {
     const int64_t S = (int64_t)y->D * y->H * y->W, ytot = (int64_t)y->B * y->C * S;
     scratch = crn_splitk_scratch((size_t)splits * ytot, st);
@@ -1418,7 +1429,7 @@ int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w
       CRN_BF3_WS_CASE(1, 1, 7) CRN_BF3_WS_CASE(2, 1, 7)
       CRN_BF3_WS_CASE(1, 1, 4) CRN_BF3_WS_CASE(2, 1, 4)
 #undef CRN_BF3_WS_CASE
-      if (rc == CRN_OK && g.mode == 3) rc = crn_splitk_reduce(yreal, scratch, splits, accumulate, st);
+      if (rc == CRN_OK && g.mode == 3) rc = finish_splits();
       return rc;
     }
   }
@@ -1427,7 +1438,7 @@ int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w
   CRN_BF3_CASE(1, 1, 4, 1) CRN_BF3_CASE(2, 1, 4, 1) CRN_BF3_CASE(4, 1, 4, 1)
   CRN_BF3_CASE(1, 2, 4, 1) CRN_BF3_CASE(2, 2, 4, 1) CRN_BF3_CASE(4, 2, 4, 1)
 #undef CRN_BF3_CASE
-  if (rc == CRN_OK && g.mode == 3) rc = crn_splitk_reduce(yreal, scratch, splits, accumulate, st);
+  if (rc == CRN_OK && g.mode == 3) rc = finish_splits();
   return rc;
 }
 }  // namespace

@@ -888,6 +888,8 @@ class Plan:
       if skip_async and k > 2:
         t.cuda.current_stream().wait_event(self._skip_ev[k - 1][1])      # the skip channels of this stage's input
       self._stats(b1_, d["u"], S, d["cin"] * S, True, training)
+      if training and eng.defer_reduce:
+        be.splitk_defer()                      # (stages 2-4 split K: the statistics below add the partial sums up)
       self._probe(f"conv3d_stage{k}_c1_fwd", lambda: self._conv(
           cv[p + "c1."], self.vw(d["u"]), Transform(b1_.scale, b1_.shift, pre_relu=True), self.vw(d["w"])))
       self._stats(b2_, d["w"], S, d["cmid"] * S, True, training)
@@ -1009,6 +1011,8 @@ class Plan:
       self._wgrad(ct, self.vw(d["w"]), tr2, gv)
       if k == 6:   # gradient of the logits comes from the loss kernel; below it is a bn_bwd output
         self._bias_grad(ct, g_out, So, ctot * So)
+      if eng.defer_reduce:
+        be.splitk_defer()                      # gv2 and gv1 are read next by their norms' backward, which add up the splits
       self._dgrad(ct, gv, self.vw(d["gv2"]))
       cc = cv[p + "c1."]
       # every conv bias gradient below is sum(dx) of the norm that consumes the conv output: fused
@@ -1018,6 +1022,8 @@ class Plan:
                 dsum=cc.dbias, ndsum=cc.n_ref)
       tr1 = Transform(b1_.scale, b1_.shift, pre_relu=True)
       self._wgrad(cc, self.vw(d["u"]), tr1, self.vw(d["gw"]))
+      if eng.defer_reduce:
+        be.splitk_defer()
       self._dgrad(cc, self.vw(d["gw"]), self.vw(d["gv1"]))
       cprev = cv[f"decoder.stage_{k - 1}.t1."]        # produced this stage's input (first n_ref channels)
       be.bn_bwd(d["u"], d["cin"] * S, d["gv1"], d["cin"] * S, B, d["cin"], S, True, False,
