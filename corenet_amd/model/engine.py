@@ -213,6 +213,7 @@ class Engine:
     self.encoder_e2d = self.decoder_math == "bf16x3" and os.environ.get("CRN_E2D", "1") != "0"
     self.wgrad_2d = os.environ.get("CRN_WG2D", "1") != "0"
     self.defer_reduce = os.environ.get("CRN_DEFER_REDUCE", "1") != "0"
+    self.fuse_tail = os.environ.get("CRN_FUSE_TAIL", "1") != "0"
     # fp32 is the only dtype of the HIP kernels; float64 exists so that the CPU
     # contract emulator (tests/) can check the host wiring far below fp32 noise.
     assert dtype == t.float32 or getattr(backend, "name", "") == "emu"
@@ -924,23 +925,34 @@ class Plan:
     self._conv(cv[p + "op_b.conv."], self.vw(blk["ya"]), Transform(ba.scale, ba.shift, post_relu=True),
                self.vw(blk["yb"]))
     self._stats(bb, blk["yb"], S, f2 * S, False, training)
-    defer()
-    self._conv(cv[p + "op_c.conv."], self.vw(blk["yb"]), Transform(bb.scale, bb.shift, post_relu=True),
-               self.vw(blk["yc"]))
-    self._stats(bc, blk["yc"], S, f3 * S, False, training)
     if blk["final"]:
       pre, sB_pre = self.feat[blk["stage"]], self.feat[blk["stage"]].stride(0)
     else:
       pre, sB_pre = None, 0
-    if blk["down"]:
+    # training on the HIP backend: the statistics of op_c's norm and the block tail (norm + shortcut + ReLU) are one
+    # launch (crn_batch_renorm_stats_tail) -- so the shortcut branch of a down-sampling block goes before op_c
+    fused_tail = training and hasattr(be, "bn_stats_tail") and self.eng.fuse_tail
+    res, rsc, rsh = cur, None, None
+    def shortcut():
       bs = bn[p + "shortcut.bn."]
       defer()
       self._conv(cv[p + "shortcut.conv."], xin, None, self.vw(blk["ys"]))
       self._stats(bs, blk["ys"], S, f3 * S, False, training)
-      be.affine_add_relu(blk["yc"], bc.scale, bc.shift, blk["ys"], bs.scale, bs.shift, B, f3, S,
-                         f3 * S, f3 * S, pre, sB_pre, blk["out"], f3 * S, True)
+      return blk["ys"], bs.scale, bs.shift
+    if blk["down"] and fused_tail:
+      res, rsc, rsh = shortcut()
+    defer()
+    self._conv(cv[p + "op_c.conv."], self.vw(blk["yb"]), Transform(bb.scale, bb.shift, post_relu=True),
+               self.vw(blk["yc"]))
+    if fused_tail:
+      with _lib.roctx_range("bn_stats_tail C%d S%d" % (bc.C, S)):
+        be.bn_stats_tail(blk["yc"], B, f3, S, f3 * S, bc.gamma, bc.beta, bc.rmean, bc.rvar, bc.nbt, BN_EPS, BN_MOMENTUM,
+                         True, bc.scale, bc.shift, bc.saved, res, rsc, rsh, f3 * S, pre, sB_pre, blk["out"], f3 * S, True)
     else:
-      be.affine_add_relu(blk["yc"], bc.scale, bc.shift, cur, None, None, B, f3, S,
+      self._stats(bc, blk["yc"], S, f3 * S, False, training)
+      if blk["down"]:
+        res, rsc, rsh = shortcut()
+      be.affine_add_relu(blk["yc"], bc.scale, bc.shift, res, rsc, rsh, B, f3, S,
                          f3 * S, f3 * S, pre, sB_pre, blk["out"], f3 * S, True)
     blk["in"] = cur
     return blk["out"]

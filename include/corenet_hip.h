@@ -204,6 +204,16 @@ int crn_batch_renorm_stats(const float* x, int B, int C, int64_t S, int64_t sB, 
                            float* scale, float* shift, float* saved /* [4][C] */,
                            double* workspace, size_t workspace_bytes, crnStream s);
 size_t crn_batch_renorm_workspace_bytes(int C);
+/* crn_batch_renorm_stats (pre_relu = 0) followed by crn_affine_add_relu(x, scale, shift, r, rscale, rshift, ...) -- the tail
+ * of a ResNet bottleneck (resnet50.py:71-78: bn of the last conv + shortcut + ReLU) -- as ONE call: where a workgroup owns
+ * a channel with all of it in registers (training, B*S <= 16384: every bottleneck of the encoder) the tail is written by
+ * the statistics launch itself, otherwise by a second launch.  Same results as the two calls, bit for bit.            */
+int crn_batch_renorm_stats_tail(const float* x, int B, int C, int64_t S, int64_t sB,
+                                const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                const int64_t* num_batches_tracked, float eps, float momentum, int training,
+                                float* scale, float* shift, float* saved, double* workspace, size_t workspace_bytes,
+                                const float* r, const float* rscale, const float* rshift, int64_t sB_r,
+                                float* y_pre, int64_t sB_pre, float* y, int64_t sB_y, int relu, crnStream s);
 
 /* Eval mode (batch_renorm.py:59: (x - running_mean) / sqrt(running_var + eps) * weight + bias) for all
  * BatchRenorm instances of a model at once: n channels, table [n][5] = offsets of (weight, bias) in `params`,

@@ -326,8 +326,9 @@ def test_deterministic_mode_two_runs_bit_identical(math):
   """CRN_DETERMINISTIC / crn_set_deterministic: five training steps (forward, iou_fgbg, backward, Adam, running
   statistics) run twice from the same state give bit-identical parameters, Adam moments, buffers and losses -- weight
   gradients without position splits, ordered bias-gradient sums, fixed-point ray-sample scatter.  The default mode is
-  run beside it (its atomics make two runs differ; printed, not asserted) and its loss must stay within 2 % of the
-  deterministic trajectory after the five steps: the switch changes the ORDER of the sums, nothing else."""
+  run beside it (its atomics make two runs differ; printed, not asserted) and its losses must follow the deterministic
+  trajectory while the trajectory is still conditioned (three steps, 2e-3): the switch changes the ORDER of the sums,
+  nothing else."""
   from corenet_amd.backend import default_backend
   be = default_backend()
   sd = O.make_state(0, 2, nbt=0)
@@ -355,8 +356,12 @@ def test_deterministic_mode_two_runs_bit_identical(math):
   print(f"[{math}] deterministic: 5 steps twice, bit-identical (loss {la[-1]:.6f}); default mode: run-to-run max |d param| "
         f"{float((tc[0] - td[0]).abs().max()):.2e}, vs deterministic {float((tc[0] - ta[0]).abs().max()):.2e}")
   # (Adam moves every parameter by ~lr per step whatever the size of its gradient, so last-bit differences in tiny
-  # gradients become 1e-3 differences in parameters within a few steps; the losses stay together)
-  assert abs(lc[-1] - la[-1]) < 2e-2 * abs(la[-1]), (lc, la)
+  # gradients become 1e-3 differences in parameters within a few steps -- and this fixture, BatchRenorm over two samples
+  # with num_batches_tracked = 0, is chaotic from there on: 24 default-mode runs from the same state gave third losses
+  # within 5e-4 of each other, fourth within 6e-3, fifth between 0.778 and 0.830.  The first three steps are the check.)
+  for i in range(3):
+    assert abs(lc[i] - la[i]) < 2e-3 * abs(la[i]), (i, lc, la)
+  assert abs(lc[-1] - la[-1]) < 0.15 * abs(la[-1]), (lc, la)
 
 
 def test_native_rccl_from_the_library_single_rank():
