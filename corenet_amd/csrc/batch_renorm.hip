@@ -289,16 +289,23 @@ __global__ __launch_bounds__(kThreads) void bn_owner_stats_reg_kernel(
 
 // part != nullptr: dy is the output of a split-K convolution (a data gradient) still in `splits` partial sums in the
 // scratch: added up while they are loaded; dy itself is NOT written (its only reader is this kernel).
-template <int NV>
+// HEAD: the backward of a bottleneck's tail in the same launch -- dy is not read but formed,
+//   dy = (act > 0 ? g : 0) + g2      (the arithmetic of relu_bwd_add_kernel; g2 may be absent),
+// and stored to `dy` on the way (the shortcut's norm and the block's input gradient read it later): 15 launches fewer
+// per backward.
+struct BnHead { const float* g; int64_t sBg; const float* act; int64_t sBact; const float* g2; int64_t sBg2; };
+template <int NV, bool HEAD = false>
 __global__ __launch_bounds__(kThreads) void bn_owner_bwd_reg_kernel(
     const float* x, int64_t sBx, const float* dy, int64_t sBdy, int B, int S4, int C, int pre_relu,
     int post_relu, const float* gamma, const float* scale, const float* shift, const float* saved, float* dx,
-    int64_t sBdx, float* dgamma, float* dbeta, int accumulate, float* dsum, int ndsum, const float* part, int splits) {
+    int64_t sBdx, float* dgamma, float* dbeta, int accumulate, float* dsum, int ndsum, const float* part, int splits,
+    BnHead head = BnHead{}) {
   __shared__ double red[2 * (kThreads / 64)];
   __shared__ float sm[2];
   __shared__ float redf[kThreads / 64];
   crn_kernargs_now(x, sBx, dy, sBdy, B, S4, C, pre_relu, post_relu, gamma, scale, shift, saved, dx, sBdx, dgamma, dbeta,
                    accumulate, dsum, ndsum, part, splits);
+  if (HEAD) crn_kernargs_now(head.g, head.sBg, head.act, head.sBact, head.g2, head.sBg2);
   const int c = blockIdx.x, total4 = B * S4;
   // every per-channel scalar of the kernel is loaded here, next to x and dy: one round trip to memory, not three
   const float sc = scale[c], sh = shift[c], mu = saved[c], rstd = saved[C + c];
@@ -313,7 +320,17 @@ __global__ __launch_bounds__(kThreads) void bn_owner_bwd_reg_kernel(
     const int64_t o = ((int64_t)c * S4 + s4) * 4;
     const bool ok = e < total4;
     xv[k] = ok ? *reinterpret_cast<const f32x4*>(x + (int64_t)b * sBx + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (part == nullptr) {
+    if (HEAD) {
+      const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const f32x4 g = ok ? *reinterpret_cast<const f32x4*>(head.g + (int64_t)b * head.sBg + o) : z;
+      const f32x4 a = ok ? *reinterpret_cast<const f32x4*>(head.act + (int64_t)b * head.sBact + o) : z;
+      const f32x4 g2 = (ok && head.g2) ? *reinterpret_cast<const f32x4*>(head.g2 + (int64_t)b * head.sBg2 + o) : z;
+      f32x4 d;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d[i] = (a[i] > 0.f ? g[i] : 0.f) + g2[i];
+      if (ok) *reinterpret_cast<f32x4*>(const_cast<float*>(dy) + (int64_t)b * sBdy + o) = d;
+      gv[k] = d;
+    } else if (part == nullptr) {
       gv[k] = ok ? *reinterpret_cast<const f32x4*>(dy + (int64_t)b * sBdy + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
     } else {
       f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -796,16 +813,41 @@ extern "C" int crn_batch_renorm_eval_affine(const float* params, const float* bu
   return CRN_OK;
 }
 
-extern "C" int crn_batch_renorm_bwd(const float* x, int64_t sB_x, const float* dy, int64_t sB_dy,
-                                    int B, int C, int64_t S, int pre_relu, int post_relu,
-                                    const float* gamma, const float* scale, const float* shift,
-                                    const float* saved, float* dx, int64_t sB_dx, float* dgamma,
-                                    float* dbeta, int accumulate, float* dsum, int ndsum, double* ws,
-                                    size_t ws_bytes, crnStream stream) {
+int crn_relu_bwd_add_impl(const float* dy, const float* y_pre, const float* dy2, int B, int C, int64_t S, int64_t sB_dy,
+                          int64_t sB_pre, int64_t sB_dy2, float* dx, int64_t sB_dx, crnStream stream);
+
+// head != nullptr: dy is to be formed first from (g, act, g2) -- in the same launch where a workgroup owns a channel in
+// registers, by crn_relu_bwd_add's kernel otherwise
+static int bn_bwd_impl(const float* x, int64_t sB_x, const float* dy, int64_t sB_dy,
+                       int B, int C, int64_t S, int pre_relu, int post_relu,
+                       const float* gamma, const float* scale, const float* shift,
+                       const float* saved, float* dx, int64_t sB_dx, float* dgamma,
+                       float* dbeta, int accumulate, float* dsum, int ndsum, double* ws,
+                       size_t ws_bytes, crnStream stream, const BnHead* head) {
   hipStream_t st = (hipStream_t)stream;
   if (B < 1 || C < 1 || S < 1 || B > 64) return CRN_EINVAL;
   const bool v = vec_ok(S, {sB_x, sB_dy, sB_dx}, {x, dy, dx});
   const bool reg_form = owner_form(S, C, B) && v && (int64_t)B * S <= 16384;
+  if (head) {
+    const int rcf = crn_splitk_flush(st);          // (dy is formed here: nothing pending can be meant for this call)
+    if (rcf != CRN_OK) return rcf;
+    const bool hv = vec_ok(S, {head->sBg, head->sBact, head->g2 ? head->sBg2 : 0}, {head->g, head->act, head->g2});
+    if (reg_form && hv) {
+      const int per = (int)crn_cdiv((int64_t)B * S / 4, kThreads);
+#define CRN_BN_BWD_HEAD(NV)                                                                                         \
+  hipLaunchKernelGGL((bn_owner_bwd_reg_kernel<NV, true>), dim3(C), dim3(kThreads), 0, st, x, sB_x, dy, sB_dy, B, (int)(S / 4), C, \
+                     pre_relu, post_relu, gamma, scale, shift, saved, dx, sB_dx, dgamma, dbeta, accumulate, dsum, ndsum, \
+                     (const float*)nullptr, 0, *head)
+      if (per <= 1) CRN_BN_BWD_HEAD(1); else if (per <= 2) CRN_BN_BWD_HEAD(2); else if (per <= 4) CRN_BN_BWD_HEAD(4);
+      else if (per <= 8) CRN_BN_BWD_HEAD(8); else CRN_BN_BWD_HEAD(16);
+#undef CRN_BN_BWD_HEAD
+      CRN_CHECK_LAUNCH();
+      return CRN_OK;
+    }
+    const int rch = crn_relu_bwd_add_impl(head->g, head->act, head->g2, B, C, S, head->sBg, head->sBact, head->sBg2,
+                                          const_cast<float*>(dy), sB_dy, stream);
+    if (rch != CRN_OK) return rch;
+  }
   const float* part = nullptr;
   int psplits = 0;
   {
@@ -879,6 +921,29 @@ extern "C" int crn_batch_renorm_bwd(const float* x, int64_t sB_x, const float* d
   return CRN_OK;
 }
 
+extern "C" int crn_batch_renorm_bwd(const float* x, int64_t sB_x, const float* dy, int64_t sB_dy,
+                                    int B, int C, int64_t S, int pre_relu, int post_relu,
+                                    const float* gamma, const float* scale, const float* shift,
+                                    const float* saved, float* dx, int64_t sB_dx, float* dgamma,
+                                    float* dbeta, int accumulate, float* dsum, int ndsum, double* ws,
+                                    size_t ws_bytes, crnStream stream) {
+  return bn_bwd_impl(x, sB_x, dy, sB_dy, B, C, S, pre_relu, post_relu, gamma, scale, shift, saved, dx, sB_dx, dgamma, dbeta,
+                     accumulate, dsum, ndsum, ws, ws_bytes, stream, nullptr);
+}
+
+extern "C" int crn_batch_renorm_bwd_head(const float* x, int64_t sB_x, float* dy, int64_t sB_dy,
+                                         const float* g, int64_t sB_g, const float* act, int64_t sB_act,
+                                         const float* g2, int64_t sB_g2,
+                                         int B, int C, int64_t S, const float* gamma, const float* scale,
+                                         const float* shift, const float* saved, float* dx, int64_t sB_dx,
+                                         float* dgamma, float* dbeta, int accumulate, float* dsum, int ndsum,
+                                         double* ws, size_t ws_bytes, crnStream stream) {
+  if (!g || !act || !dy) return CRN_EINVAL;
+  const BnHead head{g, sB_g, act, sB_act, g2, sB_g2};
+  return bn_bwd_impl(x, sB_x, dy, sB_dy, B, C, S, 0, 0, gamma, scale, shift, saved, dx, sB_dx, dgamma, dbeta,
+                     accumulate, dsum, ndsum, ws, ws_bytes, stream, &head);
+}
+
 extern "C" int crn_affine_add_relu(const float* x, const float* scale, const float* shift,
                                    const float* r, const float* rscale, const float* rshift,
                                    int B, int C, int64_t S, int64_t sB_x, int64_t sB_r,
@@ -907,6 +972,10 @@ extern "C" int crn_relu_bwd_add(const float* dy, const float* y_pre, const float
                                 int64_t S, int64_t sB_dy, int64_t sB_pre, int64_t sB_dy2, float* dx,
                                 int64_t sB_dx, crnStream stream) {
   CRN_ENTRY(stream);
+  return crn_relu_bwd_add_impl(dy, y_pre, dy2, B, C, S, sB_dy, sB_pre, sB_dy2, dx, sB_dx, stream);
+}
+int crn_relu_bwd_add_impl(const float* dy, const float* y_pre, const float* dy2, int B, int C, int64_t S, int64_t sB_dy,
+                          int64_t sB_pre, int64_t sB_dy2, float* dx, int64_t sB_dx, crnStream stream) {
   hipStream_t st = (hipStream_t)stream;
   if (B < 1 || C < 1 || S < 1 || !y_pre || !dx) return CRN_EINVAL;
   dim3 grid(nsplit_for(S, C, B), C, B);

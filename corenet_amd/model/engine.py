@@ -1115,17 +1115,25 @@ class Plan:
     f1, f2, f3 = blk["f"]
     ba, bb, bc = bn[p + "op_a.bn."], bn[p + "op_b.bn."], bn[p + "op_c.bn."]
     gpre = blk["gpre"]
-    if g_out is not None:
-      if blk["final"]:
-        ft, gf = self.feat[blk["stage"]], self.gfeat[blk["stage"]]
-        be.relu_bwd_add(g_out, ft, gf, B, f3, S, f3 * S, ft.stride(0), gf.stride(0), gpre, f3 * S)
-      else:
-        be.relu_bwd_add(g_out, blk["out"], None, B, f3, S, f3 * S, f3 * S, 0, gpre, f3 * S)
-    # else: gpre already holds d pre (last block of the encoder)
     cc, cb, ca = cv[p + "op_c.conv."], cv[p + "op_b.conv."], cv[p + "op_a.conv."]
+    # d pre = (out > 0 ? g_out : 0) [+ the gradient that arrived through the skip connection]: formed by the backward launch of
+    # op_c's norm itself on the HIP backend (crn_batch_renorm_bwd_head), by a launch of its own otherwise
+    # (g_out None: gpre already holds d pre -- last block of the encoder)
+    fused_head = g_out is not None and hasattr(be, "bn_bwd_head") and eng.fuse_tail
+    if blk["final"]:
+      act, sB_act, g2, sB_g2 = (self.feat[blk["stage"]], self.feat[blk["stage"]].stride(0),
+                                self.gfeat[blk["stage"]], self.gfeat[blk["stage"]].stride(0))
+    else:
+      act, sB_act, g2, sB_g2 = blk["out"], f3 * S, None, 0
     # conv bias gradients = sum(dx) of the following norm, fused into bn_bwd (dsum)
-    be.bn_bwd(blk["yc"], f3 * S, gpre, f3 * S, B, f3, S, False, False, bc.gamma, bc.scale, bc.shift,
-              bc.saved, blk["gyc"], f3 * S, bc.dgamma, bc.dbeta, dsum=cc.dbias, ndsum=cc.n_ref)
+    if fused_head:
+      be.bn_bwd_head(blk["yc"], f3 * S, gpre, f3 * S, g_out, f3 * S, act, sB_act, g2, sB_g2, B, f3, S, bc.gamma, bc.scale,
+                     bc.shift, bc.saved, blk["gyc"], f3 * S, bc.dgamma, bc.dbeta, dsum=cc.dbias, ndsum=cc.n_ref)
+    else:
+      if g_out is not None:
+        be.relu_bwd_add(g_out, act, g2, B, f3, S, f3 * S, sB_act, sB_g2, gpre, f3 * S)
+      be.bn_bwd(blk["yc"], f3 * S, gpre, f3 * S, B, f3, S, False, False, bc.gamma, bc.scale, bc.shift,
+                bc.saved, blk["gyc"], f3 * S, bc.dgamma, bc.dbeta, dsum=cc.dbias, ndsum=cc.n_ref)
     trb = Transform(bb.scale, bb.shift, post_relu=True)
     tra = Transform(ba.scale, ba.shift, post_relu=True)
     self._wgrad(cc, self.vw(blk["yb"]), trb, self.vw(blk["gyc"]))

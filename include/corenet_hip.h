@@ -239,6 +239,18 @@ int crn_batch_renorm_bwd(const float* x, int64_t sB_x, const float* dy, int64_t 
                          float* dsum, int ndsum,
                          double* workspace, size_t workspace_bytes, crnStream s);
 
+/* crn_relu_bwd_add(g, act, g2 -> dy) followed by crn_batch_renorm_bwd(x, dy, pre_relu = post_relu = 0, ...) -- the backward
+ * of a bottleneck's tail and of its last norm -- as ONE call: dy = (act > 0 ? g : 0) + g2 (g2 may be NULL) is formed and
+ * stored by the norm's backward launch where a workgroup owns a channel in registers (B*S <= 16384), by a launch of its
+ * own otherwise.  Same results as the two calls, bit for bit.                                                        */
+int crn_batch_renorm_bwd_head(const float* x, int64_t sB_x, float* dy, int64_t sB_dy,
+                              const float* g, int64_t sB_g, const float* act, int64_t sB_act,
+                              const float* g2 /* may be NULL */, int64_t sB_g2,
+                              int B, int C, int64_t S, const float* gamma, const float* scale, const float* shift,
+                              const float* saved, float* dx, int64_t sB_dx, float* dgamma, float* dbeta,
+                              int accumulate, float* dsum, int ndsum,
+                              double* workspace, size_t workspace_bytes, crnStream s);
+
 /* y = act( x*scale[c]+shift[c] [+ r*rscale[c]+rshift[c]] ) ; optional second
  * output y_pre (before the final ReLU).  Encoder block tails
  * (resnet50.py:72-82,109-115).                                               */
