@@ -476,6 +476,69 @@ def test_batch_renorm(be, B, C, S, pre, post, nbt):
   close(res[1][4], sd["running_var"], 1e-5, "running_var vs oracle")
 
 
+@pytest.mark.parametrize("B,C,S,shortcut,second,nbt", [
+    (4, 256, 4096, "identity", False, 12000),      # encoder stage 2 (16 float4 per thread: the widest register form)
+    (4, 1024, 256, "affine", True, 30000),          # down-sampling block of stage 4, feature map also stored pre-ReLU
+    (2, 130, 36, "identity", True, 0),              # ragged: the last float4 slots of a workgroup are empty
+    (2, 64, 16384, "affine", False, 7000)])         # too large for the register form: the two-launch fallback
+def test_bottleneck_tail_fused_equals_two_launches(be, B, C, S, shortcut, second, nbt):
+  """crn_batch_renorm_stats_tail (statistics of a bottleneck's last norm + norm, shortcut and ReLU in the same launch)
+  and crn_batch_renorm_bwd_head (d pre formed by the backward launch of that norm) against the two-launch sequences they
+  replace -- crn_batch_renorm_stats + crn_affine_add_relu, crn_relu_bwd_add + crn_batch_renorm_bwd -- bit for bit, and the
+  forward against the contract emulator."""
+  g = t.Generator().manual_seed(C + S)
+  dev = DEV
+  x = (t.randn(B, C, S, generator=g) * 1.5 + 0.2).to(dev)
+  r = t.randn(B, C, S, generator=g).to(dev)
+  rsc, rsh = ((t.rand(C, generator=g) + 0.5).to(dev), t.randn(C, generator=g).to(dev)) if shortcut == "affine" else (None, None)
+  gamma, beta = (t.rand(C, generator=g) + 0.5).to(dev), t.randn(C, generator=g).to(dev)
+  rm0, rv0 = t.randn(C, generator=g).to(dev), (t.rand(C, generator=g) * 3 + 0.1).to(dev)
+  nb = t.tensor([nbt], dtype=t.int64, device=dev)
+  outs = []
+  for fused in (False, True):
+    rm, rv = rm0.clone(), rv0.clone()
+    sc, sh, sv = t.zeros(C, device=dev), t.zeros(C, device=dev), t.zeros(4 * C, device=dev)
+    y = t.full((B, C, S), -7.0, device=dev)
+    ypre = t.full((B, C + 3, S), -7.0, device=dev) if second else None       # a wider buffer, like the skip feature maps
+    if fused:
+      be.bn_stats_tail(x, B, C, S, C * S, gamma, beta, rm, rv, nb, 1e-3, 0.01, True, sc, sh, sv, r, rsc, rsh, C * S,
+                       ypre, (C + 3) * S if second else 0, y, C * S, True)
+    else:
+      be.bn_stats(x, B, C, S, C * S, False, gamma, beta, rm, rv, nb, 1e-3, 0.01, True, sc, sh, sv)
+      be.affine_add_relu(x, sc, sh, r, rsc, rsh, B, C, S, C * S, C * S, ypre, (C + 3) * S if second else 0, y, C * S, True)
+    # backward: gradient of y, activation = y (or the pre-ReLU copy), optional second gradient
+    gy = t.randn(B, C, S, generator=t.Generator().manual_seed(5)).to(dev)
+    g2 = t.randn(B, C + 3, S, generator=t.Generator().manual_seed(6)).to(dev) if second else None
+    act, sBa = (ypre, (C + 3) * S) if second else (y, C * S)
+    dpre = t.full((B, C, S), 3.0, device=dev); dx = t.zeros(B, C, S, device=dev)
+    dg, db, ds = t.zeros(C, device=dev), t.zeros(C, device=dev), t.zeros(C, device=dev)
+    if fused:
+      be.bn_bwd_head(x, C * S, dpre, C * S, gy, C * S, act, sBa, g2, (C + 3) * S if second else 0, B, C, S, gamma, sc, sh,
+                     sv, dx, C * S, dg, db, dsum=ds, ndsum=C)
+    else:
+      be.relu_bwd_add(gy, act, g2, B, C, S, C * S, sBa, (C + 3) * S if second else 0, dpre, C * S)
+      be.bn_bwd(x, C * S, dpre, C * S, B, C, S, False, False, gamma, sc, sh, sv, dx, C * S, dg, db, dsum=ds, ndsum=C)
+    t.cuda.synchronize()
+    outs.append([v.clone() for v in (sc, sh, sv, rm, rv, y, dpre, dx, dg, db, ds)] + ([ypre.clone()] if second else []))
+  names = ["scale", "shift", "saved", "rmean", "rvar", "y", "d pre", "dx", "dgamma", "dbeta", "dsum", "y_pre"]
+  for a, b, nm in zip(outs[0], outs[1], names):
+    if nm == "dsum" and B * S > 16384:      # (the two-pass form adds sum(dx) up with atomics: order differs from run to run)
+      assert float((a - b).abs().max()) <= 1e-4 * (float(outs[0][7].abs().sum((0, 2)).max()) + 1e-6)
+      continue
+    assert t.equal(a, b), (nm, float((a - b).abs().max()))
+  if second:
+    assert float(outs[1][-1][:, C:].min()) == -7.0 and float(outs[1][-1][:, C:].max()) == -7.0      # the extra channels
+  # forward against the emulator of the two contracts
+  xc, rc = x.cpu(), r.cpu()
+  sc, sh, sv = t.zeros(C), t.zeros(C), t.zeros(4 * C)
+  EMU.bn_stats(xc, B, C, S, C * S, False, gamma.cpu(), beta.cpu(), rm0.cpu().clone(), rv0.cpu().clone(), nb.cpu(), 1e-3, 0.01,
+               True, sc, sh, sv)
+  want = t.zeros(B, C, S)
+  EMU.affine_add_relu(xc, sc, sh, rc, rsc.cpu() if rsc is not None else None, rsh.cpu() if rsh is not None else None,
+                      B, C, S, C * S, C * S, None, 0, want, C * S, True)
+  close(outs[1][5], want, 2e-5, "tail vs emulator")
+
+
 @pytest.mark.parametrize("m,B,C,dims", [(1, 3, 2, (5, 6, 7)), (2, 2, 14, (4, 5, 6)), (3, 1, 5, (3, 4, 5)), (2, 1, 2, (16, 16, 16))])
 def test_softmax_superres(be, m, B, C, dims):
   g = t.Generator().manual_seed(m * 10 + C)
