@@ -285,8 +285,11 @@ class CoreNet(nn.Module):
         return self._train_step_graph(plan, image, voxel_projection_matrix, voxel_sample_locations, grid, loss, lr,
                                       adam_eps, 1.0 / world_size)
       plan.forward(image.contiguous(), voxel_projection_matrix, voxel_sample_locations, training=True)
-      plan.gt.copy_(grid)
-      eng.be.loss_fwd_bwd(LOSS_KINDS[loss], plan.logits, plan.gt, B, C, 128 ** 3, plan.loss,
+      if grid.dtype == t.int32 and grid.device == plan.gt.device and grid.is_contiguous() and grid.shape == plan.gt.shape:
+        gt = grid                                   # (the loss kernels read it in place: no 33 MB copy per step)
+      else:
+        plan.gt.copy_(grid); gt = plan.gt           # dtype / device conversion
+      eng.be.loss_fwd_bwd(LOSS_KINDS[loss], plan.logits, gt, B, C, 128 ** 3, plan.loss,
                           plan.glogits, 1.0)
       if all_reduce is not None and getattr(all_reduce, "overlap", False):
         all_reduce.pushed.clear()
@@ -294,7 +297,9 @@ class CoreNet(nn.Module):
         plan._probe("grad_exchange_wait", all_reduce.wait)       # what is left of the exchange once backward is done
       elif all_reduce is None and plan.side is not None and plan.trace is None:
         # no exchange: every finished bucket of the grad slab is un-packed AND stepped on the side stream
-        eng.adam_step_graphable(lr, adam_eps, grad_scale=1.0 / world_size, launch=False)
+        # (the step's Adam scalars are written on the stream that runs the bucket updates: one launch off the main chain)
+        with t.cuda.stream(plan.side), _lib.pinned_stream(plan.side):
+          eng.adam_step_graphable(lr, adam_eps, grad_scale=1.0 / world_size, launch=False)
         plan.backward(plan.glogits, grad_hook=eng.adam_bucket_hook())
         eng.weights_dirty = True
         return plan.loss
