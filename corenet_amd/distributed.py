@@ -112,6 +112,14 @@ class GradientSync:
     self._staged = False
     self.probe = False          # bench.py: HIP-event pairs around the wait for every bucket ...
     self.bucket_log = []        # ... one list of (start, end) per step, buckets in push order
+    # per-bucket optimizer step behind the exchange (CoreNet.train_step sets it): called with the bucket's gradient slice
+    # on `opt_stream` once the bucket's all-reduce has finished there, so Adam runs under the rest of backward on every
+    # rank like it does on one GPU, instead of after the last bucket
+    self.after_bucket = None
+    self._opt_stream = None
+    self._opt_done = None
+    self._stepped = False       # optimizer steps are queued on the optimizer stream: wait() joins it
+    self._probe_evs = []
 
   def attach(self, engine):
     """Carry the BatchRenorm buffers of `engine` on the first gradient bucket (see the class docstring)."""
@@ -161,15 +169,62 @@ class GradientSync:
         w.wait()
     self._unstage()
 
+  def opt_stream(self):
+    """The stream of the per-bucket optimizer steps (None on the CPU)."""
+    if self._opt_stream is None and t.cuda.is_available() and self.engine is not None and self.engine.device.type == "cuda":
+      self._opt_stream = t.cuda.Stream(device=self.engine.device)
+      self._opt_done = t.cuda.Event()
+    return self._opt_stream
+
   def push(self, grads: t.Tensor):
     """Bucket hook: start the all-reduce of one finished slice of the slab (ordered after the work already
-    queued on the current stream) and return immediately."""
+    queued on the current stream) and return immediately.  With `after_bucket` set, the bucket's optimizer step is
+    queued behind the all-reduce on the optimizer stream."""
     self.pushed.append(grads.numel())
-    if self._active():
-      self._works.append(self._reduce(self._with_buffers(grads)))
+    if not self._active():
+      if self.after_bucket is not None:
+        self.after_bucket(grads)
+      return
+    w = self._reduce(self._with_buffers(grads))
+    ost = self.opt_stream() if self.after_bucket is not None else None
+    if ost is None:
+      self._works.append(w)
+      if self.after_bucket is not None:       # (no streams: CPU dry run -- reduce, then step, in order)
+        if w is not None:
+          w.wait()
+          self._works.pop()
+        self.after_bucket(grads)
+      return
+    from corenet_amd import _lib
+    cur = t.cuda.current_stream()
+    ev = t.cuda.Event()
+    ev.record(cur)                            # native transport: the all-reduce sits on `cur` itself
+    with t.cuda.stream(ost), _lib.pinned_stream(ost):
+      ost.wait_event(ev)
+      a = b = None
+      if self.probe:
+        a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        a.record(ost)
+      if w is not None:
+        w.wait()                              # the optimizer stream (not the host's current one) waits for the collective
+      if self.probe:
+        b.record(ost)
+        self._probe_evs.append((a, b))
+      self.after_bucket(grads)
+    self._stepped = True
 
   def wait(self):
-    """The current stream waits for every pushed bucket."""
+    """The current stream waits for every pushed bucket (and for the optimizer steps queued behind them)."""
+    if self._stepped:
+      self._opt_done.record(self._opt_stream)
+      t.cuda.current_stream().wait_event(self._opt_done)
+      self._stepped = False
+      if self._probe_evs:
+        self.bucket_log.append(list(self._probe_evs))
+        self._probe_evs = []
+      self._works.clear()
+      self._unstage()
+      return
     evs = []
     for w in self._works:
       if self.probe and t.cuda.is_available():

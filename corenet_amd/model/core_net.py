@@ -293,8 +293,22 @@ class CoreNet(nn.Module):
                           plan.glogits, 1.0)
       if all_reduce is not None and getattr(all_reduce, "overlap", False):
         all_reduce.pushed.clear()
+        step_buckets = (hasattr(all_reduce, "opt_stream") and plan.side is not None and plan.trace is None
+                        and os.environ.get("CRN_BUCKET_ADAM", "1") != "0" and all_reduce.opt_stream() is not None)
+        if step_buckets:
+          # Adam per bucket behind its all-reduce, on the exchange's optimizer stream: the update runs under the rest of
+          # backward on every rank, as it does without an exchange (adam_bucket_hook)
+          ost = all_reduce.opt_stream()
+          ost.wait_stream(t.cuda.current_stream())                # (first step: the moments are allocated on this stream)
+          with t.cuda.stream(ost), _lib.pinned_stream(ost):
+            eng.adam_step_graphable(lr, adam_eps, grad_scale=1.0 / world_size, launch=False)
+          all_reduce.after_bucket = eng.adam_bucket_hook()
         plan.backward(plan.glogits, grad_hook=all_reduce.push)   # buckets are reduced while backward runs
         plan._probe("grad_exchange_wait", all_reduce.wait)       # what is left of the exchange once backward is done
+        if step_buckets:
+          all_reduce.after_bucket = None
+          eng.weights_dirty = True
+          return plan.loss
       elif all_reduce is None and plan.side is not None and plan.trace is None:
         # no exchange: every finished bucket of the grad slab is un-packed AND stepped on the side stream
         # (the step's Adam scalars are written on the stream that runs the bucket updates: one launch off the main chain)
