@@ -1349,6 +1349,10 @@ int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w
   // stage_6.c1 forward its second workgroup per CU (556 vs 455 us).  Ablations of that launch (tools/bf3dbg.sh):
   // 462 us complete, 170 us without the MFMA loop, 438 us without global loads, 420 us without LDS commits --
   // the MFMA + LDS-read phase itself runs at ~60 % of the free-running loop of tools/mfma_bf3_loop.hip.
+  // Round 3, again with the pre-arranged slabs (a commit is two LDS writes per item) on the 4^3 windows of the transposed
+  // convolutions (us, ZS 1 -> 4, B = 4, alone): data gradients stage_6.t1 153 -> 147, stage_5.t1 168 -> 165, 14 classes
+  // 909 -> 841; forwards 154 -> 185, 194 -> 229, 817 -> 996; inside the step ZS = 4 on the data gradients alone: 7.72 vs
+  // 7.62 ms (the 24 KiB of extra LDS meet the weight-gradient kernels of the other stream).  ZS stays 1.
   const int ZS = 1;
   (void)KD;
   const size_t lds = lds_of(NSUB, ZS);
