@@ -5,9 +5,13 @@ for tests.  Replaces the reference's DistributedDataParallel wrapping
 
 The engine keeps every gradient in ONE contiguous fp32 slab, so the gradient
 exchange is a single (optionally chunked) all-reduce of 144.6 MB instead of
-DDP's per-bucket copies; BatchRenorm buffers are broadcast from rank 0 before
-each forward exactly like DDP's broadcast_buffers=True (the r/d clamps read the
-running statistics, batch_renorm.py:46-49)."""
+DDP's per-bucket copies -- cut into seven ranges that are reduced while backward
+still runs (GradientSync.push / wait), each followed by its own Adam launch on an
+optimizer stream.  DDP's broadcast_buffers=True (the r/d clamps read the running
+statistics, batch_renorm.py:46-49) needs no collective of its own: rank 0's
+BatchRenorm buffers ride on the staging tail of the first gradient bucket
+(GradientSync.attach); `broadcast_buffers` below is the explicit form, used once
+at start-up / after loading a checkpoint."""
 from __future__ import annotations
 
 import os
@@ -51,12 +55,23 @@ class NativeComm:
     if world is None:
       world = dist.get_world_size(group) if dist.is_initialized() else 1
     buf = (C.c_char * 128)()
+    err = None
     if rank == 0:
-      L.crn_comm_unique_id(C.cast(buf, C.c_void_p))
+      try:
+        L.crn_comm_unique_id(C.cast(buf, C.c_void_p))
+      except Exception as e:                                     # (librccl missing, no device ...): the other ranks are
+        if world == 1:                                           # waiting in the broadcast below -- tell them instead
+          raise                                                  # of leaving them there
+        err = repr(e)
     if world > 1:
-      box = [bytes(buf)]
-      dist.broadcast_object_list(box, src=0, group=group)       # through the store / the existing process group
-      buf = (C.c_char * 128).from_buffer_copy(box[0])
+      box = [(err, bytes(buf))]
+      # `src` of broadcast_object_list is a GLOBAL rank: rank 0 of a sub-group is not global rank 0
+      src = dist.get_global_rank(group, 0) if group is not None else 0
+      dist.broadcast_object_list(box, src=src, group=group)      # through the store / the existing process group
+      err, raw = box[0]
+      if err is not None:
+        raise RuntimeError(f"NativeComm: rank 0 of the group could not create the RCCL unique id: {err}")
+      buf = (C.c_char * 128).from_buffer_copy(raw)
     comm = C.c_void_p()
     L.crn_comm_init(C.cast(buf, C.c_void_p), rank, world, C.byref(comm))
     self.comm, self.rank, self.world = comm, rank, world
@@ -64,14 +79,26 @@ class NativeComm:
     L.crn_comm_info(self.comm, C.byref(ver), None, None)
     self.version = ver.value
 
-  def all_reduce(self, x: t.Tensor):
+  def all_reduce(self, x: t.Tensor, stream: Optional[int] = None):
     assert x.is_cuda and x.dtype == t.float32 and x.is_contiguous()
-    self._lib.lib().crn_allreduce_f32(self.comm, x.data_ptr(), x.numel(), self._lib.stream())
+    self._lib.lib().crn_allreduce_f32(self.comm, x.data_ptr(), x.numel(),
+                                      self._lib.stream() if stream is None else stream)
 
   def close(self):
     if self.comm is not None:
       self._lib.lib().crn_comm_destroy(self.comm)
       self.comm = None
+
+
+class _StreamWork:
+  """What dist.all_reduce(async_op=True) returns, for a collective this module enqueued on its own communication
+  stream: wait() makes the CURRENT stream wait for it (no host wait)."""
+
+  def __init__(self, done: "t.cuda.Event"):
+    self.done = done
+
+  def wait(self):
+    t.cuda.current_stream().wait_event(self.done)
 
 
 class GradientSync:
@@ -84,8 +111,11 @@ class GradientSync:
   layer order like DDP's buckets, pipeline.py:199) is reduced while the rest of backward still runs, and `wait`
   joins them before Adam.
 
-  Transport: torch.distributed (RCCL on GPUs, gloo in the CPU tests), or -- `native=True` / env CRN_NATIVE_RCCL=1 --
-  the library's own RCCL communicator (NativeComm): the all-reduce is then enqueued on the side stream itself.
+  Transport: torch.distributed (RCCL on GPUs, gloo in the CPU tests; the default until the native one has run on
+  two or more real GPUs), or -- `native=True` / env CRN_NATIVE_RCCL=1 -- the library's own RCCL communicator
+  (NativeComm) on a communication stream of its own: the stream that pushed the bucket (the engine's side stream, which
+  carries the weight gradients) records an event and goes on, later weight-gradient kernels do not queue behind the
+  collective.
 
   BatchRenorm buffers (`attach(engine)`): DDP broadcasts rank 0's buffers before every forward (broadcast_buffers=True,
   pipeline.py:199-200; the r/d clamps read them, batch_renorm.py:46-49) -- a blocking collective in front of a 8 ms
@@ -118,6 +148,7 @@ class GradientSync:
     self.after_bucket = None
     self._opt_stream = None
     self._opt_done = None
+    self._comm_stream = None    # native transport: the collectives' own stream
     self._stepped = False       # optimizer steps are queued on the optimizer stream: wait() joins it
     self._probe_evs = []
 
@@ -140,20 +171,27 @@ class GradientSync:
       return grads
     st = self.engine.store
     np_ = st.grads.numel()
-    if grads.data_ptr() + 4 * grads.numel() != st.grads.data_ptr() + 4 * np_ or self._staged:
+    es = st.gslab.element_size()                         # (float64 on the CPU contract emulator)
+    lo = (grads.data_ptr() - st.gslab.data_ptr()) // es
+    if lo + grads.numel() != np_ or self._staged:        # not the top-of-slab bucket, or staged already this step
       return grads
     if self._rank() == 0:
       st.buf_stage.copy_(st.buffers)
     else:
       st.buf_stage.zero_()
     self._staged = True
-    lo = (grads.data_ptr() - st.gslab.data_ptr()) // 4
     return st.gslab[lo:]
 
   def _reduce(self, x: t.Tensor):
     if self.native is not None:
-      self.native.all_reduce(x)
-      return None
+      if self._comm_stream is None:
+        self._comm_stream = t.cuda.Stream(device=x.device)
+      ready, done = t.cuda.Event(), t.cuda.Event()
+      ready.record()                                     # the bucket is final on the current stream
+      self._comm_stream.wait_event(ready)
+      self.native.all_reduce(x, stream=self._comm_stream.cuda_stream)
+      done.record(self._comm_stream)
+      return _StreamWork(done)
     return dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
   def __call__(self, grads: t.Tensor):
@@ -198,7 +236,7 @@ class GradientSync:
     from corenet_amd import _lib
     cur = t.cuda.current_stream()
     ev = t.cuda.Event()
-    ev.record(cur)                            # native transport: the all-reduce sits on `cur` itself
+    ev.record(cur)
     with t.cuda.stream(ost), _lib.pinned_stream(ost):
       ost.wait_event(ev)
       a = b = None
@@ -251,7 +289,7 @@ class GradientSync:
 
   def describe(self) -> dict:
     """What the N > 1 bench line reports about the exchange."""
-    be = "native RCCL (crn_allreduce_f32 on the side stream)" if self.native is not None else (
+    be = "native RCCL (crn_allreduce_f32 on its own stream)" if self.native is not None else (
         f"torch.distributed/{dist.get_backend(self.group)}" if dist.is_initialized() else "none")
     ver = None
     if self.native is not None:
@@ -265,7 +303,7 @@ class GradientSync:
   def _unstage(self):
     if self._staged:
       st = self.engine.store
-      st.buffers.copy_(st.buf_stage)       # (native transport: ordered by Plan._join_side, which ran before wait)
+      st.buffers.copy_(st.buf_stage)       # (every transport: wait() has joined the collectives on this stream)
       self._staged = False
 
 

@@ -21,7 +21,7 @@ import torch as t
 from torch import nn
 
 from corenet_amd import _lib
-from corenet_amd.model.engine import Engine
+from corenet_amd.model.engine import Engine, IMAGE_HW
 
 
 @dataclasses.dataclass(frozen=True)
@@ -197,10 +197,20 @@ class CoreNet(nn.Module):
                          "construct it with CoreNet(config, device=...) instead of .to()/.half()")
     return self
 
+  def _check_image(self, image: t.Tensor):
+    """Argument checks of resnet50.py:198-199, plus the one this engine adds: its plans hold buffers for
+    IMAGE_HW images only (configs/models/*.json5 all train and evaluate at 256x256).  The reference's encoder is fully
+    convolutional (resnet50.py:176-186); here any other size raises instead of over-running (larger) or silently
+    under-filling (smaller) the plan's buffers."""
+    assert image.dtype == t.uint8 and image.dim() == 4 and image.shape[1] == 3
+    if tuple(image.shape[2:]) != IMAGE_HW:
+      raise ValueError(f"corenet_amd.CoreNet: image batch of {tuple(image.shape[2:])} pixels; this engine is built for "
+                       f"{IMAGE_HW[0]}x{IMAGE_HW[1]} inputs (resize before the call)")
+
   def forward(self, image: t.Tensor, voxel_projection_matrix: t.Tensor,
               voxel_sample_locations: t.Tensor) -> t.Tensor:
     # same argument checks as resnet50.py:198-199 / ray_traced_skip_connection.py:81-89
-    assert image.dtype == t.uint8 and image.dim() == 4 and image.shape[1] == 3
+    self._check_image(image)
     B = image.shape[0]
     assert voxel_projection_matrix.shape == (B, 4, 4)
     assert voxel_sample_locations.shape == (B, 3)
@@ -227,7 +237,7 @@ class CoreNet(nn.Module):
     resolution_multiplier m > 0 (with n == m^3 in the reference's offset order): returns the interleaved
     [B, C, m*D, m*H, m*W] grid directly; 0: returns [n, B, C, D, H, W] like MultiOffsetInferenceFn."""
     assert not self.training, "multi-offset inference is an eval-mode path (running BatchRenorm statistics)"
-    assert image.dtype == t.uint8 and image.dim() == 4 and image.shape[1] == 3
+    self._check_image(image)
     B = image.shape[0]
     assert voxel_projection_matrix.shape == (B, 4, 4)
     assert grid_offsets.dim() == 3 and grid_offsets.shape[1:] == (B, 3)
@@ -275,11 +285,22 @@ class CoreNet(nn.Module):
     step), so launch by launch stays the default while the GPU needs more than the host's 6.5 ms per step."""
     from corenet_amd.model.engine import LOSS_KINDS
     eng = self.engine
+    self._check_image(image)
     B, C = image.shape[0], eng.num_classes
+    if tuple(grid.shape) != (B,) + tuple(eng.resolution):
+      raise ValueError(f"grid of shape {tuple(grid.shape)}, expected {(B,) + tuple(eng.resolution)}")
     with self._on_device():
       plan = eng.plan(B)
       if graph is None:
         graph = os.environ.get("CRN_GRAPH", "0") == "1"
+      if all_reduce is not None and hasattr(all_reduce, "_active") and not all_reduce._active():
+        # an exchange object with nothing to exchange (world_size 1 without `force`): the step WITHOUT an exchange, whose
+        # per-bucket Adam runs on the side stream behind the scalars written there -- not the bucket hooks of the
+        # exchange, whose inactive branch would step on the side stream while the scalars (and, on the first step, the
+        # zeroed moments) are still in flight on the optimizer stream (ADVICE r3)
+        if hasattr(all_reduce, "pushed"):
+          all_reduce.pushed.clear()
+        all_reduce = None
       graphable = (all_reduce is None and eng.device.type == "cuda" and plan.probes is None and plan.trace is None)
       if graph and graphable:
         return self._train_step_graph(plan, image, voxel_projection_matrix, voxel_sample_locations, grid, loss, lr,
@@ -289,7 +310,7 @@ class CoreNet(nn.Module):
         gt = grid                                   # (the loss kernels read it in place: no 33 MB copy per step)
       else:
         plan.gt.copy_(grid); gt = plan.gt           # dtype / device conversion
-      eng.be.loss_fwd_bwd(LOSS_KINDS[loss], plan.logits, gt, B, C, 128 ** 3, plan.loss,
+      eng.be.loss_fwd_bwd(LOSS_KINDS[loss], plan.logits, gt, B, C, plan.logits[0, 0].numel(), plan.loss,
                           plan.glogits, 1.0)
       if all_reduce is not None and getattr(all_reduce, "overlap", False):
         all_reduce.pushed.clear()
@@ -330,8 +351,8 @@ class CoreNet(nn.Module):
     eng = self.engine
     eng.weights_dirty = True                   # the step starts by packing the (just stepped) parameters
     plan.forward(plan.in_image, plan.in_v2s, plan.in_off, training=True)
-    eng.be.loss_fwd_bwd(LOSS_KINDS[loss], plan.logits, plan.gt, plan.B, eng.num_classes, 128 ** 3, plan.loss,
-                        plan.glogits, 1.0)
+    eng.be.loss_fwd_bwd(LOSS_KINDS[loss], plan.logits, plan.gt, plan.B, eng.num_classes, plan.logits[0, 0].numel(),
+                        plan.loss, plan.glogits, 1.0)
     plan.backward(plan.glogits)
     eng.adam_update_from_hyper()
 

@@ -34,6 +34,7 @@ from corenet_amd import views as V
 from corenet_amd.backend import Transform
 from corenet_amd.model import conv_geometry as G
 
+IMAGE_HW = (256, 256)   # the input size the plans' buffers are laid out for (all configs/models/*.json5; CoreNet checks it)
 BN_EPS = 1e-3        # resnet50.py:63, reconstruction_decoder.py:44
 BN_MOMENTUM = 0.01   # batch_renorm.py:19
 
@@ -555,10 +556,10 @@ class Plan:
     self.dev = dev
     f = lambda *shape: t.zeros(*shape, dtype=eng.dtype, device=dev)
     # static inputs of the captured training step (a replayed graph reads fixed addresses)
-    self.in_image = t.zeros(B, 3, 256, 256, dtype=t.uint8, device=dev)
+    self.in_image = t.zeros(B, 3, *IMAGE_HW, dtype=t.uint8, device=dev)
     self.in_v2s = f(B, 4, 4)
     self.in_off = f(B, 3)
-    self.img = f(B, 3, 256, 256)
+    self.img = f(B, 3, *IMAGE_HW)
     self.y1 = f(B, 64, 128, 128)
     self.gy1 = f(B, 64, 128, 128); self.gy1b = f(B, 64, 128, 128)
     self.p1 = f(B, 64, 64, 64)
@@ -807,6 +808,8 @@ class Plan:
   def forward_encoder(self, image_u8: t.Tensor, training: bool):
     """ResNet-50 features + global average (resnet50.py:176-186).  In eval mode the result does not depend
     on the sampling offset, so multi-offset inference (super_resolution.py:123-125) runs it once."""
+    if tuple(image_u8.shape) != tuple(self.in_image.shape):       # (backend.preprocess writes B*3*H*W floats into self.img)
+      raise ValueError(f"plan for images {tuple(self.in_image.shape)}, got {tuple(image_u8.shape)}")
     eng, be, B = self.eng, self.be, self.B
     self.generation += 1
     # (_dgrad_pack_pending / _gpacked_zeroed stay set until a backward consumes them: a second forward before

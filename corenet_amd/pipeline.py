@@ -51,9 +51,12 @@ def process_batch(model, batch: List[dataset_lib.DatasetElement], task_type: str
   """One training step from dataset elements (TrainPipeline._process_batch, pipeline.py:215-242): batch ->
   ground-truth grid -> `v2s = camera @ inverse(v2x)` -> forward, loss, backward, gradient exchange, Adam
   (`CoreNet.train_step`).  Returns the loss as a device tensor (the reference syncs on it every step)."""
-  if world_size > 1:
+  if world_size > 1 and getattr(all_reduce, "engine", None) is not model.engine:
     # DistributedDataParallel(broadcast_buffers=True) semantics (pipeline.py:199): every forward starts from rank
-    # 0's BatchRenorm running statistics, which feed the r / d clamps (batch_renorm.py:46-49)
+    # 0's BatchRenorm running statistics, which feed the r / d clamps (batch_renorm.py:46-49).  An exchange that was
+    # attached to this model (`GradientSync(world).attach(model.engine)`) delivers exactly that on the first gradient
+    # bucket of the previous step, without a collective of its own: the blocking broadcast in front of the step is only
+    # for exchange objects that do not
     dist_util.broadcast_buffers(model.engine.store)
   ex = batched_example.batch(batch, device=model.engine.device)
   ex = voxelize_batch(ex, task_type, **voxelization)

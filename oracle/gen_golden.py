@@ -436,6 +436,9 @@ if __name__ == "__main__":
   if "--only-nbt30k" in sys.argv:
     gen_model("h7_train_b2_nbt30k", 2, 30000, 2, "iou_fgbg", store_all_grads=True)
     sys.exit(0)
+  if "--only-b4-nbt30k" in sys.argv:
+    gen_model("h7_train_b4_nbt30k", 2, 30000, 4, "iou_fgbg", store_all_grads=True)
+    sys.exit(0)
   if "--only-super-resolution" in sys.argv:
     gen_super_resolution()
     sys.exit(0)
@@ -452,6 +455,7 @@ if __name__ == "__main__":
   gen_metrics()
   gen_model("h7_train_b1", 2, 0, 1, "iou_fgbg")
   gen_model("h7_train_b2_nbt30k", 2, 30000, 2, "iou_fgbg", store_all_grads=True)
+  gen_model("h7_train_b4_nbt30k", 2, 30000, 4, "iou_fgbg", store_all_grads=True)
   gen_model("h7_eval_b1", 2, 100, 1, "iou_fgbg", training=False)
   gen_model("m9_train_b1", 14, 0, 1, "xent_times_iou_agnostic")
   gen_super_resolution()

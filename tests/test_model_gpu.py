@@ -20,6 +20,9 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
+MATHS = ["bf16x3", "fp32"]        # the product default (what bench.py measures and decode_state builds) and the fp32 engine
+
+
 def _model(nc, sd, decoder_math="fp32"):
   from corenet_amd.model.core_net import CoreNet, CoreNetConfig, DecoderConfig
   m = CoreNet(CoreNetConfig(DecoderConfig((128, 128, 128), nc, 2, 64, 0.75)), device="cuda", decoder_math=decoder_math)
@@ -104,6 +107,37 @@ def test_bf16x3_mode_against_goldens_and_fp32_mode():
   assert e < 1e-3 and abs(la - lb) < 1e-4 * abs(lb)
 
 
+@pytest.mark.parametrize("math", MATHS)
+@pytest.mark.parametrize("hw", [(224, 224), (512, 512), (256, 320)])
+def test_image_size_is_validated(math, hw):
+  """The plans hold buffers for 256x256 images (engine.IMAGE_HW): any other size raises ValueError on every entry point
+  BEFORE a kernel runs (a 512x512 batch would over-run the preprocess buffer, a 224x224 one would leave the rest of it
+  stale), and the model keeps working afterwards -- the logits of the next valid batch equal those of a fresh model."""
+  from corenet_amd import super_resolution as SR
+  sd = O.make_state(0, 2, nbt=100)
+  m, mref = _model(2, sd, math), _model(2, sd, math)
+  image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(2, 0, 2)]
+  bad = t.randint(0, 256, (2, 3) + hw, dtype=t.uint8, device="cuda")
+  guard = t.full((1 << 20,), 7.0, device="cuda")                   # (allocated right after the model's buffers)
+  for mode in ("train", "eval"):
+    getattr(m, mode)()
+    with pytest.raises(ValueError, match="256x256"):
+      m(bad, v2s, off)
+  with pytest.raises(ValueError, match="256x256"):
+    m.train().train_step(bad, v2s, off, grid.to(t.int32))
+  with pytest.raises(ValueError, match="256x256"):
+    m.eval().multi_offset_pmf(bad, v2s, off[None])
+  with pytest.raises(ValueError, match="grid"):
+    m.train().train_step(image, v2s, off, grid[:, :64].to(t.int32))
+  with pytest.raises(ValueError):
+    m.engine.plan(2).forward_encoder(bad, training=False)          # the plan itself refuses, not only the module
+  t.cuda.synchronize()
+  assert bool((guard == 7.0).all())
+  m.eval(); mref.eval()
+  with t.no_grad():
+    assert relerr(m(image, v2s, off), mref(image, v2s, off)) < 1e-5
+
+
 def test_forward_eval_b4_matches_oracle():
   """The bench batch size (B=4/GPU, h7.json5:42) end to end: eval-mode logits of the HIP path against the oracle on
   the same four images, 1e-4 relative (eval mode is conditioned at 2e-6), every voxel compared."""
@@ -139,54 +173,61 @@ def test_bf16x3_eval_b4_matches_oracle(nc):
   assert errs["bf16x3"] < 1e-4 and errs["fp32"] < 1e-4, errs
 
 
-GRAD_NOISE_FACTOR, GRAD_ERR_FLOOR, GRAD_OUTLIER_CAP = 8.0, 2e-3, 0.5      # see the docstring below; measured values are printed
+GRAD_NOISE_FACTOR, GRAD_ERR_FLOOR, GRAD_BAR_CAP, GRAD_OUTLIER_CAP = 8.0, 2e-3, 0.1, 0.5   # see the docstring below
 
 
 @pytest.mark.parametrize("math", ["fp32", "bf16x3"])
-def test_all_parameter_gradients_against_fp64_truth(math):
-  """EVERY parameter gradient, element by element, on the h7 B=2 fixture with num_batches_tracked = 30000 (r/d clamps
-  live, statistics over two samples).  The logits of this fixture are well conditioned (the reference moves by 2e-6
-  between fp32 and fp64) but its gradients are not: the reference's OWN fp32 gradients sit up to 1e-1 of a tensor's
-  scale away from the same arithmetic in fp64 (encoder stage 5; oracle/gen_golden.py measures it per tensor and stores
-  it as gnoise).  So the bar is conditioning-aware and against the truth, not against another fp32 run: the fixture
-  holds a fixed strided subsample (<= 512 elements) of each of the 266 gradient tensors in fp64 arithmetic, and the HIP
-  path must be as close to it as the reference's fp32 run is -- within 8x the reference's own error for that tensor, or
-  2e-3 of the tensor's scale where the reference is more exact than that (scale = max(the tensor's own max, 1e-3 of
-  the model's largest gradient): conv biases in front of a train-mode norm have a true gradient of 0).
-  One more thing is inherent: a post-ReLU activation that lands within rounding of 0 has its mask decided by the rounding
-  order (this library applies the norm as x*scale+shift, the reference as ((x-mean)/std*r+d)*gamma+beta), and a flipped
-  mask moves ONE element of a per-channel gradient by one term of its sum (measured: channel 95 of
-  encoder.stage3.c.op_b.bn.bias, 24 % of that element, identical in both math modes; every other element of the tensor
-  within 1.3e-3).  The bar therefore applies to all but the worst 1 % of a tensor's stored elements (at most 4 of 512),
-  and those must still be within half the tensor's scale."""
+@pytest.mark.parametrize("fixture,B", [("h7_train_b2_nbt30k", 2), ("h7_train_b4_nbt30k", 4)])
+def test_all_parameter_gradients_against_fp64_truth(math, fixture, B):
+  """EVERY parameter gradient, element by element, on the h7 B=2 and B=4 (the bench batch) fixtures with
+  num_batches_tracked = 30000 (r/d clamps live).  The logits of these fixtures are well conditioned (the reference
+  moves by 2e-6 between fp32 and fp64); the fixtures hold a fixed strided subsample (<= 512 elements) of each of the
+  266 gradient tensors from the reference's fp32 run (gsub) AND from the same arithmetic in fp64 (g64sub, the truth;
+  oracle/gen_golden.py).  The HIP path must be as close to the truth as the reference's own fp32 run is:
+
+    error(tensor) = the (1 - 1/128) quantile of |got - truth| / scale over the stored elements,
+    bar(tensor)   = min(max(8 x the SAME quantile of the reference's own fp32 error, 2e-3), 0.1),
+
+  scale = max(the tensor's own max, 1e-3 of the model's largest gradient) (conv biases in front of a train-mode norm
+  have a true gradient of 0).  The quantile on BOTH sides, because one thing is inherent: a post-ReLU activation within
+  rounding of 0 has its mask decided by the rounding order (this library applies the norm as x*scale+shift, the
+  reference as ((x-mean)/std*r+d)*gamma+beta), and a flipped mask moves ONE element of a gradient by one term of its
+  sum.  The reference's fp32 run has such elements too (up to 1e-1 of a tensor's scale, `gnoise` in the fixture); with
+  them inside the bar, as in round 3, the bar of the deepest encoder tensors was 0.78 of their scale -- vacuous.  Now
+  no bar exceeds 0.1, at most 1/128 of a tensor's stored elements (4 of 512; one element of a tensor with fewer than 128) may lie above it, they must still be
+  within half the scale, and the last layer (whose gradient sees no ReLU mask) gets no such allowance at all."""
   from corenet_amd.model import losses
-  z = np.load(os.path.join(G, "model_h7_train_b2_nbt30k.npz"))
+  z = np.load(os.path.join(G, f"model_{fixture}.npz"))
   m = _model(2, O.make_state(0, 2, nbt=30000), math).train()
-  image, v2s, off, grid = O.synthetic_batch(2, 0, 2)
+  image, v2s, off, grid = O.synthetic_batch(B, 0, 2)
   loss = losses.iou_fgbg(grid.cuda(), m(image.cuda(), v2s.cuda(), off.cuda()))
   loss.backward()
   gmax = max(float(z[k]) for k in z.files if k.startswith("gmax::"))
-  rows, outliers = [], []
+  rows, outliers, bars = [], [], []
   for name, p in m.named_parameters():
     want = t.as_tensor(z["g64sub::" + name]).double()
+    ref32 = t.as_tensor(z["gsub::" + name]).double()
     g = p.grad.reshape(-1)
     got = g[::max(1, -(-g.numel() // 512))].double().cpu()
     assert got.shape == want.shape, name
     scale = max(float(z["gmax::" + name]), 1e-3 * gmax)
     e = ((got - want).abs() / scale).sort().values
-    k = e.numel() // 128                                     # 1 % of the stored elements may be mask flips
-    err, worst = float(e[-(k + 1)]), float(e[-1])
-    bar = max(GRAD_NOISE_FACTOR * float(z["gnoise::" + name]), GRAD_ERR_FLOOR)
-    rows.append((err / bar, err, float(z["gnoise::" + name]), name))
+    eref = ((ref32 - want).abs() / scale).sort().values
+    k = 0 if name.startswith("decoder.stage_6.t1.") else max(1, e.numel() // 128)    # elements that may be mask flips
+    err, worst, noise = float(e[-(k + 1)]), float(e[-1]), float(eref[-(k + 1)])
+    bar = min(max(GRAD_NOISE_FACTOR * noise, GRAD_ERR_FLOOR), GRAD_BAR_CAP)
+    assert int((e > bar).sum()) <= k, (name, int((e > bar).sum()), k)
+    rows.append((err / bar, err, noise, name)); bars.append(bar)
     outliers.append((worst, name))
   rows.sort(reverse=True); outliers.sort(reverse=True)
   errs = sorted(e for _, e, _, _ in rows)
-  print(f"[{math}] {len(rows)} parameter gradients vs fp64 truth: median error {errs[len(errs) // 2]:.1e}, 90th percentile "
-        f"{errs[len(errs) * 9 // 10]:.1e}, max {errs[-1]:.1e} of the tensor's scale; closest to their bars (error / the "
-        f"reference's own fp32 error): " + ", ".join(f"{n} {e:.1e}/{ns:.1e}" for _, e, ns, n in rows[:5]) +
+  print(f"[{math} B={B}] {len(rows)} parameter gradients vs fp64 truth: median error {errs[len(errs) // 2]:.1e}, 90th "
+        f"percentile {errs[len(errs) * 9 // 10]:.1e}, max {errs[-1]:.1e} of the tensor's scale; bars: median "
+        f"{sorted(bars)[len(bars) // 2]:.1e}, max {max(bars):.1e}; closest to their bars (error / the reference's own fp32 "
+        f"error at the same quantile): " + ", ".join(f"{n} {e:.1e}/{ns:.1e}" for _, e, ns, n in rows[:5]) +
         f"; largest single-element deviations: " + ", ".join(f"{n} {w:.1e}" for w, n in outliers[:3]))
   assert len(rows) == 266 and rows[0][0] <= 1.0, rows[:5]
-  assert outliers[0][0] <= GRAD_OUTLIER_CAP, outliers[:3]
+  assert max(bars) <= GRAD_BAR_CAP and outliers[0][0] <= GRAD_OUTLIER_CAP, outliers[:3]
 
 
 # element-wise bars of the five full gradients the fixtures store (oracle/gen_golden.py:87-90), by depth of the
@@ -244,11 +285,12 @@ def test_train_forward_backward_golden(tag, nc, nbt, B, lossname):
   assert int(sdn["decoder.stage_1.b1.num_batches_tracked"]) == nbt + 1
 
 
-def test_backward_matches_oracle_cosine():
+@pytest.mark.parametrize("math", MATHS)
+def test_backward_matches_oracle_cosine(math):
   """Direction of every parameter gradient vs the oracle's autograd (B=1, h7)."""
   from corenet_amd.model import losses
   sd = O.make_state(0, 2, nbt=0)
-  m = _model(2, sd).train()
+  m = _model(2, sd, math).train()
   image, v2s, off, grid = O.synthetic_batch(1, 0, 2)
   loss = losses.iou_fgbg(grid.cuda(), m(image.cuda(), v2s.cuda(), off.cuda()))
   loss.backward()
@@ -270,12 +312,13 @@ def test_backward_matches_oracle_cosine():
   print("worst gradient cosine vs oracle:", worst)
 
 
-def test_training_trajectory_matches_oracle():
+@pytest.mark.parametrize("math", MATHS)
+def test_training_trajectory_matches_oracle(math):
   """Six consecutive training steps (forward, iou_fgbg, backward, Adam, BatchRenorm running statistics) of the
   HIP path next to the oracle driven by torch.optim.Adam, same init and sample: the loss curves stay together
   (measured 3e-3 relative at worst over 8 steps at B=1; small batches amplify rounding)."""
   sd = O.make_state(0, 2, nbt=0)
-  m = _model(2, sd).train()
+  m = _model(2, sd, math).train()
   image, v2s, off, grid = O.synthetic_batch(1, 0, 2)
   so = {k: v.clone() for k, v in sd.items()}
   params = []
@@ -295,13 +338,14 @@ def test_training_trajectory_matches_oracle():
   assert relerr(m.state_dict()["decoder.stage_6.b1.running_mean"], so["decoder.stage_6.b1.running_mean"].detach()) < 2e-2
 
 
-def test_mean_iou_parity_on_trained_weights():
+@pytest.mark.parametrize("math", MATHS)
+def test_mean_iou_parity_on_trained_weights(math):
   """Mean-IoU parity (BASELINE metric) on weights that were actually trained: 80 HIP training steps on a fixed
   synthetic batch, then the eval-mode forward of the HIP path and of the oracle on those weights -- logits within the
   north_star tolerance, confusion matrices (fused argmax + histogram vs the oracle's) and mean IoU equal."""
   from corenet_amd import voxel_metrics as VM
   sd = O.make_state(0, 2, nbt=0)
-  m = _model(2, sd).train()
+  m = _model(2, sd, math).train()
   image, v2s, off, grid = O.synthetic_batch(2, 0, 2)
   gi, gg = [x.cuda() for x in (image, v2s, off)], grid.cuda().to(t.int32)
   for _ in range(80):
@@ -398,6 +442,37 @@ def test_native_rccl_from_the_library_single_rank():
   sync.native.close()
 
 
+def test_inactive_gradient_sync_is_the_step_without_an_exchange():
+  """An ATTACHED exchange object with nothing to exchange (world_size 1, no `force`: what a single-GPU run of a
+  multi-GPU script constructs) must drive exactly the step without an exchange.  Round 3 sent it down the bucket-hook
+  path, whose inactive branch ran the per-bucket Adam on the side stream while the step's Adam scalars (and, on the
+  first step, the zero-fill of the moments) were still in flight on the optimizer stream.  Deterministic
+  mode, three steps from the same state: parameters, moments and buffers bit-identical to all_reduce=None."""
+  from corenet_amd import distributed as D
+  from corenet_amd.backend import default_backend
+  be = default_backend()
+  sd = O.make_state(0, 2, nbt=0)
+  image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(2, 0, 2)]
+  gi = grid.to(t.int32)
+  try:
+    be.set_deterministic(True)
+    outs = []
+    for use_sync in (False, True):
+      m = _model(2, sd, "bf16x3").train()
+      sync = D.GradientSync(1).attach(m.engine) if use_sync else None
+      assert sync is None or not sync._active()
+      ls = [float(m.train_step(image, v2s, off, gi, "iou_fgbg", lr=4e-4, adam_eps=1e-4, all_reduce=sync)) for _ in range(3)]
+      t.cuda.synchronize()
+      e = m.engine
+      outs.append((ls, [x.clone() for x in (e.store.params, e.store.buffers, e.adam_m, e.adam_v)]))
+      assert e.adam_t == 3
+  finally:
+    be.set_deterministic(False)
+  assert outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])
+  for name, a, b in zip(("params", "buffers", "adam_m", "adam_v"), outs[0][1], outs[1][1]):
+    assert t.equal(a, b), (name, float((a - b).abs().max()))
+
+
 def _sync_state(dst, src):
   """dst becomes an exact replica of src (parameters, buffers, step counters, Adam moments)."""
   de, se = dst.engine, src.engine
@@ -420,7 +495,8 @@ def _slab_err(ma, m):
   return worst
 
 
-def test_train_step_reduces_loss_and_matches_autograd_path():
+@pytest.mark.parametrize("math", MATHS)
+def test_train_step_reduces_loss_and_matches_autograd_path(math):
   """The reference's loop body (pipeline.py:224-230: optimizer.zero_grad(); loss = f(model(...)); loss.backward();
   optimizer.step()) through the drop-in's autograd node + FusedAdam against the fused `train_step`, THREE steps:
   same losses, same parameters, same Adam moments (a `.grad` that aliases the engine's gradient slab doubles every
@@ -429,7 +505,7 @@ def test_train_step_reduces_loss_and_matches_autograd_path():
   from corenet_amd import state as S
   from corenet_amd.model import losses
   sd = O.make_state(0, 2, nbt=0)
-  m, ma = _model(2, sd).train(), _model(2, sd).train()
+  m, ma = _model(2, sd, math).train(), _model(2, sd, math).train()
   image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(2, 0, 2)]
   opt = S.FusedAdam(ma, lr=4e-4, eps=1e-4)
   ls = []
@@ -473,13 +549,14 @@ def test_train_step_reduces_loss_and_matches_autograd_path():
     l1.backward()
 
 
-def test_train_step_hip_graph_replay_matches_launch_by_launch():
+@pytest.mark.parametrize("math", MATHS)
+def test_train_step_hip_graph_replay_matches_launch_by_launch(math):
   """CoreNet.train_step(graph=True): the fused step captured into a HIP graph (inputs in plan-owned buffers, Adam's
   scalars in device memory) and replayed.  From identical states, every replayed step must equal the launch-by-launch
   step: loss, gradient slab (up to the atomics' summation order), Adam moments, step counters -- including a change of
   inputs and of the learning rate between replays."""
   sd = O.make_state(0, 2, nbt=0)
-  m, mg = _model(2, sd).train(), _model(2, sd).train()
+  m, mg = _model(2, sd, math).train(), _model(2, sd, math).train()
   batches = [[x.cuda() for x in O.synthetic_batch(2, s, 2)] for s in (0, 1)]
   for step in range(5):
     image, v2s, off, grid = batches[step % 2]
@@ -561,7 +638,8 @@ def test_checkpoint_interop_on_gpu():
   assert abs(la - lb) < 1e-4 * abs(la) and _slab_err(m2, m) < 1e-2
 
 
-def test_wrapped_in_distributed_data_parallel():
+@pytest.mark.parametrize("math", MATHS)
+def test_wrapped_in_distributed_data_parallel(math):
   """pipeline.py:199-200,224-230 unmodified: `DistributedDataParallel(model, device_ids=[dev])`, then
   `loss = f(ddp(...))`, `loss.backward()`, `optimizer.step()` -- world 1 over RCCL.  DDP broadcasts parameters and
   buffers from rank 0 (in place: they stay views of the engine's slabs), hooks every parameter's gradient
@@ -571,10 +649,10 @@ def test_wrapped_in_distributed_data_parallel():
   from torch.nn.parallel import DistributedDataParallel
   from corenet_amd import state as S
   from corenet_amd.model import losses
-  dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29850 + os.getpid() % 100}", rank=0, world_size=1)
+  dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29850 + os.getpid() % 100 + 1000 * MATHS.index(math)}", rank=0, world_size=1)
   try:
     sd = O.make_state(0, 2, nbt=0)
-    m, ma = _model(2, sd).train(), _model(2, sd).train()
+    m, ma = _model(2, sd, math).train(), _model(2, sd, math).train()
     image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(2, 0, 2)]
     ddp = DistributedDataParallel(ma, device_ids=[t.cuda.current_device()])
     assert ma.get_parameter("decoder.stage_6.t1.weight").data_ptr() == \
@@ -599,17 +677,18 @@ def test_wrapped_in_distributed_data_parallel():
     dist.destroy_process_group()
 
 
-def test_overlapped_gradient_exchange_single_rank_rccl():
+@pytest.mark.parametrize("math", MATHS)
+def test_overlapped_gradient_exchange_single_rank_rccl(math):
   """The bucketed backward + RCCL all-reduce on its own stream (distributed.GradientSync.push/wait,
   engine.GRAD_BUCKET_LABELS) against the plain one-slab backward: with one rank the all-reduce is the
   identity, so gradients and parameters must agree up to the atomics' summation order."""
   import torch.distributed as dist
   from corenet_amd import distributed as D
-  dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29650 + os.getpid() % 200}", rank=0, world_size=1)
+  dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29650 + os.getpid() % 200 + 1000 * MATHS.index(math)}", rank=0, world_size=1)
   try:
     sd = O.make_state(0, 2, nbt=0)
     image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(2, 0, 2)]
-    ma, mb = _model(2, sd).train(), _model(2, sd).train()
+    ma, mb = _model(2, sd, math).train(), _model(2, sd, math).train()
     sync = D.GradientSync(1, force=True)
     assert sync.overlap
     for i in range(3):
@@ -631,7 +710,8 @@ def test_overlapped_gradient_exchange_single_rank_rccl():
     dist.destroy_process_group()
 
 
-def test_pipeline_process_batch_from_dataset():
+@pytest.mark.parametrize("math", MATHS)
+def test_pipeline_process_batch_from_dataset(math):
   """dataset elements -> batch (GPU) -> ground-truth voxelization -> v2s -> train step (pipeline.process_batch,
   reference TrainPipeline._process_batch pipeline.py:215-242): runs end to end on the fixture dataset (images
   replaced by 256x256 ones through the dataset's data_transforms hook), the loss is finite and equals the loss of
@@ -648,7 +728,7 @@ def test_pipeline_process_batch_from_dataset():
   sd = O.make_state(0, 4, nbt=0)
   for task, nc in (("semantic", 4), ("fg_bg", 2)):
     sd = O.make_state(0, nc, nbt=0)
-    ma, mb = _model(nc, sd).train(), _model(nc, sd).train()
+    ma, mb = _model(nc, sd, math).train(), _model(nc, sd, math).train()
     la = pipeline.process_batch(ma, els, task)
     ex = pipeline.voxelize_batch(B.batch(els), task)
     assert ex.grid.shape == (2, 128, 128, 128) and int(ex.grid.max()) == (3 if task == "semantic" else 1)
@@ -660,14 +740,15 @@ def test_pipeline_process_batch_from_dataset():
     assert pmf.shape == (2, nc, 128, 128, 128) and t.equal(ex2.grid, ex.grid)
 
 
-def test_super_resolution_x2_golden_and_encoder_reuse():
+@pytest.mark.parametrize("math", MATHS)
+def test_super_resolution_x2_golden_and_encoder_reuse(math):
   """N1: x2 super-resolution through the drop-in of corenet.super_resolution.
   (i) golden pmf generated by the reference's SuperResolutionInference (oracle/gen_golden.py);
   (ii) sub-grid (iz,iy,ix) of the result == softmax of an ordinary eval forward at that offset:
        running the encoder once instead of 8 times changes nothing beyond run-to-run rounding."""
   from corenet_amd import super_resolution as SR
   z = np.load(os.path.join(G, "super_resolution_h7_x2.npz"))
-  m = _model(2, O.make_state(0, 2, nbt=100, logit_scale=2e-4)).eval()
+  m = _model(2, O.make_state(0, 2, nbt=100, logit_scale=2e-4), math).eval()
   image, v2s, off, _ = O.synthetic_batch(1, 0, 2)
   camera = O.canonical_camera()[None].cuda()
   v2v = O.scale([128.0] * 3)[None].cuda()
