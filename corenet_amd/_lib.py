@@ -52,6 +52,9 @@ _SIGS = {
                          C.POINTER(CrnView), i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "crn_conv_fwd_bf3_slabs": [C.POINTER(CrnView), C.POINTER(CrnInTransform), vp, i32, vp, i32,
                                C.POINTER(CrnView), i32, i32, i32, i32, i32, i32, i32, vp, vp],
+    "crn_bf3_act_image": [C.POINTER(CrnView), C.POINTER(CrnInTransform), vp, vp],
+    "crn_conv_fwd_bf3_ring": [vp, i32, i32, i32, i32, i32, vp, i32, vp, i32, C.POINTER(CrnView), i32, i32, i32, i32, i32, i32,
+                              i32, vp, vp],
     "crn_conv_wgrad_bf3": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32,
                            i32, i32, i32, i32, i32, i32, i32, vp],
     "crn_conv_wgrad": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32,
@@ -119,6 +122,8 @@ _SIZE_FNS = {
     "crn_batch_renorm_workspace_bytes": [i32],
     "crn_loss_workspace_bytes": [i32, i32],
     "crn_fill_voxels_workspace_bytes": [i32, i32, i32, i32],
+    "crn_bf3_act_image_bytes": [i32, i32, i32, i32, i32],
+    "crn_bf3_ring_covers": [i32, i32, i32, i32, i32, i32, i32, i32],
 }
 _PTR_FNS = {
     "crn_loss_status_ptr": [vp, i32],

@@ -108,6 +108,26 @@ class HipBackend:
                           pad_lo[0], pad_lo[1], pad_lo[2], splits, int(accumulate), _ctapboxes(boxes),
                           _lib.stream())
 
+  # -- ring-buffered, DMA-fed form of the bf16x3 engine (csrc/conv_bf3_ring.hip) ---------------------------------
+  def bf3_image_bytes(self, B, Cn, D, H, W) -> int:
+    return int(self.lib.crn_bf3_act_image_bytes(B, Cn, D, H, W))
+
+  def bf3_ring_covers(self, cin: int, npad: int, ydims, window) -> bool:
+    return bool(self.lib.crn_bf3_ring_covers(cin, npad, ydims[0], ydims[1], ydims[2], window[0], window[1], window[2]))
+
+  def bf3_act_image(self, x: View, tr: Optional[Transform], image: t.Tensor):
+    """T(x) split into bf16 hi / lo terms in the conv kernels' patch format (crn_bf3_act_image)."""
+    assert image.numel() * image.element_size() >= self.bf3_image_bytes(x.B, x.C, x.D, x.H, x.W)
+    self.lib.crn_bf3_act_image(C.byref(_cview(x)), _ctr(tr), ptr(image), _lib.stream())
+
+  def conv_fwd_ring(self, image: t.Tensor, xdims, wslab: t.Tensor, npad: int, bias: Optional[t.Tensor], bias_sB: int,
+                    y: View, window, pad_lo, accumulate: bool = False, boxes=None):
+    """crn_conv_fwd_bf3_slabs on the view the image was made from; xdims = (B, C, D, H, W) of that view."""
+    B, Cn, D, H, W = xdims
+    self.lib.crn_conv_fwd_bf3_ring(ptr(image), B, Cn, D, H, W, ptr(wslab), npad, ptr(bias), bias_sB, C.byref(_cview(y)),
+                                   window[0], window[1], window[2], pad_lo[0], pad_lo[1], pad_lo[2], int(accumulate),
+                                   _ctapboxes(boxes), _lib.stream())
+
   def splitk_defer(self, on: bool = True):
     """The next conv call may leave its split-K sum to the BatchRenorm launch that follows (crn_splitk_defer)."""
     self.lib.crn_splitk_defer(int(on))

@@ -94,6 +94,24 @@ int crn_conv_fwd_bf3_slabs(const crnView* x, const crnInTransform* tr, const voi
                            int kd, int kh, int kw, int pd, int ph, int pw,
                            int accumulate, const crnTapBoxes* boxes /* may be NULL */, crnStream stream);
 
+/* Ring-buffered, DMA-fed form of crn_conv_fwd_bf3_slabs (csrc/conv_bf3_ring.hip) for the Conv3d k5 / ConvTranspose3d k7
+ * layers of decoder stages 4-6 (reconstruction_decoder.py:72-95), forward pass and data gradient.  The input arrives as
+ * an ACTIVATION IMAGE written by crn_bf3_act_image: T(x) (the fused BatchRenorm + ReLU transform of crn_conv_fwd) of
+ * the logical view x, split into bf16 hi and lo terms and laid out as the conv kernels' LDS patch format --
+ * [B][ceil(C/8)][D][H][W] entries of 8 channels x bf16 (16 bytes; zeros past C), the hi image followed by the lo image,
+ * crn_bf3_act_image_bytes(B, C, D, H, W) bytes in all.  One image serves the forward convolution and the weight
+ * gradient of a layer.  crn_conv_fwd_bf3_ring computes exactly what crn_conv_fwd_bf3_slabs(x, tr, ...) computes on the
+ * view the image was made from (same products, same summation order: bit-identical), with persistent workgroups that
+ * stage patch planes and weight slabs by LDS-DMA ahead of the MFMA waves.  Covers cubic 5^3 / 4^3 windows, output W a
+ * multiple of 16, H >= 8, D >= 4 (crn_bf3_ring_covers returns 1); CRN_EINVAL otherwise.                                */
+size_t crn_bf3_act_image_bytes(int B, int C, int D, int H, int W);
+int crn_bf3_act_image(const crnView* x, const crnInTransform* tr /* may be NULL */, void* image, crnStream stream);
+size_t crn_bf3_ring_covers(int C, int Npad, int yD, int yH, int yW, int kd, int kh, int kw);
+int crn_conv_fwd_bf3_ring(const void* image, int B, int C, int D, int H, int W, const void* wslab, int Npad,
+                          const float* bias, int bias_sB, const crnView* y,
+                          int kd, int kh, int kw, int pd, int ph, int pw,
+                          int accumulate, const crnTapBoxes* boxes /* may be NULL */, crnStream stream);
+
 /* A convolution that splits its reduction writes partial sums to the library's scratch and adds them up in a
  * second launch.  crn_splitk_defer(1) arms, for the NEXT convolution call of this host thread (crn_conv2d_bf3, or
  * the 1x1 path of crn_conv_fwd), the following shortcut: if that call splits and does not accumulate, the sum is

@@ -297,6 +297,41 @@ def test_conv_bf16x3_fwd_dgrad(be, name, kind, wshape, pad, dims, B):
   be.conv_fwd(V.view_of(xg), trg, None, fwd.npad, bpack.to(DEV), 0, yview(yg2), fwd.window, fwd.pad_lo, 0,
               boxes=(fwd.n_boxes, fwd.c_boxes), math="bf16x3", wslab=slabs_g[:nsf * 32])
   assert t.equal(yg2, yg), (name, "fwd slabs")
+  # the ring-buffered, DMA-fed form (crn_bf3_act_image + crn_conv_fwd_bf3_ring): the activation image equals the
+  # split the staging of the kernels above performs, bit for bit, and the convolution on it equals theirs
+  def ring(xv, trv, geo, slab, outv, accumulate=False):
+    dims_in = (xv.B, xv.C, xv.D, xv.H, xv.W)
+    if not be.bf3_ring_covers(xv.C, geo.npad, (outv.D, outv.H, outv.W), geo.window):
+      return False
+    img = t.full((be.bf3_image_bytes(*dims_in),), 0x5a, dtype=t.uint8, device=DEV)
+    be.bf3_act_image(xv, trv, img)
+    be.conv_fwd_ring(img, dims_in, slab, geo.npad, bpack.to(DEV) if outv is not None and trv is not None else None, 0, outv,
+                     geo.window, geo.pad_lo, accumulate=accumulate, boxes=(geo.n_boxes, geo.c_boxes))
+    return img
+  yg3 = t.zeros_like(yg)
+  img = ring(V.view_of(xg), trg, fwd, slabs_g[:nsf * 32], yview(yg3))
+  if img is not False:
+    xt_ = x.relu() * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)
+    nchk = (cin + 7) // 8
+    xp = t.zeros((B, nchk * 8) + dims); xp[:, :cin] = xt_
+    hi = xp.to(t.bfloat16); lo = (xp - hi.float()).to(t.bfloat16)
+    want_img = t.stack([hi, lo]).view(2, B, nchk, 8, *dims).permute(0, 1, 2, 4, 5, 6, 3).contiguous()
+    got_img = img.cpu().view(t.bfloat16).view(want_img.shape)
+    assert t.equal(got_img.view(t.int16), want_img.view(t.int16)), (name, "activation image")
+    # the same products in the same order -- unless the launch above split its channel reduction (small grids), or the ring
+    # kernel groups the taps of a 5 x 5 window plane differently (16-column blocks: row-sliding order)
+    yg_ref = t.zeros_like(yg)
+    os.environ["CRN_BF3_SPLITS"] = "1"
+    try:
+      be.conv_fwd(V.view_of(xg), trg, None, fwd.npad, bpack.to(DEV), 0, yview(yg_ref), fwd.window, fwd.pad_lo, 0,
+                  boxes=(fwd.n_boxes, fwd.c_boxes), math="bf16x3", wslab=slabs_g[:nsf * 32])
+    finally:
+      del os.environ["CRN_BF3_SPLITS"]
+    e3 = float((yg3.cpu() - y).abs().max() / y.abs().max())
+    assert e3 <= 2e-5, (name, "fwd ring vs contract", e3)
+    if fwd.npad > 16 or fwd.window[2] == 4:
+      assert t.equal(yg3, yg_ref), (name, "fwd ring", float((yg3 - yg_ref).abs().max()))
+    print(f"bf16x3 {name} fwd: ring kernel {e3:.2e}" + (", bit-identical" if t.equal(yg3, yg_ref) else ""))
   ye = t.zeros_like(y)
   EMU.conv_fwd(V.view_of(x), trc, None, fwd.npad, bpack, 0, yview(ye), fwd.window, fwd.pad_lo, wslab=slabs[:nsf * 32])
   assert float((ye - y).abs().max() / y.abs().max()) < 2e-5
@@ -305,7 +340,7 @@ def test_conv_bf16x3_fwd_dgrad(be, name, kind, wshape, pad, dims, B):
   dx = t.randn(x.shape, generator=g); dxg = dx.to(DEV)
   dyg = dyb.to(DEV)
   EMU.conv_fwd(yview(dyb), None, wd, dgr.npad, None, 0, V.view_of(dx), dgr.window, dgr.pad_lo, accumulate=True)
-  dxg2 = dxg.clone()
+  dxg2 = dxg.clone(); dx0g = dxg.clone()
   be.conv_fwd(yview(dyg), None, wd.to(DEV), dgr.npad, None, 0, V.view_of(dxg), dgr.window, dgr.pad_lo, 0, True,
               boxes=(dgr.n_boxes, dgr.c_boxes), math="bf16x3")
   e = float((dxg.cpu() - dx).abs().max() / dx.abs().max())
@@ -314,6 +349,20 @@ def test_conv_bf16x3_fwd_dgrad(be, name, kind, wshape, pad, dims, B):
   be.conv_fwd(yview(dyg), None, None, dgr.npad, None, 0, V.view_of(dxg2), dgr.window, dgr.pad_lo, 0, True,
               boxes=(dgr.n_boxes, dgr.c_boxes), math="bf16x3", wslab=slabs_g[nsf * 32:])
   assert t.equal(dxg2, dxg), (name, "dgrad slabs")
+  dxg3 = dx0g.clone()
+  if ring(yview(dyg), None, dgr, slabs_g[nsf * 32:], V.view_of(dxg3), accumulate=True) is not False:
+    dx_ref = dx0g.clone()
+    os.environ["CRN_BF3_SPLITS"] = "1"
+    try:
+      be.conv_fwd(yview(dyg), None, None, dgr.npad, None, 0, V.view_of(dx_ref), dgr.window, dgr.pad_lo, 0, True,
+                  boxes=(dgr.n_boxes, dgr.c_boxes), math="bf16x3", wslab=slabs_g[nsf * 32:])
+    finally:
+      del os.environ["CRN_BF3_SPLITS"]
+    e3 = float((dxg3.cpu() - dx).abs().max() / dx.abs().max())
+    assert e3 <= 2e-5, (name, "dgrad ring vs contract", e3)
+    if dgr.npad > 16 or dgr.window[2] == 4:
+      assert t.equal(dxg3, dx_ref), (name, "dgrad ring", float((dxg3 - dx_ref).abs().max()))
+    print(f"bf16x3 {name} dgrad: ring kernel {e3:.2e}" + (", bit-identical" if t.equal(dxg3, dx_ref) else ""))
   # weight gradient (crn_conv_wgrad_bf3): real entries of the packed gradient against the contract, and the
   # un-packed gradient against autograd of torch's own op
   dw = t.zeros(wf.numel()); dwg = t.full((wf.numel(),), 7.0, device=DEV)
