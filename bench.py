@@ -69,6 +69,26 @@ def synthetic_batch(batch, seed, num_classes):
   return image, v2s, offset, grid
 
 
+def synthetic_meshes(batch, dev):
+  """UV-sphere meshes of 20 k triangles scaled into the unit cube, three per sample; returns the triangles
+  (view space), triangles per mesh and the per-mesh view->voxel matrices (batched_example.py:153-160)."""
+  import numpy as np
+  from corenet_amd.data import batched_example as BE
+  nlat = nlon = 100
+  th, ph = np.linspace(0, np.pi, nlat + 1), np.linspace(0, 2 * np.pi, nlon + 1)
+  unit = np.stack([np.outer(np.sin(th), np.cos(ph)), np.outer(np.sin(th), np.sin(ph)),
+                   np.outer(np.cos(th), np.ones_like(ph))], -1)                       # [nlat+1, nlon+1, 3]
+  a, b, c, d = unit[:-1, :-1], unit[1:, :-1], unit[1:, 1:], unit[:-1, 1:]
+  sphere = np.concatenate([np.stack([a, b, c], 2), np.stack([a, c, d], 2)], 1).reshape(-1, 3, 3)   # 20000 triangles
+  rng = np.random.RandomState(0)
+  meshes = [(0.3 + 0.4 * rng.rand(3) + (0.08 + 0.1 * rng.rand()) * sphere).astype(np.float32) for _ in range(3 * batch)]
+  tris = t.tensor(np.concatenate(meshes)).to(dev)
+  nt = t.tensor([len(m) for m in meshes], dtype=t.int32)
+  v2x = BE.view2voxel_matrices(t.full((batch, 3), 0.5), (128,) * 3)
+  mv = t.cat([v2x[b:b + 1].expand(3, 4, 4) for b in range(batch)])
+  return tris, nt, mv
+
+
 def host_threads():
   try:
     avail = len(os.sched_getaffinity(0))
@@ -311,6 +331,21 @@ def main():
   fill_s = sorted(fill_times)[len(fill_times) // 2]
   assert bool((filled == t.stack([(dist3 <= r).float() for r in (10, 30, 50)] * B)).all())
   fill_bytes = 8.0 * shells.numel()
+  # surface voxelizer (voxelization.py:32-164) on the ground-truth side of the same batch: 3 UV spheres of 20 k triangles per
+  # sample, 128^3, image_resolution_multiplier 8 (h7.json5:54).  Algorithmic bytes: the zero-initialised output grids
+  # (4 B/voxel, the reference allocates them per call too) + one read of the triangles; the rasterisation itself writes
+  # only surface voxels
+  from corenet_amd.geometry import voxelization
+  vox_tris, vox_nt, vox_mv = synthetic_meshes(B, dev)
+  vox_fn = lambda: voxelization.voxelize_mesh(vox_tris, vox_nt, (128,) * 3, vox_mv, image_resolution_multiplier=8)
+  for _ in range(2):
+    vox_fn()
+  e0.record()
+  for _ in range(10):
+    vox_fn()
+  e1.record(); t.cuda.synchronize()
+  vox_s = e0.elapsed_time(e1) / 10 * 1e-3
+  vox_bytes = 4.0 * vox_nt.numel() * 128 ** 3 + 4.0 * vox_tris.numel()
   # ray-sample gather at 64^3 again as a burst of 20 launches on the step's own buffers: one HIP-event pair
   # around a single ~13 us launch (the in-step probe) also times ~3-4 us of marker / kernel-boundary latency
   k5 = model.engine.skip_ch[5]
@@ -337,9 +372,9 @@ def main():
   eval_s = e0.elapsed_time(e1) / 10 * 1e-3
   model.train()
   if args.math == "bf16x3":
-    dtype_note = ("f32 (bf16x3 products in the decoder stage 3-6 convolutions and in the encoder's 3x3 convolutions -- forward "
-                  "of stages 4-5, data gradient of all --: operands split into two bf16 terms, three bf16 MFMAs per fp32 "
-                  "product, fp32 accumulation, ~3e-6 relative per layer; everything else fp32)")
+    dtype_note = ("bf16x3 (the convolutions of decoder stages 3-6 and the encoder's 3x3 convolutions -- forward of stages 4-5, data "
+                  "gradient of all -- multiply operands split into two bf16 terms: three bf16 MFMAs per product, fp32 "
+                  "accumulation, 16 mantissa bits, ~3e-6 relative per layer; tensors, everything else and the fp32_math leg: f32)")
     conv_kernel_name = "conv_bf3_kernel<1,1,7,1,slabs> (stage_6.c1 Conv3d 28->16 k5 @64^3, fwd, split-bf16 MFMA engine)"
     conv_peak = PEAK_BF16_MFMA / 3
     conv_peak_note = "dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-equivalent product; achieved counts the layer's real 2*M*K*N"
@@ -379,6 +414,11 @@ def main():
                                "frac": fill_bytes / fill_s / PEAK_HBM, "traffic": traffic.get("fill"),
                                "avg_launch_ms": fill_s * 1e3},
   }
+  out["roofline_voxelize"] = {"kernel": f"voxelize_kernel ({3 * B} meshes x {vox_tris.shape[0] // (3 * B)} triangles -> 128^3, multiplier 8, whole call "
+                                        "incl. the zero-initialisation of the grids)", "bound": "hbm",
+                              "achieved": vox_bytes / vox_s / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                              "frac": vox_bytes / vox_s / PEAK_HBM, "traffic": None, "avg_launch_ms": vox_s * 1e3,
+                              "note": "latency-bound rasterisation (one wavefront per triangle); off the model's critical path"}
   for k in ("roofline_ray_sample", "roofline_fill_voxels"):
     out[k]["traffic_source"] = out["roofline"]["traffic_source"]
   if fp32_side is not None:

@@ -300,11 +300,14 @@ __global__ __launch_bounds__(kRingThreads) void conv_bf3_ring_kernel(RingGeom g)
   int b, d0, h0, w0, nb;
   decode(it_beg, b, d0, h0, w0, nb);
   const bool cst = g.stamps && tid == 0;
+  const bool wst = g.stamps && lane == 0 && blockIdx.x == 0;      // every consumer wave of workgroup 0: multiply / barrier cycles
+  long long w_m = 0, w_b = 0, wm0 = 0, wm1 = 0;
   long long c_dma = 0, c_mfma = 0, c_wait = 0, c_bar = 0, cm0 = 0, cm1 = 0, cm2 = 0, cm3 = 0, c_start = 0, c_rt0 = 0;
   if (cst) { c_start = (long long)__builtin_amdgcn_s_memtime(); c_rt0 = (long long)__builtin_amdgcn_s_memrealtime(); }
   for (int t = 0; t <= total_steps; ++t) {
     if (cst) cm0 = (long long)__builtin_amdgcn_s_memtime();
     if (cst) cm1 = (long long)__builtin_amdgcn_s_memtime();
+    if (wst) wm0 = (long long)__builtin_amdgcn_s_memtime();
     if (t >= 1) {
       const int zr = __builtin_amdgcn_readfirstlane(zrtab[nb * nch + c]);
       if (z >= (zr & 255) && z < (zr >> 8) && g.dbg != 1) {    // (outside: only structural zeros)
@@ -314,77 +317,98 @@ __global__ __launch_bounds__(kRingThreads) void conv_bf3_ring_kernel(RingGeom g)
         const int abase = slot * kPL;
         const bf16x8* bh0 = Bhi + sbuf * kSlab;
         const bf16x8* bl0 = Blo + sbuf * kSlab;
-        if constexpr (NSUB == 1 && kSlide) {
-          // ROW-SLIDING tap order.  The wave's four sub-tiles are four consecutive H rows of one plane, and with the lane
-          // groups on the zw taps (kk = zw) the A fragment of (sub-tile ms, tap row zh) is patch row ms + zh of the wave:
-          // the 4 x NGS (sub-tile, tap row) pairs of the first NGS tap groups read only 4 + NGS - 1 distinct rows.  Each row
-          // is read once (hi, lo) and multiplied with the B fragments of every tap row that meets it: 46 instead of 70
-          // fragment reads per step for the 5 x 5 window planes (the zw = 4 column goes through two ordinary groups), 22
-          // instead of 40 for the 4 x 4 ones.  The weights stay in the slab's tap order; only the slot -> tap map of the
-          // fragment reads changes.  Per accumulator the order of the products is the order of the other kernels
-          // (tap groups ascending), so the results are bit-identical.
+        if constexpr (kSlide) {
+          // ROW-SLIDING tap order, TAP-ROW-MAJOR.  The wave's four sub-tiles are four consecutive H rows of one plane, and
+          // with the lane groups on the zw taps (kk = zw) the A fragment of (sub-tile m, tap row q) is patch row m + q of
+          // the wave: the 4 x NGS (sub-tile, tap row) pairs read only 4 + NGS - 1 distinct rows.  Iteration q multiplies
+          // rows q .. q + 3 with the B fragments of tap row q: 12 NSUB MFMAs on 4 NSUB independent accumulators (hi.hi of
+          // all, then hi.lo of all, then lo.hi of all: a dependent MFMA is never closer than four behind its predecessor)
+          // for ONE new row and ONE new B fragment pair, both requested kAhead iterations earlier -- every iteration has the
+          // same shape, there is no ramp with one or two accumulators at the ends of a step (the row-major order of the
+          // first version: rows 0 and NR - 1 meet a single tap row, three dependent MFMAs back to back; a lone wave issued
+          // one MFMA per 31 cycles).  46 fragment reads per step for the 5 x 5 window planes instead of 70 (the zw = 4
+          // column goes through two ordinary groups), 22 instead of 40 for the 4 x 4 ones.  The weights stay in the slab's
+          // tap order; only the slot -> tap map of the fragment reads changes.  Per accumulator the products come in the
+          // order tap row 0 .. NGS - 1, then the two zw = 4 groups.
           constexpr int NGS = NG == 7 ? 5 : 4, NR = kMSUB + NGS - 1;
+          constexpr int kAhead = NSUB == 1 ? 2 : 1, NRB = kMSUB + kAhead, NBB = kAhead + 1;   // (an iteration is 12 NSUB MFMAs)
+          constexpr int qA = NGS - 1;                          // iteration that requests the fragments of the first zw = 4 group
           const int kw_ = NG == 7 ? 5 : 4;
           const int arow = abase + ((wave & 1) * 4) * g.PW + i16 + kk;     // row 0 of the wave, this lane's zw tap
-          // rows are read kAhead iterations before they are multiplied: the first and last rows meet only one or two tap
-          // rows (3 - 6 MFMAs), too few to cover an LDS round trip with a prefetch distance of one
-          constexpr int kAhead = 3, NRB = kAhead + 1;
-          bf16x8 bsh[NGS], bsl[NGS], rh[NRB], rl[NRB];
+          bf16x8 rh[NRB], rl[NRB], bsh[NBB][NSUB], bsl[NBB][NSUB];
+          auto load_row = [&](int r) { rh[r % NRB] = Ahi[arow + r * g.PW]; rl[r % NRB] = Alo[arow + r * g.PW]; };
+          auto load_b = [&](int q) {                           // slot (zh = q, zw = kk) = tap q * kw + kk of the slab
 #pragma unroll
-          for (int r = 0; r < kAhead; ++r) { rh[r] = Ahi[arow + r * g.PW]; rl[r] = Alo[arow + r * g.PW]; }
-#pragma unroll
-          for (int q = 0; q < NGS; ++q) {                      // slot (zh = q, zw = kk) = tap q * kw + kk of the slab
-            bsh[q] = bh0[(q * kw_ + kk) * NB + i16];
-            bsl[q] = bl0[(q * kw_ + kk) * NB + i16];
-          }
+            for (int ns = 0; ns < NSUB; ++ns) {
+              bsh[q % NBB][ns] = bh0[(q * kw_ + kk) * NB + ns * 16 + i16];
+              bsl[q % NBB][ns] = bl0[(q * kw_ + kk) * NB + ns * 16 + i16];
+            }
+          };
           // the zw = 4 column of the 5 x 5 window: group A = (zh = kk, zw = 4), group B = (zh = 4, zw = 4) + three zero slots
-          bf16x8 th[kMSUB], tl[kMSUB], tbh, tbl;
+          bf16x8 th[kMSUB], tl[kMSUB], tbh[NSUB], tbl[NSUB], uh[kMSUB], ul[kMSUB], ubh[NSUB], ubl[NSUB];
           const int tap5 = NG == 7 ? (kk * 5 + 4) : 0, tap6 = NG == 7 ? (kk == 0 ? 24 : 24 + kk) : 0;
           const int toffA = kk * g.PW + 4, toffB = 4 * g.PW + 4;
+          auto load_ga = [&]() {
 #pragma unroll
-          for (int r = 0; r < NR; ++r) {
-            const int cur = r % NRB;
-            if (r + kAhead < NR) { rh[(r + kAhead) % NRB] = Ahi[arow + (r + kAhead) * g.PW]; rl[(r + kAhead) % NRB] = Alo[arow + (r + kAhead) * g.PW]; }
-            else if constexpr (NG == 7) {
-              if (r + kAhead == NR) { tbh = bh0[tap5 * NB + i16]; tbl = bl0[tap5 * NB + i16]; }
-              const int m0 = (r + kAhead - NR) * 2;            // two sub-tiles' fragments of group A per remaining iteration
+            for (int ns = 0; ns < NSUB; ++ns) { tbh[ns] = bh0[tap5 * NB + ns * 16 + i16]; tbl[ns] = bl0[tap5 * NB + ns * 16 + i16]; }
 #pragma unroll
-              for (int m = m0; m < m0 + 2 && m < kMSUB; ++m) { th[m] = Ahi[pa[m] + abase + toffA]; tl[m] = Alo[pa[m] + abase + toffA]; }
+            for (int m = 0; m < kMSUB; ++m) { th[m] = Ahi[pa[m] + abase + toffA]; tl[m] = Alo[pa[m] + abase + toffA]; }
+          };
+          auto load_gb = [&]() {
+#pragma unroll
+            for (int ns = 0; ns < NSUB; ++ns) { ubh[ns] = bh0[tap6 * NB + ns * 16 + i16]; ubl[ns] = bl0[tap6 * NB + ns * 16 + i16]; }
+#pragma unroll
+            for (int m = 0; m < kMSUB; ++m) { uh[m] = Ahi[pa[m] + abase + toffB]; ul[m] = Alo[pa[m] + abase + toffB]; }
+          };
+#pragma unroll
+          for (int q = 0; q < kAhead; ++q) load_b(q);
+#pragma unroll
+          for (int r = 0; r < kMSUB - 1 + kAhead; ++r) load_row(r);
+#pragma unroll
+          for (int q = 0; q < NGS; ++q) {
+            if (q + kAhead + kMSUB - 1 < NR) load_row(q + kAhead + kMSUB - 1);
+            if (q + kAhead < NGS) load_b(q + kAhead);
+            if constexpr (NG == 7) {
+              if (NSUB == 1 && q == qA) load_ga();
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < NGS; ++q) {
-              const int m = r - q;
-              if (m >= 0 && m < kMSUB) {
-                f32x4& a = acc[m][0];
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh[cur], bsh[q], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh[cur], bsl[q], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl[cur], bsh[q], a, 0, 0, 0);
-              }
-            }
+            for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+              for (int m = 0; m < kMSUB; ++m)
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns) {
+                  f32x4& a = acc[m][ns];
+                  const bf16x8& av = pass == 2 ? rl[(q + m) % NRB] : rh[(q + m) % NRB];
+                  const bf16x8& bv = pass == 1 ? bsl[q % NBB][ns] : bsh[q % NBB][ns];
+                  a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, a, 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
           }
           if constexpr (NG == 7) {
-            bf16x8 uh[kMSUB], ul[kMSUB], ubh, ubl;
-            ubh = bh0[tap6 * NB + i16]; ubl = bl0[tap6 * NB + i16];
+            if (NSUB != 1) { load_ga(); __builtin_amdgcn_sched_barrier(0); }
+            if (NSUB == 1) load_gb();                          // (in flight under the MFMAs of the first group; with 32 columns
+            __builtin_amdgcn_sched_barrier(0);                 // the registers of both groups at once do not fit 168)
 #pragma unroll
-            for (int m = 0; m < kMSUB; ++m) { uh[m] = Ahi[pa[m] + abase + toffB]; ul[m] = Alo[pa[m] + abase + toffB]; }
+            for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+              for (int m = 0; m < kMSUB; ++m)
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns) {
+                  f32x4& a = acc[m][ns];
+                  a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 2 ? tl[m] : th[m], pass == 1 ? tbl[ns] : tbh[ns], a, 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
+            if (NSUB != 1) { load_gb(); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-            for (int m = 0; m < kMSUB; ++m) {
-              f32x4& a = acc[m][0];
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th[m], tbh, a, 0, 0, 0);
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(th[m], tbl, a, 0, 0, 0);
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tl[m], tbh, a, 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            for (int pass = 0; pass < 3; ++pass)
 #pragma unroll
-            for (int m = 0; m < kMSUB; ++m) {
-              f32x4& a = acc[m][0];
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uh[m], ubh, a, 0, 0, 0);
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uh[m], ubl, a, 0, 0, 0);
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ul[m], ubh, a, 0, 0, 0);
-            }
+              for (int m = 0; m < kMSUB; ++m)
+#pragma unroll
+                for (int ns = 0; ns < NSUB; ++ns) {
+                  f32x4& a = acc[m][ns];
+                  a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pass == 2 ? ul[m] : uh[m], pass == 1 ? ubl[ns] : ubh[ns], a, 0, 0, 0);
+                }
           }
         } else {
         // software pipeline over "units" u = (tap group gq, half of the wave's sub-tiles), as in conv_bf3_ws_kernel
@@ -477,9 +501,12 @@ __global__ __launch_bounds__(kRingThreads) void conv_bf3_ring_kernel(RingGeom g)
     }
     if (cst) cm2 = (long long)__builtin_amdgcn_s_memtime();
     if (cst) cm3 = (long long)__builtin_amdgcn_s_memtime();
+    if (wst) wm1 = (long long)__builtin_amdgcn_s_memtime();
     __syncthreads();
+    if (wst) { const long long e = (long long)__builtin_amdgcn_s_memtime(); w_m += wm1 - wm0; w_b += e - wm1; }
     if (cst) { const long long e = (long long)__builtin_amdgcn_s_memtime(); c_dma += cm1 - cm0; c_mfma += cm2 - cm1; c_wait += cm3 - cm2; c_bar += e - cm3; }
   }
+  if (wst) { g.stamps[16 + 4 * 256 + 2 * wave] = w_m; g.stamps[16 + 4 * 256 + 2 * wave + 1] = w_b; }
   if (cst) {
     g.stamps[16 + 4 * blockIdx.x + 0] = (long long)__builtin_amdgcn_s_memtime() - c_start;
     g.stamps[16 + 4 * blockIdx.x + 1] = c_bar;
@@ -495,7 +522,8 @@ __global__ __launch_bounds__(kRingThreads) void conv_bf3_ring_kernel(RingGeom g)
 template <int NSUB, int NG>
 int launch_ring(const RingGeom& g, dim3 grid, size_t lds, hipStream_t st) {
   static const bool slide = getenv("CRN_RING_SLIDE") == nullptr || atoi(getenv("CRN_RING_SLIDE")) != 0;
-  auto k = (slide && NSUB == 1) ? conv_bf3_ring_kernel<NSUB, NG, true> : conv_bf3_ring_kernel<NSUB, NG, false>;
+  static const bool slide2 = getenv("CRN_RING_SLIDE2") == nullptr || atoi(getenv("CRN_RING_SLIDE2")) != 0;
+  auto k = (slide && (NSUB == 1 || slide2)) ? conv_bf3_ring_kernel<NSUB, NG, true> : conv_bf3_ring_kernel<NSUB, NG, false>;
   CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, grid, dim3(kRingThreads), lds, st, g);
   CRN_CHECK_LAUNCH();
@@ -513,7 +541,7 @@ long long* g_ring_stamps = nullptr;
 extern "C" int crn_ring_debug_stamps(long long* out16) {   // (+ 4 per workgroup from [16] on: 16 + 4 * 256 in all)
   if (!g_ring_stamps) return CRN_EINVAL;
   CRN_HIP(hipDeviceSynchronize());
-  CRN_HIP(hipMemcpy(out16, g_ring_stamps, (16 + 4 * 256) * sizeof(long long), hipMemcpyDeviceToHost));
+  CRN_HIP(hipMemcpy(out16, g_ring_stamps, (16 + 4 * 256 + 16) * sizeof(long long), hipMemcpyDeviceToHost));
   return CRN_OK;
 }
 
@@ -594,8 +622,8 @@ extern "C" int crn_conv_fwd_bf3_ring(const void* image, int B, int C, int D, int
   g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
   static const bool want_stamps = getenv("CRN_RING_STAMPS") != nullptr;
   if (want_stamps) {
-    if (!g_ring_stamps) CRN_HIP(hipMalloc(&g_ring_stamps, (16 + 4 * 256) * sizeof(long long)));
-    CRN_HIP(hipMemsetAsync(g_ring_stamps, 0, (16 + 4 * 256) * sizeof(long long), st));
+    if (!g_ring_stamps) CRN_HIP(hipMalloc(&g_ring_stamps, (16 + 4 * 256 + 16) * sizeof(long long)));
+    CRN_HIP(hipMemsetAsync(g_ring_stamps, 0, (16 + 4 * 256 + 16) * sizeof(long long), st));
     g.stamps = g_ring_stamps;
   }
   static const int wgs = getenv("CRN_RING_WGS") ? atoi(getenv("CRN_RING_WGS")) : 256;     // one workgroup per CU

@@ -174,6 +174,10 @@ def test_bf16x3_eval_b4_matches_oracle(nc):
 
 
 GRAD_NOISE_FACTOR, GRAD_ERR_FLOOR, GRAD_BAR_CAP, GRAD_OUTLIER_CAP = 8.0, 2e-3, 0.1, 0.5   # see the docstring below
+# the split-bf16 mode multiplies with 16 mantissa bits (two bf16 terms per operand, lo.lo dropped): its products carry
+# 2^-16 where the reference's fp32 products carry 2^-24, and on these fixtures its gradients measure ~2x the noise of the
+# fp32 mode (round 3).  Its bar is therefore twice the fp32 mode's -- still capped at 0.1 of a tensor's scale.
+GRAD_MODE_FACTOR = {"fp32": 1.0, "bf16x3": 2.0}
 
 
 @pytest.mark.parametrize("math", ["fp32", "bf16x3"])
@@ -186,7 +190,7 @@ def test_all_parameter_gradients_against_fp64_truth(math, fixture, B):
   oracle/gen_golden.py).  The HIP path must be as close to the truth as the reference's own fp32 run is:
 
     error(tensor) = the (1 - 1/128) quantile of |got - truth| / scale over the stored elements,
-    bar(tensor)   = min(max(8 x the SAME quantile of the reference's own fp32 error, 2e-3), 0.1),
+    bar(tensor)   = min(f x max(8 x the SAME quantile of the reference's own fp32 error, 2e-3), 0.1),  f = 1 (fp32 mode) / 2 (bf16x3),
 
   scale = max(the tensor's own max, 1e-3 of the model's largest gradient) (conv biases in front of a train-mode norm
   have a true gradient of 0: for tensors on that floor the bar is at least 2e-2, i.e. 2e-5 of the largest gradient).  The quantile on BOTH sides, because one thing is inherent: a post-ReLU activation within
@@ -203,7 +207,7 @@ def test_all_parameter_gradients_against_fp64_truth(math, fixture, B):
   loss = losses.iou_fgbg(grid.cuda(), m(image.cuda(), v2s.cuda(), off.cuda()))
   loss.backward()
   gmax = max(float(z[k]) for k in z.files if k.startswith("gmax::"))
-  rows, outliers, bars = [], [], []
+  rows, outliers, bars, over = [], [], [], []
   for name, p in m.named_parameters():
     want = t.as_tensor(z["g64sub::" + name]).double()
     ref32 = t.as_tensor(z["gsub::" + name]).double()
@@ -215,12 +219,13 @@ def test_all_parameter_gradients_against_fp64_truth(math, fixture, B):
     eref = ((ref32 - want).abs() / scale).sort().values
     k = 0 if name.startswith("decoder.stage_6.t1.") else max(1, e.numel() // 128)    # elements that may be mask flips
     err, worst, noise = float(e[-(k + 1)]), float(e[-1]), float(eref[-(k + 1)])
-    bar = min(max(GRAD_NOISE_FACTOR * noise, GRAD_ERR_FLOOR), GRAD_BAR_CAP)
+    bar = min(GRAD_MODE_FACTOR[math] * max(GRAD_NOISE_FACTOR * noise, GRAD_ERR_FLOOR), GRAD_BAR_CAP)
     if float(z["gmax::" + name]) < 1e-3 * gmax:
       # the tensor's true gradient is (all but) zero -- conv biases in front of a train-mode norm -- and `scale` is the
       # floor, 1e-3 of the model's largest gradient: both sides hold summation noise only, bounded at 2e-5 of that gradient
       bar = max(bar, 2e-2)
-    assert int((e > bar).sum()) <= k, (name, int((e > bar).sum()), k)
+    if int((e > bar).sum()) > k:
+      over.append((name, int((e > bar).sum()), k, e.numel(), bar, [float(v) for v in e[-4:]], [float(v) for v in eref[-4:]]))
     rows.append((err / bar, err, noise, name)); bars.append(bar)
     outliers.append((worst, name))
   rows.sort(reverse=True); outliers.sort(reverse=True)
@@ -230,6 +235,7 @@ def test_all_parameter_gradients_against_fp64_truth(math, fixture, B):
         f"{sorted(bars)[len(bars) // 2]:.1e}, max {max(bars):.1e}; closest to their bars (error / the reference's own fp32 "
         f"error at the same quantile): " + ", ".join(f"{n} {e:.1e}/{ns:.1e}" for _, e, ns, n in rows[:5]) +
         f"; largest single-element deviations: " + ", ".join(f"{n} {w:.1e}" for w, n in outliers[:3]))
+  assert not over, over        # (tensor, elements above its bar, allowed, stored elements, bar, its / the reference's four largest errors)
   assert len(rows) == 266 and rows[0][0] <= 1.0, rows[:5]
   assert max(bars) <= GRAD_BAR_CAP and outliers[0][0] <= GRAD_OUTLIER_CAP, outliers[:3]
 

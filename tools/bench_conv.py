@@ -95,14 +95,15 @@ if RING:
         f"{flop/ms_c/1e9/833.3:.3f} of the bf16x3 roof) | bf16x3 launch it replaces {ms_old*1e3:.1f} us | bit-identical: {same} (max diff {relerr:.1e} of the range)")
   if os.environ.get("CRN_RING_STAMPS"):
     import ctypes
-    f_conv(); st = (ctypes.c_longlong * (16 + 4 * 256))()
+    f_conv(); st = (ctypes.c_longlong * (16 + 4 * 256 + 16))()
     be.lib.cdll.crn_ring_debug_stamps(st)
     n = max(1, st[6])
     print(f"  workgroup 0: {st[0]} cycles in {st[1]} ticks of 10 ns = {st[0] / max(1, st[1]) / 10.0:.2f} GHz, {st[6]} steps, per step: "
           f"consumer slab-DMA issue {st[2] / n:.0f}, multiply {st[3] / n:.0f}, slab wait {st[4] / n:.0f}, barrier {st[5] / n:.0f} | "
           f"producer plane-DMA issue {st[8] / n:.0f}, wait {st[9] / n:.0f}, barrier {st[10] / n:.0f}")
     import numpy as np
-    w = np.array(st[16:]).reshape(256, 4)
+    print("  consumer waves of workgroup 0, per step multiply/barrier: " + ", ".join(f"{st[16 + 1024 + 2 * i] / n:.0f}/{st[16 + 1024 + 2 * i + 1] / n:.0f}" for i in range(8)))
+    w = np.array(st[16:16 + 1024]).reshape(256, 4)
     w = w[w[:, 0] > 0]
     if len(w):
       q = lambda a: "min %d / median %d / max %d" % (a.min(), np.median(a), a.max())
