@@ -41,6 +41,12 @@ class CrnInTransform(C.Structure):
   _fields_ = [("scale", vp), ("shift", vp), ("pre_relu", C.c_int32), ("post_relu", C.c_int32)]
 
 
+class CrnBnBwdFuse(C.Structure):
+  """Mirror of crnBnBwdFuse (include/corenet_hip.h)."""
+  _fields_ = [("x", vp), ("sB_x", i64), ("saved", vp), ("pre_relu", C.c_int32), ("ws", vp), ("ws_bytes", sz),
+              ("dsum", vp), ("ndsum", C.c_int32), ("nparts", C.c_int32)]
+
+
 class HipError(RuntimeError):
   pass
 
@@ -52,6 +58,10 @@ _SIGS = {
                          C.POINTER(CrnView), i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "crn_conv_fwd_bf3_slabs": [C.POINTER(CrnView), C.POINTER(CrnInTransform), vp, i32, vp, i32,
                                C.POINTER(CrnView), i32, i32, i32, i32, i32, i32, i32, vp, vp],
+    "crn_conv_fwd_bf3_slabs_bnbwd": [C.POINTER(CrnView), C.POINTER(CrnInTransform), vp, i32, vp, i32,
+                                     C.POINTER(CrnView), i32, i32, i32, i32, i32, i32, i32, vp, C.POINTER(CrnBnBwdFuse), vp],
+    "crn_batch_renorm_bwd_apply": [vp, i64, vp, i64, i32, i32, i64, i32, vp, vp, vp, vp, vp, i64, vp, vp, i32, vp, i32,
+                                   vp, sz, i32, vp],
     "crn_bf3_act_image": [C.POINTER(CrnView), C.POINTER(CrnInTransform), vp, vp],
     "crn_conv_fwd_bf3_ring": [vp, i32, i32, i32, i32, i32, vp, i32, vp, i32, C.POINTER(CrnView), i32, i32, i32, i32, i32, i32,
                               i32, vp, vp],

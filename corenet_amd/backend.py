@@ -108,6 +108,26 @@ class HipBackend:
                           pad_lo[0], pad_lo[1], pad_lo[2], splits, int(accumulate), _ctapboxes(boxes),
                           _lib.stream())
 
+  def conv_dgrad_bn_bwd(self, dyv: View, wslab: t.Tensor, npad: int, gv: View, g: t.Tensor, window, pad_lo, boxes,
+                        x, sB_x, B, Cn, S, pre_relu, gamma, scale, shift, saved, dx, sB_dx, dgamma, dbeta,
+                        dsum=None, ndsum=0) -> bool:
+    """Data gradient g = conv(dyv) on the split-bf16 engine (gv = the dense view of g) together with the first pass of the
+    backward of the BatchRenorm whose output gradient g is (x = the norm's input, dense [B][Cn][S]; decoder blocks,
+    reconstruction_decoder.py:56-60): the conv launch leaves the norm's two reduction sums per workgroup
+    (crn_conv_fwd_bf3_slabs_bnbwd) and the norm runs its second pass only (crn_batch_renorm_bwd_apply).  Returns False
+    when the conv launch could not produce the sums (g is written all the same): the caller runs bn_bwd."""
+    ws, n = self._bn_ws(Cn, x.device)
+    f = _lib.CrnBnBwdFuse(ptr(x), sB_x, ptr(saved), int(pre_relu), ptr(ws), n, ptr(dsum), int(ndsum), 0)
+    self.lib.crn_conv_fwd_bf3_slabs_bnbwd(C.byref(_cview(dyv)), None, ptr(wslab), npad, None, 0, C.byref(_cview(gv)),
+                                          window[0], window[1], window[2], pad_lo[0], pad_lo[1], pad_lo[2], 0,
+                                          _ctapboxes(boxes), C.byref(f), _lib.stream())
+    if f.nparts <= 0:
+      return False
+    self.lib.crn_batch_renorm_bwd_apply(ptr(x), sB_x, ptr(g), Cn * S, B, Cn, S, int(pre_relu), ptr(gamma),
+                                        ptr(scale), ptr(shift), ptr(saved), ptr(dx), sB_dx, ptr(dgamma), ptr(dbeta),
+                                        0, ptr(dsum), int(ndsum), ptr(ws), n, f.nparts, _lib.stream())
+    return True
+
   # -- ring-buffered, DMA-fed form of the bf16x3 engine (csrc/conv_bf3_ring.hip) ---------------------------------
   def bf3_image_bytes(self, B, Cn, D, H, W) -> int:
     return int(self.lib.crn_bf3_act_image_bytes(B, Cn, D, H, W))

@@ -931,6 +931,47 @@ extern "C" int crn_batch_renorm_bwd(const float* x, int64_t sB_x, const float* d
                      accumulate, dsum, ndsum, ws, ws_bytes, stream, nullptr);
 }
 
+extern "C" int crn_batch_renorm_bwd_apply(const float* x, int64_t sB_x, const float* dy, int64_t sB_dy,
+                                          int B, int C, int64_t S, int pre_relu,
+                                          const float* gamma, const float* scale, const float* shift,
+                                          const float* saved, float* dx, int64_t sB_dx, float* dgamma,
+                                          float* dbeta, int accumulate, float* dsum, int ndsum, double* ws,
+                                          size_t ws_bytes, int nparts, crnStream stream) {
+  CRN_ENTRY(stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (B < 1 || C < 1 || S < 1 || B > 64 || nparts < 1 || !ws) return CRN_EINVAL;
+  if (ws_bytes < (size_t)C * nparts * 2 * sizeof(double)) return CRN_ENOMEM;
+  { const int rcf = crn_splitk_flush(st); if (rcf != CRN_OK) return rcf; }
+  const int ns = nsplit_for(S, C, B);
+  dim3 grid(ns, C, B);
+  // deterministic mode: sum(dx) by the ordered two-level reduction over dx afterwards (as in crn_batch_renorm_bwd); it re-uses
+  // `ws` once the apply kernel has read the partial sums
+  float* const dsum_det = (dsum && ndsum > 0 && crn_deterministic()) ? dsum : nullptr;
+  if (dsum_det) dsum = nullptr;
+  if (vec_ok(S, {sB_x, sB_dy, sB_dx}, {x, dy, dx}))
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(kThreads), 0, st, x, sB_x, dy, sB_dy, S, C,
+                       pre_relu, 0, gamma, scale, shift, saved, ws, nparts,
+                       (double)B * (double)S, dx, sB_dx, dgamma, dbeta, accumulate, dsum, ndsum);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(kThreads), 0, st, x, sB_x, dy, sB_dy, S, C,
+                       pre_relu, 0, gamma, scale, shift, saved, ws, nparts,
+                       (double)B * (double)S, dx, sB_dx, dgamma, dbeta, accumulate, dsum, ndsum);
+  CRN_CHECK_LAUNCH();
+  if (dsum_det) {
+    const int nparts2 = ns * B;
+    if (ws_bytes < (size_t)ndsum * nparts2 * sizeof(double)) return CRN_ENOMEM;
+    dim3 gridb(ns, ndsum, B);
+    if (vec_ok(S, {sB_dx}, {dx}))
+      hipLaunchKernelGGL(bias_grad_partial_kernel<true>, gridb, dim3(kThreads), 0, st, dx, S, sB_dx, ws);
+    else
+      hipLaunchKernelGGL(bias_grad_partial_kernel<false>, gridb, dim3(kThreads), 0, st, dx, S, sB_dx, ws);
+    CRN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bias_grad_final_kernel, dim3(crn_cdiv(ndsum, 4)), dim3(256), 0, st, ws, nparts2, ndsum, dsum_det, 0);
+    CRN_CHECK_LAUNCH();
+  }
+  return CRN_OK;
+}
+
 extern "C" int crn_batch_renorm_bwd_head(const float* x, int64_t sB_x, float* dy, int64_t sB_dy,
                                          const float* g, int64_t sB_g, const float* act, int64_t sB_act,
                                          const float* g2, int64_t sB_g2,

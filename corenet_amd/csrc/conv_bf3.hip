@@ -71,7 +71,47 @@ struct Bf3Geom {
   unsigned magic_UP;
   int dbg;
   long long* stamps;       // tuning aid (CRN_BF3_STAMPS=1): shader-clock stamps of workgroup 0, 4 per staging step
+  // fused sums of the BatchRenorm backward whose output gradient this launch writes (crn_conv_fwd_bf3_slabs_bnbwd)
+  const float* bn_x; int64_t bn_sB, bn_S; const float* bn_saved; int bn_pre_relu;
+  double* bn_ws; float* bn_dsum; int bn_ndsum;
 };
+
+// Epilogue of a data gradient in front of a BatchRenorm backward: s1[ns] / s2[ns] hold this lane's share of sum(g) and
+// sum(g * xn) of channel n0 + ns * 16 + i16 (16 values: 4 sub-tiles x 4 W positions).  Lanes kk = 0..3 of a channel are
+// added by shuffles, the 8 MFMA waves through LDS (the first bytes of the workgroup's LDS: the channel tables are dead),
+// in double from there on; workgroup slot blockIdx.x of [C][gridDim.x][2].  Every wave of the workgroup that is still
+// running must call this (two barriers).
+template <int NSUB>
+__device__ __forceinline__ void bn_bwd_sums_store(const Bf3Geom& g, char* smem, float (&s1)[NSUB], float (&s2)[NSUB],
+                                                  int wave, int kk, int i16, int n0, int tid) {
+  constexpr int NB = NSUB * 16;
+  float* red = reinterpret_cast<float*>(smem);                 // [8 waves][NB][2]
+#pragma unroll
+  for (int ns = 0; ns < NSUB; ++ns) {
+    s1[ns] += __shfl_xor(s1[ns], 16); s1[ns] += __shfl_xor(s1[ns], 32);
+    s2[ns] += __shfl_xor(s2[ns], 16); s2[ns] += __shfl_xor(s2[ns], 32);
+  }
+  __syncthreads();                                             // every wave is past its last read of the LDS images
+  if (kk == 0 && wave < 8) {
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) {
+      red[((wave * NB) + ns * 16 + i16) * 2 + 0] = s1[ns];
+      red[((wave * NB) + ns * 16 + i16) * 2 + 1] = s2[ns];
+    }
+  }
+  __syncthreads();
+  if (tid < NB) {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { a += (double)red[(w * NB + tid) * 2]; b += (double)red[(w * NB + tid) * 2 + 1]; }
+    const int n = n0 + tid;
+    if (n < g.y.C) {
+      double* o = g.bn_ws + ((int64_t)n * gridDim.x + blockIdx.x) * 2;
+      o[0] = a; o[1] = b;
+    }
+  }
+  if (g.bn_dsum && blockIdx.x == 0 && blockIdx.y == 0 && tid < g.bn_ndsum) g.bn_dsum[tid] = 0.f;
+}
 
 __device__ __forceinline__ void bload2(f32x2& dst, const crn_rsrc& rs, unsigned byte_off) {
   asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(byte_off), "s"(rs));
@@ -432,6 +472,14 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
   // epilogue: D row = kk*4 + r = position (kk*4 + r) of the mh x mw sub-tile, col = i16 = channel.
   // mode 3: split-K partial sums go to a dense scratch tensor [split][b][n][pos]; a reduction launch adds them up
   float* yb = g.y.base + (int64_t)(g.mode >= 3 ? split * g.x.B + b : b) * g.y.sB;
+  float bn_s1[NSUB], bn_s2[NSUB], bn_mu[NSUB], bn_rstd[NSUB];
+#pragma unroll
+  for (int ns = 0; ns < NSUB; ++ns) {
+    bn_s1[ns] = bn_s2[ns] = 0.f;
+    const int n = n0 + ns * 16 + i16;
+    const bool on = g.bn_x && n < g.y.C;
+    bn_mu[ns] = on ? g.bn_saved[n] : 0.f; bn_rstd[ns] = on ? g.bn_saved[g.y.C + n] : 0.f;
+  }
 #pragma unroll
   for (int ns = 0; ns < NSUB; ++ns) {
     const int n = n0 + ns * 16 + i16;
@@ -451,6 +499,16 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
         f32x4 v = acc[ms][ns] + bsv;
         if (g.mode == 1) v += *reinterpret_cast<const f32x4*>(dst);
         *reinterpret_cast<f32x4*>(dst) = v;
+        if (g.bn_x) {                            // (fused only with vector stores: dense y, dense x of the same shape)
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(g.bn_x + (int64_t)b * g.bn_sB + (int64_t)n * g.bn_S +
+                                                            ((int64_t)od * g.y.H + oh) * g.y.W + ow);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float xr = g.bn_pre_relu ? fmaxf(xv[r], 0.f) : xv[r];
+            bn_s1[ns] += v[r];
+            bn_s2[ns] += v[r] * ((xr - bn_mu[ns]) * bn_rstd[ns]);
+          }
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -463,6 +521,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
       }
     }
   }
+  if (g.bn_x) bn_bwd_sums_store<NSUB>(g, smem, bn_s1, bn_s2, wave, kk, i16, n0, tid);
   if (g.mode == 4) {      // fused split-K reduction by the last workgroup of the tile (see conv_fwd_kernel, mode 4)
     __threadfence();
     int* s_last = reinterpret_cast<int*>(smem);           // the channel tables are dead by now
@@ -824,6 +883,14 @@ __global__ __launch_bounds__(kWsThreads) void conv_bf3_ws_kernel(Bf3Geom g) {
 
   // epilogue: D row = kk*4 + r = position (kk*4 + r) of the mh x mw sub-tile, col = i16 = channel
   float* yb = g.y.base + (int64_t)(g.mode >= 3 ? split * g.x.B + b : b) * g.y.sB;
+  float bn_s1[NSUB], bn_s2[NSUB], bn_mu[NSUB], bn_rstd[NSUB];
+#pragma unroll
+  for (int ns = 0; ns < NSUB; ++ns) {
+    bn_s1[ns] = bn_s2[ns] = 0.f;
+    const int n = n0 + ns * 16 + i16;
+    const bool on = g.bn_x && n < g.y.C;
+    bn_mu[ns] = on ? g.bn_saved[n] : 0.f; bn_rstd[ns] = on ? g.bn_saved[g.y.C + n] : 0.f;
+  }
 #pragma unroll
   for (int ns = 0; ns < NSUB; ++ns) {
     const int n = n0 + ns * 16 + i16;
@@ -843,6 +910,16 @@ __global__ __launch_bounds__(kWsThreads) void conv_bf3_ws_kernel(Bf3Geom g) {
         f32x4 v = acc[ms][ns] + bsv;
         if (g.mode == 1) v += *reinterpret_cast<const f32x4*>(dst);
         *reinterpret_cast<f32x4*>(dst) = v;
+        if (g.bn_x) {                            // (fused only with vector stores: dense y, dense x of the same shape)
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(g.bn_x + (int64_t)b * g.bn_sB + (int64_t)n * g.bn_S +
+                                                            ((int64_t)od * g.y.H + oh) * g.y.W + ow);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float xr = g.bn_pre_relu ? fmaxf(xv[r], 0.f) : xv[r];
+            bn_s1[ns] += v[r];
+            bn_s2[ns] += v[r] * ((xr - bn_mu[ns]) * bn_rstd[ns]);
+          }
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -855,6 +932,7 @@ __global__ __launch_bounds__(kWsThreads) void conv_bf3_ws_kernel(Bf3Geom g) {
       }
     }
   }
+  if (g.bn_x) bn_bwd_sums_store<NSUB>(g, smem, bn_s1, bn_s2, wave, kk, i16, n0, tid);
 }
 
 // MEASURED AND REMOVED: a "sliding" variant of the kernel above (K = 4 (zd, zw) tap pairs x 8 channels, the zh taps
@@ -1267,7 +1345,7 @@ extern "C" int crn_bf3_debug_stamps(long long* out192) {
 namespace {
 int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w, const void* wslab, int Npad,
                       const float* bias, int bias_sB, const crnView* y, int kd, int kh, int kw, int pd, int ph, int pw,
-                      int accumulate, const crnTapBoxes* boxes, crnStream stream);
+                      int accumulate, const crnTapBoxes* boxes, crnStream stream, crnBnBwdFuse* fuse = nullptr);
 }
 extern "C" int crn_conv_fwd_bf3(const crnView* x, const crnInTransform* tr, const float* w, int Npad,
                                 const float* bias, int bias_sB, const crnView* y,
@@ -1283,10 +1361,18 @@ extern "C" int crn_conv_fwd_bf3_slabs(const crnView* x, const crnInTransform* tr
   if (!wslab) return CRN_EINVAL;
   return conv_fwd_bf3_impl(x, tr, nullptr, wslab, Npad, bias, bias_sB, y, kd, kh, kw, pd, ph, pw, accumulate, boxes, stream);
 }
+extern "C" int crn_conv_fwd_bf3_slabs_bnbwd(const crnView* x, const crnInTransform* tr, const void* wslab, int Npad,
+                                            const float* bias, int bias_sB, const crnView* y,
+                                            int kd, int kh, int kw, int pd, int ph, int pw,
+                                            int accumulate, const crnTapBoxes* boxes, crnBnBwdFuse* fuse, crnStream stream) {
+  if (!wslab || !fuse || !fuse->x || !fuse->saved || !fuse->ws) return CRN_EINVAL;
+  return conv_fwd_bf3_impl(x, tr, nullptr, wslab, Npad, bias, bias_sB, y, kd, kh, kw, pd, ph, pw, accumulate, boxes, stream, fuse);
+}
 namespace {
 int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w, const void* wslab, int Npad,
                       const float* bias, int bias_sB, const crnView* y, int kd, int kh, int kw, int pd, int ph, int pw,
-                      int accumulate, const crnTapBoxes* boxes, crnStream stream) {
+                      int accumulate, const crnTapBoxes* boxes, crnStream stream, crnBnBwdFuse* fuse) {
+  if (fuse) fuse->nparts = 0;
   if (boxes && (boxes->n_groups < 0 || boxes->n_groups > 8 || boxes->c_groups < 0 || boxes->c_groups > 8)) return CRN_EINVAL;
   if (!x || !y || (!w && !wslab) || Npad <= 0 || (Npad & 15) || x->B != y->B || kd < 1 || kh < 1 || kw < 1) return CRN_EINVAL;
   if (y->C > Npad || x->C > kTabC) return CRN_EINVAL;
@@ -1395,6 +1481,15 @@ int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w
   const crnView& yo = g.y;
   g.vec_store = (g.mw >= 4 && yo.sW == 1 && (yo.W & 3) == 0 && (yo.sH & 3) == 0 && (yo.sD & 3) == 0 && (yo.sB & 3) == 0 &&
                  (yo.sC & 3) == 0 && (((uintptr_t)yo.base) & 15) == 0 && yo.chan_off == nullptr) ? 1 : 0;
+  const int64_t tiles_bn = tiles;
+  static const bool bn_fuse_off = getenv("CRN_BN_BWD_FUSE") != nullptr && atoi(getenv("CRN_BN_BWD_FUSE")) == 0;
+  if (fuse && !bn_fuse_off && splits == 1 && g.vec_store && y->sW == 1 && tiles_bn <= 0x7fffffff &&
+      fuse->ws_bytes >= (size_t)y->C * (size_t)tiles_bn * 2 * sizeof(double) && fuse->ndsum <= kThreads &&
+      (fuse->sB_x & 3) == 0 && (((uintptr_t)fuse->x) & 15) == 0 && (((int64_t)y->D * y->H * y->W) & 3) == 0) {
+    g.bn_x = fuse->x; g.bn_sB = fuse->sB_x; g.bn_S = (int64_t)y->D * y->H * y->W; g.bn_saved = fuse->saved;
+    g.bn_pre_relu = fuse->pre_relu; g.bn_ws = fuse->ws; g.bn_dsum = fuse->dsum; g.bn_ndsum = fuse->dsum ? fuse->ndsum : 0;
+    fuse->nparts = (int)tiles_bn;
+  }
   g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
   static const bool want_stamps = getenv("CRN_BF3_STAMPS") != nullptr;
   if (want_stamps) {

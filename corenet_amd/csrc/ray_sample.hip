@@ -152,6 +152,16 @@ __device__ __forceinline__ void project_uv(const Cam& c, float x, float y, float
 // for bit correct, but 56 / 19 / 18 / 18 us at the four scales against 49 / 24 / 16 / 14 us here: the exact
 // membership test needs ~8 IEEE divisions per (pixel, z), the reads come in 64-byte pieces, and general cameras
 // still need this kernel as a second launch.
+// Tried and dropped in round 4: a LOAD-FIRST form (a thread owns 4 consecutive x columns x 4 channels x 8 planes and issues all
+// of its 32 16-byte loads before it touches camera, window box or LDS; the eight z segments of a tile are the eight waves
+// of ONE workgroup and share one 16 KiB window, which goes to HBM once per tile: 8x fewer device-scope atomics; the box from
+// 8 lanes at once).  Correct on every test, and slower: 50 / 26 / 21 / 18 us (burst incl. the 4 us memset) against
+// 44 / 17 / 14 / 14 us here.  Its ablations at 64^3 say where the time of BOTH kernels is: 29 us with the projection
+// replaced by a constant pixel (one flush per column: loads + the shell of the launch), 30 us with the projection but
+// without the LDS adds, 51 us with them -- the ~36 divergent flush sites of a wave (4 columns x 9) each issue 4
+// ds_add_f32 for whatever lanes changed pixel at that plane, ~1150 LDS atomic instructions per CU; the window write-out
+// (3 us) and the tile shape (whole 256-byte rows: the same 28 us floor) do not matter.  What would help is fewer,
+// fuller LDS atomics (runs kept as records and flushed together), not more loads in flight.
 constexpr int kTMax = 16;                      // tile: 32x8 columns (full 128-B rows) for grids >= 64, else 8x8
 constexpr int kWinFloats = 12 * 1024;          // 48 KiB of LDS
 // DET (deterministic mode, crn_common.h): the sums are taken in 64-bit fixed point -- integer adds commute, so the

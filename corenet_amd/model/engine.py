@@ -214,6 +214,8 @@ class Engine:
     self.encoder_e2d = self.decoder_math == "bf16x3" and os.environ.get("CRN_E2D", "1") != "0"
     self.wgrad_2d = os.environ.get("CRN_WG2D", "1") != "0"
     self.defer_reduce = os.environ.get("CRN_DEFER_REDUCE", "1") != "0"
+    # decoder data gradients leave the two sums of the following BatchRenorm backward (crn_conv_fwd_bf3_slabs_bnbwd)
+    self.bn_bwd_fuse = os.environ.get("CRN_BN_BWD_FUSE", "1") != "0"
     self.fuse_tail = os.environ.get("CRN_FUSE_TAIL", "1") != "0"
     # fp32 is the only dtype of the HIP kernels; float64 exists so that the CPU
     # contract emulator (tests/) can check the host wiring far below fp32 noise.
@@ -730,6 +732,30 @@ class Plan:
         dy, None, cv.wd, g.npad, None, 0, dx, g.window, g.pad_lo, 0, accumulate, boxes=(g.n_boxes, g.c_boxes),
         math=self._math(cv, "dgrad"), wslab=cv.wop_d if cv.wop_kind == "slab" else None))
 
+  def _dgrad_bn_bwd(self, cv: Conv, dy: V.View, g: t.Tensor, x: t.Tensor, Cn: int, S: int, b, dx: t.Tensor, cprev: Conv) -> bool:
+    """Data gradient g of decoder conv `cv` + backward of the BatchRenorm `b` in front of it (input x, output gradient g,
+    input gradient dx; dsum = the bias gradient of the conv `cprev` that produced x).  True: the norm's backward is done
+    (its sums came out of the conv launch, crn_conv_fwd_bf3_slabs_bnbwd); False: g is written, the caller runs bn_bwd."""
+    eng, be = self.eng, self.be
+    gvw = self.vw(g)
+    fusable = (eng.bn_bwd_fuse and hasattr(be, "conv_dgrad_bn_bwd") and cv.wop_kind == "slab" and cv.wop_d is not None
+               and self._math(cv, "dgrad") == "bf16x3")
+    if not fusable:
+      if eng.defer_reduce:
+        be.splitk_defer()                        # g is read next by the norm's backward, which adds up the splits
+      self._dgrad(cv, dy, gvw)
+      return False
+    gd = cv.dgrad
+    done = [False]
+    if eng.defer_reduce:
+      be.splitk_defer()                          # (a launch that splits cannot fuse: its sum goes to the norm's own first pass)
+    def run():
+      done[0] = be.conv_dgrad_bn_bwd(dy, cv.wop_d, gd.npad, gvw, g, gd.window, gd.pad_lo, (gd.n_boxes, gd.c_boxes),
+                                     x, Cn * S, self.B, Cn, S, True, b.gamma, b.scale, b.shift, b.saved, dx, Cn * S,
+                                     b.dgamma, b.dbeta, dsum=cprev.dbias, ndsum=cprev.n_ref)
+    self._timed("dgrad " + cv.name, run)
+    return done[0]
+
   def _wgrad(self, cv: Conv, x: V.View, tr, dy: V.View):
     """Weight gradient of one conv.  On the GPU it goes to a second HIP stream: it only reads
     (saved activation, dy) and writes its own slice of the packed gradient slab, so it can run
@@ -1026,24 +1052,23 @@ class Plan:
       self._wgrad(ct, self.vw(d["w"]), tr2, gv)
       if k == 6:   # gradient of the logits comes from the loss kernel; below it is a bn_bwd output
         self._bias_grad(ct, g_out, So, ctot * So)
-      if eng.defer_reduce:
-        be.splitk_defer()                      # gv2 and gv1 are read next by their norms' backward, which add up the splits
-      self._dgrad(ct, gv, self.vw(d["gv2"]))
       cc = cv[p + "c1."]
       # every conv bias gradient below is sum(dx) of the norm that consumes the conv output: fused
-      # into bn_bwd (dsum) instead of a second pass over dx
-      be.bn_bwd(d["w"], d["cmid"] * S, d["gv2"], d["cmid"] * S, B, d["cmid"], S, True, False,
-                b2_.gamma, b2_.scale, b2_.shift, b2_.saved, d["gw"], d["cmid"] * S, b2_.dgamma, b2_.dbeta,
-                dsum=cc.dbias, ndsum=cc.n_ref)
+      # into bn_bwd (dsum) instead of a second pass over dx.
+      # A data gradient is the output gradient of the norm in front of its conv: where the launch does not split its
+      # reduction (stages 5-6 at the bench batch) it also leaves that norm's two backward sums, and the norm's backward
+      # is its second pass alone (_dgrad_bn_bwd)
+      if not self._dgrad_bn_bwd(ct, gv, d["gv2"], d["w"], d["cmid"], S, b2_, d["gw"], cc):
+        be.bn_bwd(d["w"], d["cmid"] * S, d["gv2"], d["cmid"] * S, B, d["cmid"], S, True, False,
+                  b2_.gamma, b2_.scale, b2_.shift, b2_.saved, d["gw"], d["cmid"] * S, b2_.dgamma, b2_.dbeta,
+                  dsum=cc.dbias, ndsum=cc.n_ref)
       tr1 = Transform(b1_.scale, b1_.shift, pre_relu=True)
       self._wgrad(cc, self.vw(d["u"]), tr1, self.vw(d["gw"]))
-      if eng.defer_reduce:
-        be.splitk_defer()
-      self._dgrad(cc, self.vw(d["gw"]), self.vw(d["gv1"]))
       cprev = cv[f"decoder.stage_{k - 1}.t1."]        # produced this stage's input (first n_ref channels)
-      be.bn_bwd(d["u"], d["cin"] * S, d["gv1"], d["cin"] * S, B, d["cin"], S, True, False,
-                b1_.gamma, b1_.scale, b1_.shift, b1_.saved, d["gu"], d["cin"] * S, b1_.dgamma, b1_.dbeta,
-                dsum=cprev.dbias, ndsum=cprev.n_ref)
+      if not self._dgrad_bn_bwd(cc, self.vw(d["gw"]), d["gv1"], d["u"], d["cin"], S, b1_, d["gu"], cprev):
+        be.bn_bwd(d["u"], d["cin"] * S, d["gv1"], d["cin"] * S, B, d["cin"], S, True, False,
+                  b1_.gamma, b1_.scale, b1_.shift, b1_.saved, d["gu"], d["cin"] * S, b1_.dgamma, b1_.dbeta,
+                  dsum=cprev.dbias, ndsum=cprev.n_ref)
       g_out = d["gu"]
       if k == 3:
         self._grads_ready("decoder.stage_3.", grad_hook)

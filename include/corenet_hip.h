@@ -94,6 +94,31 @@ int crn_conv_fwd_bf3_slabs(const crnView* x, const crnInTransform* tr, const voi
                            int kd, int kh, int kw, int pd, int ph, int pw,
                            int accumulate, const crnTapBoxes* boxes /* may be NULL */, crnStream stream);
 
+/* crn_conv_fwd_bf3_slabs as the DATA GRADIENT in front of a BatchRenorm's backward (reconstruction_decoder.py:56-60: a decoder
+ * block is ReLU -> BatchRenorm -> conv, so the data gradient of the conv is the output gradient dy of the norm, and
+ * batch_renorm.py:41-47's autograd needs sum(dy) and sum(dy * xn) over the tensor before it can form dx).  The launch that
+ * writes dy = y also accumulates those two sums per channel from its accumulators, reading the norm's input x once, and
+ * stores them per workgroup in `ws` ([C][nparts][2] doubles, the layout of crn_batch_renorm_bwd's own first pass), so that
+ * crn_batch_renorm_bwd_apply can run without that pass: one full read of dy and of x less per norm.  The order of the sums is
+ * fixed (lane, wave, workgroup slot): results do not depend on scheduling.
+ * fuse->nparts is set to 0 when the launch could not produce the sums (split reduction, strided / non-dense y or x, more
+ * workgroups than `ws` holds): the caller then runs crn_batch_renorm_bwd; y is written either way.  dsum (may be NULL) is
+ * zeroed by the launch as crn_batch_renorm_bwd's first pass would.                                                       */
+typedef struct crnBnBwdFuse {
+  const float* x;      /* input of the norm: dense [B][C][D*H*W] inside each sample, D, H, W, C of y */
+  int64_t sB_x;
+  const float* saved;  /* [4][C] of crn_batch_renorm_stats: mu, rstd, r, d */
+  int pre_relu;        /* the norm sees max(x, 0) */
+  double* ws; size_t ws_bytes;
+  float* dsum; int ndsum;
+  int nparts;          /* out */
+} crnBnBwdFuse;
+int crn_conv_fwd_bf3_slabs_bnbwd(const crnView* x, const crnInTransform* tr, const void* wslab, int Npad,
+                                 const float* bias, int bias_sB, const crnView* y,
+                                 int kd, int kh, int kw, int pd, int ph, int pw,
+                                 int accumulate, const crnTapBoxes* boxes /* may be NULL */, crnBnBwdFuse* fuse,
+                                 crnStream stream);
+
 /* Ring-buffered, DMA-fed form of crn_conv_fwd_bf3_slabs (csrc/conv_bf3_ring.hip) for the Conv3d k5 / ConvTranspose3d k7
  * layers of decoder stages 4-6 (reconstruction_decoder.py:72-95), forward pass and data gradient.  The input arrives as
  * an ACTIVATION IMAGE written by crn_bf3_act_image: T(x) (the fused BatchRenorm + ReLU transform of crn_conv_fwd) of
@@ -256,6 +281,18 @@ int crn_batch_renorm_bwd(const float* x, int64_t sB_x, const float* dy, int64_t 
                          float* dgamma, float* dbeta, int accumulate,
                          float* dsum, int ndsum,
                          double* workspace, size_t workspace_bytes, crnStream s);
+
+/* The second pass of crn_batch_renorm_bwd alone: `workspace` already holds the per-channel partial sums
+ * [C][nparts][2] (sum g, sum g*xn) written by crn_conv_fwd_bf3_slabs_bnbwd (fuse->nparts > 0) on the same stream.
+ * post_relu must be 0 (the fused sums do not mask).  Same dx / dgamma / dbeta / dsum as crn_batch_renorm_bwd up to the
+ * summation order of the two sums.                                                                                */
+int crn_batch_renorm_bwd_apply(const float* x, int64_t sB_x, const float* dy, int64_t sB_dy,
+                               int B, int C, int64_t S, int pre_relu,
+                               const float* gamma, const float* scale, const float* shift,
+                               const float* saved, float* dx, int64_t sB_dx,
+                               float* dgamma, float* dbeta, int accumulate,
+                               float* dsum, int ndsum,
+                               double* workspace, size_t workspace_bytes, int nparts, crnStream s);
 
 /* crn_relu_bwd_add(g, act, g2 -> dy) followed by crn_batch_renorm_bwd(x, dy, pre_relu = post_relu = 0, ...) -- the backward
  * of a bottleneck's tail and of its last norm -- as ONE call: dy = (act > 0 ? g : 0) + g2 (g2 may be NULL) is formed and

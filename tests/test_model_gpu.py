@@ -519,21 +519,30 @@ def test_train_step_reduces_loss_and_matches_autograd_path(math):
   image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(2, 0, 2)]
   opt = S.FusedAdam(ma, lr=4e-4, eps=1e-4)
   ls = []
-  for step in range(3):
-    _sync_state(ma, m)                 # same state in: the step itself is what is compared (training at B=2 is
-    ls.append(float(m.train_step(image, v2s, off, grid, "iou_fgbg", lr=4e-4, adam_eps=1e-4)))    # chaotic over steps)
-    opt.zero_grad()
-    loss = losses.iou_fgbg(grid, ma(image, v2s, off))
-    loss.backward()
-    opt.step()
-    assert abs(float(loss) - ls[-1]) < 1e-4 * abs(ls[-1]), (step, float(loss), ls[-1])
-    e = _slab_err(ma, m)
-    print(f"autograd path vs train_step, step {step}: gradient slab err {e:.2e}")
-    assert e < 1e-3, (step, e)                      # measured 2e-6
-    assert ma.engine.adam_t == m.engine.adam_t == step + 1
-    if step == 0:
-      t.cuda.synchronize(); mem0 = t.cuda.memory_allocated()
-  t.cuda.synchronize()
+  # Both paths launch the same kernels; in the default mode the weight-gradient and ray-sample atomics arrive in another
+  # order every run, and BatchRenorm over B = 2 at nbt = 0 amplifies that noise to 1e-3 ... 6e-3 of the slab in the bf16x3
+  # mode (measured, round 4: also between two runs of the SAME path).  The comparison therefore runs in deterministic mode
+  # (crn_set_deterministic: ordered sums), where the two paths have to agree to the last bit of summation order.
+  be = m.engine.be
+  try:
+    be.set_deterministic(True)
+    for step in range(3):
+      _sync_state(ma, m)               # same state in: the step itself is what is compared (training at B=2 is
+      ls.append(float(m.train_step(image, v2s, off, grid, "iou_fgbg", lr=4e-4, adam_eps=1e-4)))    # chaotic over steps)
+      opt.zero_grad()
+      loss = losses.iou_fgbg(grid, ma(image, v2s, off))
+      loss.backward()
+      opt.step()
+      assert abs(float(loss) - ls[-1]) < 1e-6 * abs(ls[-1]), (step, float(loss), ls[-1])
+      e = _slab_err(ma, m)
+      print(f"autograd path vs train_step ({math}, deterministic sums), step {step}: gradient slab err {e:.2e}")
+      assert e < 1e-6, (step, e)
+      assert ma.engine.adam_t == m.engine.adam_t == step + 1
+      if step == 0:
+        t.cuda.synchronize(); mem0 = t.cuda.memory_allocated()
+    t.cuda.synchronize()
+  finally:
+    be.set_deterministic(False)
   assert t.cuda.memory_allocated() <= mem0 + (1 << 20), (mem0, t.cuda.memory_allocated())
   assert np.isfinite(ls[-1]) and ls[-1] < ls[0]
   assert relerr(ma.engine.adam_m, m.engine.adam_m) < 1e-2
