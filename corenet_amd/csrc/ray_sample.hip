@@ -160,8 +160,10 @@ __device__ __forceinline__ void project_uv(const Cam& c, float x, float y, float
 // replaced by a constant pixel (one flush per column: loads + the shell of the launch), 30 us with the projection but
 // without the LDS adds, 51 us with them -- the ~36 divergent flush sites of a wave (4 columns x 9) each issue 4
 // ds_add_f32 for whatever lanes changed pixel at that plane, ~1150 LDS atomic instructions per CU; the window write-out
-// (3 us) and the tile shape (whole 256-byte rows: the same 28 us floor) do not matter.  What would help is fewer,
-// fuller LDS atomics (runs kept as records and flushed together), not more loads in flight.
+// (3 us) and the tile shape (whole 256-byte rows: the same 28 us floor) do not matter.  Fewer, fuller LDS atomic
+// INSTRUCTIONS do not help either: with the last two runs of a column kept as records in registers and flushed together at
+// the end of the segment (two nearly full flush sites instead of nine sparse ones) this kernel takes 48 us instead of 44 --
+// the cost follows the lane-adds (4.7 M at 64^3, same-pixel neighbours serialise), not the instruction count.
 constexpr int kTMax = 16;                      // tile: 32x8 columns (full 128-B rows) for grids >= 64, else 8x8
 constexpr int kWinFloats = 12 * 1024;          // 48 KiB of LDS
 // DET (deterministic mode, crn_common.h): the sums are taken in 64-bit fixed point -- integer adds commute, so the
