@@ -1037,7 +1037,14 @@ class Plan:
       if k < 6:    # ray-traced skip: scatter-add, compress conv grads
         skip_bwd_async = self.async_skip and self.side is not None and self.trace is None
         if skip_bwd_async:
-          # off the data-gradient chain: the feature-map gradients are only needed when the encoder's backward starts
+          # off the data-gradient chain: the feature-map gradients are only needed when the encoder's backward starts.
+          # The scatter itself stays on the main stream: launched on the side stream it starts the moment the norm's backward
+          # that wrote g_out ends, next to the stage's data gradient, and its sums then differ from run to run by 1e-2 of the
+          # map's range (round 4, tools/run_noise.py: only decoder.rt_skip_5's weight gradient, 1e-3 ... 7e-3 of its bucket;
+          # float atomics or not, LDS window or not, non-temporal loads or not -- and never on the main stream, after a device
+          # synchronize, or in deterministic mode, whose max-|g| pass reads g_out first).  Until that hand-over is understood
+          # the 4 scatters (0.09 ms) are worth less than a gradient that is the same every time.
+          self._ray_bwd(k, g_out)
           self._skip_bwd_ev[k].record()
           with t.cuda.stream(self.side), _lib.pinned_stream(self.side):
             self.side.wait_event(self._skip_bwd_ev[k])
@@ -1114,14 +1121,20 @@ class Plan:
     self._join_side()
     be.copy_tiles(eng.gpacked, eng.store.grads, eng.unpack_tiles, reverse=True)
 
+  def _ray_bwd(self, k: int, g_out: t.Tensor):
+    """Scatter-add of the skip channels' gradient into the 2-D map gradient (ray_traced_skip_connection.py:135, autograd)."""
+    d = self.dec[k]
+    ro, hw = 2 * d["r"], self.skip_hw[k]
+    self.be.ray_sample_bwd(g_out[:, d["cout"]:], g_out.stride(0), self.B, self.eng.skip_ch[k], ro, ro, ro,
+                           self.layer_mats[k - 2], self.offset, self.gsmap[k], self.gsmap[k].stride(0), hw, hw, False)
+
   def _skip_bwd(self, k: int, g_out: t.Tensor, on_side: bool):
     """Backward of the skip connection into decoder stage k+1 (g_out = gradient of that stage's concat buffer)."""
     eng, be, B = self.eng, self.be, self.B
     d = self.dec[k]
-    ro, hw, ns = 2 * d["r"], self.skip_hw[k], eng.skip_ch[k]
-    be.ray_sample_bwd(g_out[:, d["cout"]:], g_out.stride(0), B, ns, ro, ro, ro,
-                      self.layer_mats[k - 2], self.offset, self.gsmap[k], self.gsmap[k].stride(0),
-                      hw, hw, False)
+    hw, ns = self.skip_hw[k], eng.skip_ch[k]
+    if not on_side:                             # (asynchronous skip path: the caller ran the scatter on the main stream)
+      self._ray_bwd(k, g_out)
     cs = eng.convs[f"decoder.rt_skip_{k}.compress_channels."]
     ft = self.feat[self.skip_src[k]]
     if on_side:                                 # already on the weight-gradient stream: no hand-over event
