@@ -240,6 +240,19 @@ def main():
     return float(tt), pr, loss
 
   dt, probes, loss = timed(model, plan)
+  replicas = None
+  if world > 1:
+    # data parallelism keeps the replicas identical (pipeline.py:199: DDP averages the gradients, every rank takes the same
+    # Adam step): after the timed steps the parameters (and the BatchRenorm buffers, which ride on the first bucket) must
+    # have the same checksum on every rank -- MIN == MAX over the communicator, whose own size is reported beside it
+    st = model.engine.store
+    chk = t.stack([st.params.double().sum(), st.params.double().abs().sum(), st.buffers.double().sum()])
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    replicas = {"equal": bool(t.equal(lo, hi)), "comm_ranks": dist.get_world_size(),
+                "checksum_spread": float((hi - lo).abs().max())}
+    if not replicas["equal"] and rank == 0:      # loud, but the measured line is still printed (with equal: false in it)
+      print(f"bench.py: REPLICAS DIVERGED after {args.warmup + args.steps} steps: {replicas}", file=sys.stderr)
   fp32_side = None
   if world == 1 and args.math != "fp32" and not args.no_fp32_side:
     # the same step with every convolution on the fp32 MFMA engine (the parity default), printed beside the headline
@@ -429,7 +442,7 @@ def main():
     out["rccl"] = dict(sync.describe(), backend=dist.get_backend(),
                        buckets_mb=[round((hi - lo) * 4 / 1e6, 1) for _, lo, hi in model.engine.grad_buckets],
                        exposed_ms_per_bucket=[round(v, 4) for v in sync.exposed_ms_per_bucket()],
-                       exposed_exchange_ms=probes.get("grad_exchange_wait", 0.0) * 1e3)
+                       exposed_exchange_ms=probes.get("grad_exchange_wait", 0.0) * 1e3, replicas=replicas)
   if not args.no_cpu_baseline and world == 1:
     out["cpu_baseline"] = cpu_baseline(state0, batch_cpu, loss_name)
     del model, plan

@@ -74,4 +74,7 @@ def test_bench_two_rank_launch_path_dry_run():
   assert d["rccl"]["transport"] == "torch.distributed/gloo" and d["rccl"]["buffers_on_first_bucket"] is True
   assert len(d["rccl"]["exposed_ms_per_bucket"]) == 7 and all(v >= 0 for v in d["rccl"]["exposed_ms_per_bucket"])
   assert "NCCL_ALGO" in d["rccl"] and d["rccl"]["exposed_exchange_ms"] >= 0
+  # the replicas hold the same parameters and buffers after the timed steps (MIN == MAX of their checksums over the
+  # communicator), and the line names the communicator's own size
+  assert d["rccl"]["replicas"] == {"equal": True, "comm_ranks": 2, "checksum_spread": 0.0}
   assert "cpu_baseline" not in d

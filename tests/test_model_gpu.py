@@ -569,6 +569,30 @@ def test_train_step_reduces_loss_and_matches_autograd_path(math):
 
 
 @pytest.mark.parametrize("math", MATHS)
+@pytest.mark.parametrize("B,nbt", [(2, 0), (4, 30000)])
+def test_run_to_run_gradient_spread_default_mode(math, B, nbt):
+  """Default (non-deterministic) mode: the same training step from the same state on two model instances may differ only by
+  the order in which atomics arrive -- 1e-6 ... 1e-5 of a gradient bucket's range (tools/run_noise.py).  Round 4 found the
+  ray-sample scatter of the 64^3 skip, launched on the side stream the moment its input was complete, returning sums that
+  differed by 1e-2 from run to run (decoder.rt_skip_5's weight gradient: 1e-3 ... 7e-3 of its bucket) while every golden
+  test still passed; the bar here is 1e-4 per bucket, and identical logits and losses."""
+  sd = O.make_state(0, 2, nbt=nbt)
+  image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(B, 0, 2)]
+  gi = grid.to(t.int32)
+  ms = [_model(2, sd, math).train() for _ in range(2)]
+  for rep in range(2):
+    ls = [float(m.train_step(image, v2s, off, gi, "iou_fgbg", lr=0.0, adam_eps=1e-4)) for m in ms]
+    t.cuda.synchronize()
+    assert ls[0] == ls[1], ls
+    assert t.equal(ms[0].engine.plan(B).logits, ms[1].engine.plan(B).logits)
+    g1, g2 = ms[0].engine.store.grads, ms[1].engine.store.grads
+    per = {lb or "stem..stage3": float((g1[lo:hi] - g2[lo:hi]).abs().max() / g1[lo:hi].abs().max())
+           for lb, lo, hi in ms[0].engine.grad_buckets}
+    print(f"[{math} B={B} nbt={nbt}] run-to-run spread per gradient bucket: " + ", ".join(f"{k} {v:.1e}" for k, v in per.items()))
+    assert max(per.values()) < 1e-4, per
+
+
+@pytest.mark.parametrize("math", MATHS)
 def test_train_step_hip_graph_replay_matches_launch_by_launch(math):
   """CoreNet.train_step(graph=True): the fused step captured into a HIP graph (inputs in plan-owned buffers, Adam's
   scalars in device memory) and replayed.  From identical states, every replayed step must equal the launch-by-launch
