@@ -70,6 +70,7 @@ struct Bf3Geom {
   int UP;                  // wave-specialised kernel: staging units per patch plane (PH * pw2)
   unsigned magic_UP;
   int dbg;
+  int half_last;           // the last chunk has <= 4 real channels: 8 taps x 4 channels per MFMA (conv_bf3_kernel, plane_half)
   long long* stamps;       // tuning aid (CRN_BF3_STAMPS=1): shader-clock stamps of workgroup 0, 4 per staging step
   // fused sums of the BatchRenorm backward whose output gradient this launch writes (crn_conv_fwd_bf3_slabs_bnbwd)
   const float* bn_x; int64_t bn_sB, bn_S; const float* bn_saved; int bn_pre_relu;
@@ -171,8 +172,8 @@ template <> struct XLoad<2> {            // stride-2 (space-to-depth) view: elem
 // 8 hi + 8 lo bf16, crn_bf3_operands): staging a slab is then two 16-byte loads and two LDS writes per item instead of
 // eight dword loads, eight splits and two writes (per staging step: ~930 -> ~300 cycles of load issue and ~400 -> ~150
 // of commit, CRN_BF3_STAMPS; both sit outside the MFMA phase).
-template <int NSUB, int XM, int NG, int ZS, bool WS>
-__global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
+template <int NSUB, int XM, int NG, int ZS, bool WS, bool HALF>
+__device__ __forceinline__ void conv_bf3_body(const Bf3Geom& g) {
   crn_kernarg_touch(g);
   constexpr int NB = NSUB * 16;
   constexpr int kSlab = ZS * NG * 4 * NB;                                 // weight items (16-byte units) per slab
@@ -225,6 +226,9 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
     const int sh = s_ % g.nsh, sd = s_ / g.nsh;
     pa[ms] = (sd * g.PH + sh * g.mh + ri) * g.PW + sw * g.mw + rj + g.lead;
   }
+  // (HALF: the launcher guarantees 16-wide sub-tiles on a row pitch of 20 -- a wave's four sub-tiles are four consecutive rows,
+  // so three of the four base addresses are immediates of the LDS reads: the registers this instantiation has to give back)
+  auto PA = [&](int ms) -> unsigned { if constexpr (HALF) return (unsigned)pa[0] + (unsigned)(ms * 20); else return (unsigned)pa[ms]; };
   f32x4 acc[kMSUB][NSUB];
 #pragma unroll
   for (int ms = 0; ms < kMSUB; ++ms)
@@ -398,7 +402,11 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
     patch_issue(chunk * kCK);
     weights_issue(chunk * kCK, zd);
   }
-  while (chunk < cend) {
+  // (the steps of a last chunk that multiplies 8 taps x 4 channels -- plane_half below -- are a second copy of the loop: a
+  // branch inside it would be a control-flow merge under the staging registers, +8 VGPRs and the second workgroup of the CU)
+  auto run_steps = [&](auto half_tag, int cstop) {
+  constexpr bool kHalf = decltype(half_tag)::value;
+  while (chunk < cstop) {
     const int c0 = chunk * kCK;
     // next step
     int nchunk = chunk, nzd = zd + ZS, nzend = zend;
@@ -437,7 +445,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
             bl[ns] = bl0[(gq * 4 + kk) * NB + ns * 16 + i16];
           }
 #pragma unroll
-          for (int ms = 0; ms < kMSUB; ++ms) { ah[ms] = Ahi[pa[ms] + off]; al[ms] = Alo[pa[ms] + off]; }
+          for (int ms = 0; ms < kMSUB; ++ms) { ah[ms] = Ahi[PA(ms) + (unsigned)off]; al[ms] = Alo[PA(ms) + (unsigned)off]; }
 #pragma unroll
           for (int ms = 0; ms < kMSUB; ++ms)
 #pragma unroll
@@ -448,8 +456,59 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
             }
         }
       };
+      // HALF CHUNK.  A last chunk with at most 4 real channels (stage_6.c1: 28 = 3 x 8 + 4) multiplies 8 TAPS x 4 channels per
+      // MFMA instead of 4 taps x 8 channels of which half are padding: lane group kk owns taps 8 gq + 2 kk and + 1, its operand
+      // registers are the low halves (channels 0-3: 8 bytes) of the two taps' entries, for the patch and for the weight slab
+      // alike -- two ds_read_b64 per fragment, the same LDS images.  ceil(KHW / 8) groups per plane instead of ceil(KHW / 4):
+      // 4 instead of 7 for a 5 x 5 plane, 125 instead of 140 MFMA triples per sub-tile for stage_6.c1 (the matrix pipe of
+      // this part is power-limited at ~1.4 PFLOP/s under this load -- a lone wave per SIMD issues one MFMA per 28 cycles with
+      // or without its LDS reads, round 4 -- so executed MFMAs, not bubbles, are what is left to remove).
+      auto plane_half = [&](int z, const bf16x8* bh0, const bf16x8* bl0) {
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        constexpr int NGH = (NG * 4 + 7) / 8;
+        const int zoff = z * g.PHW;
+        auto lo8 = [](const bf16x8* p) { return *reinterpret_cast<const unsigned long long*>(p); };
+        int kk2 = kk;
+        asm volatile("" : "+v"(kk2));                           // (the tap arithmetic below stays inside the step: 5 of a tile's 20)
+#pragma unroll
+        for (int gq = 0; gq < NGH; ++gq) {
+          // (slots KHW .. 4 NG - 1 of the slab hold zero weights; a slot past the slab reads the last of them)
+          const int t0 = min(gq * 8 + 2 * kk2, NG * 4 - 1), t1 = min(gq * 8 + 2 * kk2 + 1, NG * 4 - 1);
+          const int u0 = t0 < g.KHW ? t0 : 0, u1 = t1 < g.KHW ? t1 : 0;
+          const int zh0 = mdiv(u0, g.magic_kw), zh1 = mdiv(u1, g.magic_kw);
+          const int o0 = zh0 * g.PW + (u0 - zh0 * g.kw) + zoff, o1 = zh1 * g.PW + (u1 - zh1 * g.kw) + zoff;
+          const int s0 = t0 * NB + i16, s1 = t1 * NB + i16;
+          bf16x8 bh[NSUB], bl[NSUB];
+#pragma unroll
+          for (int ns = 0; ns < NSUB; ++ns) {
+            bh[ns] = __builtin_bit_cast(bf16x8, (u64x2){lo8(bh0 + s0 + ns * 16), lo8(bh0 + s1 + ns * 16)});
+            bl[ns] = __builtin_bit_cast(bf16x8, (u64x2){lo8(bl0 + s0 + ns * 16), lo8(bl0 + s1 + ns * 16)});
+          }
+          constexpr int MQ = 1;                                  // sub-tiles per pass: the kernel has to stay at 128 registers
+#pragma unroll
+          for (int mh = 0; mh < kMSUB; mh += MQ) {
+            bf16x8 ah[MQ], al[MQ];
+#pragma unroll
+            for (int m = 0; m < MQ; ++m) {
+              ah[m] = __builtin_bit_cast(bf16x8, (u64x2){lo8(Ahi + (PA(mh + m) + (unsigned)o0)), lo8(Ahi + (PA(mh + m) + (unsigned)o1))});
+              al[m] = __builtin_bit_cast(bf16x8, (u64x2){lo8(Alo + (PA(mh + m) + (unsigned)o0)), lo8(Alo + (PA(mh + m) + (unsigned)o1))});
+            }
+#pragma unroll
+            for (int m = 0; m < MQ; ++m)
+#pragma unroll
+              for (int ns = 0; ns < NSUB; ++ns) {
+                f32x4& a = acc[mh + m][ns];
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[ns], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[ns], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[ns], a, 0, 0, 0);
+              }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      };
       if constexpr (ZS == 1) {
-        plane(zd, Bhi, Blo);
+        if constexpr (kHalf) plane_half(zd, Bhi, Blo);
+        else plane(zd, Bhi, Blo);
       } else {
         int z0, z1;
         chunk_zrange(c0, z0, z1);
@@ -468,6 +527,10 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
     fresh = nchunk != chunk;
     chunk = nchunk; zd = nzd; zend = nzend;
   }
+  };
+  const int chalf = (HALF && cend * kCK >= g.x.C) ? cend - 1 : cend;
+  run_steps(std::false_type(), chalf);
+  if constexpr (HALF) run_steps(std::true_type(), cend);
 
   // epilogue: D row = kk*4 + r = position (kk*4 + r) of the mh x mw sub-tile, col = i16 = channel.
   // mode 3: split-K partial sums go to a dense scratch tensor [split][b][n][pos]; a reduction launch adds them up
@@ -566,6 +629,13 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) {
     }
   }
 }
+
+template <int NSUB, int XM, int NG, int ZS, bool WS>
+__global__ __launch_bounds__(kThreads) void conv_bf3_kernel(Bf3Geom g) { conv_bf3_body<NSUB, XM, NG, ZS, WS, false>(g); }
+// ... with a half last chunk (plane_half): two workgroups per CU are worth more than the two registers the second copy of the
+// step loop costs: its sub-tile addresses are immediates (PA), 123 registers
+template <int NSUB, int XM, int NG, int ZS, bool WS>
+__global__ __launch_bounds__(kThreads) void conv_bf3_half_kernel(Bf3Geom g) { conv_bf3_body<NSUB, XM, NG, ZS, WS, true>(g); }
 
 template <typename G>
 __host__ __device__ __forceinline__ void bf3_chunk_zrange(const G& g, const TapBox& nbox, int c0, int& z0, int& z1) {
@@ -1277,6 +1347,8 @@ unsigned magic20b(int d) { return (unsigned)(((1u << 20) + d - 1) / d); }
 template <int NSUB, int XM, int NG, int ZS>
 int launch_bf3(const Bf3Geom& g, dim3 grid, size_t lds, hipStream_t st) {
   auto k = g.wslab ? conv_bf3_kernel<NSUB, XM, NG, ZS, true> : conv_bf3_kernel<NSUB, XM, NG, ZS, false>;
+  if constexpr (NSUB == 1 && XM == 1 && ZS == 1)         // (instantiated where a model layer needs it: stage_6.c1, 28 channels)
+    if (g.half_last && g.PW == 20 && g.mw == 16 && g.mh == 1 && g.nsw == 1 && g.nsh == 8) k = g.wslab ? conv_bf3_half_kernel<NSUB, XM, NG, ZS, true> : conv_bf3_half_kernel<NSUB, XM, NG, ZS, false>;
   if (lds > 65536) CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, st, g);
   CRN_CHECK_LAUNCH();
@@ -1491,6 +1563,8 @@ int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w
     fuse->nparts = (int)tiles_bn;
   }
   g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
+  static const bool half_off = getenv("CRN_BF3_HALF") != nullptr && atoi(getenv("CRN_BF3_HALF")) == 0;
+  g.half_last = (!half_off && x->C % kCK >= 1 && x->C % kCK <= 4 && ZS == 1) ? 1 : 0;
   static const bool want_stamps = getenv("CRN_BF3_STAMPS") != nullptr;
   if (want_stamps) {
     if (!g_bf3_stamps) CRN_HIP(hipMalloc(&g_bf3_stamps, 24 * 8 * sizeof(long long)));

@@ -124,16 +124,22 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
   else wait_vmcnt<0>();
 }
 
-template <int NSUB, int NG, bool kSlide>
+template <int NSUB, int NG, bool kSlide, bool kFlags>
 __global__ __launch_bounds__(kRingThreads) void conv_bf3_ring_kernel(RingGeom g) {
   crn_kernarg_touch(g);
   constexpr int NB = NSUB * 16;
   constexpr int KD = NG == 7 ? 5 : 4, PD = KD + 3;             // 5^3 / 4^3 windows on 4 x 8 x 16 tiles
+  constexpr int kPW = 16 + KD - 1;                             // patch row pitch (positions): 16 + kw - 1
   constexpr int kSlab = NG * 4 * NB;                           // weight items (hi 16 B + lo 16 B) per slab
   static_assert(kSlab % 64 == 0, "a slab is a whole number of 64-lane DMA instructions");
   constexpr int kSlabI = kSlab / 64;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   int* zrtab = reinterpret_cast<int*>(smem);                   // [NBK * nch] z range (z0 | z1 << 8) of a (N block, chunk)
+  // kFlags: the waves meet through words in LDS instead of one workgroup barrier per step (below)
+  int* f_planes = reinterpret_cast<int*>(smem + kHdr - 128);   // [4] planes landed, per producer wave (its quarter of each plane)
+  int* f_slabs = f_planes + 4;                                 // [4] slabs landed, per producer wave (its pieces of each slab)
+  int* f_done = f_planes + 8;                                  // [8] steps completed, per consumer wave
+  int* f_abort = f_planes + 16;                                // a spin ran out: every wave leaves
   bf16x8* Ahi = reinterpret_cast<bf16x8*>(smem + kHdr);        // [R][kPL]
   bf16x8* Alo = Ahi + g.R * kPL;
   bf16x8* Bhi = Alo + g.R * kPL;                               // [3][kSlab]
@@ -157,6 +163,7 @@ __global__ __launch_bounds__(kRingThreads) void conv_bf3_ring_kernel(RingGeom g)
     if (tb.h1 <= tb.h0 || tb.w1 <= tb.w0) z1 = z0;
     zrtab[i] = z0 | (z1 << 8);
   }
+  if (tid < 32) f_planes[tid] = 0;
   __syncthreads();
 
   auto decode = [&](int item, int& b, int& d0, int& h0, int& w0, int& nb) {
@@ -248,6 +255,49 @@ __global__ __launch_bounds__(kRingThreads) void conv_bf3_ring_kernel(RingGeom g)
       }
     };
     set_item(0);
+    if constexpr (kFlags) {
+      // FLAG-SYNCHRONISED (no workgroup barrier in the main loop).  A producer wave runs as far ahead as the ring and the
+      // three slab buffers allow, given the slowest consumer (t_min = min of the consumers' completed-step counts): slab s
+      // may overwrite slab s - 3 once t_min >= s - 2, plane P may overwrite plane P - R once P - R is dead
+      // (dead = PD * (t_min / KD) + t_min % KD: the wave on output plane 0 of the tile reads patch plane z at window plane z).
+      // What it issued in EARLIER passes has landed once vmcnt <= what THIS pass issued; then the wave publishes those
+      // counts (release) and the consumers that wait for them go on.  The consumers drift apart by up to a step: while one
+      // wave of a SIMD waits for its first fragments of a step, the other is still multiplying the previous one -- with
+      // the barrier both waited together at the start of every step (1.2 k of a step's 4.1 k cycles, round 4).
+      int pub_p = 0, pub_s = 0, spins = 0;
+      while (true) {
+        int tmin = __hip_atomic_load(f_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int i = 1; i < kCons; ++i) tmin = min(tmin, __hip_atomic_load(f_done + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        tmin = __builtin_amdgcn_readfirstlane(tmin);
+        const int iP0 = iP, sn0 = s_n;
+        issued = 0;
+        while (s_n < total_steps && s_n <= tmin + 2 && issued < 20 && g.dbg != 6) issue_slab();
+        const int dead = PD * (tmin / KD) + tmin % KD;
+        const int limit = min(dead + R, total_planes);
+        while (iP < limit && issued < 24 && g.dbg != 6) { issue_plane(); issued += 2; }
+        if (g.dbg == 6) { iP = total_planes; s_n = total_steps; }
+        wait_vmcnt_le(issued);
+        if (iP0 != pub_p || sn0 != pub_s) {
+          pub_p = iP0; pub_s = sn0;
+          if (lane == 0) {
+            __hip_atomic_store(f_planes + pwv, pub_p, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(f_slabs + pwv, pub_s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+        if (pub_p == total_planes && pub_s == total_steps) break;
+        if (issued == 0 && iP == pub_p && s_n == pub_s) {          // nothing to do until a consumer moves on
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > (1 << 22) || __hip_atomic_load(f_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+            if (lane == 0) __hip_atomic_store(f_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+          }
+        } else {
+          spins = 0;
+        }
+      }
+      return;
+    }
     int G = 0, z = 0;                                          // step t = (global chunk G, window plane z)
     const bool pst = g.stamps && tid == kCons * 64;
     long long p_issue = 0, p_wait = 0, p_bar = 0, pm0 = 0, pm1 = 0, pm2 = 0;
@@ -286,11 +336,11 @@ __global__ __launch_bounds__(kRingThreads) void conv_bf3_ring_kernel(RingGeom g)
   for (int gq = 0; gq < NG; ++gq) {
     const int t = gq * 4 + kk < g.KHW ? gq * 4 + kk : 0;       // slots past the window carry zero weights
     const int zh = mdiv(t, g.magic_kw), zw = t - zh * g.kw;
-    toff[gq] = zh * g.PW + zw;
+    toff[gq] = zh * kPW + zw;
   }
   const int sd_w = wave >> 1;                                  // the wave's output plane of the 4 x 8 x 16 tile
 #pragma unroll
-  for (int ms = 0; ms < kMSUB; ++ms) pa[ms] = ((wave & 1) * 4 + ms) * g.PW + i16;
+  for (int ms = 0; ms < kMSUB; ++ms) pa[ms] = ((wave & 1) * 4 + ms) * kPW + i16;
 #pragma unroll
   for (int ms = 0; ms < kMSUB; ++ms)
 #pragma unroll
@@ -304,13 +354,10 @@ __global__ __launch_bounds__(kRingThreads) void conv_bf3_ring_kernel(RingGeom g)
   long long w_m = 0, w_b = 0, wm0 = 0, wm1 = 0;
   long long c_dma = 0, c_mfma = 0, c_wait = 0, c_bar = 0, cm0 = 0, cm1 = 0, cm2 = 0, cm3 = 0, c_start = 0, c_rt0 = 0;
   if (cst) { c_start = (long long)__builtin_amdgcn_s_memtime(); c_rt0 = (long long)__builtin_amdgcn_s_memrealtime(); }
-  for (int t = 0; t <= total_steps; ++t) {
-    if (cst) cm0 = (long long)__builtin_amdgcn_s_memtime();
-    if (cst) cm1 = (long long)__builtin_amdgcn_s_memtime();
-    if (wst) wm0 = (long long)__builtin_amdgcn_s_memtime();
-    if (t >= 1) {
+  auto multiply_step = [&]() {
+    {
       const int zr = __builtin_amdgcn_readfirstlane(zrtab[nb * nch + c]);
-      if (z >= (zr & 255) && z < (zr >> 8) && g.dbg != 1) {    // (outside: only structural zeros)
+      if (z >= (zr & 255) && z < (zr >> 8) && g.dbg != 1 && !((g.dbg == 7 || g.dbg == 11) && wave >= 4) && !(g.dbg == 8 && wave < 4)) {    // (outside: only structural zeros)
         int slot = pslot + z + sd_w;
         if (slot >= R) slot -= R;
         if (slot >= R) slot -= R;
@@ -333,32 +380,40 @@ __global__ __launch_bounds__(kRingThreads) void conv_bf3_ring_kernel(RingGeom g)
           constexpr int NGS = NG == 7 ? 5 : 4, NR = kMSUB + NGS - 1;
           constexpr int kAhead = NSUB == 1 ? 2 : 1, NRB = kMSUB + kAhead, NBB = kAhead + 1;   // (an iteration is 12 NSUB MFMAs)
           constexpr int qA = NGS - 1;                          // iteration that requests the fragments of the first zw = 4 group
-          const int kw_ = NG == 7 ? 5 : 4;
-          const int arow = abase + ((wave & 1) * 4) * g.PW + i16 + kk;     // row 0 of the wave, this lane's zw tap
+          constexpr int kw_ = NG == 7 ? 5 : 4;
+          const unsigned brow = (unsigned)(kk * NB + i16);
+          // (the row pitch is a compile-time constant: a row, a tap row, a sub-tile are IMMEDIATE offsets of the LDS reads --
+          // with a run-time pitch the 46 reads of a step carried 57 address VALU instructions next to its 84 MFMAs, and a wave
+          // alone issued one MFMA per 30 cycles instead of 17, round 4)
+          const unsigned arow = (unsigned)(abase + ((wave & 1) * 4) * kPW + i16 + kk);     // row 0 of the wave, this lane's zw tap
           bf16x8 rh[NRB], rl[NRB], bsh[NBB][NSUB], bsl[NBB][NSUB];
-          auto load_row = [&](int r) { rh[r % NRB] = Ahi[arow + r * g.PW]; rl[r % NRB] = Alo[arow + r * g.PW]; };
+          const bool rd = g.dbg != 9 && g.dbg != 11;             // (ablation: no fragment reads)
+          auto load_row = [&](int r) { if (rd) { rh[r % NRB] = Ahi[arow + (unsigned)(r * kPW)]; rl[r % NRB] = Alo[arow + (unsigned)(r * kPW)]; } };
           auto load_b = [&](int q) {                           // slot (zh = q, zw = kk) = tap q * kw + kk of the slab
+            if (rd)
 #pragma unroll
             for (int ns = 0; ns < NSUB; ++ns) {
-              bsh[q % NBB][ns] = bh0[(q * kw_ + kk) * NB + ns * 16 + i16];
-              bsl[q % NBB][ns] = bl0[(q * kw_ + kk) * NB + ns * 16 + i16];
+              bsh[q % NBB][ns] = bh0[brow + (unsigned)(q * kw_ * NB + ns * 16)];
+              bsl[q % NBB][ns] = bl0[brow + (unsigned)(q * kw_ * NB + ns * 16)];
             }
           };
           // the zw = 4 column of the 5 x 5 window: group A = (zh = kk, zw = 4), group B = (zh = 4, zw = 4) + three zero slots
           bf16x8 th[kMSUB], tl[kMSUB], tbh[NSUB], tbl[NSUB], uh[kMSUB], ul[kMSUB], ubh[NSUB], ubl[NSUB];
-          const int tap5 = NG == 7 ? (kk * 5 + 4) : 0, tap6 = NG == 7 ? (kk == 0 ? 24 : 24 + kk) : 0;
-          const int toffA = kk * g.PW + 4, toffB = 4 * g.PW + 4;
+          const unsigned tap5n = (unsigned)((NG == 7 ? (kk * 5 + 4) : 0) * NB + i16), tap6n = (unsigned)((NG == 7 ? 24 + kk : 0) * NB + i16);
+          const unsigned rowA = arow + (unsigned)(kk * (kPW - 1) + 4), rowB = arow + (unsigned)(4 * kPW + 4) - (unsigned)kk;
           auto load_ga = [&]() {
+            if (!rd) return;
 #pragma unroll
-            for (int ns = 0; ns < NSUB; ++ns) { tbh[ns] = bh0[tap5 * NB + ns * 16 + i16]; tbl[ns] = bl0[tap5 * NB + ns * 16 + i16]; }
+            for (int ns = 0; ns < NSUB; ++ns) { tbh[ns] = bh0[tap5n + (unsigned)(ns * 16)]; tbl[ns] = bl0[tap5n + (unsigned)(ns * 16)]; }
 #pragma unroll
-            for (int m = 0; m < kMSUB; ++m) { th[m] = Ahi[pa[m] + abase + toffA]; tl[m] = Alo[pa[m] + abase + toffA]; }
+            for (int m = 0; m < kMSUB; ++m) { th[m] = Ahi[rowA + (unsigned)(m * kPW)]; tl[m] = Alo[rowA + (unsigned)(m * kPW)]; }
           };
           auto load_gb = [&]() {
+            if (!rd) return;
 #pragma unroll
-            for (int ns = 0; ns < NSUB; ++ns) { ubh[ns] = bh0[tap6 * NB + ns * 16 + i16]; ubl[ns] = bl0[tap6 * NB + ns * 16 + i16]; }
+            for (int ns = 0; ns < NSUB; ++ns) { ubh[ns] = bh0[tap6n + (unsigned)(ns * 16)]; ubl[ns] = bl0[tap6n + (unsigned)(ns * 16)]; }
 #pragma unroll
-            for (int m = 0; m < kMSUB; ++m) { uh[m] = Ahi[pa[m] + abase + toffB]; ul[m] = Alo[pa[m] + abase + toffB]; }
+            for (int m = 0; m < kMSUB; ++m) { uh[m] = Ahi[rowB + (unsigned)(m * kPW)]; ul[m] = Alo[rowB + (unsigned)(m * kPW)]; }
           };
 #pragma unroll
           for (int q = 0; q < kAhead; ++q) load_b(q);
@@ -499,6 +554,53 @@ __global__ __launch_bounds__(kRingThreads) void conv_bf3_ring_kernel(RingGeom g)
         }
       }
     }
+  };
+  if constexpr (kFlags) {
+    // step t needs: slab t, and patch plane z + sd_w of its chunk = plane PD * (chunk count) + z + sd_w in issue order
+    int need = sd_w, zc = 0;
+    for (int t = 0; t < total_steps; ++t) {
+      if (wst) wm0 = (long long)__builtin_amdgcn_s_memtime();
+      int spins = 0;
+      while (true) {
+        int fp = __hip_atomic_load(f_planes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        int fs = __hip_atomic_load(f_slabs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int i = 1; i < kProd; ++i) {
+          fp = min(fp, __hip_atomic_load(f_planes + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+          fs = min(fs, __hip_atomic_load(f_slabs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        }
+        if (__builtin_amdgcn_readfirstlane((fp > need && fs > t) ? 1 : 0)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22) || __hip_atomic_load(f_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+          if (lane == 0) __hip_atomic_store(f_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          return;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (wst) wm1 = (long long)__builtin_amdgcn_s_memtime();
+      multiply_step();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // (the step's LDS reads are complete: the MFMAs consumed them)
+      if (lane == 0) __hip_atomic_store(f_done + wave, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (wst) { const long long e = (long long)__builtin_amdgcn_s_memtime(); w_m += e - wm1; w_b += wm1 - wm0; }
+      if (++zc == KD) { zc = 0; need += PD - (KD - 1); } else ++need;
+    }
+    if (wst) { g.stamps[16 + 4 * 256 + 2 * wave] = w_m; g.stamps[16 + 4 * 256 + 2 * wave + 1] = w_b; }
+    if (cst) {
+      g.stamps[16 + 4 * blockIdx.x + 0] = (long long)__builtin_amdgcn_s_memtime() - c_start;
+      g.stamps[16 + 4 * blockIdx.x + 3] = (long long)__builtin_amdgcn_s_memrealtime();
+      if (blockIdx.x == 0) {
+        g.stamps[0] = (long long)__builtin_amdgcn_s_memtime() - c_start;
+        g.stamps[1] = (long long)__builtin_amdgcn_s_memrealtime() - c_rt0;
+        g.stamps[6] = total_steps; g.stamps[7] = c_rt0;
+      }
+    }
+    return;
+  }
+  for (int t = 0; t <= total_steps; ++t) {
+    if (cst) cm0 = (long long)__builtin_amdgcn_s_memtime();
+    if (cst) cm1 = (long long)__builtin_amdgcn_s_memtime();
+    if (wst) wm0 = (long long)__builtin_amdgcn_s_memtime();
+    if (t >= 1) multiply_step();
     if (cst) cm2 = (long long)__builtin_amdgcn_s_memtime();
     if (cst) cm3 = (long long)__builtin_amdgcn_s_memtime();
     if (wst) wm1 = (long long)__builtin_amdgcn_s_memtime();
@@ -523,7 +625,10 @@ template <int NSUB, int NG>
 int launch_ring(const RingGeom& g, dim3 grid, size_t lds, hipStream_t st) {
   static const bool slide = getenv("CRN_RING_SLIDE") == nullptr || atoi(getenv("CRN_RING_SLIDE")) != 0;
   static const bool slide2 = getenv("CRN_RING_SLIDE2") == nullptr || atoi(getenv("CRN_RING_SLIDE2")) != 0;
-  auto k = (slide && (NSUB == 1 || slide2)) ? conv_bf3_ring_kernel<NSUB, NG, true> : conv_bf3_ring_kernel<NSUB, NG, false>;
+  static const bool flags = getenv("CRN_RING_FLAGS") == nullptr || atoi(getenv("CRN_RING_FLAGS")) != 0;
+  const bool sl = slide && (NSUB == 1 || slide2);
+  auto k = flags ? (sl ? conv_bf3_ring_kernel<NSUB, NG, true, true> : conv_bf3_ring_kernel<NSUB, NG, false, true>)
+                 : (sl ? conv_bf3_ring_kernel<NSUB, NG, true, false> : conv_bf3_ring_kernel<NSUB, NG, false, false>);
   CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, grid, dim3(kRingThreads), lds, st, g);
   CRN_CHECK_LAUNCH();
@@ -571,7 +676,7 @@ extern "C" size_t crn_bf3_ring_covers(int C, int Npad, int yD, int yH, int yW, i
   if (!((kd == 5 && kh == 5 && kw == 5) || (kd == 4 && kh == 4 && kw == 4))) return 0;
   if (yW % 16 != 0 || yH < 8 || yD < 4) return 0;
   const int NB = Npad <= 16 ? 16 : 32;
-  return ((Npad + NB - 1) / NB) * ((C + kCK - 1) / kCK) <= kHdr / 4 ? 1 : 0;
+  return ((Npad + NB - 1) / NB) * ((C + kCK - 1) / kCK) <= kHdr / 4 - 32 ? 1 : 0;     // (the last 32 words: the waves' sync flags)
 }
 
 // Returns CRN_EINVAL for shapes this kernel does not cover (the caller keeps crn_conv_fwd_bf3_slabs for those).
@@ -592,13 +697,13 @@ extern "C" int crn_conv_fwd_bf3_ring(const void* image, int B, int C, int D, int
   g.y = *y; g.bias = bias; g.bias_sB = bias_sB; g.wslab = wslab; g.Npad = Npad;
   g.kd = kd; g.kh = kh; g.kw = kw; g.pd = pd; g.ph = ph; g.pw = pw; g.KHW = kh * kw;
   const int NG = (g.KHW + 3) / 4;
-  g.PH = 8 + kh - 1; g.PW = 16 + kw - 1; g.PHW = g.PH * g.PW;
+  g.PH = 8 + kh - 1; g.PW = 16 + kw - 1; g.PHW = g.PH * g.PW;       // (cubic windows: the kernels take PW = 16 + kd - 1 as a constant)
   if (g.PHW > kPL) return CRN_EINVAL;
   g.tilesD = crn_cdiv(y->D, 4); g.tilesH = crn_cdiv(y->H, 8); g.tilesW = y->W / 16;
   const int NSUB = Npad <= 16 ? 1 : 2, NB = NSUB * 16;
   g.NBK = crn_cdiv(Npad, NB);
   g.nch = g.NCH;
-  if (g.NBK * g.nch > kHdr / 4) return CRN_EINVAL;
+  if (g.NBK * g.nch > kHdr / 4 - 32) return CRN_EINVAL;
   const int64_t nitems = (int64_t)g.tilesD * g.tilesH * g.tilesW * B * g.NBK;
   if (nitems >= ((int64_t)1 << 24)) return CRN_EINVAL;
   g.nitems = (int)nitems;
