@@ -37,8 +37,8 @@ PEAK_BF16_MFMA = 2500e12                           # MI355X_MICROARCH.md: dense 
 PEAK_HBM = 8.0e12                                  # HBM3E spec peak
 # HBM bytes per launch come from separate rocprofv3 --pmc passes of this command (tools/pmc_traffic.sh); the record is
 # keyed by kernel name + grid, so both are named here, next to the kernel they describe
-TRAFFIC_FILES = {"bf16x3": "r03_pmc_traffic.json", "fp32": "r01_pmc_traffic.json"}
-CONV_BF3_TRAFFIC_KERNEL, CONV_BF3_THREADS = "conv_bf3_kernel<1, 1, 7, 1", 512
+TRAFFIC_FILES = {"bf16x3": "r04_pmc_traffic.json", "fp32": "r01_pmc_traffic.json"}
+CONV_BF3_TRAFFIC_KERNEL, CONV_BF3_THREADS = "conv_bf3_half_kernel<1, 1, 7, 1", 512
 
 
 def canonical_camera():
@@ -303,7 +303,7 @@ def main():
     if B == 4 and C == 2:
       for k, v in tj.get("kernels", {}).items():
         if args.math == "bf16x3":
-          # stage_6.c1 fwd is the only launch of conv_bf3_kernel<NSUB 1, unit-stride x, 5x5 plane> on 2048 tiles
+          # stage_6.c1 fwd is the only launch of conv_bf3_half_kernel<NSUB 1, unit-stride x, 5x5 plane> on 2048 tiles
           if CONV_BF3_TRAFFIC_KERNEL in k and k.endswith(f"grid {2048 * CONV_BF3_THREADS}"):
             traffic["conv"] = v["hbm_bytes"]
         # stage_6.c1 fwd (fp32 engine): conv_fwd_kernel<8,1,xvec>, 2048 tiles x 1 N-block.  stage_5.t1 and stage_6.t1 fwd
@@ -388,7 +388,8 @@ def main():
     dtype_note = ("bf16x3 (the convolutions of decoder stages 3-6 and the encoder's 3x3 convolutions -- forward of stages 4-5, data "
                   "gradient of all -- multiply operands split into two bf16 terms: three bf16 MFMAs per product, fp32 "
                   "accumulation, 16 mantissa bits, ~3e-6 relative per layer; tensors, everything else and the fp32_math leg: f32)")
-    conv_kernel_name = "conv_bf3_kernel<1,1,7,1,slabs> (stage_6.c1 Conv3d 28->16 k5 @64^3, fwd, split-bf16 MFMA engine)"
+    conv_kernel_name = ("conv_bf3_half_kernel<1,1,7,1,slabs> (stage_6.c1 Conv3d 28->16 k5 @64^3, fwd, split-bf16 MFMA engine; the last "
+                        "chunk of 4 channels multiplies 8 taps x 4 channels per MFMA)")
     conv_peak = PEAK_BF16_MFMA / 3
     conv_peak_note = "dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-equivalent product; achieved counts the layer's real 2*M*K*N"
   else:
