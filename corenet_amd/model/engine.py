@@ -553,6 +553,8 @@ class Plan:
     self.generation = 0            # bumped by every forward: CoreNet's autograd node checks it in backward
     self.graphs = {}               # captured training steps (CoreNet.train_step): loss name -> CUDAGraph
     self.eager_steps = 0           # fused steps run eagerly on this plan (the first one also sizes every workspace)
+    self.eval_graph = None         # captured eval-mode forward (CoreNet._forward_eval_graph)
+    self.eval_eager = 0
     self._views = {}
     dev = eng.device
     self.dev = dev

@@ -568,6 +568,48 @@ def test_train_step_reduces_loss_and_matches_autograd_path(math):
     l1.backward()
 
 
+def test_inference_forward_graph_replay_follows_the_weights():
+  """Inference forwards (eval mode, no_grad) replay a captured HIP graph from the third call of a batch size on
+  (CoreNet._forward_eval_graph) and re-derive the packed weights only when the parameter / buffer slabs were written:
+  replayed logits equal the launch-by-launch forward bit for bit, for new inputs too, and follow the weights after an in-place
+  torch update of a parameter, a load_state_dict and a fused training step; another batch size gets its own graph."""
+  sd = O.make_state(0, 2, nbt=100)
+  m = _model(2, sd).eval()
+  batches = [[x.cuda() for x in O.synthetic_batch(2, s, 2)[:3]] for s in (0, 1)]
+  def eager(b):
+    m.engine.weights_dirty = True
+    return m.engine.plan(2).forward(*b, training=False).clone()
+  with t.no_grad():
+    outs = [m(*batches[0]) for _ in range(4)]
+    plan = m.engine.plan(2)
+    assert plan.eval_graph is not None and plan.eval_eager == 2           # two launch-by-launch calls, then replays
+    assert all(t.equal(o, outs[0]) for o in outs[1:])
+    assert t.equal(m(*batches[1]), eager(batches[1]))                     # new inputs through the replay
+    assert not t.equal(m(*batches[1]), outs[0])
+    # (i) an in-place torch write to a parameter (what an optimizer does) is seen through the version counter
+    p = m.get_parameter("decoder.stage_6.t1.weight")
+    p.mul_(1.5)
+    got = m(*batches[0])
+    assert t.equal(got, eager(batches[0])) and not t.equal(got, outs[0])
+    assert t.equal(m(*batches[0]), got)                                   # (replay again, same weights)
+    # (ii) load_state_dict
+    m.load_state_dict(O.make_state(1, 2, nbt=100))
+    got = m(*batches[0])
+    assert t.equal(got, eager(batches[0])) and not t.equal(got, outs[0])
+    # (iii) another batch size has its own plan and graph
+    b1 = [x.cuda() for x in O.synthetic_batch(1, 0, 2)[:3]]
+    o1 = [m(*b1) for _ in range(3)]
+    assert m.engine.plan(1).eval_graph is not None and t.equal(o1[0], o1[2])
+    assert relerr(o1[2], got[:1]) < 1e-5            # (the same sample at another batch size: other tiles and splits, same math)
+  # (iv) a fused training step in between: the next inference forward sees the stepped weights and the new running statistics
+  image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(2, 0, 2)]
+  m.train(); m.train_step(image, v2s, off, grid.to(t.int32), "iou_fgbg", lr=1e-2, adam_eps=1e-4); m.eval()
+  with t.no_grad():
+    got2 = m(*batches[0])
+    assert t.equal(got2, eager(batches[0])) and not t.equal(got2, got)
+    assert t.equal(m(*batches[0]), got2)
+
+
 @pytest.mark.parametrize("math", MATHS)
 @pytest.mark.parametrize("B,nbt", [(2, 0), (4, 30000)])
 def test_run_to_run_gradient_spread_default_mode(math, B, nbt):
