@@ -297,7 +297,10 @@ class CoreNet(nn.Module):
     m = int(resolution_multiplier)
     if m > 0 and n != m ** 3:
       raise ValueError("resolution_multiplier**3 offsets expected")
-    self.engine.weights_dirty = True
+    ver = (self.engine.store.params._version, self.engine.store.buffers._version)     # (as in forward(): inference keeps its packs)
+    if ver != self._packed_version:
+      self.engine.weights_dirty = True
+      self._packed_version = ver
     plan = self.engine.plan(B)
     v2s = voxel_projection_matrix.to(t.float32).contiguous()
     offs = grid_offsets.to(t.float32).contiguous()
