@@ -72,6 +72,7 @@ _SIGS = {
     "crn_bf3_operands": [vp, vp, i32, i64, vp, vp],
     "crn_splitk_defer": [i32],
     "crn_splitk_reserve": [i64, vp],
+    "crn_splitk_release": [vp],
     "crn_set_deterministic": [i32],
     "crn_roctx_push": [C.c_char_p],
     "crn_roctx_pop": [],

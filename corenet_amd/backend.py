@@ -160,6 +160,12 @@ class HipBackend:
     """Give `stream` its split-K scratch ahead of a HIP-graph capture (crn_splitk_reserve)."""
     self.lib.crn_splitk_reserve(int(floats), stream.cuda_stream)
 
+  def splitk_release(self, stream: t.cuda.Stream):
+    """Give the split-K scratch of `stream` back (crn_splitk_release) and forget its BatchRenorm workspace."""
+    self.lib.crn_splitk_release(stream.cuda_stream)
+    for k in [k for k in self._ws if k[0] == "bn@%x" % stream.cuda_stream]:
+      del self._ws[k]
+
   def bf3_operands(self, packed: t.Tensor, table, out: t.Tensor):
     """table = (desc int64 [n, 6] on the device, total workgroups): conv_geometry.operand_table."""
     desc, blocks = table

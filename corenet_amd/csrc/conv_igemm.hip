@@ -24,6 +24,7 @@
 //    (crnInTransform), so normalised activations are never written to HBM.
 #include "conv_kernels.h"
 #include <algorithm>
+#include <mutex>
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
@@ -553,7 +554,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_plain_kernel(float* y, int6
 constexpr int kSkSlots = 64;
 struct SkSlot { int dev; hipStream_t st; float* buf; size_t cap; bool used; };
 SkSlot g_sk_slots[kSkSlots] = {};
+std::mutex g_sk_mu;                      // the table is shared by every host thread that launches (autograd worker, main)
 float* splitk_scratch(size_t floats, hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_sk_mu);
   constexpr int kSlots = kSkSlots;
   SkSlot* const slots = g_sk_slots;
   typedef SkSlot Slot;
@@ -701,11 +704,28 @@ extern "C" int crn_splitk_reserve(int64_t floats, crnStream stream) {
   int dev = 0;
   CRN_HIP(hipGetDevice(&dev));
   size_t want = floats > 0 ? (size_t)floats : 0;
-  if (!want)
+  if (!want) {
+    std::lock_guard<std::mutex> lock(g_sk_mu);
     for (int i = 0; i < kSkSlots; ++i)
       if (g_sk_slots[i].used && g_sk_slots[i].dev == dev) want = std::max(want, g_sk_slots[i].cap);
+  }
   if (!want) return CRN_OK;
   return splitk_scratch(want, (hipStream_t)stream) ? CRN_OK : CRN_ENOMEM;
+}
+// Gives back the scratch of a stream that is about to be destroyed (a capture stream whose graphs are gone); hipFree waits for
+// the device, so nothing that still reads the buffer can be running.  Unknown streams are not an error.
+extern "C" int crn_splitk_release(crnStream stream) {
+  int dev = 0;
+  CRN_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_sk_mu);
+  for (int i = 0; i < kSkSlots; ++i) {
+    SkSlot& sl = g_sk_slots[i];
+    if (sl.used && sl.dev == dev && sl.st == (hipStream_t)stream) {
+      if (sl.buf) CRN_HIP(hipFree(sl.buf));
+      sl = SkSlot{};
+    }
+  }
+  return CRN_OK;
 }
 int* crn_splitk_counters(size_t n) { return splitk_counters(n); }
 int crn_splitk_reduce(const crnView& y, const float* scratch, int splits, int accumulate, hipStream_t st) {

@@ -263,8 +263,7 @@ class CoreNet(nn.Module):
       if plan.eval_graph is None and plan.eval_eager >= 2 and not eng.weights_dirty:
         plan.in_image.copy_(image); plan.in_v2s.copy_(v2s); plan.in_off.copy_(off)
         g = t.cuda.CUDAGraph()
-        cap = t.cuda.Stream(device=eng.device)
-        eng.be.splitk_reserve(cap)
+        cap = eng.capture_stream()
         cap.wait_stream(t.cuda.current_stream())
         with t.cuda.graph(g, stream=cap), _lib.pinned_stream(cap):
           plan.forward(plan.in_image, plan.in_v2s, plan.in_off, training=False)
@@ -422,8 +421,7 @@ class CoreNet(nn.Module):
       return plan.loss
     if g is None:
       g = t.cuda.CUDAGraph()
-      cap = t.cuda.Stream(device=eng.device)
-      eng.be.splitk_reserve(cap)                   # (the split-K scratch is per stream and cannot grow inside a capture)
+      cap = eng.capture_stream()
       cap.wait_stream(t.cuda.current_stream())
       with t.cuda.graph(g, stream=cap), _lib.pinned_stream(cap):      # (the library calls follow the capture stream)
         self._step_body(plan, loss)

@@ -240,11 +240,30 @@ class Engine:
     self.dgrad_dirty = True
     self.weights_dirty = True
     self._side = False             # created on first use (side_stream)
+    self._capture = None           # created on first use (capture_stream)
     self._pack_ev = self._dgrad_packed = self._dec_packed = self._enc_late_packed = None
     self._enc_late_pending = False     # the side stream still owes the main stream: encoder stage 3-5 weights,
     self._dec_pack_pending = False     # ... the decoder's forward weights,
     self._dgrad_pack_pending = False   # ... the data-gradient weights;
     self._gpacked_zeroed = False       # the packed gradient slab was zeroed (on the side stream) for the next backward
+
+  def capture_stream(self):
+    """The ONE stream every HIP graph of this engine is captured on (fused training steps, inference forwards of every batch
+    size): a capture stream owns a split-K scratch slot (>= 16 MB, 64 per process) and a BatchRenorm workspace, so one per
+    captured graph would leak both.  Replays run on the caller's stream; graphs of one engine are replayed one
+    after the other."""
+    if self._capture is None:
+      self._capture = t.cuda.Stream(device=self.device)
+      # the largest scratch the library ever uses (256 MB; larger reductions take the atomic path), once: a scratch that grew for a
+      # later capture would be freed under the graphs captured before
+      self.be.splitk_reserve(self._capture, floats=(256 << 20) // 4)
+    return self._capture
+
+  def release_graph_resources(self):
+    """Drops the capture stream's scratch (after the graphs captured on it were reset)."""
+    if self._capture is not None:
+      self.be.splitk_release(self._capture)
+      self._capture = None
 
   def side_stream(self):
     """The engine's second HIP stream (weight gradients, weight packs, gradient buckets) or None (CPU emulator,

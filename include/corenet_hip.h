@@ -153,6 +153,9 @@ int crn_splitk_defer(int on);
 /* Split-K scratch is kept per (device, stream) and grown on demand -- which a stream under HIP-graph capture cannot do.
  * Call this BEFORE the capture: reserves `floats` (or, with 0, as much as any stream of the device has needed so far).  */
 int crn_splitk_reserve(int64_t floats, crnStream stream);
+/* Releases the scratch of `stream` (call before destroying a stream that was given one; waits for the device).  The table of
+ * per-stream scratch buffers holds 64 entries per process and is guarded by a mutex.                                      */
+int crn_splitk_release(crnStream stream);
 
 /* Weight gradient in the same packed layout:
  *   dw[(c*T+t)*Npad+n] = sum_{b,o} T(x)[b,c,o-pad_lo+t] * dy[b,n,o]
