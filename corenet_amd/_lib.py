@@ -139,7 +139,9 @@ _SIZE_FNS = {
 _PTR_FNS = {
     "crn_loss_status_ptr": [vp, i32],
 }
-ALL_SYMBOLS = list(_SIGS) + list(_SIZE_FNS) + list(_PTR_FNS) + ["crn_version"]
+# tuning aids of tools/ (reached through `.cdll`, no error check: they return CRN_EINVAL unless their switch is set)
+_DEBUG_FNS = ["crn_bf3_debug_stamps", "crn_ring_debug_stamps", "crn_e2d_debug_stamps", "crn_pw_debug_stamps"]
+ALL_SYMBOLS = list(_SIGS) + list(_SIZE_FNS) + list(_PTR_FNS) + _DEBUG_FNS + ["crn_version"]
 
 
 class _Lib:

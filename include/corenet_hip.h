@@ -496,6 +496,15 @@ int crn_zero_f32(float* p, int64_t n, crnStream s);
 int crn_add_i64(int64_t* p, int n, int64_t v, crnStream s);
 const char* crn_version(void);
 
+/* Tuning aids (not part of the drop-in surface; tools/ only): shader-clock stamps of workgroup 0 of the last launch of the
+ * split-bf16 decoder kernels (CRN_BF3_STAMPS=1), the ring-buffered form (CRN_RING_STAMPS=1: 16 + 4 * 256 + 16 values), the
+ * encoder engine (CRN_E2D_DBG=16) and the pointwise kernel (CRN_PW_STAMPS=1), copied to the host after a device synchronize.
+ * CRN_EINVAL when the corresponding switch was not set.                                                               */
+int crn_bf3_debug_stamps(long long* out192);
+int crn_ring_debug_stamps(long long* out1056);
+int crn_e2d_debug_stamps(long long* out32);
+int crn_pw_debug_stamps(long long* out32);
+
 #ifdef __cplusplus
 }
 #endif
