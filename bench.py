@@ -323,8 +323,8 @@ def main():
         # silently empty number (tools/pmc_traffic.sh regenerates the file)
         print(f"bench.py: {traffic_file} has no record for {missing} (kernel names / grids changed?) -- "
               f"re-run tools/pmc_traffic.sh; roofline.traffic = null for those", file=sys.stderr)
-  # ground-truth side: fill_voxels on 3 hollow shells per sample, whole call (the single-launch kernel +
-  # the conditional rescue kernel) timed with HIP events; the kernel-only time is in profiles/
+  # ground-truth side: fill_voxels on 3 hollow shells per sample, whole call (one launch) timed with HIP
+  # events; the kernel-only time is in profiles/
   ax = t.arange(128, device=dev, dtype=t.float32) - 63.5
   dist3 = (ax[:, None, None] ** 2 + ax[None, :, None] ** 2 + ax[None, None, :] ** 2).sqrt()
   shells = t.stack([((dist3 <= r) & (dist3 > r - 1.5)).float() for r in (10, 30, 50)] * B)
@@ -333,7 +333,7 @@ def main():
   for _ in range(2):
     be.fill_voxels(shells, filled)
   e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
-  # the call is asynchronous (kernel + a rescue kernel that returns at once); a host-side synchronize on this shared
+  # the call is asynchronous; a host-side synchronize on this shared
   # host occasionally takes tens of milliseconds whatever was launched, so: median of 9 timed calls
   fill_times = []
   for _ in range(9):

@@ -15,6 +15,8 @@
 // HBM traffic: read grid once, write result once (+ 2 bits/voxel of bitmaps).
 #include "crn_common.h"
 #include <algorithm>
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -219,28 +221,28 @@ __device__ int relax_slab(const u64* El, u64* Rl, int nz, int H) {
   return any;
 }
 
+// Control block of one grid for the single-launch kernel (fill_fused_kernel): one word per exchange round -- arrivals
+// in the low 16 bits, "my slab changed" votes in the high 16 -- and one departure counter per round.  The block is
+// all zeros between calls: the last slab to LEAVE a round clears that round's two words (everybody else has read the
+// final value by then), so no memset precedes a call; after a failed launch the rescue kernel clears the blocks
+// (and the status words behind them).  The blocks live in a buffer owned by the library (zeroed once, when it is
+// allocated), keyed by the caller's workspace pointer -- the caller's workspace may hold anything.
+constexpr int kFusedIters = 64;
+struct FusedCtl { unsigned word[kFusedIters]; unsigned depart[kFusedIters]; unsigned exits, raised, pad[2]; };   // per grid
+// exits / raised: used in the block of a launch's FIRST grid -- workgroups that have left the launch, and "a workgroup
+// gave up" (a partner never arrived, or the round limit): the last workgroup out then redoes the launch's grids itself.
+
 // ---- device-side rescue path ---------------------------------------------------------------------
-// Enqueued behind the single-launch kernel on every call; returns at once unless that kernel raised its
-// status word (a partner workgroup was not resident, or more slab exchanges were needed than kFusedIters).
-// One workgroup per grid: pack -> sweep the slabs of the grid through LDS until a whole pass changes
-// nothing -> unpack.  No inter-workgroup dependency, so it always terminates; the host never has to look
-// at the status, i.e. crn_fill_voxels stays asynchronous (the reference op is: fill_voxels_gpu.cu:158-165).
-// Reads `grid` again: a failed single-launch kernel leaves each grid either untouched or (in place, some
-// slabs) already at the final answer, and the fill is idempotent on such a mix (empties only shrink to
-// the reached set), so the result is the same fixed point.
+// Runs inside the single-launch kernel when one of its workgroups gave up (a partner workgroup was not resident within
+// the spin bound, or more slab exchanges were needed than the round limit) -- see the end of fill_fused_kernel -- and
+// as a kernel of its own for tests (CRN_FILL_RESCUE=1).
+// One grid, one workgroup (any size): pack -> sweep the slabs of the grid through LDS until a whole pass changes
+// nothing -> unpack.  sm: (2 * zs + 2) planes of LDS.
 template <typename T, int WX>
-__global__ __launch_bounds__(512) void fill_rescue_kernel(const T* grid, T* out, u64* E, u64* R, int D, int H, int W,
-                                                          int zs, int nslabs, const int* status, int force) {
-  extern __shared__ __attribute__((aligned(16))) u64 sm[];
-  if (!force && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
-  const int n = blockIdx.x;
+__device__ void rescue_grid(const T* gsrc, T* gdst, u64* Eg, u64* Rg, int D, int H, int W, int zs, int nslabs, u64* sm) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int rowsz = H * WX;
   const int64_t gwords = (int64_t)D * rowsz;
-  u64* Eg = E + n * gwords;
-  u64* Rg = R + n * gwords;
-  const T* gsrc = grid + (int64_t)n * D * H * W;
-  T* gdst = out + (int64_t)n * D * H * W;
   for (int64_t wi = wave; wi < gwords; wi += nwaves) {          // fill_pack_kernel for this grid
     const int k = (int)(wi % WX);
     const int64_t row = wi / WX;                                // z*H + y
@@ -287,6 +289,17 @@ __global__ __launch_bounds__(512) void fill_rescue_kernel(const T* grid, T* out,
     const u64 outside = Eg[wi] & Rg[wi];
     if (x < W) gdst[row * W + x] = ((outside >> lane) & 1ull) ? (T)0 : (T)1;
   }
+  __syncthreads();
+}
+
+template <typename T, int WX>
+__global__ __launch_bounds__(512) void fill_rescue_kernel(const T* grid, T* out, u64* E, u64* R, int D, int H, int W,
+                                                          int zs, int nslabs) {
+  extern __shared__ __attribute__((aligned(16))) u64 sm[];
+  const int n = blockIdx.x;
+  const int64_t gwords = (int64_t)D * H * WX;
+  rescue_grid<T, WX>(grid + (int64_t)n * D * H * W, out + (int64_t)n * D * H * W, E + n * gwords, R + n * gwords, D, H, W, zs,
+                     nslabs, sm);
 }
 
 // ---- wave-level plane closure (single-launch path) --------------------------------------------
@@ -437,18 +450,14 @@ __device__ int relax_slab_waves(const u64* El, u64* Rl, int nz, int H) {
 // writes the {0,1} result from LDS: 8 B/voxel of HBM traffic for fp32, no bitmap round trip, no host
 // synchronisation.  The slabs of one grid meet at a counter barrier once per exchange; the host
 // launches at most as many workgroups as are co-resident (<= 1 per CU), so the spin-wait cannot
-// starve a workgroup that has not started.  A bounded spin plus an iteration cap turn any surprise
-// into status != 0, and the caller falls back to the multi-launch path.
-constexpr int kFusedIters = 64;
-struct FusedCtl { int count[kFusedIters]; int flag[kFusedIters]; };   // per grid
+// starve a workgroup that has not started.  A bounded spin plus a round limit turn any surprise into the launch's
+// `raised` flag, and the last workgroup to leave the launch redoes its grids alone (rescue_grid).
 
-__device__ __forceinline__ int ld_acquire(const int* p) {
-  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 template <typename T, int WX>
 __global__ __launch_bounds__(1024) void fill_fused_kernel(const T* grid, T* out, int D, int H, int W, int zs,
-                                                         int nslabs, u64* halo, FusedCtl* ctl, int* status) {
+                                                         int nslabs, u64* halo, FusedCtl* ctl, u64* E, u64* R,
+                                                         int max_rounds, int fused_relaxed) {
   extern __shared__ __attribute__((aligned(16))) u64 sm[];
   const int slab = blockIdx.x % nslabs, n = blockIdx.x / nslabs;
   const int z0 = slab * zs, nz = min(zs, D - z0);
@@ -530,6 +539,33 @@ __global__ __launch_bounds__(1024) void fill_fused_kernel(const T* grid, T* out,
   T* gdst = out + ((int64_t)n * D + z0) * H * W;
   // unpack + store from the LDS bitmaps (an in-place call overwrites its input only here)
   auto store_slab = [&]() {
+    // 16-byte path (same condition as the load): the slab is one flat array of 64-voxel words, word w = El[w]; 16 lanes
+    // write the 64 voxels of a word as float4s, a wave 4 words per instruction -- a quarter of the store instructions
+    // of the one-voxel-per-lane path below (the store phase was bound by their rate, like the load phase before it)
+    if (vec4 && (reinterpret_cast<uintptr_t>(gdst) & 15) == 0) {
+      typedef T __attribute__((ext_vector_type(4))) T4;
+      T4* d4 = reinterpret_cast<T4*>(gdst);
+      const int nwords = nrows * WX, sub = lane >> 4, q4 = lane & 15;
+      constexpr int NU = 4;
+      for (int w0 = wave * 4 * NU; w0 < nwords; w0 += nwaves * 4 * NU) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+          const int w = w0 + j * 4 + sub;
+          if (w < nwords) {
+            const u64 outside = El[w] & Rl[rowsz + w];
+            const unsigned nib = (unsigned)(outside >> (4 * q4)) & 15u;
+            T4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ((nib >> i) & 1u) ? (T)0 : (T)1;
+            // written through (sc0 sc1): the result is not read again by this launch, and lines left dirty in the L2s are
+            // written back at the end of the kernel, when nothing else runs (52.6 -> 50.3 us per call against nt stores)
+            if constexpr (sizeof(T) == 4)
+              asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(d4 + (int64_t)w * 16 + q4), "v"(v) : "memory");
+          }
+        }
+      }
+      return;
+    }
     for (int r0 = wave; r0 < nrows; r0 += nwaves) {
 #pragma unroll
       for (int k = 0; k < WX; ++k) {
@@ -541,39 +577,68 @@ __global__ __launch_bounds__(1024) void fill_fused_kernel(const T* grid, T* out,
   };
   bool ok = true;
   int pend = 0;
-  for (int it = 0; it < kFusedIters; ++it) {
+  // the departure from a round (which clears its words) is issued by lane 0 of wave 1 and looked at one round later,
+  // when the counter's old value has long arrived: off the critical path of the round
+  const bool janitor = threadIdx.x == 64;
+  unsigned dep_old = 0; int dep_it = -1;
+  auto dep_finish = [&]() {
+    if (janitor && dep_it >= 0) {
+      if (dep_old == (unsigned)nslabs - 1u) {
+        __hip_atomic_store(&c->word[dep_it], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&c->depart[dep_it], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      dep_it = -1;
+    }
+  };
+  for (int it = 0; it < max_rounds; ++it) {
     const int any = (it == 0 || pend) ? relax_slab_waves<WX>(El, Rl, nz, H) : 0;
     if (nslabs == 1) break;
+    dep_finish();
     // publish my boundary planes, then meet the other slabs of this grid
     u64* mine = hb + ((int64_t)(it & 1) * nslabs + slab) * 2 * rowsz;
     for (int i = threadIdx.x; i < rowsz; i += blockDim.x) {
-      mine[i] = Rl[rowsz + i];
-      mine[rowsz + i] = Rl[(size_t)nz * rowsz + i];
+      __hip_atomic_store(mine + i, Rl[rowsz + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mine + rowsz + i, Rl[(size_t)nz * rowsz + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // The exchange never touches the caches' maintenance instructions.  Plane words are agent-scope atomic stores (written
+    // through to the agent's coherence point) and agent-scope atomic loads (which bypass the non-coherent caches); every
+    // wave waits for its own stores to be acknowledged, the workgroup barrier collects the waves, and only then does
+    // thread 0 announce the slab with ONE relaxed read-modify-write (arrival + vote in one word; separate count / flag words
+    // cost two more memory round trips per round) and poll with relaxed loads.  The release / acquire form of the same
+    // protocol (CRN_FILL_RELAXED=0: buffer_wbl2 + buffer_inv at agent scope) writes back every dirty line this XCD's L2
+    // holds -- the previous call's output, other kernels' data -- before the arrival counts: 3.4 us per round against
+    // 0.8 us, 62-64 us per call against 54-58 (12 x 128^3).
+    // The words of round `it` are those of round it - kFusedIters, cleared long ago by that round's last leaver.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ int s_go;
+    unsigned* wp = &c->word[it & (kFusedIters - 1)];
     if (threadIdx.x == 0) {
-      if (any || it == 0) __hip_atomic_fetch_or(&c->flag[it], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(&c->count[it], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(wp, 1u + ((any || it == 0) ? 0x10000u : 0u), fused_relaxed ? __ATOMIC_RELAXED : __ATOMIC_RELEASE,
+                             __HIP_MEMORY_SCOPE_AGENT);
       int spins = 0;
-      // spin on relaxed agent-scope loads (they bypass the non-coherent caches); ONE acquire when the count is
-      // complete -- an acquire per poll invalidates this XCD's L2 every time round the loop
-      while (__hip_atomic_load(&c->count[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nslabs && ++spins < (1 << 22))
+      unsigned v;
+      while (((v = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xFFFFu) < (unsigned)nslabs &&
+             ++spins < (1 << 22))
         __builtin_amdgcn_s_sleep(2);
-      const int arrived = ld_acquire(&c->count[it]);
-      s_go = arrived < nslabs ? -1 : ld_acquire(&c->flag[it]);
+      if (!fused_relaxed) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      s_go = (v & 0xFFFFu) < (unsigned)nslabs ? -1 : (int)(v >> 16);
     }
     __syncthreads();
     const int go = s_go;
     __syncthreads();
+    if (janitor && go >= 0) {
+      dep_old = __hip_atomic_fetch_add(&c->depart[it & (kFusedIters - 1)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      dep_it = it & (kFusedIters - 1);
+    }
     if (go < 0) { ok = false; break; }          // a partner never arrived (should not happen)
     if (go == 0) break;                         // no slab of this grid changed: fixed point
-    if (it + 1 == kFusedIters) { ok = false; break; }
-    // neighbours' boundary planes -> halos (acquire above made them visible)
+    if (it + 1 == max_rounds) { ok = false; break; }
+    // neighbours' boundary planes -> halos
     const u64* par = hb + (int64_t)(it & 1) * nslabs * 2 * rowsz;
     for (int i = threadIdx.x; i < rowsz; i += blockDim.x) {
-      if (slab > 0) Rl[i] = __builtin_nontemporal_load(par + ((int64_t)(slab - 1) * 2 + 1) * rowsz + i);
-      if (slab + 1 < nslabs) Rl[(size_t)(nz + 1) * rowsz + i] = __builtin_nontemporal_load(par + ((int64_t)(slab + 1) * 2) * rowsz + i);
+      if (slab > 0) Rl[i] = __hip_atomic_load(par + ((int64_t)(slab - 1) * 2 + 1) * rowsz + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (slab + 1 < nslabs) Rl[(size_t)(nz + 1) * rowsz + i] = __hip_atomic_load(par + ((int64_t)(slab + 1) * 2) * rowsz + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     // does a halo reach an empty, not yet reached voxel of my boundary planes?  If not, this slab is at its fixed
@@ -585,35 +650,80 @@ __global__ __launch_bounds__(1024) void fill_fused_kernel(const T* grid, T* out,
     }
     pend = __syncthreads_or(pnd);
   }
-  // on failure this workgroup writes nothing and raises the status word: the rescue kernel enqueued behind this
-  // launch (fill_rescue_kernel) redoes the call
-  if (!ok) {
-    if (threadIdx.x == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
+  // A workgroup that gave up writes nothing and raises the launch's flag.  Every workgroup, once its own stores are
+  // acknowledged, counts itself out; the last one out looks at the flag and, if it is up, redoes the launch's grids
+  // alone (rescue_grid: no inter-workgroup dependency, so it always terminates; the host never has to look, i.e.
+  // crn_fill_voxels stays asynchronous like the reference op, fill_voxels_gpu.cu:158-165).  It reads `grid` again: a
+  // failed launch leaves each grid either untouched or (in place, some slabs) already at the final answer, and the fill
+  // is idempotent on such a mix (empties only shrink to the reached set), so the result is the same fixed point.
+  // The control blocks are all zeros again when the launch ends, whatever happened.
+  FusedCtl* L = ctl;                                        // the launch's words live in its first grid's block
+  if (ok) { store_slab(); dep_finish(); }
+  else if (threadIdx.x == 0) __hip_atomic_store(&L->raised, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    const unsigned left = __hip_atomic_fetch_add(&L->exits, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int last = left == gridDim.x - 1u, redo = 0;
+    if (last) {
+      redo = __hip_atomic_load(&L->raised, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+      if (!redo) __hip_atomic_store(&L->exits, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_last = last && redo;
   }
-  store_slab();
+  __syncthreads();
+  if (!s_last) return;
+  const int G = gridDim.x / nslabs;
+  const int64_t gwords = (int64_t)D * rowsz;
+  const int nsl = (D + zs - 1) / zs;
+  for (int g = 0; g < G; ++g)
+    rescue_grid<T, WX>(grid + (int64_t)g * D * H * W, out + (int64_t)g * D * H * W, E + g * gwords, R + g * gwords, D, H, W, zs,
+                       nsl, sm);
+  unsigned* cw = reinterpret_cast<unsigned*>(ctl);
+  for (int i = threadIdx.x; i < (int)(G * sizeof(FusedCtl) / 4); i += blockDim.x)
+    __hip_atomic_store(cw + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 
 
 constexpr int CRN_EAGAIN = -1000;     // internal: use the multi-launch path
+
+// Control buffer of the single-launch path for one caller workspace: allocated and zeroed (on the call's stream) the
+// first time that workspace is seen or when it has to grow -- that call cannot be part of a stream capture, every
+// later one can.  Calls that share a workspace are ordered by the caller anyway (they share its bitmaps and halos).
+struct FillControl { const void* ws; char* buf; size_t bytes; };
+std::mutex g_fill_mu;
+std::vector<FillControl> g_fill_controls;
+char* fill_control(const void* ws, size_t bytes, hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_fill_mu);
+  FillControl* slot = nullptr;
+  for (auto& f : g_fill_controls) if (f.ws == ws) slot = &f;
+  if (slot && slot->bytes >= bytes) return slot->buf;
+  const size_t want = std::max(bytes, (size_t)64 * 1024);
+  char* buf = nullptr;
+  if (hipMalloc(&buf, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipMemsetAsync(buf, 0, want, st) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(buf); return nullptr; }
+  if (slot) { (void)hipFree(slot->buf); slot->buf = buf; slot->bytes = want; }      // (hipFree waits for the device)
+  else g_fill_controls.push_back({ws, buf, want});
+  return buf;
+}
 constexpr size_t kSweepLds = 144 * 1024;
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 inline size_t fused_offset(int64_t nwords) { return 2 * align256((size_t)nwords * 8) + 4096 * sizeof(int) + 256; }
 
 template <typename T, int WX>
 int launch_fused(const T* grid, T* out, int G, int D, int H, int W, int zs, int nslabs, size_t lds, u64* halo,
-                 FusedCtl* ctl, int* status, hipStream_t st) {
+                 FusedCtl* ctl, u64* E, u64* R, int max_rounds, int relaxed, hipStream_t st) {
   auto k = fill_fused_kernel<T, WX>;
   if (lds > 65536) CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k, dim3(G * nslabs), dim3(1024), lds, st, grid, out, D, H, W, zs, nslabs, halo, ctl, status);
+  hipLaunchKernelGGL(k, dim3(G * nslabs), dim3(1024), lds, st, grid, out, D, H, W, zs, nslabs, halo, ctl, E, R, max_rounds, relaxed);
   CRN_CHECK_LAUNCH();
   return CRN_OK;
 }
 
 template <typename T, int WX>
-int launch_rescue(const T* grid, T* out, u64* E, u64* R, int N, int D, int H, int W, const int* status, int force,
-                  hipStream_t st) {
+int launch_rescue(const T* grid, T* out, u64* E, u64* R, int N, int D, int H, int W, hipStream_t st) {
   const size_t plane = (size_t)H * WX * 8;
   int zs = (int)std::min<size_t>((size_t)D, (kSweepLds / plane - 2) / 2);
   if (zs < 1) return CRN_EINVAL;
@@ -622,13 +732,13 @@ int launch_rescue(const T* grid, T* out, u64* E, u64* R, int N, int D, int H, in
   const size_t lds = (size_t)(2 * zs + 2) * plane;
   auto k = fill_rescue_kernel<T, WX>;
   if (lds > 65536) CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k, dim3(N), dim3(512), lds, st, grid, out, E, R, D, H, W, zs, nslabs, status, force);
+  hipLaunchKernelGGL(k, dim3(N), dim3(512), lds, st, grid, out, E, R, D, H, W, zs, nslabs);
   CRN_CHECK_LAUNCH();
   return CRN_OK;
 }
 
-// Single-launch kernel + the rescue kernel behind it: nothing here waits for the GPU.
-// CRN_FILL_RESCUE=1 (tests): skip the single-launch kernel and run the rescue path alone.
+// ONE launch per call (per G grids): the single-launch kernel carries its own rescue path (its last workgroup out);
+// nothing here waits for the GPU.  CRN_FILL_RESCUE=1 (tests): run the rescue body alone, one workgroup per grid.
 template <typename T>
 int run_fill_fused(const T* grid, T* out, int N, int D, int H, int W, int WX, void* ws, hipStream_t st) {
   static const bool off = getenv("CRN_FILL_MULTI") != nullptr;
@@ -655,25 +765,28 @@ int run_fill_fused(const T* grid, T* out, int N, int D, int H, int W, int WX, vo
   u64* E = reinterpret_cast<u64*>(ws);
   u64* R = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + align256((size_t)nwords * 8));
   char* base = reinterpret_cast<char*>(ws) + fused_offset(nwords);
-  FusedCtl* ctl = reinterpret_cast<FusedCtl*>(base);
-  // status word in device memory right behind the control blocks (cleared by the same memset); only the rescue
-  // kernel reads it
-  int* status = reinterpret_cast<int*>(base + align256((size_t)N * sizeof(FusedCtl)));
+  // control blocks: library-owned, all zeros between calls (see FusedCtl) -- no memset in front of the launch
+  char* cbase = fill_control(ws, align256((size_t)N * sizeof(FusedCtl)), st);
+  if (!cbase) return CRN_ENOMEM;
+  FusedCtl* ctl = reinterpret_cast<FusedCtl*>(cbase);
   u64* halo = reinterpret_cast<u64*>(base + align256((size_t)N * sizeof(FusedCtl)) + 256);
-  CRN_HIP(hipMemsetAsync(base, 0, align256((size_t)N * sizeof(FusedCtl)) + 256, st));
+  // rounds: bounded only to bound a launch's run time (tests: CRN_FILL_MAXROUNDS forces the failure path)
+  static const int max_rounds = getenv("CRN_FILL_MAXROUNDS") ? std::max(2, atoi(getenv("CRN_FILL_MAXROUNDS"))) : (1 << 16);
+  static const int relaxed = (getenv("CRN_FILL_RELAXED") && atoi(getenv("CRN_FILL_RELAXED")) == 0) ? 0 : 1;
   const int64_t gstride = (int64_t)D * H * W;
   const int64_t hstride = (int64_t)nslabs * 2 * 2 * H * WX;
   for (int g0 = 0; g0 < N && !rescue_only; g0 += G) {
     const int Gn = std::min(G, N - g0);
     int rc = CRN_EINVAL;
 #define CRN_FUSED(K) case K: rc = launch_fused<T, K>(grid + g0 * gstride, out + g0 * gstride, Gn, D, H, W, zs, nslabs, lds, \
-                                                     halo + g0 * hstride, ctl + g0, status, st); break;
+                                                     halo + g0 * hstride, ctl + g0, E + g0 * (int64_t)D * H * WX, R + g0 * (int64_t)D * H * WX, max_rounds, relaxed, st); break;
     switch (WX) { CRN_FUSED(1) CRN_FUSED(2) CRN_FUSED(3) CRN_FUSED(4) CRN_FUSED(5) CRN_FUSED(6) CRN_FUSED(7) CRN_FUSED(8) }
 #undef CRN_FUSED
     if (rc != CRN_OK) return rc;
   }
+  if (!rescue_only) return CRN_OK;
   int rc = CRN_EINVAL;
-#define CRN_RESCUE(K) case K: rc = launch_rescue<T, K>(grid, out, E, R, N, D, H, W, status, rescue_only ? 1 : 0, st); break;
+#define CRN_RESCUE(K) case K: rc = launch_rescue<T, K>(grid, out, E, R, N, D, H, W, st); break;
   switch (WX) { CRN_RESCUE(1) CRN_RESCUE(2) CRN_RESCUE(3) CRN_RESCUE(4) CRN_RESCUE(5) CRN_RESCUE(6) CRN_RESCUE(7) CRN_RESCUE(8) }
 #undef CRN_RESCUE
   return rc;

@@ -424,8 +424,11 @@ int crn_fill_voxels(const void* grid, void* out, int dtype, int N, int D, int H,
                     void* workspace, size_t workspace_bytes, crnStream s);
 size_t crn_fill_voxels_workspace_bytes(int N, int D, int H, int W);
 /* crn_fill_voxels never waits for the GPU (the reference op is asynchronous too,
- * fill_voxels_gpu.cu:158-165): a single-launch kernel plus a rescue kernel that
- * only does work when the first one raised its device-side status word.        */
+ * fill_voxels_gpu.cu:158-165): ONE kernel launch per call (per 256-CU load of
+ * grids); a workgroup that gives up raises a device-side flag and the last
+ * workgroup to leave the launch redoes its grids.  The launch's control words
+ * live in a buffer owned by the library, keyed by `workspace`: the first call
+ * with a new workspace allocates it (not capturable), later calls are.        */
 
 /* fill_inside_voxels_cpu (cc/module.cc:24-29, cc/fill_voxels_cpu.cc:158-183):
  * HOST memory in and out (out may alias grid), same dtype codes.  Reference CPU

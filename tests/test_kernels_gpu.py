@@ -969,9 +969,10 @@ def test_fill_full_size_shells(be):
 
 
 def test_fill_serpentine_rescue_and_multi_launch_paths(be):
-  """A corridor that snakes up and down z behind every wall needs far more slab exchanges than the
-  single-launch kernel allows: it raises its device-side status word and the rescue kernel enqueued behind
-  it (one workgroup per grid, no host involvement) must deliver the bit-exact answer, also in place.
+  """A corridor that snakes up and down z behind every wall needs hundreds of slab exchanges: the single-launch
+  kernel runs them on its ring of self-cleaning control words (bit-exact, also in place); with the round limit
+  forced down (CRN_FILL_MAXROUNDS) a workgroup gives up, raises the launch's flag, and the last workgroup to leave
+  the launch redoes its grids alone (no second launch, no host involvement): same answer.
   The rescue path and the any-size path (one persistent workgroup per grid on global bitmaps, which replaced the
   multi-launch sweeps and their host-side convergence check) are also run on their own (CRN_FILL_RESCUE /
   CRN_FILL_MULTI) in fresh processes, on random grids of three dtypes."""
@@ -1004,8 +1005,10 @@ def test_fill_serpentine_rescue_and_multi_launch_paths(be):
           "    be.fill_voxels(x, x); assert t.equal(x, out)\n"
           "print('path ok')"
           % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
-  for var in ("CRN_FILL_MULTI", "CRN_FILL_RESCUE"):
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{var: "1"}), capture_output=True,
+  # CRN_FILL_MAXROUNDS=3: most of these grids need more exchange rounds than that -- a workgroup gives up, the last one out
+  # redoes the grids and clears the self-cleaning control blocks for the calls that follow in the same process
+  for var, val in (("CRN_FILL_MULTI", "1"), ("CRN_FILL_RESCUE", "1"), ("CRN_FILL_MAXROUNDS", "3")):
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{var: val}), capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "path ok" in r.stdout, (var, r.stderr[-2000:])
 
@@ -1037,9 +1040,9 @@ def test_fill_any_size_bit_exact(be, shape):
 
 def test_fill_is_asynchronous_graph_capturable(be):
   """crn_fill_voxels never waits for the GPU (the reference op does not either, fill_voxels_gpu.cu:158-165): the
-  whole call -- memset, single-launch kernel, rescue kernel -- is captured into a HIP graph (a host-side
+  whole call -- one kernel launch -- is captured into a HIP graph (a host-side
   synchronisation inside the call would abort the capture) and replayed on new contents of the same buffers,
-  including a serpentine grid that needs the rescue kernel."""
+  including a serpentine grid that needs hundreds of exchange rounds."""
   if _SELF:
     return
   import fill_oracle_c
