@@ -705,7 +705,13 @@ char* fill_control(const void* ws, size_t bytes, hipStream_t st) {
   if (hipMalloc(&buf, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   if (hipMemsetAsync(buf, 0, want, st) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(buf); return nullptr; }
   if (slot) { (void)hipFree(slot->buf); slot->buf = buf; slot->bytes = want; }      // (hipFree waits for the device)
-  else g_fill_controls.push_back({ws, buf, want});
+  else {
+    if (g_fill_controls.size() >= 32) {          // a caller with a new workspace per call: forget the oldest one
+      (void)hipFree(g_fill_controls.front().buf);
+      g_fill_controls.erase(g_fill_controls.begin());
+    }
+    g_fill_controls.push_back({ws, buf, want});
+  }
   return buf;
 }
 constexpr size_t kSweepLds = 144 * 1024;
