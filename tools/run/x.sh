@@ -1,1 +1,2 @@
-python tools/layer_times.py 14 40 bf16x3 2>&1 | grep -v amdgpu > gpurun_out/r04_layers_m9.txt
+DET=1 python tools/run/fg.py 2>&1 | grep -v amdgpu | tail -12 > gpurun_out/r04_fg.log
+python tools/run/fg.py 2>&1 | grep -v amdgpu | tail -12 >> gpurun_out/r04_fg.log
