@@ -8,10 +8,10 @@ min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 15.0
 q = collections.Counter(r["Queue_Id"] for r in rows)
 main = q.most_common(1)[0][0]
 rs = sorted((r for r in rows if r["Queue_Id"] == main), key=lambda r: int(r["Start_Timestamp"]))
-# one steady-state step: between the last two adam kernels
-adam = [i for i, r in enumerate(rs) if "adam" in r["Kernel_Name"]]
-a, b = adam[-2], adam[-1]
-step = rs[a + 1:b + 1]
+# one steady-state step: between the last two image pre-processing kernels (the first launch of a forward)
+first = [i for i, r in enumerate(rs) if "preprocess" in r["Kernel_Name"]]
+a, b = first[-2], first[-1]
+step = rs[a:b]
 t0, t1 = int(step[0]["Start_Timestamp"]), int(step[-1]["End_Timestamp"])
 busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in step) / 1e3
 print(f"main queue {main}: last step {len(step)} launches, span {(t1 - t0) / 1e3:.0f} us, busy {busy:.0f} us, idle {(t1 - t0) / 1e3 - busy:.0f} us")
