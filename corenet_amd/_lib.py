@@ -140,7 +140,7 @@ _PTR_FNS = {
     "crn_loss_status_ptr": [vp, i32],
 }
 # tuning aids of tools/ (reached through `.cdll`, no error check: they return CRN_EINVAL unless their switch is set)
-_DEBUG_FNS = ["crn_bf3_debug_stamps", "crn_ring_debug_stamps", "crn_e2d_debug_stamps", "crn_pw_debug_stamps"]
+_DEBUG_FNS = ["crn_bf3_debug_stamps", "crn_ring_debug_stamps", "crn_e2d_debug_stamps", "crn_pw_debug_stamps", "crn_mfma_probe"]
 ALL_SYMBOLS = list(_SIGS) + list(_SIZE_FNS) + list(_PTR_FNS) + _DEBUG_FNS + ["crn_version"]
 
 

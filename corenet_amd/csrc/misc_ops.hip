@@ -590,6 +590,58 @@ extern "C" int crn_stride2_scatter(const float* dy, float* dx, int B, int C, int
   return CRN_OK;
 }
 
+
+// ---- hardware probe (tools/mfma_neighbour.py) ------------------------------------------------------------
+// A kernel that does nothing but issue v_mfma_f32_16x16x32_bf16 in a fixed pattern (inline assembly: the compiler's scheduler
+// cannot reorder it), to be run beside a victim kernel on another stream:
+//   mode 0  four independent accumulators, round robin                                   (victim exact)
+//   mode 1  ONE accumulator chain: every MFMA's SrcC is the vDst of the MFMA before it, 8 idle cycles in between
+//           (the dependency is left to the hardware)                                       (victim wrong in 29 of 30 runs)
+//   mode 2  two chains interleaved: one other MFMA between dependent ones                 (victim exact)
+//   mode 3  one chain, the dependent MFMA held back by 48 idle cycles in software          (victim exact)
+//   mode 4  two chains interleaved, the two MFMAs of a pair read the same A registers     (victim exact)
+namespace {
+typedef __bf16 probe_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float probe_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(512) void mfma_probe_kernel(int mode, int iters, float* sink) {
+  probe_bf16x8 a0, a1, b0, b1;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a0[i] = (__bf16)(float)((threadIdx.x + i) & 3); a1[i] = (__bf16)(float)((threadIdx.x * 3 + i) & 3);
+    b0[i] = (__bf16)0.25f; b1[i] = (__bf16)0.125f;
+  }
+  probe_f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+#define CRN_PROBE_OPS : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a0), "v"(a1), "v"(b0), "v"(b1)
+  for (int it = 0; it < iters; ++it) {
+    if (mode == 0)
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %4, %6, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %4, %7, %1\n\t"
+                   "v_mfma_f32_16x16x32_bf16 %2, %5, %6, %2\n\tv_mfma_f32_16x16x32_bf16 %3, %5, %7, %3\n\ts_nop 7" CRN_PROBE_OPS);
+    else if (mode == 1)
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %4, %6, %0\n\ts_nop 7\n\tv_mfma_f32_16x16x32_bf16 %0, %5, %7, %0\n\ts_nop 7\n\t"
+                   "v_mfma_f32_16x16x32_bf16 %0, %4, %7, %0\n\ts_nop 7\n\tv_mfma_f32_16x16x32_bf16 %0, %5, %6, %0\n\ts_nop 7" CRN_PROBE_OPS);
+    else if (mode == 2)
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %4, %6, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %5, %7, %1\n\t"
+                   "v_mfma_f32_16x16x32_bf16 %0, %4, %7, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %5, %6, %1\n\ts_nop 7" CRN_PROBE_OPS);
+    else if (mode == 3)
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %4, %6, %0\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\t"
+                   "v_mfma_f32_16x16x32_bf16 %0, %5, %7, %0\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" CRN_PROBE_OPS);
+    else
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %4, %6, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %4, %7, %1\n\t"
+                   "v_mfma_f32_16x16x32_bf16 %0, %5, %6, %0\n\tv_mfma_f32_16x16x32_bf16 %1, %5, %7, %1\n\ts_nop 7" CRN_PROBE_OPS);
+  }
+#undef CRN_PROBE_OPS
+  const probe_f32x4 r = c0 + c1 + c2 + c3;
+  if (r[0] + r[1] + r[2] + r[3] == 123456.f) sink[0] = r[0];      // (keeps the accumulators live)
+}
+}  // namespace
+extern "C" int crn_mfma_probe(int mode, int iters, int workgroups, float* sink, crnStream s) {
+  CRN_ENTRY(s);
+  if (!sink || iters < 1 || workgroups < 1 || mode < 0 || mode > 4) return CRN_EINVAL;
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(workgroups), dim3(512), 0, (hipStream_t)s, mode, iters, sink);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
 static int g_crn_det = -1;
 bool crn_deterministic() {
   if (g_crn_det < 0) { const char* e = getenv("CRN_DETERMINISTIC"); g_crn_det = (e && atoi(e) != 0) ? 1 : 0; }

@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Two kernels alone: a neighbour on the main stream and the ray-sample scatter (64^3, 12 channels) on a side stream, started
+together; the scatter's result is compared with its serial run.  Round 4 found with this pair what made the scatter's sums differ
+from run to run inside the training step: a wave that issues an MFMA while the MFMA that produces its SrcC
+is still in the pipe (a dependent accumulator chain left to the hardware) makes VALU results of OTHER waves on its SIMD go missing
+(lanes 48-63 keep the old register content).
+  neighbour = crn_mfma_probe, a kernel of nothing but v_mfma_f32_16x16x32_bf16 in a fixed order (30 runs each, MI355X):
+    mode 0  four independent accumulators                        0 of 30 scatters wrong
+    mode 1  one chain, 8 idle cycles between dependent MFMAs    29 of 30
+    mode 2  two chains interleaved                               0 of 30
+    mode 3  one chain, 48 idle cycles between dependent MFMAs    0 of 30
+    mode 4  two chains interleaved, shared A registers           0 of 30
+  neighbour = a convolution of the library (tools/bench_conv.py layer keys): `fwd s6c1`, `fwd s6t1`, `dgrad s6t1`, `dgrad s5t1`
+  (bf16x3) 4 ... 30 of 30 wrong; `dgrad s6c1`, `wgrad s6c1`, every fp32 launch: 0 of 30.
+usage: mfma_neighbour.py probe <0..4>
+       mfma_neighbour.py <fwd|dgrad|wgrad> <layer key of tools/bench_conv.py> [fp32|bf16x3]"""
+import os, sys, runpy, io, contextlib, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+mode, key = sys.argv[1], sys.argv[2]
+math = sys.argv[3] if len(sys.argv) > 3 else "bf16x3"
+if mode == "probe":
+  import torch as t0
+  from corenet_amd.backend import HipBackend
+  from corenet_amd import _lib as _l0
+  be = HipBackend()
+  sink = t0.zeros(16, device="cuda")
+  iters = int(os.environ.get("PROBE_ITERS", "3000"))
+  def run():
+    rc = be.lib.cdll.crn_mfma_probe(int(key), iters, 256, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(_l0.stream()))
+    assert rc == 0, rc
+else:
+  sys.argv = ["bench_conv.py", mode, key, "1", "2", math]
+  with contextlib.redirect_stdout(io.StringIO()):
+    G = runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_conv.py"), run_name="aggressor")
+  run, be = G["run"], G["be"]
+import torch as t
+from oracle import corenet_oracle as O
+from corenet_amd import _lib
+B, C, res = 2, 28, 64
+g = t.Generator().manual_seed(0)
+gu = (t.randn(B, C, res, res, res, generator=g) * 1e-6).cuda()
+m = (O.canonical_camera() @ O.scale([1.0 / 128] * 3) @ O.scale([128.0 / res] * 3))[None].expand(B, 4, 4).reshape(B, 16).contiguous().cuda()
+off = t.full((B, 3), 0.5).cuda()
+gmap = t.zeros(B, 12, res, res).cuda()
+def scatter():
+  be.ray_sample_bwd(gu[:, 16:], gu.stride(0), B, 12, res, res, res, m, off, gmap, gmap.stride(0), res, res, True)
+scatter(); t.cuda.synchronize(); ref = gmap.clone()
+side = t.cuda.Stream()
+for delay in (0, 20000, 60000):
+  nbad, worst = 0, 0.0
+  for i in range(30):
+    t.cuda.synchronize()
+    ev = t.cuda.Event(); ev.record()
+    run()
+    with t.cuda.stream(side), _lib.pinned_stream(side):
+      side.wait_event(ev)
+      if delay: t.cuda._sleep(delay)
+      scatter()
+    t.cuda.synchronize()
+    e = float((gmap - ref).abs().max() / ref.abs().max())
+    worst = max(worst, e); nbad += e > 1e-5
+  print(f"neighbour {mode} {key}{'' if mode == 'probe' else ' ' + math}, scatter delayed by _sleep({delay}): {nbad} of 30 scatters off by more than 1e-5 (worst {worst:.1e})")
