@@ -508,8 +508,8 @@ int crn_ring_debug_stamps(long long* out1056);
 int crn_e2d_debug_stamps(long long* out32);
 int crn_pw_debug_stamps(long long* out32);
 /* hardware probe (tools/mfma_neighbour.py): `workgroups` x 512 threads that only issue bf16 MFMAs in a fixed order;
- * mode 0: four independent accumulators, 1: one accumulator chain (every MFMA depends on the one before it, 8 idle cycles between),
- * 2: two chains interleaved, 3: one chain with 48 idle cycles between dependent MFMAs, 4: as 2 with shared A registers.          */
+ * the modes (0 ... 33: independent accumulators, dependent chains with and without idle cycles, interleaved chains) are listed
+ * with their measured effect on a neighbouring kernel in csrc/misc_ops.hip.                                                   */
 int crn_mfma_probe(int mode, int iters, int workgroups, float* sink, crnStream s);
 
 #ifdef __cplusplus

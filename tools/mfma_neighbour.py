@@ -1,18 +1,18 @@
 #!/usr/bin/env python
 """Two kernels alone: a neighbour on the main stream and the ray-sample scatter (64^3, 12 channels) on a side stream, started
 together; the scatter's result is compared with its serial run.  Round 4 found with this pair what made the scatter's sums differ
-from run to run inside the training step: a wave that issues an MFMA while the MFMA that produces its SrcC
-is still in the pipe (a dependent accumulator chain left to the hardware) makes VALU results of OTHER waves on its SIMD go missing
-(lanes 48-63 keep the old register content).
+from run to run inside the training step: MFMA-dense neighbours on the same CU whose MFMAs wait for each
+other (accumulator chains) make VALU results of OTHER waves go missing (lanes 48-63 keep the old register content).
   neighbour = crn_mfma_probe, a kernel of nothing but v_mfma_f32_16x16x32_bf16 in a fixed order (30 runs each, MI355X):
-    mode 0  four independent accumulators                        0 of 30 scatters wrong
-    mode 1  one chain, 8 idle cycles between dependent MFMAs    29 of 30
-    mode 2  two chains interleaved                               0 of 30
-    mode 3  one chain, 48 idle cycles between dependent MFMAs    0 of 30
-    mode 4  two chains interleaved, shared A registers           0 of 30
+    mode 0   four independent accumulators                                              0 of 30 scatters wrong
+    mode 1   one accumulator, four MFMAs per loop trip, 8 idle cycles after each       29 of 30
+    mode 33  the same without the idle cycles                                           0 of 30
+    modes 2, 4 (interleaved chains), 3, 10, 12-15, 20-28, 30, 31 (two-MFMA chains with 0 ... 48 idle cycles, shared A or B
+    registers), 32 (the split-bf16 triple back to back)                                 0 of 30 each
+  -- one pattern does it reliably, its nearest relatives do not; the exact condition is not pinned down.
   neighbour = a convolution of the library (tools/bench_conv.py layer keys): `fwd s6c1`, `fwd s6t1`, `dgrad s6t1`, `dgrad s5t1`
   (bf16x3) 4 ... 30 of 30 wrong; `dgrad s6c1`, `wgrad s6c1`, every fp32 launch: 0 of 30.
-usage: mfma_neighbour.py probe <0..4>
+usage: mfma_neighbour.py probe <mode>
        mfma_neighbour.py <fwd|dgrad|wgrad> <layer key of tools/bench_conv.py> [fp32|bf16x3]"""
 import os, sys, runpy, io, contextlib, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
