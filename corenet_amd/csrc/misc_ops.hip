@@ -602,8 +602,12 @@ extern "C" int crn_stride2_scatter(const float* dy, float* dx, int B, int C, int
 //   mode 3   one accumulator, two MFMAs per trip, 48 idle cycles after each; 12-15: 16-40; 20-28: 1-12       exact
 //   mode 10  one accumulator, two MFMAs per trip back to back; 30 / 31: sharing the A / the B registers      exact
 //   mode 32  the split-bf16 triple (a0,b0) (a0,b1) (a1,b0) on one accumulator, then on the next, back to back exact
-// i.e. one pattern of dependent MFMAs with small gaps does it, reliably, and its nearest relatives do not: the effect is there, its
-// exact condition is not pinned down (the library's kernels have LDS reads and address arithmetic between dependent MFMAs).
+//   modes 40-43  mode 1 with 1, 2, 4, 6 idle cycles after each MFMA                                          exact
+//   modes 44-47  mode 1 with 12, 16, 24, 32 idle cycles                                             wrong in 28-29 of 30
+//   mode 48  three MFMAs per trip, 8 idle cycles after each                                          wrong in 29 of 30
+// i.e. three or more dependent MFMAs in a row with 8 or more idle cycles between them -- time in which the SIMD issues other waves'
+// instructions while the accumulator is still owed -- do it, reliably; back to back, or two per loop trip, they do not.  The
+// library's kernels have LDS reads and address arithmetic between the dependent MFMAs of an accumulator.
 namespace {
 typedef __bf16 probe_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float probe_f32x4 __attribute__((ext_vector_type(4)));
@@ -657,6 +661,21 @@ __global__ __launch_bounds__(512) void mfma_probe_kernel(int mode, int iters, fl
     else if (mode == 33)      // mode 1 without its idle cycles
       asm volatile("v_mfma_f32_16x16x32_bf16 %0, %4, %6, %0\n\tv_mfma_f32_16x16x32_bf16 %0, %5, %7, %0\n\t"
                    "v_mfma_f32_16x16x32_bf16 %0, %4, %7, %0\n\tv_mfma_f32_16x16x32_bf16 %0, %5, %6, %0\n\ts_nop 0" CRN_PROBE_OPS);
+#define CRN_CHAIN4(NOPS) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %4, %6, %0\n\t" NOPS "v_mfma_f32_16x16x32_bf16 %0, %5, %7, %0\n\t" NOPS \
+                                      "v_mfma_f32_16x16x32_bf16 %0, %4, %7, %0\n\t" NOPS "v_mfma_f32_16x16x32_bf16 %0, %5, %6, %0\n\t" NOPS "s_nop 0" CRN_PROBE_OPS)
+#define CRN_CHAIN3(NOPS) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %4, %6, %0\n\t" NOPS "v_mfma_f32_16x16x32_bf16 %0, %5, %7, %0\n\t" NOPS \
+                                      "v_mfma_f32_16x16x32_bf16 %0, %4, %7, %0\n\t" NOPS "s_nop 0" CRN_PROBE_OPS)
+    else if (mode == 40) CRN_CHAIN4("s_nop 0\n\t");                      // modes 40 ... 47: mode 1 with 1, 2, 4, 6, 12, 16, 24, 32 idle cycles
+    else if (mode == 41) CRN_CHAIN4("s_nop 1\n\t");
+    else if (mode == 42) CRN_CHAIN4("s_nop 3\n\t");
+    else if (mode == 43) CRN_CHAIN4("s_nop 5\n\t");
+    else if (mode == 44) CRN_CHAIN4("s_nop 7\n\ts_nop 3\n\t");
+    else if (mode == 45) CRN_CHAIN4("s_nop 7\n\ts_nop 7\n\t");
+    else if (mode == 46) CRN_CHAIN4("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t");
+    else if (mode == 47) CRN_CHAIN4("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7\n\t");
+    else if (mode == 48) CRN_CHAIN3("s_nop 7\n\t");                      // three MFMAs per trip, 8 idle cycles after each
+#undef CRN_CHAIN4
+#undef CRN_CHAIN3
     else CRN_CHAIN("");                                                  // mode 10: one chain, back to back
 #undef CRN_CHAIN
 #undef CRN_N8
@@ -668,7 +687,7 @@ __global__ __launch_bounds__(512) void mfma_probe_kernel(int mode, int iters, fl
 }  // namespace
 extern "C" int crn_mfma_probe(int mode, int iters, int workgroups, float* sink, crnStream s) {
   CRN_ENTRY(s);
-  if (!sink || iters < 1 || workgroups < 1 || mode < 0 || mode > 33) return CRN_EINVAL;
+  if (!sink || iters < 1 || workgroups < 1 || mode < 0 || mode > 48) return CRN_EINVAL;
   hipLaunchKernelGGL(mfma_probe_kernel, dim3(workgroups), dim3(512), 0, (hipStream_t)s, mode, iters, sink);
   CRN_CHECK_LAUNCH();
   return CRN_OK;
