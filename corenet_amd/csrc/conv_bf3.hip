@@ -149,6 +149,17 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
   }
 }
 
+
+// The three products of one accumulator -- hi*hi, hi*lo, lo*hi -- as ONE block of three adjacent MFMAs.  Left to the compiler they
+// come out as two adjacent MFMAs and a third one behind LDS reads and address arithmetic; three dependent MFMAs with idle cycles
+// between them make VALU results of OTHER waves on the SIMD go missing (the ray scatter beside these kernels, DESIGN section 3e,
+// tools/mfma_neighbour.py: crn_mfma_probe mode 48 does it in 29 of 30 runs, mode 32 -- this shape -- never).  Same additions in the
+// same order: results are bit-identical.
+__device__ __forceinline__ void mfma3(f32x4& acc, const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl) {
+  asm("v_mfma_f32_16x16x32_bf16 %0, %1, %3, %0\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %4, %0\n\tv_mfma_f32_16x16x32_bf16 %0, %2, %3, %0"
+               : "+v"(acc) : "v"(ah), "v"(al), "v"(bh), "v"(bl));
+}
+
 template <int XM> struct XLoad;
 template <> struct XLoad<1> {            // unit-stride view: 2 consecutive positions = one 8-byte load
   typedef f32x2 T;
@@ -450,9 +461,7 @@ __device__ __forceinline__ void conv_bf3_body(const Bf3Geom& g) {
           for (int ms = 0; ms < kMSUB; ++ms)
 #pragma unroll
             for (int ns = 0; ns < NSUB; ++ns) {
-              acc[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ms], bh[ns], acc[ms][ns], 0, 0, 0);
-              acc[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ms], bl[ns], acc[ms][ns], 0, 0, 0);
-              acc[ms][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[ms], bh[ns], acc[ms][ns], 0, 0, 0);
+              mfma3(acc[ms][ns], ah[ms], al[ms], bh[ns], bl[ns]);
             }
         }
       };
@@ -497,10 +506,7 @@ __device__ __forceinline__ void conv_bf3_body(const Bf3Geom& g) {
             for (int m = 0; m < MQ; ++m)
 #pragma unroll
               for (int ns = 0; ns < NSUB; ++ns) {
-                f32x4& a = acc[mh + m][ns];
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[ns], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[ns], a, 0, 0, 0);
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[ns], a, 0, 0, 0);
+                mfma3(acc[mh + m][ns], ah[m], al[m], bh[ns], bl[ns]);
               }
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -937,10 +943,7 @@ __global__ __launch_bounds__(kWsThreads) void conv_bf3_ws_kernel(Bf3Geom g) {
           for (int m = 0; m < MH; ++m)
 #pragma unroll
             for (int ns = 0; ns < NSUB; ++ns) {
-              f32x4& a = acc[hf * MH + m][ns];
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q][m], bh[qb][ns], a, 0, 0, 0);
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q][m], bl[qb][ns], a, 0, 0, 0);
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[q][m], bh[qb][ns], a, 0, 0, 0);
+              mfma3(acc[hf * MH + m][ns], ah[q][m], al[q][m], bh[qb][ns], bl[qb][ns]);
             }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -1257,9 +1260,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
           const bf16x8 al = cat(trd(xa + xlo), trd(xa + xlo + 64));
 #pragma unroll
           for (int ns = 0; ns < NSUB; ++ns) {
-            acc[ti][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ns], acc[ti][ns], 0, 0, 0);
-            acc[ti][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ns], acc[ti][ns], 0, 0, 0);
-            acc[ti][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ns], acc[ti][ns], 0, 0, 0);
+            mfma3(acc[ti][ns], ah, al, bh[ns], bl[ns]);
           }
         }
       }
@@ -1298,9 +1299,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ns = 0; ns < NSUB; ++ns) {
-          acc[ti][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q], bh[qb][ns], acc[ti][ns], 0, 0, 0);
-          acc[ti][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[q], bl[qb][ns], acc[ti][ns], 0, 0, 0);
-          acc[ti][ns] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[q], bh[qb][ns], acc[ti][ns], 0, 0, 0);
+          mfma3(acc[ti][ns], ah[q], al[q], bh[qb][ns], bl[qb][ns]);
         }
         __builtin_amdgcn_sched_barrier(0);
       }

@@ -497,9 +497,9 @@ __global__ __launch_bounds__(kRingThreads) void conv_bf3_ring_kernel(RingGeom g)
 #pragma unroll
             for (int ns = 0; ns < NSUB; ++ns) {
               f32x4& a = acc[hf * MH + m][ns];
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[qq][m], bh[qb][ns], a, 0, 0, 0);
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[qq][m], bl[qb][ns], a, 0, 0, 0);
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[qq][m], bh[qb][ns], a, 0, 0, 0);
+              // the three products as one block of adjacent MFMAs (see mfma3 in conv_bf3.hip)
+              asm("v_mfma_f32_16x16x32_bf16 %0, %1, %3, %0\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %4, %0\n\tv_mfma_f32_16x16x32_bf16 %0, %2, %3, %0"
+                  : "+v"(a) : "v"(ah[qq][m]), "v"(al[qq][m]), "v"(bh[qb][ns]), "v"(bl[qb][ns]));
             }
           __builtin_amdgcn_sched_barrier(0);
         }

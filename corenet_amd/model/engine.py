@@ -573,6 +573,7 @@ class Plan:
     self.graphs = {}               # captured training steps (CoreNet.train_step): loss name -> CUDAGraph
     self.eager_steps = 0           # fused steps run eagerly on this plan (the first one also sizes every workspace)
     self.eval_graph = None         # captured eval-mode forward (CoreNet._forward_eval_graph)
+    self.ray_side = os.environ.get("CRN_RAY_SIDE", "1") != "0"      # the ray scatters of the backward on the side stream
     self.eval_eager = 0
     self._views = {}
     dev = eng.device
@@ -1059,16 +1060,20 @@ class Plan:
         skip_bwd_async = self.async_skip and self.side is not None and self.trace is None
         if skip_bwd_async:
           # off the data-gradient chain: the feature-map gradients are only needed when the encoder's backward starts.
-          # The scatter itself stays on the main stream: launched on the side stream it starts the moment the norm's backward
-          # that wrote g_out ends, next to the stage's data gradient, and its sums then differ from run to run by 1e-2 of the
-          # map's range (round 4, tools/run_noise.py: only decoder.rt_skip_5's weight gradient, 1e-3 ... 7e-3 of its bucket;
-          # float atomics or not, LDS window or not, non-temporal loads or not -- and never on the main stream, after a device
-          # synchronize, or in deterministic mode, whose max-|g| pass reads g_out first).  Until that hand-over is understood
-          # the 4 scatters (0.09 ms) are worth less than a gradient that is the same every time.
-          self._ray_bwd(k, g_out)
+          # The scatter goes with it (CRN_RAY_SIDE=0 keeps it on the main stream: +0.07 ms per step).  Beside the split-bf16
+          # convolutions of round 3 its sums differed from run to run by 1e-2 ... 1e-1 of the map's range: three dependent
+          # MFMAs of a neighbour wave with idle cycles between them made VALU results of the scatter's waves go missing
+          # (tools/mfma_neighbour.py).  The convolutions issue their three products as one block of adjacent
+          # MFMAs now (mfma3, csrc/conv_bf3.hip): beside them the scatter is exact in 82 of 82 steps and in 660 of 660
+          # two-kernel runs; test_run_to_run_gradient_spread_default_mode watches it.
+          ray_side = self.ray_side
+          if not ray_side:
+            self._ray_bwd(k, g_out)
           self._skip_bwd_ev[k].record()
           with t.cuda.stream(self.side), _lib.pinned_stream(self.side):
             self.side.wait_event(self._skip_bwd_ev[k])
+            if ray_side:
+              self._ray_bwd(k, g_out)
             self._skip_bwd(k, g_out, on_side=True)
             if k == 2:
               self._skip_bwd_done.record(self.side)
