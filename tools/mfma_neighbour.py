@@ -12,8 +12,10 @@ other (accumulator chains) make VALU results of OTHER waves go missing (lanes 48
     modes 40-43 (mode 1 with 1, 2, 4, 6 idle cycles)                                    0 of 30 each
     modes 44-47 (mode 1 with 12, 16, 24, 32 idle cycles), 48 (three MFMAs per trip, 8)  28-29 of 30 each
   -- three or more dependent MFMAs in a row with >= 8 idle cycles between them do it; back to back, or two per loop trip, do not.
-  neighbour = a convolution of the library (tools/bench_conv.py layer keys): `fwd s6c1`, `fwd s6t1`, `dgrad s6t1`, `dgrad s5t1`
-  (bf16x3) 4 ... 30 of 30 wrong; `dgrad s6c1`, `wgrad s6c1`, every fp32 launch: 0 of 30.
+  neighbour = a convolution of the library (tools/bench_conv.py layer keys): with the three products of an accumulator left to the
+  compiler's scheduler (two adjacent MFMAs and a third behind LDS reads) `fwd s6c1`, `fwd s6t1`, `dgrad s6t1`, `fwd s5t1`, `dgrad s5t1`
+  (bf16x3) made 29 / 20 / 5 / 20 / 28 of 30 scatters wrong; as one block of three adjacent MFMAs (mfma3, csrc/conv_bf3.hip, the
+  library now) every layer and direction: 0 of 60.
 usage: mfma_neighbour.py probe <mode>
        mfma_neighbour.py <fwd|dgrad|wgrad> <layer key of tools/bench_conv.py> [fp32|bf16x3]"""
 import os, sys, runpy, io, contextlib, ctypes
