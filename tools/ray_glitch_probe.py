@@ -30,7 +30,7 @@ for dl in ():
   print(f"scatter delayed by _sleep({dl}) = {e0.elapsed_time(e1) * 1e3:.1f} us (incl. launch): {tot} glitched threads in 8 steps; canaries at kernel start {cans[:4]}, right after the flush [mul+add, lcg, mul+add, u64 mad] {cans[8:12]}, after the third pass {cans[4:8]}")
 os.environ["CRN_DBG_DELAY"] = "0"
 for rep in range(8):
-  os.environ["CRN_DBG_SKIP"] = "" if rep < 2 else "side"
+  m.engine.plan(B).ray_side = rep >= 2                      # (the first two steps: scatter on the main stream = the reference)
   m.train_step(image, v2s, off, grid.to(t.int32), "iou_fgbg", lr=0.0, adam_eps=1e-4)
   t.cuda.synchronize()
   rc = cd.crn_ray_dbg_wg(buf, 1)
