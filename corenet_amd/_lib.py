@@ -13,7 +13,10 @@ from typing import Optional
 import torch as t
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("CORENET_HIP_LIB", os.path.join(_HERE, "lib", "libcorenet_hip.so"))
+TOOLS_LIB_PATH = os.path.join(os.path.dirname(_HERE), "tools", "_build", "libcorenet_hip_tools.so")
+PROBE_LIB_PATH = os.path.join(os.path.dirname(_HERE), "tools", "_build", "libcrn_probe.so")
+LIB_PATH = os.environ.get("CORENET_HIP_LIB", TOOLS_LIB_PATH if os.environ.get("CRN_TOOLS_LIB") == "1" else
+                          os.path.join(_HERE, "lib", "libcorenet_hip.so"))
 
 c_i32p = C.POINTER(C.c_int32)
 c_f32p = C.c_void_p     # raw device pointers are passed as integers
@@ -62,9 +65,6 @@ _SIGS = {
                                      C.POINTER(CrnView), i32, i32, i32, i32, i32, i32, i32, vp, C.POINTER(CrnBnBwdFuse), vp],
     "crn_batch_renorm_bwd_apply": [vp, i64, vp, i64, i32, i32, i64, i32, vp, vp, vp, vp, vp, i64, vp, vp, i32, vp, i32,
                                    vp, sz, i32, vp],
-    "crn_bf3_act_image": [C.POINTER(CrnView), C.POINTER(CrnInTransform), vp, vp],
-    "crn_conv_fwd_bf3_ring": [vp, i32, i32, i32, i32, i32, vp, i32, vp, i32, C.POINTER(CrnView), i32, i32, i32, i32, i32, i32,
-                              i32, vp, vp],
     "crn_conv_wgrad_bf3": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32,
                            i32, i32, i32, i32, i32, i32, i32, vp],
     "crn_conv_wgrad": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32,
@@ -114,6 +114,9 @@ _SIGS = {
     "crn_fill_offset_channels": [vp, i32, i64, i64, i32, vp, vp],
     "crn_ray_sample_fwd": [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp],
     "crn_ray_sample_bwd": [vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp],
+    "crn_ray_sample_fwd_idx": [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp, vp],
+    "crn_ray_project": [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp],
+    "crn_ray_sample_bwd_idx": [vp, i64, i32, i32, i32, i32, i32, vp, vp, i64, i32, i32, i32, vp],
     "crn_loss_fwd_bwd": [i32, vp, vp, vp, i32, i32, i64, vp, vp, f32, vp, sz, vp],
     "crn_argmax_confusion": [vp, vp, i32, i32, i64, vp, vp, vp],
     "crn_softmax_superres": [vp, i32, i32, i32, i32, i32, i32, vp, vp],
@@ -133,15 +136,14 @@ _SIZE_FNS = {
     "crn_batch_renorm_workspace_bytes": [i32],
     "crn_loss_workspace_bytes": [i32, i32],
     "crn_fill_voxels_workspace_bytes": [i32, i32, i32, i32],
-    "crn_bf3_act_image_bytes": [i32, i32, i32, i32, i32],
-    "crn_bf3_ring_covers": [i32, i32, i32, i32, i32, i32, i32, i32],
 }
 _PTR_FNS = {
     "crn_loss_status_ptr": [vp, i32],
 }
-# tuning aids of tools/ (reached through `.cdll`, no error check: they return CRN_EINVAL unless their switch is set)
-_DEBUG_FNS = ["crn_bf3_debug_stamps", "crn_ring_debug_stamps", "crn_e2d_debug_stamps", "crn_pw_debug_stamps", "crn_mfma_probe"]
-ALL_SYMBOLS = list(_SIGS) + list(_SIZE_FNS) + list(_PTR_FNS) + _DEBUG_FNS + ["crn_version"]
+# tuning aids of tools/: only in tools/_build/libcorenet_hip_tools.so (CRN_TOOLS_LIB=1 loads that build instead; reached through
+# `.cdll`, no error check: they return CRN_EINVAL unless their switch is set).  The product library does not export them.
+TOOL_SYMBOLS = ["crn_bf3_debug_stamps", "crn_e2d_debug_stamps", "crn_pw_debug_stamps"]
+ALL_SYMBOLS = list(_SIGS) + list(_SIZE_FNS) + list(_PTR_FNS) + ["crn_version"]
 
 
 class _Lib:

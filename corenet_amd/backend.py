@@ -128,26 +128,6 @@ class HipBackend:
                                         0, ptr(dsum), int(ndsum), ptr(ws), n, f.nparts, _lib.stream())
     return True
 
-  # -- ring-buffered, DMA-fed form of the bf16x3 engine (csrc/conv_bf3_ring.hip) ---------------------------------
-  def bf3_image_bytes(self, B, Cn, D, H, W) -> int:
-    return int(self.lib.crn_bf3_act_image_bytes(B, Cn, D, H, W))
-
-  def bf3_ring_covers(self, cin: int, npad: int, ydims, window) -> bool:
-    return bool(self.lib.crn_bf3_ring_covers(cin, npad, ydims[0], ydims[1], ydims[2], window[0], window[1], window[2]))
-
-  def bf3_act_image(self, x: View, tr: Optional[Transform], image: t.Tensor):
-    """T(x) split into bf16 hi / lo terms in the conv kernels' patch format (crn_bf3_act_image)."""
-    assert image.numel() * image.element_size() >= self.bf3_image_bytes(x.B, x.C, x.D, x.H, x.W)
-    self.lib.crn_bf3_act_image(C.byref(_cview(x)), _ctr(tr), ptr(image), _lib.stream())
-
-  def conv_fwd_ring(self, image: t.Tensor, xdims, wslab: t.Tensor, npad: int, bias: Optional[t.Tensor], bias_sB: int,
-                    y: View, window, pad_lo, accumulate: bool = False, boxes=None):
-    """crn_conv_fwd_bf3_slabs on the view the image was made from; xdims = (B, C, D, H, W) of that view."""
-    B, Cn, D, H, W = xdims
-    self.lib.crn_conv_fwd_bf3_ring(ptr(image), B, Cn, D, H, W, ptr(wslab), npad, ptr(bias), bias_sB, C.byref(_cview(y)),
-                                   window[0], window[1], window[2], pad_lo[0], pad_lo[1], pad_lo[2], int(accumulate),
-                                   _ctapboxes(boxes), _lib.stream())
-
   def splitk_defer(self, on: bool = True):
     """The next conv call may leave its split-K sum to the BatchRenorm launch that follows (crn_splitk_defer)."""
     self.lib.crn_splitk_defer(int(on))
@@ -316,6 +296,19 @@ class HipBackend:
                      zero_first=True):
     self.lib.crn_ray_sample_bwd(ptr(dout), dout_sB, B, Cn, D, H, W, ptr(matrix), ptr(offset),
                                 ptr(dmap), dmap_sB, h, w, int(zero_first), _lib.stream())
+
+  def ray_sample_fwd_idx(self, fmap, map_sB, B, Cn, h, w, matrix, offset, out, out_sB, D, H, W, idx,
+                         map_sC=None, map_sP=1):
+    """ray_sample_fwd that also leaves the saved index tensor idx (uint16 [B][D][H][W]; int16 storage is fine) of the backward."""
+    self.lib.crn_ray_sample_fwd_idx(ptr(fmap), map_sB, h * w if map_sC is None else map_sC, map_sP, B, Cn, h, w,
+                                    ptr(matrix), ptr(offset), ptr(out), out_sB, D, H, W, ptr(idx), _lib.stream())
+
+  def ray_project(self, matrix, offset, B, D, H, W, h, w, idx):
+    self.lib.crn_ray_project(ptr(matrix), ptr(offset), B, D, H, W, h, w, ptr(idx), _lib.stream())
+
+  def ray_sample_bwd_idx(self, dout, dout_sB, B, Cn, D, H, W, idx, dmap, dmap_sB, h, w, zero_first=True):
+    self.lib.crn_ray_sample_bwd_idx(ptr(dout), dout_sB, B, Cn, D, H, W, ptr(idx), ptr(dmap), dmap_sB, h, w,
+                                    int(zero_first), _lib.stream())
 
   # -- losses / metrics / optimizer ---------------------------------------------------------
   def loss_fwd_bwd(self, kind, logits, gt_i32, B, Cn, S, loss, dlogits, grad_scale=1.0, weights=None):

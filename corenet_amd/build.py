@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcorenet_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_bf3.hip", "conv_bf3_ring.hip", "conv_e2d.hip", "batch_renorm.hip", "ray_sample.hip", "misc_ops.hip", "losses.hip", "fill_voxels.hip",
+SOURCES = ["conv_igemm.hip", "conv_bf3.hip", "conv_e2d.hip", "batch_renorm.hip", "ray_sample.hip", "misc_ops.hip", "losses.hip", "fill_voxels.hip",
            "voxelize.hip", "comm_rccl.hip", "fill_voxels_cpu.cpp"]
 # conv engine tile configurations (conv_kernels.h CRN_FWD_CONFIGS / CRN_WG_CONFIGS): one object each
 CONV_CONFIGS = [(8, 1), (4, 2), (4, 1), (2, 4), (2, 2), (2, 1), (1, 4), (1, 2), (1, 1)]
@@ -60,6 +60,48 @@ def build(verbose=True, force=False):
   return LIB
 
 
+TOOLS_DIR = os.path.join(HERE, "..", "tools", "_build")
+TOOLS_LIB = os.path.join(TOOLS_DIR, "libcorenet_hip_tools.so")
+PROBE_LIB = os.path.join(TOOLS_DIR, "libcrn_probe.so")
+TOOLS_SOURCES = ["conv_igemm.hip", "conv_bf3.hip", "conv_e2d.hip", "ray_sample.hip"]     # the sources with CRN_TOOLS sections (stamp read-backs)
+
+
+def build_tools(verbose=True, force=False):
+  """What tools/ and the neighbour tests need beyond the product library, kept OUT of it: the MFMA hardware probe
+  (tools/mfma_probe.hip -> tools/_build/libcrn_probe.so) and a second link of the library whose stamp read-backs are compiled in
+  (-DCRN_TOOLS -> tools/_build/libcorenet_hip_tools.so; every other object is shared with the product build)."""
+  build(verbose=verbose)
+  os.makedirs(TOOLS_DIR, exist_ok=True)
+  hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+  jobs, objs = [], []
+  probe_src = os.path.join(HERE, "..", "tools", "mfma_probe.hip")
+  if force or not os.path.exists(PROBE_LIB) or os.path.getmtime(probe_src) > os.path.getmtime(PROBE_LIB):
+    jobs.append([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", probe_src, "-o", PROBE_LIB])
+  for s in SOURCES:
+    base = os.path.splitext(s)[0]
+    if s in TOOLS_SOURCES:
+      obj = os.path.join(TOOLS_DIR, base + ".o")
+      if force or _stale(obj, os.path.join(CSRC, s)):
+        jobs.append([hipcc] + FLAGS + ["-DCRN_TOOLS", "-c", os.path.join(CSRC, s), "-o", obj])
+    else:
+      obj = os.path.join(LIBDIR, base + ".o")
+    objs.append(obj)
+  for kind in ("wgrad", "fwd"):
+    for m, n in CONV_CONFIGS:
+      objs.append(os.path.join(LIBDIR, "conv_inst_%s_%d_%d.o" % (kind, m, n)))
+  def run(cmd):
+    if verbose:
+      print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+  with ThreadPoolExecutor(max_workers=8) as ex:
+    list(ex.map(run, jobs))
+  if jobs or not os.path.exists(TOOLS_LIB) or os.path.getmtime(LIB) > os.path.getmtime(TOOLS_LIB):
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", TOOLS_LIB] + objs + ["-ldl"])
+  return TOOLS_LIB
+
+
 if __name__ == "__main__":
   build(force="--force" in sys.argv)
   print(LIB)
+  if "--tools" in sys.argv:
+    print(build_tools(force="--force" in sys.argv))

@@ -1405,12 +1405,14 @@ long long* g_bf3_stamps = nullptr;
 
 // tuning aid (CRN_BF3_STAMPS=1): shader-clock stamps of workgroup 0 of the last crn_conv_fwd_bf3 launch
 // (24 staging steps x 8: loop top, loads landed, barrier, commit done, barrier, next loads issued, MFMAs issued)
+#ifdef CRN_TOOLS      // tools/_build/libcorenet_hip_tools.so only (corenet_amd.build.build_tools)
 extern "C" int crn_bf3_debug_stamps(long long* out192) {
   if (!g_bf3_stamps) return CRN_EINVAL;
   CRN_HIP(hipDeviceSynchronize());
   CRN_HIP(hipMemcpy(out192, g_bf3_stamps, 24 * 8 * sizeof(long long), hipMemcpyDeviceToHost));
   return CRN_OK;
 }
+#endif
 
 // Returns CRN_EINVAL for shapes this engine does not cover (the caller keeps the fp32 engine for those).
 namespace {
@@ -1564,7 +1566,11 @@ int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w
   g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
   static const bool half_off = getenv("CRN_BF3_HALF") != nullptr && atoi(getenv("CRN_BF3_HALF")) == 0;
   g.half_last = (!half_off && x->C % kCK >= 1 && x->C % kCK <= 4 && ZS == 1) ? 1 : 0;
+#ifdef CRN_TOOLS
   static const bool want_stamps = getenv("CRN_BF3_STAMPS") != nullptr;
+#else
+  constexpr bool want_stamps = false;
+#endif
   if (want_stamps) {
     if (!g_bf3_stamps) CRN_HIP(hipMalloc(&g_bf3_stamps, 24 * 8 * sizeof(long long)));
     CRN_HIP(hipMemsetAsync(g_bf3_stamps, 0, 24 * 8 * sizeof(long long), st));

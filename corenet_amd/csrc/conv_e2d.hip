@@ -826,12 +826,14 @@ extern "C" int crn_conv2d_bf3(const crnView* x, const crnInTransform* tr, const 
 }
 
 // tuning aid (CRN_E2D_DBG=16): the shader-clock stamps of the last crn_conv2d_bf3 call (synchronises the device)
+#ifdef CRN_TOOLS      // tools/_build/libcorenet_hip_tools.so only (corenet_amd.build.build_tools)
 extern "C" int crn_e2d_debug_stamps(long long* out32) {
   if (!g_stamps) return CRN_EINVAL;
   CRN_HIP(hipDeviceSynchronize());
   CRN_HIP(hipMemcpy(out32, g_stamps, 32 * sizeof(long long), hipMemcpyDeviceToHost));
   return CRN_OK;
 }
+#endif
 
 // The weight gradient of a 1x1 layer on the split-bf16 MFMA (see wgrad1x1_bf3_kernel); same contract as
 // crn_conv_wgrad with a 1x1x1 window: dw[c*Npad + n] += sum T(x)[b,c,p] * dy[b,n,p], dw zeroed by the caller or by

@@ -745,12 +745,14 @@ int crn_splitk_reduce(const crnView& y, const float* scratch, int splits, int ac
 }
 
 static long long* g_pw_stamps = nullptr;
+#ifdef CRN_TOOLS      // tools/_build/libcorenet_hip_tools.so only (corenet_amd.build.build_tools)
 extern "C" int crn_pw_debug_stamps(long long* out32) {       // tuning aid (CRN_PW_STAMPS=1)
   if (!g_pw_stamps) return CRN_EINVAL;
   CRN_HIP(hipDeviceSynchronize());
   CRN_HIP(hipMemcpy(out32, g_pw_stamps, 32 * sizeof(long long), hipMemcpyDeviceToHost));
   return CRN_OK;
 }
+#endif
 extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const float* w, int Npad,
                             const float* bias, int bias_sB, const crnView* y,
                             int kd, int kh, int kw, int pd, int ph, int pw,
@@ -865,7 +867,11 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
     }
     static const int pw_ablate = getenv("CRN_PW_ABLATE") ? atoi(getenv("CRN_PW_ABLATE")) : 0;
     p.ablate = pw_ablate;
+#ifdef CRN_TOOLS
     static const bool want_stamps = getenv("CRN_PW_STAMPS") != nullptr;
+#else
+    constexpr bool want_stamps = false;
+#endif
     static long long* pw_stamps = nullptr;
     if (want_stamps) {
       if (!pw_stamps) CRN_HIP(hipMalloc(&pw_stamps, 32 * sizeof(long long)));

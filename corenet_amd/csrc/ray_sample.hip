@@ -56,8 +56,8 @@ template <int VX, bool CL>
 __global__ __launch_bounds__(256) void ray_sample_fwd_kernel(
     const float* __restrict__ map, int64_t map_sB, int64_t map_sC, int64_t map_sP, int C, int h, int w,
     const float* matrix, const float* offset, float* __restrict__ out, int64_t out_sB, int D, int H, int W,
-    int64_t per_b) {
-  crn_kernargs_now(map, map_sB, map_sC, map_sP, C, h, w, matrix, offset, out, out_sB, D, H, W, per_b);
+    int64_t per_b, uint16_t* __restrict__ idx) {
+  crn_kernargs_now(map, map_sB, map_sC, map_sP, C, h, w, matrix, offset, out, out_sB, D, H, W, per_b, idx);
   const int b = blockIdx.y;
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (t >= per_b) return;
@@ -73,6 +73,19 @@ __global__ __launch_bounds__(256) void ray_sample_fwd_kernel(
   const int64_t S = (int64_t)D * H * W;
   const float* mb = map + (int64_t)b * map_sB;
   float* ob = out + (int64_t)b * out_sB + ((int64_t)z * H + y) * W + x0;
+  if (idx && blockIdx.z == 0) {                 // the saved index tensor of the backward pass (crn_ray_sample_bwd_idx)
+    uint16_t* ib = idx + (int64_t)b * S + ((int64_t)z * H + y) * W + x0;
+    if (VX == 4) {
+      typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+      u16x4 v4;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v4[k] = (unsigned short)(po[k] >= 0 ? po[k] : 0xFFFF);
+      *reinterpret_cast<u16x4*>(ib) = v4;
+    } else {
+#pragma unroll
+      for (int k = 0; k < VX; ++k) ib[k] = (uint16_t)(po[k] >= 0 ? po[k] : 0xFFFF);
+    }
+  }
   // 12 channels per iteration (every skip width 96/48/24/12 is a multiple): all gathers of the group in
   // flight, then 12 streaming (non-temporal) float4 stores -- the output is consumed much later by the
   // next decoder stage, so it should not displace the feature map from L2.
@@ -126,167 +139,229 @@ __global__ __launch_bounds__(256) void ray_sample_fwd_kernel(
   }
 }
 
-// un-truncated pixel coordinates (fu, fv) and the w clip coordinate: used only to bound the pixel
-// window of a voxel box (a projective map of a box has its extremes at the corners when pw keeps
-// its sign); the sampling decision itself is always project().
-__device__ __forceinline__ void project_uv(const Cam& c, float x, float y, float z, int w, int h, float& fu,
-                                           float& fv, float& pw) {
-  const float cx = x + c.ox, cy = y + c.oy, cz = z + c.oz;
-  const float px = row_dot(c.m + 0, cx, cy, cz), py = row_dot(c.m + 4, cx, cy, cz);
-  pw = row_dot(c.m + 12, cx, cy, cz);
-  fu = (px / pw * 0.5f + 0.5f) * (float)w;
-  fv = (py / pw * 0.5f + 0.5f) * (float)h;
+// The saved index tensor of the backward pass (the reference's autograd keeps the int64 index tensors of the forward's
+// advanced indexing and scatters with index_put_(accumulate=True), ray_traced_skip_connection.py:124-135): one entry
+// per voxel, flat pixel iy*w+ix, kOut<IT>() for "outside value".  16-bit entries when h*w < 65535 (2 B per voxel next
+// to the 4*C B of gradient the scatter reads), 32-bit otherwise.
+template <typename IT> __device__ __host__ constexpr int idx_out();
+template <> __device__ __host__ constexpr int idx_out<uint16_t>() { return 0xFFFF; }
+template <> __device__ __host__ constexpr int idx_out<int32_t>() { return -1; }
+
+// idx[b][z][y][x] for every voxel: the projection alone (loop-free: one thread = VX consecutive x voxels, like the gather)
+template <int VX, typename IT>
+__global__ __launch_bounds__(256) void ray_project_kernel(const float* matrix, const float* offset, IT* __restrict__ idx,
+                                                          int D, int H, int W, int h, int w, int64_t per_b) {
+  crn_kernargs_now(matrix, offset, idx, D, H, W, h, w, per_b);
+  const int b = blockIdx.y;
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= per_b) return;
+  const int wx = W / VX;
+  int64_t r = t;
+  const int x0 = (int)(r % wx) * VX; r /= wx;
+  const int y = (int)(r % H);
+  const int z = (int)(r / H);
+  const Cam cam = load_cam(matrix, offset, b);
+  IT* ib = idx + (int64_t)b * D * H * W + ((int64_t)z * H + y) * W + x0;
+#pragma unroll
+  for (int k = 0; k < VX; ++k) {
+    const int po = project(cam, x0 + k, y, z, w, h);
+    ib[k] = (IT)(po >= 0 ? po : idx_out<IT>());
+  }
 }
 
-// backward: a workgroup owns a TX x TY tile of (x,y) voxel columns over a z segment; one thread =
-// one column and CN channels (12 = every skip width, so the projection is evaluated once per voxel).
-// Consecutive z usually hit the same pixel -> run-length accumulate in registers.  Neighbouring
-// columns hit the SAME pixels, and same-address float atomics in L2 serialise (measured: 100 us
-// with them, 13 us without): runs are therefore added into an LDS copy of the pixel window that
-// the tile can reach (bounding box of the projected box corners), and the window goes to HBM
-// with one atomic per touched (pixel, channel).  Pixels outside the window (box straddling the
-// camera plane, or a window larger than the LDS budget) fall back to global atomics.
-// Tried and dropped in round 2: a gather by PIXEL OWNERS (one thread per pixel x depth x 12 channels inverts the
-// projection of a view-space camera -- clip x depends on (x, z) only, clip y on (y, z), clip w on z -- finds the
-// few voxels that land in its pixel with the same bit-defined project(), sums them, no atomics, no memset).  Bit
-// for bit correct, but 56 / 19 / 18 / 18 us at the four scales against 49 / 24 / 16 / 14 us here: the exact
-// membership test needs ~8 IEEE divisions per (pixel, z), the reads come in 64-byte pieces, and general cameras
-// still need this kernel as a second launch.
-// Tried and dropped in round 4: a LOAD-FIRST form (a thread owns 4 consecutive x columns x 4 channels x 8 planes and issues all
-// of its 32 16-byte loads before it touches camera, window box or LDS; the eight z segments of a tile are the eight waves
-// of ONE workgroup and share one 16 KiB window, which goes to HBM once per tile: 8x fewer device-scope atomics; the box from
-// 8 lanes at once).  Correct on every test, and slower: 50 / 26 / 21 / 18 us (burst incl. the 4 us memset) against
-// 44 / 17 / 14 / 14 us here.  Its ablations at 64^3 say where the time of BOTH kernels is: 29 us with the projection
-// replaced by a constant pixel (one flush per column: loads + the shell of the launch), 30 us with the projection but
-// without the LDS adds, 51 us with them -- the ~36 divergent flush sites of a wave (4 columns x 9) each issue 4
-// ds_add_f32 for whatever lanes changed pixel at that plane, ~1150 LDS atomic instructions per CU; the window write-out
-// (3 us) and the tile shape (whole 256-byte rows: the same 28 us floor) do not matter.  Fewer, fuller LDS atomic
-// INSTRUCTIONS do not help either: with the last two runs of a column kept as records in registers and flushed together at
-// the end of the segment (two nearly full flush sites instead of nine sparse ones) this kernel takes 48 us instead of 44 --
-// the cost follows the lane-adds (4.7 M at 64^3, same-pixel neighbours serialise), not the instruction count.
-constexpr int kTMax = 16;                      // tile: 32x8 columns (full 128-B rows) for grids >= 64, else 8x8
-constexpr int kWinFloats = 12 * 1024;          // 48 KiB of LDS
-// DET (deterministic mode, crn_common.h): the sums are taken in 64-bit fixed point -- integer adds commute, so the
-// result does not depend on the order in which threads reach a pixel.  scale_p[0] = 2^k chosen from max |dout| so
-// that a pixel's sum cannot overflow; detmap = int64 image of dmap ([B][C][h][w], zeroed), converted by
-// ray_det_finish_kernel.  The LDS window is not used (its float adds are the order-dependent part).
-template <int CN, bool DET>
-__global__ __launch_bounds__(kTMax * kTMax) void ray_sample_bwd_kernel(
-    const float* __restrict__ dout, int64_t dout_sB, int C, int D, int H, int W, const float* matrix,
-    const float* offset, float* dmap, int64_t dmap_sB, int h, int w, int zseg, int tilesX, int tilesY, int kTX, int kTY,
-    unsigned long long* detmap, const float* scale_p) {
-  __shared__ float win[kWinFloats];
+// backward (scatter-add of the gradient into the 2-D map) from the saved index tensor.
+// A workgroup owns a kTX x kTY tile of (x, y) voxel columns over a z segment of <= ZS planes and CN channels; one thread = one
+// column.  Everything a thread needs (ZS indices, ZS x CN gradients) is loaded up front -- no load sits behind a branch and
+// the whole segment is in flight at once --, then the column is walked: consecutive z usually hit the same pixel, so runs are
+// summed in registers and a run goes into an LDS image of the pixel window the tile reaches; the window goes to HBM with one
+// float atomic per touched (pixel, channel).  Same-address float atomics in L2 serialise (measured in round 1: 100 us with
+// them, 13 us without), neighbouring columns hit the SAME pixels, hence the window.
+// THE WINDOW IS 64-BIT FIXED POINT.  ds_add_f32 executes one lane at a time on this part: 12 cycles per active lane, 768
+// cycles for a full wave instruction, whatever the addresses and however many waves wait (tools/lds_atomic_probe.hip,
+// profiles/r05_lds_atomic_probe.txt) -- the float window of rounds 1-4 spent 35 of the kernel's 48 us there.  ds_add_u64 is
+// 24-33 cycles per wave instruction (48 when pairs of lanes share an address), ds_add_u32 19.  So a run sum v becomes
+// F = trunc(v * 2^(44 - e)) with 2^e > M = the largest |gradient| the workgroup loaded (block floating point: every addend is
+// resolved to 2^-44 M, a thousand times finer than an fp32 ulp of M, so the window's sum is MORE exact than a chain of float
+// adds; |F| < 2^48 and a pixel takes at most 256 x ZS runs, no overflow), integer adds commute (the window's sum does not depend
+// on the order of the threads) and the write-out converts once.  A workgroup whose M is inf / NaN adds to HBM directly in
+// float (the reference's index_put_ propagates them).
+// The window box is the bounding box of the pixels of the tile's 8 corner voxels (a projective map of a box has its extremes
+// at the corners as long as pw keeps its sign); it only decides where a run is ADDED, never what is added: a run whose pixel
+// lies outside the box (corner voxels outside the image, a box larger than the LDS window, cameras that break the corner
+// argument) goes to HBM directly.
+// There is no floating-point projection in this kernel (rounds 1-4 projected every voxel again, three times over for the
+// three channel groups, and the loop-invariant products of that projection were what the MFMA-neighbour glitch of DESIGN
+// section 3e hit); index compares, float adds of run sums and integer atomics are all that is left.
+// DET (deterministic mode, crn_common.h): ALL sums are taken in 64-bit fixed point, in HBM -- scale_p[0] = 2^k chosen from
+// max |dout| of the whole tensor so that a pixel's sum cannot overflow; detmap = int64 image of dmap ([B][C][h][w], zeroed),
+// converted by ray_det_finish_kernel.  The LDS window is not used.
+struct ScatterArgs {
+  const float* dout; int64_t dout_sB; int C, D, H, W;
+  const void* idx;
+  float* dmap; int64_t dmap_sB; int h, w;
+  unsigned wrecip;                 // ceil(2^32 / w): iy = umulhi(po, wrecip) is exact for po < 2^16
+  int zseg, tilesX, tilesY, kTX, kTY, win_floats;      // win_floats: entries (8 bytes each) of the LDS window
+  unsigned long long* detmap; const float* scale_p;
+  int dbg;                         // tools build only (CRN_RAY_DBG): 1 no LDS adds, 2 no window write-out, 4 every plane = plane z0
+};
+#ifdef CRN_TOOLS
+#define RAY_DBG(a, bit) ((a).dbg & (bit))
+#else
+#define RAY_DBG(a, bit) 0
+#endif
+
+constexpr int kFixBits = 44;        // fixed-point window: a run sum v is added as trunc(v * 2^(kFixBits - e)), M < 2^e
+
+// v * s as a 64-bit integer (|v * s| < 2^55, s a power of two: the product is exact): hi = floor(t / 2^24) and
+// lo = t - hi * 2^24 in [0, 2^24) are both exact floats that fit a 32-bit conversion
+__device__ __forceinline__ unsigned long long to_fixed(float v, float s) {
+  const float t = v * s;
+  const float hf = floorf(t * 5.9604644775390625e-08f);                  // 2^-24
+  const float lf = __builtin_fmaf(hf, -16777216.f, t);                   // exact
+  const long long hi = (long long)(int)hf;
+  return (unsigned long long)((hi << 24) + (long long)(unsigned)lf);
+}
+
+template <int CN, int ZS, typename IT, bool DET>
+__global__ __launch_bounds__(256) void ray_scatter_kernel(const ScatterArgs a) {
+  extern __shared__ unsigned long long win[];
   __shared__ int wbox[4];
-  crn_kernargs_now(dout, dout_sB, C, D, H, W, matrix, offset, dmap, dmap_sB, h, w, zseg, tilesX, tilesY, kTX, kTY);
+  __shared__ float wmax[4];
+  crn_kernarg_touch(a);
+  const int C = a.C, D = a.D, H = a.H, W = a.W, h = a.h, w = a.w;
   const int b = blockIdx.z;
   const int cbase = blockIdx.y * CN;
   int tile = blockIdx.x;
-  const int tx = tile % tilesX; tile /= tilesX;
-  const int ty = tile % tilesY; tile /= tilesY;
-  const int z0 = tile * zseg, z1 = min(D, z0 + zseg);
-  const int x0 = tx * kTX, y0 = ty * kTY;
-  const int x = x0 + (int)(threadIdx.x % kTX), y = y0 + (int)(threadIdx.x / kTX);
-  const Cam cam = load_cam(matrix, offset, b);
-  if (threadIdx.x == 0) {
-    const int x1 = min(W, x0 + kTX) - 1, y1 = min(H, y0 + kTY) - 1;
-    float umin = 3e38f, umax = -3e38f, vmin = 3e38f, vmax = -3e38f;
-    bool front = true;
-    for (int k = 0; k < 8; ++k) {
-      float fu, fv, pw;
-      project_uv(cam, (float)((k & 1) ? x1 : x0), (float)((k & 2) ? y1 : y0), (float)((k & 4) ? z1 - 1 : z0), w, h,
-                 fu, fv, pw);
-      front = front && pw > 1e-6f;
-      umin = fminf(umin, fu); umax = fmaxf(umax, fu); vmin = fminf(vmin, fv); vmax = fmaxf(vmax, fv);
+  const int tx = tile % a.tilesX; tile /= a.tilesX;
+  const int ty = tile % a.tilesY; tile /= a.tilesY;
+  const int z0 = tile * a.zseg, z1 = min(D, z0 + a.zseg);
+  const int x0 = tx * a.kTX, y0 = ty * a.kTY;
+  const int x = min(W - 1, x0 + (int)(threadIdx.x % a.kTX)), y = min(H - 1, y0 + (int)(threadIdx.x / a.kTX));
+  const bool mine = x0 + (int)(threadIdx.x % a.kTX) < W && y0 + (int)(threadIdx.x / a.kTX) < H;
+  const int64_t HW = (int64_t)H * W, S = HW * D, hw = (int64_t)h * w;
+  const IT* ib = reinterpret_cast<const IT*>(a.idx) + (int64_t)b * S;
+  // every load of the thread, clamped into the tensor: ZS indices, ZS x CN gradients
+  int pi[ZS];
+  float g[ZS][CN];
+  {
+    const IT* ip = ib + (int64_t)y * W + x;
+    const float* gp = a.dout + (int64_t)b * a.dout_sB + (int64_t)cbase * S + (int64_t)y * W + x;
+#pragma unroll
+    for (int j = 0; j < ZS; ++j) {
+      const int64_t zo = (int64_t)(RAY_DBG(a, 4) ? z0 : min(z0 + j, z1 - 1)) * HW;
+      pi[j] = (int)__builtin_nontemporal_load(ip + zo);
+#pragma unroll
+      for (int k = 0; k < CN; ++k) g[j][k] = __builtin_nontemporal_load(gp + (cbase + k < C ? k : 0) * S + zo);
     }
-    int ix0 = 0, ix1 = -1, iy0 = 0, iy1 = -1;                 // empty window
-    if (front && umax > -1e6f && umin < 1e6f && vmax > -1e6f && vmin < 1e6f) {
-      ix0 = max(0, (int)floorf(umin) - 1); ix1 = min(w - 1, (int)ceilf(umax) + 1);
-      iy0 = max(0, (int)floorf(vmin) - 1); iy1 = min(h - 1, (int)ceilf(vmax) + 1);
-      if (ix1 < ix0 || iy1 < iy0 || (int64_t)(ix1 - ix0 + 1) * (iy1 - iy0 + 1) * CN > kWinFloats) { ix1 = -1; iy1 = -1; ix0 = iy0 = 0; }
+  }
+  // window box from the 8 corner voxels of the tile: lanes 0-7 of the first wave load one corner each
+  if (!DET && threadIdx.x < 64) {
+    const int k = threadIdx.x & 7;
+    const int cx = (k & 1) ? min(W, x0 + a.kTX) - 1 : x0, cy = (k & 2) ? min(H, y0 + a.kTY) - 1 : y0, cz = (k & 4) ? z1 - 1 : z0;
+    const int po = (int)ib[((int64_t)cz * H + cy) * W + cx];
+    const bool in = po != idx_out<IT>() && po >= 0;
+    const int iy = in ? (sizeof(IT) == 2 ? (int)__umulhi((unsigned)po << 0, a.wrecip) : po / w) : 0;
+    const int ix = po - iy * w;
+    int lox = in ? ix : 0x7fffffff, hix = in ? ix : -1, loy = in ? iy : 0x7fffffff, hiy = in ? iy : -1;
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+      lox = min(lox, __shfl_xor(lox, o)); hix = max(hix, __shfl_xor(hix, o));
+      loy = min(loy, __shfl_xor(loy, o)); hiy = max(hiy, __shfl_xor(hiy, o));
     }
-    if (DET) { ix0 = iy0 = 0; ix1 = iy1 = -1; }              // no LDS window: every run goes to the fixed-point image
-    wbox[0] = ix0; wbox[1] = ix1; wbox[2] = iy0; wbox[3] = iy1;
+    if (threadIdx.x == 0) {
+      // one pixel of margin: truncation makes the extreme pixel of an interior voxel at most the corners' extreme, the margin is
+      // for free (a pixel outside the box is still added, to HBM directly)
+      int ix0 = max(0, lox - 1), ix1 = min(w - 1, hix + 1), iy0 = max(0, loy - 1), iy1 = min(h - 1, hiy + 1);
+      if (hix < 0 || (int64_t)(ix1 - ix0 + 1) * (iy1 - iy0 + 1) * CN > a.win_floats) { ix0 = iy0 = 0; ix1 = iy1 = -1; }
+      wbox[0] = ix0; wbox[1] = ix1 - ix0 + 1; wbox[2] = iy0; wbox[3] = iy1 - iy0 + 1;
+    }
+  }
+  if (DET && threadIdx.x == 0) { wbox[0] = wbox[2] = 0; wbox[1] = wbox[3] = 0; }
+  float fix_scale = 0.f, fix_inv = 0.f;
+  if (!DET) {
+    for (int i = threadIdx.x; i < a.win_floats; i += blockDim.x) win[i] = 0ull;
+    // M = the largest |gradient| of the workgroup (NaN-propagating: integer max of the absolute bit patterns)
+    unsigned mb = 0;
+#pragma unroll
+    for (int j = 0; j < ZS; ++j)
+#pragma unroll
+      for (int k = 0; k < CN; ++k) mb = max(mb, __float_as_uint(g[j][k]) & 0x7fffffffu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mb = max(mb, (unsigned)__shfl_xor((int)mb, o));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = __uint_as_float(mb);
   }
   __syncthreads();
-  const int ix0 = wbox[0], ix1 = wbox[1], iy0 = wbox[2], iy1 = wbox[3];
-  const int ww = ix1 - ix0 + 1, wh = iy1 - iy0 + 1, wn = ww > 0 && wh > 0 ? ww * wh : 0;
-  for (int i = threadIdx.x; i < wn * CN; i += blockDim.x) win[i] = 0.f;
-  __syncthreads();
-  const int64_t S = (int64_t)D * H * W, hw = (int64_t)h * w;
-  float* mb = dmap + (int64_t)b * dmap_sB + (int64_t)cbase * hw;
-  if (x < W && y < H) {
-    const float* gb = dout + (int64_t)b * dout_sB + (int64_t)cbase * S + (int64_t)y * W + x;
+  const int ix0 = wbox[0], iy0 = wbox[2], wn_box = wbox[1] * wbox[3];
+  int ww = wbox[1], wh = wbox[3];
+  if (!DET) {
+    unsigned mb = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) mb = max(mb, __float_as_uint(wmax[i]));
+    if (mb == 0) return;                                // every gradient of the workgroup is +-0: nothing to add
+    const int E = (int)(mb >> 23);                      // M < 2^(E - 126)
+    if (E == 255) { ww = 0; wh = 0; }                   // inf / NaN: no window, float atomics to HBM propagate them
+    // scale 2^(kFixBits - (E - 126)): exponent field 127 + kFixBits + 126 - E
+    const int ex = 127 + kFixBits + 126 - E;
+    fix_scale = __uint_as_float((unsigned)min(ex, 254) << 23);
+    fix_inv = __uint_as_float((unsigned)max(254 - min(ex, 254), 1) << 23);     // 1 / fix_scale
+    if (ex > 253) { ww = 0; wh = 0; }                   // M < 2^-83: the scale is not a float; such gradients take the float path
+  }
+  const int wn = wn_box;
+  float* mb = a.dmap + (int64_t)b * a.dmap_sB + (int64_t)cbase * hw;
+  if (mine) {
     float acc[CN];
 #pragma unroll
     for (int k = 0; k < CN; ++k) acc[k] = 0.f;
-    int cur = -1;
+    int cur = idx_out<IT>();
     auto flush = [&]() {
-      if (cur >= 0) {
-        const int iy = cur / w, ix = cur - iy * w;
-        if (ix >= ix0 && ix <= ix1 && iy >= iy0 && iy <= iy1) {
-          float* wp = win + (iy - iy0) * ww + (ix - ix0);
+      if (cur != idx_out<IT>()) {
+        const int iy = sizeof(IT) == 2 ? (int)__umulhi((unsigned)cur, a.wrecip) : cur / w;
+        const int ix = cur - iy * w;
+        const unsigned ux = (unsigned)(ix - ix0), uy = (unsigned)(iy - iy0);
+        if (!DET && ux < (unsigned)ww && uy < (unsigned)wh) {
+          unsigned long long* wp = win + uy * ww + ux;
+          if (RAY_DBG(a, 1)) { if (acc[0] == 123.456f) wp[0] = (unsigned long long)acc[CN - 1]; } else
 #pragma unroll
           for (int k = 0; k < CN; ++k)
-            if (cbase + k < C) atomicAdd(wp + k * wn, acc[k]);          // ds_add_f32
+            if (cbase + k < C) atomicAdd(wp + k * wn, to_fixed(acc[k], fix_scale));          // ds_add_u64
         } else if (DET) {
-          const float sc = scale_p[0];
-          unsigned long long* ib = detmap + ((int64_t)b * C + cbase) * hw;
+          const float sc = a.scale_p[0];
+          unsigned long long* db = a.detmap + ((int64_t)b * C + cbase) * hw;
 #pragma unroll
           for (int k = 0; k < CN; ++k)
-            if (cbase + k < C) atomicAdd(ib + k * hw + cur, (unsigned long long)(long long)__float2ll_rn(acc[k] * sc));
+            if (cbase + k < C) atomicAdd(db + k * hw + cur, (unsigned long long)(long long)__float2ll_rn(acc[k] * sc));
         } else {
 #pragma unroll
           for (int k = 0; k < CN; ++k)
             if (cbase + k < C) atomicAdd(mb + k * hw + cur, acc[k]);
         }
       }
-#pragma unroll
-      for (int k = 0; k < CN; ++k) acc[k] = 0.f;
     };
-    // The z loop is a chain of (load, project, compare, maybe flush) steps whose branches keep the compiler from
-    // hoisting the next loads: with one wave per SIMD (256 workgroups at 64^3) every step paid a full HBM latency
-    // (49 us for 50 MB).  Loads are therefore issued kZC planes at a time into two register buffers, the next
-    // chunk in flight while the current one is consumed; addresses are clamped so that no load sits under a branch.
-    constexpr int kZC = 4;
-    float ga[kZC][CN], gb2[kZC][CN];
-    auto load_chunk = [&](float (&g)[kZC][CN], int zc) {
 #pragma unroll
-      for (int j = 0; j < kZC; ++j) {
-        const int64_t zo = (int64_t)min(zc + j, z1 - 1) * H * W;
+    for (int j = 0; j < ZS; ++j) {
+      if (z0 + j < z1) {
+        if (pi[j] != cur) {
+          flush();
+          cur = pi[j];
 #pragma unroll
-        for (int k = 0; k < CN; ++k) g[j][k] = __builtin_nontemporal_load(gb + (cbase + k < C ? k : 0) * S + zo);
-      }
-    };
-    auto consume = [&](float (&g)[kZC][CN], int zc) {
+          for (int k = 0; k < CN; ++k) acc[k] = g[j][k];
+        } else {
 #pragma unroll
-      for (int j = 0; j < kZC; ++j) {
-        const int z = zc + j;
-        if (z < z1) {
-          const int po = project(cam, x, y, z, w, h);
-          if (po != cur) { flush(); cur = po; }
-          if (po >= 0) {
-#pragma unroll
-            for (int k = 0; k < CN; ++k) acc[k] += g[j][k];
-          }
+          for (int k = 0; k < CN; ++k) acc[k] += g[j][k];
         }
       }
-    };
-    load_chunk(ga, z0);
-    for (int zc = z0; zc < z1; zc += 2 * kZC) {
-      load_chunk(gb2, zc + kZC);
-      consume(ga, zc);
-      load_chunk(ga, zc + 2 * kZC);
-      consume(gb2, zc + kZC);
     }
     flush();
   }
+  if (DET || RAY_DBG(a, 2)) return;
   __syncthreads();
+  if (ww == 0) return;
   for (int i = threadIdx.x; i < wn * CN; i += blockDim.x) {
-    const float v = win[i];
-    if (v != 0.f) {
+    const long long f = (long long)win[i];
+    if (f != 0) {
       const int k = i / wn, p = i - k * wn;
       const int iy = iy0 + p / ww, ix = ix0 + p % ww;
-      if (cbase + k < C) atomicAdd(mb + k * hw + (int64_t)iy * w + ix, v);
+      // one rounding: |f| < 2^60 is exact in double up to 2^53, beyond that the double conversion rounds at 2^-53 relative
+      if (cbase + k < C) atomicAdd(mb + k * hw + (int64_t)iy * w + ix, (float)((double)f * (double)fix_inv));
     }
   }
 }
@@ -317,23 +392,22 @@ __global__ void ray_det_finish_kernel(const unsigned long long* detmap, const fl
 void* g_ray_det_buf = nullptr;
 size_t g_ray_det_bytes = 0;
 
-}  // namespace
+void* g_ray_idx_buf = nullptr;         // index scratch of crn_ray_sample_bwd (grow-only: a captured graph may hold the pointer)
+size_t g_ray_idx_bytes = 0;
 
-extern "C" int crn_ray_sample_fwd(const float* map, int64_t map_sB, int64_t map_sC, int64_t map_sP, int B, int C,
-                                  int h, int w, const float* matrix, const float* offset, float* out,
-                                  int64_t out_sB, int D, int H, int W, crnStream stream) {
-  CRN_ENTRY(stream);
-  hipStream_t st = (hipStream_t)stream;
+int ray_fwd(const float* map, int64_t map_sB, int64_t map_sC, int64_t map_sP, int B, int C, int h, int w, const float* matrix,
+            const float* offset, float* out, int64_t out_sB, int D, int H, int W, uint16_t* idx, hipStream_t st) {
   if (!map || !out || B < 1 || C < 1 || h < 1 || w < 1 || D < 1 || H < 1 || W < 1 || map_sC < 1 || map_sP < 1)
     return CRN_EINVAL;
-  const bool v4 = (W % 4 == 0) && (out_sB % 4 == 0) && (((uintptr_t)out & 15) == 0);
+  if (idx && (int64_t)h * w >= 65535) return CRN_EINVAL;
+  const bool v4 = (W % 4 == 0) && (out_sB % 4 == 0) && (((uintptr_t)out & 15) == 0) && (((uintptr_t)idx & 7) == 0);
   // channel-last map with 16-byte aligned pixels: dwordx4 gathers
   const bool cl = map_sC == 1 && (map_sP % 4 == 0) && (map_sB % 4 == 0) && (C % 4 == 0) && (((uintptr_t)map & 15) == 0);
   const int64_t per_b = (int64_t)D * H * (v4 ? W / 4 : W);
   dim3 grid((unsigned)crn_cdiv(per_b, 256), (unsigned)B, (unsigned)std::max(1, C / 12));
 #define CRN_RAY_LAUNCH(VX, CL)                                                                                      \
   hipLaunchKernelGGL((ray_sample_fwd_kernel<VX, CL>), grid, dim3(256), 0, st, map, map_sB, map_sC, map_sP, C, h, w, \
-                     matrix, offset, out, out_sB, D, H, W, per_b)
+                     matrix, offset, out, out_sB, D, H, W, per_b, idx)
   if (v4 && cl) CRN_RAY_LAUNCH(4, true);
   else if (v4) CRN_RAY_LAUNCH(4, false);
   else if (cl) CRN_RAY_LAUNCH(1, true);
@@ -343,12 +417,20 @@ extern "C" int crn_ray_sample_fwd(const float* map, int64_t map_sB, int64_t map_
   return CRN_OK;
 }
 
-extern "C" int crn_ray_sample_bwd(const float* dout, int64_t dout_sB, int B, int C, int D, int H, int W,
-                                  const float* matrix, const float* offset, float* dmap,
-                                  int64_t dmap_sB, int h, int w, int zero_first, crnStream stream) {
-  CRN_ENTRY(stream);
-  hipStream_t st = (hipStream_t)stream;
-  if (!dout || !dmap || B < 1 || C < 1) return CRN_EINVAL;
+template <typename IT>
+int ray_project(const float* matrix, const float* offset, int B, int D, int H, int W, int h, int w, IT* idx, hipStream_t st) {
+  const bool v4 = W % 4 == 0;
+  const int64_t per_b = (int64_t)D * H * (v4 ? W / 4 : W);
+  dim3 grid((unsigned)crn_cdiv(per_b, 256), (unsigned)B);
+  if (v4) hipLaunchKernelGGL((ray_project_kernel<4, IT>), grid, dim3(256), 0, st, matrix, offset, idx, D, H, W, h, w, per_b);
+  else hipLaunchKernelGGL((ray_project_kernel<1, IT>), grid, dim3(256), 0, st, matrix, offset, idx, D, H, W, h, w, per_b);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+template <typename IT>
+int ray_scatter(const float* dout, int64_t dout_sB, int B, int C, int D, int H, int W, const IT* idx, float* dmap,
+                int64_t dmap_sB, int h, int w, int zero_first, hipStream_t st) {
   if (zero_first) {
     if (dmap_sB == (int64_t)C * h * w) {
       CRN_HIP(hipMemsetAsync(dmap, 0, (size_t)B * C * h * w * 4, st));
@@ -356,22 +438,39 @@ extern "C" int crn_ray_sample_bwd(const float* dout, int64_t dout_sB, int B, int
       for (int b = 0; b < B; ++b) CRN_HIP(hipMemsetAsync(dmap + b * dmap_sB, 0, (size_t)C * h * w * 4, st));
     }
   }
+  // tuning aids (tools/ray_bwd_sweep.sh): CRN_RAY_ZSEG = planes per thread (8 or 16), CRN_RAY_CN = channels per thread (4 or 12),
+  // CRN_RAY_TX = tile width for grids >= 64 (32 or 64)
   static const int zseg_env = getenv("CRN_RAY_ZSEG") ? atoi(getenv("CRN_RAY_ZSEG")) : 0;
-  // z segment and channels per thread, measured at the four decoder scales (tools/ray_bwd_sweep.sh,
-  // profiles/r03_ray_bwd_sweep.txt): 4 channels per thread (three times the waves of the 12-channel variant: the kernel is
-  // latency bound, one workgroup of four waves per CU at 64^3) and z segments of 8 (16 at 32^3):
-  // 64^3 48.7 -> 44.4 us, 32^3 24.0 -> 17.3 us, 16^3 19.0 -> 11.7 us, 8^3 13.2 -> 11.5 us
-  const int zseg = zseg_env > 0 ? std::min(zseg_env, D) : (D == 32 ? 16 : std::min(D, 8));
+  static const int cn_env = getenv("CRN_RAY_CN") ? atoi(getenv("CRN_RAY_CN")) : 0;
+  static const int tx_env = getenv("CRN_RAY_TX") ? atoi(getenv("CRN_RAY_TX")) : 0;
+  const bool det = crn_deterministic();
+  const int CN = (C % 12 == 0 && (cn_env == 12 || (det && !cn_env))) ? 12 : 4;
+  // measured (profiles/r05_ray_sweep.txt, B = 4, us at 64^3 / 32^3): 4 channels x 8 planes 17.9 / 14.4, x 16 planes 26.5 / 16.1,
+  // 12 channels x 8 planes 22.9 / 20.8; 64-wide tiles 17.4 / 14.4
+  const int ZS = CN == 4 && zseg_env == 16 ? 16 : 8;      // (12 channels x 16 planes: 255 registers)
+  const int zseg = std::min(D, ZS);
   const int nseg = (D + zseg - 1) / zseg;
   const bool big = W >= 64 && H >= 64;
-  const int kTX = big ? 32 : 8, kTY = 8;
+  const int kTX = big ? (tx_env == 64 ? 64 : 32) : 8, kTY = big ? 256 / kTX : 8;
   const int tilesX = crn_cdiv(W, kTX), tilesY = crn_cdiv(H, kTY);
-  if (crn_deterministic()) {
-    // 64-bit fixed-point accumulation (see ray_sample_bwd_kernel<.., DET>): scratch = int64 image + max bits + scale
+  // LDS window: the pixels a tile can reach when a voxel covers s pixels (s = map size / grid size, >= 1), with margins; a
+  // tile that reaches further adds to HBM directly
+  const double sx = std::max(1.0, (double)w / W), sy = std::max(1.0, (double)h / H);
+  int64_t wpix = (int64_t)(kTX * sx + 4) * (int64_t)(kTY * sy + 4);
+  int win_floats = det ? 0 : (int)std::min<int64_t>(wpix * CN, 6 * 1024);     // entries of 8 bytes: <= 48 KiB
+  ScatterArgs a{dout, dout_sB, C, D, H, W, idx, dmap, dmap_sB, h, w, (unsigned)((((uint64_t)1 << 32) + w - 1) / w),
+                zseg, tilesX, tilesY, kTX, kTY, win_floats, nullptr, nullptr, 0};
+#ifdef CRN_TOOLS
+  a.dbg = getenv("CRN_RAY_DBG") ? atoi(getenv("CRN_RAY_DBG")) : 0;
+#endif
+  dim3 grid((unsigned)(tilesX * tilesY * nseg), (unsigned)crn_cdiv(C, CN), (unsigned)B), block((unsigned)(kTX * kTY));
+  const size_t lds = (size_t)win_floats * 8;
+  if (det) {
+    // 64-bit fixed-point accumulation: scratch = int64 image + max bits + scale
     const int64_t per_b = (int64_t)C * h * w;
     const size_t need = (size_t)B * per_b * 8 + 256;
     if (need > g_ray_det_bytes) {
-      if (g_ray_det_buf) CRN_HIP(hipFree(g_ray_det_buf));
+      // grow-only, the outgrown buffer is kept (a captured graph may hold its address)
       CRN_HIP(hipMalloc(&g_ray_det_buf, need));
       g_ray_det_bytes = need;
     }
@@ -384,29 +483,74 @@ extern "C" int crn_ray_sample_bwd(const float* dout, int64_t dout_sB, int B, int
     int lg = 0;
     while (((int64_t)1 << lg) < (int64_t)D * H * W) ++lg;
     hipLaunchKernelGGL(ray_det_scale_kernel, dim3(1), dim3(1), 0, st, maxbits, scale, lg);
-    if (C % 12 == 0) {
-      dim3 grid((unsigned)(tilesX * tilesY * nseg), (unsigned)(C / 12), (unsigned)B);
-      hipLaunchKernelGGL((ray_sample_bwd_kernel<12, true>), grid, dim3(kTX * kTY), 0, st, dout, dout_sB, C, D, H, W, matrix,
-                         offset, dmap, dmap_sB, h, w, zseg, tilesX, tilesY, kTX, kTY, detmap, scale);
-    } else {
-      dim3 grid((unsigned)(tilesX * tilesY * nseg), (unsigned)crn_cdiv(C, 4), (unsigned)B);
-      hipLaunchKernelGGL((ray_sample_bwd_kernel<4, true>), grid, dim3(kTX * kTY), 0, st, dout, dout_sB, C, D, H, W, matrix,
-                         offset, dmap, dmap_sB, h, w, zseg, tilesX, tilesY, kTX, kTY, detmap, scale);
-    }
+    a.detmap = detmap; a.scale_p = scale;
+    if (CN == 12) hipLaunchKernelGGL((ray_scatter_kernel<12, 8, IT, true>), grid, block, 0, st, a);
+    else if (ZS == 8) hipLaunchKernelGGL((ray_scatter_kernel<4, 8, IT, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((ray_scatter_kernel<4, 16, IT, true>), grid, block, 0, st, a);
     hipLaunchKernelGGL(ray_det_finish_kernel, dim3(256), dim3(256), 0, st, detmap, scale, dmap, dmap_sB, per_b, B);
     CRN_CHECK_LAUNCH();
     return CRN_OK;
   }
-  static const bool cn4 = !(getenv("CRN_RAY_CN") && atoi(getenv("CRN_RAY_CN")) == 12);
-  if (C % 12 == 0 && !cn4) {
-    dim3 grid((unsigned)(tilesX * tilesY * nseg), (unsigned)(C / 12), (unsigned)B);
-    hipLaunchKernelGGL((ray_sample_bwd_kernel<12, false>), grid, dim3(kTX * kTY), 0, st, dout, dout_sB, C, D, H, W, matrix,
-                       offset, dmap, dmap_sB, h, w, zseg, tilesX, tilesY, kTX, kTY, (unsigned long long*)nullptr, (const float*)nullptr);
-  } else {
-    dim3 grid((unsigned)(tilesX * tilesY * nseg), (unsigned)crn_cdiv(C, 4), (unsigned)B);
-    hipLaunchKernelGGL((ray_sample_bwd_kernel<4, false>), grid, dim3(kTX * kTY), 0, st, dout, dout_sB, C, D, H, W, matrix,
-                       offset, dmap, dmap_sB, h, w, zseg, tilesX, tilesY, kTX, kTY, (unsigned long long*)nullptr, (const float*)nullptr);
-  }
+  if (CN == 12) hipLaunchKernelGGL((ray_scatter_kernel<12, 8, IT, false>), grid, block, lds, st, a);
+  else if (ZS == 8) hipLaunchKernelGGL((ray_scatter_kernel<4, 8, IT, false>), grid, block, lds, st, a);
+  else hipLaunchKernelGGL((ray_scatter_kernel<4, 16, IT, false>), grid, block, lds, st, a);
   CRN_CHECK_LAUNCH();
   return CRN_OK;
+}
+
+}  // namespace
+
+extern "C" int crn_ray_sample_fwd(const float* map, int64_t map_sB, int64_t map_sC, int64_t map_sP, int B, int C,
+                                  int h, int w, const float* matrix, const float* offset, float* out,
+                                  int64_t out_sB, int D, int H, int W, crnStream stream) {
+  CRN_ENTRY(stream);
+  return ray_fwd(map, map_sB, map_sC, map_sP, B, C, h, w, matrix, offset, out, out_sB, D, H, W, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int crn_ray_sample_fwd_idx(const float* map, int64_t map_sB, int64_t map_sC, int64_t map_sP, int B, int C,
+                                      int h, int w, const float* matrix, const float* offset, float* out,
+                                      int64_t out_sB, int D, int H, int W, uint16_t* idx, crnStream stream) {
+  CRN_ENTRY(stream);
+  if (!idx) return CRN_EINVAL;
+  return ray_fwd(map, map_sB, map_sC, map_sP, B, C, h, w, matrix, offset, out, out_sB, D, H, W, idx, (hipStream_t)stream);
+}
+
+extern "C" int crn_ray_project(const float* matrix, const float* offset, int B, int D, int H, int W, int h, int w,
+                               uint16_t* idx, crnStream stream) {
+  CRN_ENTRY(stream);
+  if (!matrix || !offset || !idx || B < 1 || D < 1 || H < 1 || W < 1 || h < 1 || w < 1 || (int64_t)h * w >= 65535)
+    return CRN_EINVAL;
+  return ray_project<uint16_t>(matrix, offset, B, D, H, W, h, w, idx, (hipStream_t)stream);
+}
+
+extern "C" int crn_ray_sample_bwd_idx(const float* dout, int64_t dout_sB, int B, int C, int D, int H, int W,
+                                      const uint16_t* idx, float* dmap, int64_t dmap_sB, int h, int w, int zero_first,
+                                      crnStream stream) {
+  CRN_ENTRY(stream);
+  if (!dout || !dmap || !idx || B < 1 || C < 1 || D < 1 || H < 1 || W < 1 || h < 1 || w < 1 || (int64_t)h * w >= 65535)
+    return CRN_EINVAL;
+  return ray_scatter<uint16_t>(dout, dout_sB, B, C, D, H, W, idx, dmap, dmap_sB, h, w, zero_first, (hipStream_t)stream);
+}
+
+extern "C" int crn_ray_sample_bwd(const float* dout, int64_t dout_sB, int B, int C, int D, int H, int W,
+                                  const float* matrix, const float* offset, float* dmap,
+                                  int64_t dmap_sB, int h, int w, int zero_first, crnStream stream) {
+  CRN_ENTRY(stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (!dout || !dmap || !matrix || !offset || B < 1 || C < 1 || D < 1 || H < 1 || W < 1 || h < 1 || w < 1) return CRN_EINVAL;
+  // no saved index tensor: project into the library's scratch, then the same scatter
+  const bool small = (int64_t)h * w < 65535;
+  const size_t need = (size_t)B * D * H * W * (small ? 2 : 4);
+  if (need > g_ray_idx_bytes) {
+    CRN_HIP(hipMalloc(&g_ray_idx_buf, need));      // grow-only; the outgrown buffer is kept (see g_ray_idx_buf)
+    g_ray_idx_bytes = need;
+  }
+  if (small) {
+    const int rc = ray_project<uint16_t>(matrix, offset, B, D, H, W, h, w, (uint16_t*)g_ray_idx_buf, st);
+    if (rc != CRN_OK) return rc;
+    return ray_scatter<uint16_t>(dout, dout_sB, B, C, D, H, W, (const uint16_t*)g_ray_idx_buf, dmap, dmap_sB, h, w, zero_first, st);
+  }
+  const int rc = ray_project<int32_t>(matrix, offset, B, D, H, W, h, w, (int32_t*)g_ray_idx_buf, st);
+  if (rc != CRN_OK) return rc;
+  return ray_scatter<int32_t>(dout, dout_sB, B, C, D, H, W, (const int32_t*)g_ray_idx_buf, dmap, dmap_sB, h, w, zero_first, st);
 }

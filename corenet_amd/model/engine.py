@@ -640,6 +640,11 @@ class Plan:
     # compressed skip maps are channel-last [B][h][w][C]: the ray-sample gather then fetches four channels of a
     # pixel per load (crn_ray_sample_fwd); their gradients stay channel-major (scatter-add per channel plane)
     self.smap = {k: f(B, self.skip_hw[k], self.skip_hw[k], sk[k]) for k in sk}
+    # the saved index tensors of the ray-sample backward (autograd keeps them in the reference: ray_traced_skip_connection.py:
+    # 118-135): one uint16 per voxel of the 8^3 ... 64^3 skip grids, written by the training-mode gather, read by the scatter
+    self.ray_idx = ({k: t.zeros(B, (2 * self.dec[k]["r"]) ** 3, dtype=t.int16, device=dev) for k in sk}
+                    if hasattr(self.be, "ray_sample_fwd_idx") and os.environ.get("CRN_RAY_IDX", "1") != "0" and
+                    max(self.skip_hw.values()) ** 2 < 65535 else None)
     gs_n = {k: B * sk[k] * self.skip_hw[k] ** 2 for k in sk}
     self.gsmap_slab = f(sum(gs_n.values()))
     self.gsmap, o = {}, 0
@@ -839,9 +844,14 @@ class Plan:
     be.fill_offset_channels(ft, B, ft.stride(0), ft.shape[2] * ft.shape[3], ft.shape[1] - 3, self.offset)
     self._conv(eng.convs[f"decoder.rt_skip_{k}.compress_channels."], self.vw(ft), None,
                self.vw(self.smap[k].permute(0, 3, 1, 2)))
-    self._probe(f"ray_sample_fwd_{ro}", lambda: be.ray_sample_fwd(
-        self.smap[k], self.smap[k].stride(0), B, eng.skip_ch[k], hw, hw, self.layer_mats[k - 2],
-        self.offset, out[:, d["cout"]:], out.stride(0), ro, ro, ro, map_sC=1, map_sP=eng.skip_ch[k]))
+    if self.ray_idx is not None and self.training:
+      self._probe(f"ray_sample_fwd_{ro}", lambda: be.ray_sample_fwd_idx(
+          self.smap[k], self.smap[k].stride(0), B, eng.skip_ch[k], hw, hw, self.layer_mats[k - 2],
+          self.offset, out[:, d["cout"]:], out.stride(0), ro, ro, ro, self.ray_idx[k], map_sC=1, map_sP=eng.skip_ch[k]))
+    else:
+      self._probe(f"ray_sample_fwd_{ro}", lambda: be.ray_sample_fwd(
+          self.smap[k], self.smap[k].stride(0), B, eng.skip_ch[k], hw, hw, self.layer_mats[k - 2],
+          self.offset, out[:, d["cout"]:], out.stride(0), ro, ro, ro, map_sC=1, map_sP=eng.skip_ch[k]))
 
   def _skip_fwd_async(self, stage: str):
     """The stage's pre-ReLU feature map is final on the main stream: its skip path goes to the side stream."""
@@ -1151,6 +1161,10 @@ class Plan:
     """Scatter-add of the skip channels' gradient into the 2-D map gradient (ray_traced_skip_connection.py:135, autograd)."""
     d = self.dec[k]
     ro, hw = 2 * d["r"], self.skip_hw[k]
+    if self.ray_idx is not None:
+      self.be.ray_sample_bwd_idx(g_out[:, d["cout"]:], g_out.stride(0), self.B, self.eng.skip_ch[k], ro, ro, ro,
+                                 self.ray_idx[k], self.gsmap[k], self.gsmap[k].stride(0), hw, hw, False)
+      return
     self.be.ray_sample_bwd(g_out[:, d["cout"]:], g_out.stride(0), self.B, self.eng.skip_ch[k], ro, ro, ro,
                            self.layer_mats[k - 2], self.offset, self.gsmap[k], self.gsmap[k].stride(0), hw, hw, False)
 

@@ -119,24 +119,6 @@ int crn_conv_fwd_bf3_slabs_bnbwd(const crnView* x, const crnInTransform* tr, con
                                  int accumulate, const crnTapBoxes* boxes /* may be NULL */, crnBnBwdFuse* fuse,
                                  crnStream stream);
 
-/* Ring-buffered, DMA-fed form of crn_conv_fwd_bf3_slabs (csrc/conv_bf3_ring.hip) for the Conv3d k5 / ConvTranspose3d k7
- * layers of decoder stages 4-6 (reconstruction_decoder.py:72-95), forward pass and data gradient.  The input arrives as
- * an ACTIVATION IMAGE written by crn_bf3_act_image: T(x) (the fused BatchRenorm + ReLU transform of crn_conv_fwd) of
- * the logical view x, split into bf16 hi and lo terms and laid out as the conv kernels' LDS patch format --
- * [B][ceil(C/8)][D][H][W] entries of 8 channels x bf16 (16 bytes; zeros past C), the hi image followed by the lo image,
- * crn_bf3_act_image_bytes(B, C, D, H, W) bytes in all.  One image serves the forward convolution and the weight
- * gradient of a layer.  crn_conv_fwd_bf3_ring computes exactly what crn_conv_fwd_bf3_slabs(x, tr, ...) computes on the
- * view the image was made from (same products, same summation order: bit-identical), with persistent workgroups that
- * stage patch planes and weight slabs by LDS-DMA ahead of the MFMA waves.  Covers cubic 5^3 / 4^3 windows, output W a
- * multiple of 16, H >= 8, D >= 4 (crn_bf3_ring_covers returns 1); CRN_EINVAL otherwise.                                */
-size_t crn_bf3_act_image_bytes(int B, int C, int D, int H, int W);
-int crn_bf3_act_image(const crnView* x, const crnInTransform* tr /* may be NULL */, void* image, crnStream stream);
-size_t crn_bf3_ring_covers(int C, int Npad, int yD, int yH, int yW, int kd, int kh, int kw);
-int crn_conv_fwd_bf3_ring(const void* image, int B, int C, int D, int H, int W, const void* wslab, int Npad,
-                          const float* bias, int bias_sB, const crnView* y,
-                          int kd, int kh, int kw, int pd, int ph, int pw,
-                          int accumulate, const crnTapBoxes* boxes /* may be NULL */, crnStream stream);
-
 /* A convolution that splits its reduction writes partial sums to the library's scratch and adds them up in a
  * second launch.  crn_splitk_defer(1) arms, for the NEXT convolution call of this host thread (crn_conv2d_bf3, or
  * the 1x1 path of crn_conv_fwd), the following shortcut: if that call splits and does not accumulate, the sum is
@@ -367,10 +349,25 @@ int crn_ray_sample_fwd(const float* map, int64_t map_sB, int64_t map_sC, int64_t
                        int B, int C, int h, int w, const float* matrix, const float* offset,
                        float* out, int64_t out_sB, int D, int H, int W, crnStream s);
 /* Backward (reference: autograd index_put_(accumulate=True)): dmap must be
- * zeroed by the caller unless zero_first.                                     */
+ * zeroed by the caller unless zero_first.  dmap is channel-major [B][C][h][w] with batch stride dmap_sB.
+ * Without a saved index tensor the library projects into its own scratch first (crn_ray_project).          */
 int crn_ray_sample_bwd(const float* dout, int64_t dout_sB, int B, int C, int D, int H, int W,
                        const float* matrix, const float* offset,
                        float* dmap, int64_t dmap_sB, int h, int w, int zero_first, crnStream s);
+/* The saved index tensor.  The reference's forward builds the index tensors of its advanced indexing
+ * (ray_traced_skip_connection.py:118-135) and autograd keeps them for the index_put_ of the backward pass; here the
+ * forward leaves ONE uint16 per voxel, idx[b][z][y][x] = iy*w+ix of the pixel the voxel reads, 0xFFFF = the outside
+ * value (behind the camera or off the image), and the backward scatters from it without projecting again (no
+ * floating-point arithmetic but the sums themselves).  Needs h*w < 65535 (CRN_EINVAL otherwise: use the plain entry
+ * points above).  crn_ray_project writes the index tensor alone.                                            */
+int crn_ray_sample_fwd_idx(const float* map, int64_t map_sB, int64_t map_sC, int64_t map_sP,
+                           int B, int C, int h, int w, const float* matrix, const float* offset,
+                           float* out, int64_t out_sB, int D, int H, int W, uint16_t* idx, crnStream s);
+int crn_ray_project(const float* matrix, const float* offset, int B, int D, int H, int W, int h, int w,
+                    uint16_t* idx, crnStream s);
+int crn_ray_sample_bwd_idx(const float* dout, int64_t dout_sB, int B, int C, int D, int H, int W,
+                           const uint16_t* idx, float* dmap, int64_t dmap_sB, int h, int w, int zero_first,
+                           crnStream s);
 
 /* ---------------- losses (losses.py) ---------------------------------------
  * kind: 0 iou_fgbg (:64-114), 1 xent_times_iou_agnostic (:144-160),
@@ -499,18 +496,16 @@ int crn_zero_f32(float* p, int64_t n, crnStream s);
 int crn_add_i64(int64_t* p, int n, int64_t v, crnStream s);
 const char* crn_version(void);
 
-/* Tuning aids (not part of the drop-in surface; tools/ only): shader-clock stamps of workgroup 0 of the last launch of the
- * split-bf16 decoder kernels (CRN_BF3_STAMPS=1), the ring-buffered form (CRN_RING_STAMPS=1: 16 + 4 * 256 + 16 values), the
- * encoder engine (CRN_E2D_DBG=16) and the pointwise kernel (CRN_PW_STAMPS=1), copied to the host after a device synchronize.
- * CRN_EINVAL when the corresponding switch was not set.                                                               */
+#ifdef CRN_TOOLS
+/* Tuning aids: NOT in libcorenet_hip.so.  corenet_amd.build.build_tools() compiles the library a second time with
+ * -DCRN_TOOLS into tools/_build/libcorenet_hip_tools.so for the scripts under tools/ (shader-clock stamps of workgroup 0 of
+ * the last launch of the split-bf16 decoder kernels, CRN_BF3_STAMPS=1, the encoder engine, CRN_E2D_DBG=16, and the pointwise
+ * kernel, CRN_PW_STAMPS=1; copied to the host after a device synchronize; CRN_EINVAL when the switch was not set).  The MFMA
+ * hardware probe of DESIGN section 3e is tools/mfma_probe.hip -> tools/_build/libcrn_probe.so.                          */
 int crn_bf3_debug_stamps(long long* out192);
-int crn_ring_debug_stamps(long long* out1056);
 int crn_e2d_debug_stamps(long long* out32);
 int crn_pw_debug_stamps(long long* out32);
-/* hardware probe (tools/mfma_neighbour.py): `workgroups` x 512 threads that only issue bf16 MFMAs in a fixed order;
- * the modes (0 ... 33: independent accumulators, dependent chains with and without idle cycles, interleaved chains) are listed
- * with their measured effect on a neighbouring kernel in csrc/misc_ops.hip.                                                   */
-int crn_mfma_probe(int mode, int iters, int workgroups, float* sink, crnStream s);
+#endif
 
 #ifdef __cplusplus
 }

@@ -328,6 +328,35 @@ class EmuBackend:
     if zero_first: dst.copy_(res)
     else: dst += res
 
+  @staticmethod
+  def ray_indices_u16(matrix, offset, B, D, H, W, h, w):
+    """Contract of the saved index tensor (crn_ray_project / crn_ray_sample_fwd_idx): flat pixel iy*w+ix, 0xFFFF outside."""
+    iy, ix, keep = O.ray_sample_indices(matrix.view(B, 4, 4).float(), offset.view(B, 3).float(), (D, H, W), (w, h))
+    inside = keep & (iy >= 1) & (iy <= h) & (ix >= 1) & (ix <= w)
+    return t.where(inside, (iy - 1) * w + (ix - 1), t.full_like(iy, 0xFFFF))
+
+  def ray_project(self, matrix, offset, B, D, H, W, h, w, idx):
+    assert h * w < 65535 and idx.dtype == t.int16       # (uint16 values in int16 storage: the cast wraps)
+    idx.view(B, D, H, W).copy_(self.ray_indices_u16(matrix, offset, B, D, H, W, h, w).to(t.int32).to(t.int16))
+
+  def ray_sample_fwd_idx(self, fmap, map_sB, B, Cn, h, w, matrix, offset, out, out_sB, D, H, W, idx, map_sC=None, map_sP=1):
+    self.ray_sample_fwd(fmap, map_sB, B, Cn, h, w, matrix, offset, out, out_sB, D, H, W, map_sC=map_sC, map_sP=map_sP)
+    self.ray_project(matrix, offset, B, D, H, W, h, w, idx)
+
+  def ray_sample_bwd_idx(self, dout, dout_sB, B, Cn, D, H, W, idx, dmap, dmap_sB, h, w, zero_first=True):
+    """index_put_(accumulate=True) from the saved indices alone (ray_traced_skip_connection.py:135, autograd)."""
+    g = t.as_strided(dout, (B, Cn, D, H, W), (dout_sB, D * H * W, H * W, W, 1), dout.storage_offset())
+    po = idx.view(B, D, H, W).to(t.int64) & 0xFFFF
+    keep = po != 0xFFFF
+    flat = t.zeros(B * h * w + 1, Cn, dtype=g.dtype)
+    bb = t.arange(B)[:, None, None, None].expand_as(po)
+    lin = t.where(keep, bb * (h * w) + po, t.full_like(po, B * h * w)).reshape(-1)
+    flat.index_add_(0, lin, g.permute(0, 2, 3, 4, 1).reshape(-1, Cn))
+    res = flat[:-1].view(B, h, w, Cn).permute(0, 3, 1, 2)
+    dst = t.as_strided(dmap, (B, Cn, h, w), (dmap_sB, h * w, w, 1), dmap.storage_offset())
+    if zero_first: dst.copy_(res)
+    else: dst += res
+
   # -- losses / metrics / optimizer ---------------------------------------------------------
   LOSSES = {0: "iou_fgbg", 1: "xent_times_iou_agnostic", 2: "iou_agnostic", 3: "xent",
             4: "xent_times_iou_fgbg"}

@@ -2,6 +2,7 @@
 torch.nn.functional, the complete forward/backward plan of engine.py against the
 oracle in float64 (far below fp32 rounding noise), and the C ABI surface."""
 import ctypes
+import subprocess
 import os
 
 import numpy as np
@@ -207,10 +208,15 @@ def test_c_abi_surface():
     B.build(verbose=False)
   lib = ctypes.CDLL(B.LIB)
   hdr = open(os.path.join(os.path.dirname(B.HERE), "include", "corenet_hip.h")).read()
-  declared = set(re.findall(r"\b(crn_[a-z0-9_]+)\s*\(", hdr))
+  tools_block = re.search(r"#ifdef CRN_TOOLS.*?#endif", hdr, re.S).group(0)     # tuning aids: tools build only
+  declared = set(re.findall(r"\b(crn_[a-z0-9_]+)\s*\(", hdr.replace(tools_block, "")))
   assert declared == set(_lib.ALL_SYMBOLS), declared ^ set(_lib.ALL_SYMBOLS)
   for sym in declared:
     getattr(lib, sym)
+  # the drop-in surface is ALL the product library exports: no probe, no stamp read-backs
+  exported = set(subprocess.run(["nm", "-D", "--defined-only", B.LIB], capture_output=True, text=True, check=True).stdout.split())
+  assert {s for s in exported if s.startswith("crn_")} == declared
+  assert set(re.findall(r"\b(crn_[a-z0-9_]+)\s*\(", tools_block)) == set(_lib.TOOL_SYMBOLS)
   lib.crn_version.restype = ctypes.c_char_p
   assert b"gfx950" in lib.crn_version()
 

@@ -297,41 +297,6 @@ def test_conv_bf16x3_fwd_dgrad(be, name, kind, wshape, pad, dims, B):
   be.conv_fwd(V.view_of(xg), trg, None, fwd.npad, bpack.to(DEV), 0, yview(yg2), fwd.window, fwd.pad_lo, 0,
               boxes=(fwd.n_boxes, fwd.c_boxes), math="bf16x3", wslab=slabs_g[:nsf * 32])
   assert t.equal(yg2, yg), (name, "fwd slabs")
-  # the ring-buffered, DMA-fed form (crn_bf3_act_image + crn_conv_fwd_bf3_ring): the activation image equals the
-  # split the staging of the kernels above performs, bit for bit, and the convolution on it equals theirs
-  def ring(xv, trv, geo, slab, outv, accumulate=False):
-    dims_in = (xv.B, xv.C, xv.D, xv.H, xv.W)
-    if not be.bf3_ring_covers(xv.C, geo.npad, (outv.D, outv.H, outv.W), geo.window):
-      return False
-    img = t.full((be.bf3_image_bytes(*dims_in),), 0x5a, dtype=t.uint8, device=DEV)
-    be.bf3_act_image(xv, trv, img)
-    be.conv_fwd_ring(img, dims_in, slab, geo.npad, bpack.to(DEV) if outv is not None and trv is not None else None, 0, outv,
-                     geo.window, geo.pad_lo, accumulate=accumulate, boxes=(geo.n_boxes, geo.c_boxes))
-    return img
-  yg3 = t.zeros_like(yg)
-  img = ring(V.view_of(xg), trg, fwd, slabs_g[:nsf * 32], yview(yg3))
-  if img is not False:
-    xt_ = x.relu() * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)
-    nchk = (cin + 7) // 8
-    xp = t.zeros((B, nchk * 8) + dims); xp[:, :cin] = xt_
-    hi = xp.to(t.bfloat16); lo = (xp - hi.float()).to(t.bfloat16)
-    want_img = t.stack([hi, lo]).view(2, B, nchk, 8, *dims).permute(0, 1, 2, 4, 5, 6, 3).contiguous()
-    got_img = img.cpu().view(t.bfloat16).view(want_img.shape)
-    assert t.equal(got_img.view(t.int16), want_img.view(t.int16)), (name, "activation image")
-    # the same products in the same order -- unless the launch above split its channel reduction (small grids), or the ring
-    # kernel groups the taps of a 5 x 5 window plane differently (row-sliding order: the zw = 4 column comes last)
-    yg_ref = t.zeros_like(yg)
-    os.environ["CRN_BF3_SPLITS"] = "1"
-    try:
-      be.conv_fwd(V.view_of(xg), trg, None, fwd.npad, bpack.to(DEV), 0, yview(yg_ref), fwd.window, fwd.pad_lo, 0,
-                  boxes=(fwd.n_boxes, fwd.c_boxes), math="bf16x3", wslab=slabs_g[:nsf * 32])
-    finally:
-      del os.environ["CRN_BF3_SPLITS"]
-    e3 = float((yg3.cpu() - y).abs().max() / y.abs().max())
-    assert e3 <= 2e-5, (name, "fwd ring vs contract", e3)
-    if fwd.window[2] == 4:
-      assert t.equal(yg3, yg_ref), (name, "fwd ring", float((yg3 - yg_ref).abs().max()))
-    print(f"bf16x3 {name} fwd: ring kernel {e3:.2e}" + (", bit-identical" if t.equal(yg3, yg_ref) else ""))
   ye = t.zeros_like(y)
   EMU.conv_fwd(V.view_of(x), trc, None, fwd.npad, bpack, 0, yview(ye), fwd.window, fwd.pad_lo, wslab=slabs[:nsf * 32])
   assert float((ye - y).abs().max() / y.abs().max()) < 2e-5
@@ -340,7 +305,7 @@ def test_conv_bf16x3_fwd_dgrad(be, name, kind, wshape, pad, dims, B):
   dx = t.randn(x.shape, generator=g); dxg = dx.to(DEV)
   dyg = dyb.to(DEV)
   EMU.conv_fwd(yview(dyb), None, wd, dgr.npad, None, 0, V.view_of(dx), dgr.window, dgr.pad_lo, accumulate=True)
-  dxg2 = dxg.clone(); dx0g = dxg.clone()
+  dxg2 = dxg.clone()
   be.conv_fwd(yview(dyg), None, wd.to(DEV), dgr.npad, None, 0, V.view_of(dxg), dgr.window, dgr.pad_lo, 0, True,
               boxes=(dgr.n_boxes, dgr.c_boxes), math="bf16x3")
   e = float((dxg.cpu() - dx).abs().max() / dx.abs().max())
@@ -349,20 +314,6 @@ def test_conv_bf16x3_fwd_dgrad(be, name, kind, wshape, pad, dims, B):
   be.conv_fwd(yview(dyg), None, None, dgr.npad, None, 0, V.view_of(dxg2), dgr.window, dgr.pad_lo, 0, True,
               boxes=(dgr.n_boxes, dgr.c_boxes), math="bf16x3", wslab=slabs_g[nsf * 32:])
   assert t.equal(dxg2, dxg), (name, "dgrad slabs")
-  dxg3 = dx0g.clone()
-  if ring(yview(dyg), None, dgr, slabs_g[nsf * 32:], V.view_of(dxg3), accumulate=True) is not False:
-    dx_ref = dx0g.clone()
-    os.environ["CRN_BF3_SPLITS"] = "1"
-    try:
-      be.conv_fwd(yview(dyg), None, None, dgr.npad, None, 0, V.view_of(dx_ref), dgr.window, dgr.pad_lo, 0, True,
-                  boxes=(dgr.n_boxes, dgr.c_boxes), math="bf16x3", wslab=slabs_g[nsf * 32:])
-    finally:
-      del os.environ["CRN_BF3_SPLITS"]
-    e3 = float((dxg3.cpu() - dx).abs().max() / dx.abs().max())
-    assert e3 <= 2e-5, (name, "dgrad ring vs contract", e3)
-    if dgr.window[2] == 4:
-      assert t.equal(dxg3, dx_ref), (name, "dgrad ring", float((dxg3 - dx_ref).abs().max()))
-    print(f"bf16x3 {name} dgrad: ring kernel {e3:.2e}" + (", bit-identical" if t.equal(dxg3, dx_ref) else ""))
   # weight gradient (crn_conv_wgrad_bf3): real entries of the packed gradient against the contract, and the
   # un-packed gradient against autograd of torch's own op
   dw = t.zeros(wf.numel()); dwg = t.full((wf.numel(),), 7.0, device=DEV)
@@ -740,6 +691,162 @@ def test_ray_sample_backward_cameras_and_accumulate(be, res, C):
   be.ray_sample_bwd(gy.to(DEV), C * res ** 3, B, C, res, res, res, m.reshape(B, 16).to(DEV), off.to(DEV), dm2,
                     C * res * res, res, res, False)
   close(dm2, prev + cmap.grad, 2e-5, "ray bwd accumulate")
+
+
+def _ray_cameras(res):
+  base = O.canonical_camera() @ O.scale([1.0 / 128] * 3) @ O.scale([128.0 / res] * 3)
+  shift = O.translate([0.9, -0.4, -0.95]) @ base
+  a = np.deg2rad(20.0)
+  roll = t.tensor([[np.cos(a), -np.sin(a), 0, 0], [np.sin(a), np.cos(a), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=t.float32) @ base
+  return t.stack([base, shift, roll]), t.tensor([[0.5, 0.5, 0.5], [0.25, 0.5, 0.75], [0.5, 0.5, 0.5]])
+
+
+@pytest.mark.parametrize("res,C,hw", [(8, 96, 8), (16, 48, 16), (32, 24, 32), (64, 12, 64), (16, 10, 16), (32, 12, 80), (20, 8, 12)])
+def test_ray_saved_index_tensor_and_scatter(be, res, C, hw):
+  """The saved index tensor (crn_ray_sample_fwd_idx / crn_ray_project) against the oracle's index arithmetic, bit for bit
+  (ray_traced_skip_connection.py:118-133; 0xFFFF = outside value), and crn_ray_sample_bwd_idx against the oracle's autograd
+  (index_put_ accumulate, :135) on three cameras, incl. maps that are larger / smaller than the grid, a grid whose width is
+  not a multiple of the tile (20) and accumulation into an existing gradient."""
+  g = t.Generator().manual_seed(res * 7 + C)
+  B = 3
+  m, off = _ray_cameras(res)
+  cmap = t.randn(B, C, hw, hw, generator=g).requires_grad_(True)
+  gy = t.randn(B, C, res, res, res, generator=g)
+  y = O.ray_sample(cmap, m, off, (res,) * 3)
+  y.backward(gy)
+  want = EmuBackend.ray_indices_u16(m.reshape(B, 16), off, B, res, res, res, hw, hw)
+  md, od = m.reshape(B, 16).to(DEV), off.to(DEV)
+  idx = t.full((B, res ** 3), 77, dtype=t.int16, device=DEV)
+  be.ray_project(md, od, B, res, res, res, hw, hw, idx)
+  assert t.equal(idx.cpu().to(t.int64).view(B, res, res, res) & 0xFFFF, want)
+  idx2 = t.full((B, res ** 3), 77, dtype=t.int16, device=DEV)
+  out = t.zeros(B, C, res, res, res, device=DEV)
+  be.ray_sample_fwd_idx(cmap.detach().permute(0, 2, 3, 1).contiguous().to(DEV), C * hw * hw, B, C, hw, hw, md, od, out, C * res ** 3,
+                        res, res, res, idx2, map_sC=1, map_sP=C)
+  assert t.equal(idx2, idx) and int((out.cpu() != y.detach()).sum()) == 0
+  dmap = t.full((B, C, hw, hw), 5.0, device=DEV)
+  be.ray_sample_bwd_idx(gy.to(DEV), C * res ** 3, B, C, res, res, res, idx, dmap, C * hw * hw, hw, hw, True)
+  for b in range(B):
+    close(dmap[b], cmap.grad[b], 2e-5, f"ray bwd (saved indices) sample {b}")
+  prev = t.randn(B, C, hw, hw, generator=g)
+  dm2 = prev.to(DEV).clone()
+  be.ray_sample_bwd_idx(gy.to(DEV), C * res ** 3, B, C, res, res, res, idx, dm2, C * hw * hw, hw, hw, False)
+  close(dm2, prev + cmap.grad, 2e-5, "ray bwd (saved indices) accumulate")
+  # integer-valued gradients: every sum is exact in fp32 whatever the order -> bit-exact against index_put_
+  gi = t.randint(-8, 9, gy.shape, generator=g).float()
+  cm2 = cmap.detach().clone().requires_grad_(True)
+  O.ray_sample(cm2, m, off, (res,) * 3).backward(gi)
+  dm3 = t.zeros(B, C, hw, hw, device=DEV)
+  be.ray_sample_bwd_idx(gi.to(DEV), C * res ** 3, B, C, res, res, res, idx, dm3, C * hw * hw, hw, hw, True)
+  assert t.equal(dm3.cpu(), cm2.grad), "integer gradients: the scatter must be exact"
+
+
+def test_ray_index_entry_points_reject_large_maps(be):
+  """h*w >= 65535 does not fit the 16-bit index tensor: the _idx entry points say so (CRN_EINVAL), the plain backward takes 32-bit
+  indices in its own scratch and still matches the oracle."""
+  from corenet_amd._lib import HipError
+  B, C, res, hw = 1, 4, 8, 256
+  m, off = _ray_cameras(res)
+  m, off = m[:1], off[:1]
+  idx = t.zeros(B, res ** 3, dtype=t.int16, device=DEV)
+  with pytest.raises(HipError):
+    be.ray_project(m.reshape(B, 16).to(DEV), off.to(DEV), B, res, res, res, hw, hw, idx)
+  g = t.Generator().manual_seed(1)
+  cmap = t.randn(B, C, hw, hw, generator=g).requires_grad_(True)
+  gy = t.randn(B, C, res, res, res, generator=g)
+  O.ray_sample(cmap, m, off, (res,) * 3).backward(gy)
+  dmap = t.zeros(B, C, hw, hw, device=DEV)
+  be.ray_sample_bwd(gy.to(DEV), C * res ** 3, B, C, res, res, res, m.reshape(B, 16).to(DEV), off.to(DEV), dmap, C * hw * hw, hw, hw, True)
+  close(dmap, cmap.grad, 2e-5, "ray bwd 32-bit indices")
+
+
+def _probe_lib():
+  import ctypes
+  from corenet_amd import _lib
+  if not os.path.exists(_lib.PROBE_LIB_PATH):
+    pytest.skip("tools/_build/libcrn_probe.so not built (python -m corenet_amd.build --tools)")
+  return ctypes.CDLL(_lib.PROBE_LIB_PATH)
+
+
+def _conv_aggressor(be, key, direction):
+  """One bf16x3 launch of the plan on its real shape at B = 2 (the layer keys of tools/bench_conv.py), as a callable."""
+  from corenet_amd.model import conv_geometry as G
+  from corenet_amd import views as V
+  from corenet_amd.backend import Transform
+  kind, wshape, pad, dims = {"s6c1": ("conv", (16, 28, 5, 5, 5), 2, (64, 64, 64)), "s6t1": ("convT", (16, 2, 7, 7, 7), 3, (64, 64, 64)),
+                             "s5t1": ("convT", (32, 16, 7, 7, 7), 3, (32, 32, 32))}[key]
+  B = 2
+  g = t.Generator().manual_seed(5)
+  if kind == "conv":
+    cin, cout = wshape[1], wshape[0]; fwd, dgr = G.conv_fwd(wshape, pad), G.conv_dgrad(wshape, pad); odims = dims
+  else:
+    cin, cout = wshape[0], wshape[1]; fwd, dgr = G.convt_fwd(wshape, pad), G.convt_dgrad(wshape, pad); odims = tuple(2 * d for d in dims)
+  x = t.randn((B, cin) + dims, generator=g).to(DEV); y = t.randn((B, cout) + odims, generator=g).to(DEV)
+  w = t.randn(wshape, generator=g) * 0.05
+  wf, wd = EMU_pack(w, fwd).to(DEV), EMU_pack(w, dgr).to(DEV)
+  tr = Transform((t.rand(cin, generator=g) + 0.5).to(DEV), t.randn(cin, generator=g).to(DEV), pre_relu=True)
+  yv = V.space_to_depth_view(V.view_of(y), (2, 2, 2), parity_major=True) if kind == "convT" else V.view_of(y)
+  if direction == "fwd":
+    return lambda: be.conv_fwd(V.view_of(x), tr, wf, fwd.npad, None, 0, yv, fwd.window, fwd.pad_lo, 0, boxes=(fwd.n_boxes, fwd.c_boxes), math="bf16x3")
+  return lambda: be.conv_fwd(yv, None, wd, dgr.npad, None, 0, V.view_of(x), dgr.window, dgr.pad_lo, 0, boxes=(dgr.n_boxes, dgr.c_boxes), math="bf16x3")
+
+
+@pytest.mark.parametrize("neighbour", ["probe 1", "probe 44", "probe 48", "fwd s6c1", "fwd s6t1", "dgrad s6t1", "fwd s5t1", "dgrad s5t1"])
+def test_ray_scatter_beside_mfma_neighbours(be, neighbour):
+  """The 64^3 ray-sample scatter on a side stream BESIDE an MFMA-dense neighbour on the main stream, 30 runs per neighbour and
+  start delay, each compared with the oracle's index_put_ gradient (ray_traced_skip_connection.py:135) to 2e-5.  Round 4 found that
+  dependent-MFMA chains of a neighbour wave (the probe's modes 1, 44-48; the split-bf16 convolutions before their products became
+  one block of adjacent MFMAs) made loop-invariant projection products of the round 1-4 scatter go missing in 28-29 of 30 runs
+  (DESIGN section 3e).  The scatter no longer projects (saved index tensor, integer compares + float adds only): this test holds
+  the victim side; the plain entry point (projection launch + scatter) and the gather + index tensor run beside the same
+  neighbours."""
+  import ctypes
+  from corenet_amd import _lib
+  B, Cs, res = 2, 12, 64
+  g = t.Generator().manual_seed(0)
+  gu = (t.randn(B, 28, res, res, res, generator=g) * 1e-6)
+  m = (O.canonical_camera() @ O.scale([1.0 / 128] * 3) @ O.scale([128.0 / res] * 3))[None].expand(B, 4, 4).contiguous()
+  off = t.full((B, 3), 0.5)
+  cmap = t.randn(B, Cs, res, res, generator=g).requires_grad_(True)
+  yref = O.ray_sample(cmap, m, off, (res,) * 3)
+  yref.backward(gu[:, 16:])
+  want, scale = cmap.grad, float(cmap.grad.abs().max())
+  want_idx = EmuBackend.ray_indices_u16(m.reshape(B, 16), off, B, res, res, res, res, res)
+  gud, md, od = gu.to(DEV), m.reshape(B, 16).to(DEV), off.to(DEV)
+  cl = cmap.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+  idx = t.zeros(B, res ** 3, dtype=t.int16, device=DEV)
+  be.ray_project(md, od, B, res, res, res, res, res, idx)
+  gmap, gmap2 = t.zeros(B, Cs, res, res, device=DEV), t.zeros(B, Cs, res, res, device=DEV)
+  out = t.zeros(B, Cs, res, res, res, device=DEV)
+  idx2 = t.zeros_like(idx)
+  if neighbour.startswith("probe"):
+    probe, mode = _probe_lib(), int(neighbour.split()[1])
+    sink = t.zeros(16, device=DEV)
+    def aggressor():
+      assert probe.crn_mfma_probe(mode, 3000, 256, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(_lib.stream())) == 0
+  else:
+    aggressor = _conv_aggressor(be, neighbour.split()[1], neighbour.split()[0])
+  side = t.cuda.Stream()
+  bad = []
+  for delay in (0, 20000):
+    for i in range(30):
+      gmap.fill_(3.0); gmap2.fill_(3.0); idx2.zero_(); out.zero_()
+      t.cuda.synchronize()
+      ev = t.cuda.Event(); ev.record()
+      aggressor()
+      with t.cuda.stream(side), _lib.pinned_stream(side):
+        side.wait_event(ev)
+        if delay: t.cuda._sleep(delay)
+        be.ray_sample_bwd_idx(gud[:, 16:], gud.stride(0), B, Cs, res, res, res, idx, gmap, gmap.stride(0), res, res, True)
+        be.ray_sample_bwd(gud[:, 16:], gud.stride(0), B, Cs, res, res, res, md, od, gmap2, gmap2.stride(0), res, res, True)
+        be.ray_sample_fwd_idx(cl, cl.stride(0), B, Cs, res, res, md, od, out, out.stride(0), res, res, res, idx2, map_sC=1, map_sP=Cs)
+      t.cuda.synchronize()
+      e1 = float((gmap.cpu() - want).abs().max()) / scale
+      e2 = float((gmap2.cpu() - want).abs().max()) / scale
+      ok3 = t.equal(idx2.cpu().to(t.int64).view(B, res, res, res) & 0xFFFF, want_idx) and int((out.cpu() != yref.detach()).sum()) == 0
+      if e1 > 2e-5 or e2 > 2e-5 or not ok3:
+        bad.append((delay, i, e1, e2, ok3))
+  assert not bad, (neighbour, len(bad), bad[:5])
 
 
 @pytest.mark.parametrize("Cin,N,hw", [(2048, 96, 8), (256, 12, 64), (96, 20, 16)])

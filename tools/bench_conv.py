@@ -1,9 +1,11 @@
 #!/usr/bin/env python
 """Micro-benchmark of one conv layer through the C ABI (for rocprofv3 --pmc runs).
-usage: bench_conv.py <fwd|dgrad|wgrad> <layer-key> [iters] [B] [fp32|bf16x3|ring]
-ring: the ring-buffered, DMA-fed form of the bf16x3 engine (crn_bf3_act_image + crn_conv_fwd_bf3_ring), timed in its two
-parts and compared bit for bit with the bf16x3 launch it replaces."""
+usage: bench_conv.py <fwd|dgrad|wgrad> <layer-key> [iters] [B] [fp32|bf16x3]
+The stamp switches (CRN_BF3_STAMPS, CRN_PW_STAMPS) need the tools build of the library (tools/_build/libcorenet_hip_tools.so,
+python -m corenet_amd.build --tools), which this script selects when one of them is set."""
 import os, sys, time
+if os.environ.get("CRN_BF3_STAMPS") or os.environ.get("CRN_PW_STAMPS"):
+  os.environ.setdefault("CRN_TOOLS_LIB", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch as t
 from corenet_amd import views as V
@@ -34,9 +36,6 @@ mode, key = sys.argv[1], sys.argv[2]
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 MATH = sys.argv[5] if len(sys.argv) > 5 else "fp32"
-RING = MATH == "ring"
-if RING:
-  MATH = "bf16x3"
 kind, wshape, pad, dims = LAYERS[key]
 be = HipBackend()
 g = t.Generator().manual_seed(0)
@@ -73,43 +72,6 @@ def timeit(fn):
   for _ in range(iters): fn()
   b.record(); t.cuda.synchronize()
   return a.elapsed_time(b) / iters
-if RING:
-  import numpy as np
-  assert mode in ("fwd", "dgrad")
-  xin, trn, geo, slab, out = (V.view_of(x), tr, fwd, sf, yv) if mode == "fwd" else (yv, None, dgr, sd, V.view_of(x))
-  if mode == "dgrad":
-    y.normal_()
-  dims_in = (xin.B, xin.C, xin.D, xin.H, xin.W)
-  assert be.bf3_ring_covers(xin.C, geo.npad, (out.D, out.H, out.W), geo.window), "layer not covered by the ring kernel"
-  img = t.zeros(be.bf3_image_bytes(*dims_in), dtype=t.uint8, device="cuda")
-  f_img = lambda: be.bf3_act_image(xin, trn, img)
-  f_conv = lambda: be.conv_fwd_ring(img, dims_in, slab, geo.npad, None, 0, out, geo.window, geo.pad_lo, boxes=(geo.n_boxes, geo.c_boxes))
-  ms_i, ms_c = timeit(f_img), timeit(f_conv)
-  got = out.storage.clone()
-  out.storage.zero_()
-  ms_old = timeit(run)
-  same = bool(t.equal(got, out.storage))
-  relerr = float((got - out.storage).abs().max() / out.storage.abs().max())
-  flop = 2.0 * B * np.prod(dims) * cin * cout * np.prod(wshape[2:])
-  print(f"{mode} {key} B={B} ring: image {ms_i*1e3:.1f} us + conv {ms_c*1e3:.1f} us ({flop/ms_c/1e9:.1f} TFLOP/s real = "
-        f"{flop/ms_c/1e9/833.3:.3f} of the bf16x3 roof) | bf16x3 launch it replaces {ms_old*1e3:.1f} us | bit-identical: {same} (max diff {relerr:.1e} of the range)")
-  if os.environ.get("CRN_RING_STAMPS"):
-    import ctypes
-    f_conv(); st = (ctypes.c_longlong * (16 + 4 * 256 + 16))()
-    be.lib.cdll.crn_ring_debug_stamps(st)
-    n = max(1, st[6])
-    print(f"  workgroup 0: {st[0]} cycles in {st[1]} ticks of 10 ns = {st[0] / max(1, st[1]) / 10.0:.2f} GHz, {st[6]} steps, per step: "
-          f"consumer slab-DMA issue {st[2] / n:.0f}, multiply {st[3] / n:.0f}, slab wait {st[4] / n:.0f}, barrier {st[5] / n:.0f} | "
-          f"producer plane-DMA issue {st[8] / n:.0f}, wait {st[9] / n:.0f}, barrier {st[10] / n:.0f}")
-    import numpy as np
-    print("  consumer waves of workgroup 0, per step multiply/barrier: " + ", ".join(f"{st[16 + 1024 + 2 * i] / n:.0f}/{st[16 + 1024 + 2 * i + 1] / n:.0f}" for i in range(8)))
-    w = np.array(st[16:16 + 1024]).reshape(256, 4)
-    w = w[w[:, 0] > 0]
-    if len(w):
-      q = lambda a: "min %d / median %d / max %d" % (a.min(), np.median(a), a.max())
-      print(f"  {len(w)} workgroups: total cycles {q(w[:, 0])}; consumer barrier cycles {q(w[:, 1])}; producer wait cycles {q(w[:, 2])}; "
-            f"end time after workgroup 0's start (us) {q((w[:, 3] - st[7]) / 100)}")
-  sys.exit(0 if relerr < 1e-5 else 1)
 for _ in range(3): run()
 t.cuda.synchronize(); a = t.cuda.Event(enable_timing=True); b = t.cuda.Event(enable_timing=True)
 a.record()

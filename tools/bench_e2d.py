@@ -3,6 +3,8 @@
 HIP events around `iters` back-to-back calls (kernel + split-K reduction when one is used), forward form (fused
 transform + bias).  usage: bench_e2d.py [iters]      tuning knobs: CRN_E2D_FILL, CRN_E2D_SPLITS"""
 import os, sys
+if os.environ.get("CRN_E2D_DBG"):
+  os.environ.setdefault("CRN_TOOLS_LIB", "1")        # the stamp read-back exists only in the tools build of the library
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch as t

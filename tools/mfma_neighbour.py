@@ -27,10 +27,11 @@ if mode == "probe":
   from corenet_amd.backend import HipBackend
   from corenet_amd import _lib as _l0
   be = HipBackend()
+  probe = ctypes.CDLL(_l0.PROBE_LIB_PATH)          # tools/mfma_probe.hip (python -m corenet_amd.build --tools)
   sink = t0.zeros(16, device="cuda")
   iters = int(os.environ.get("PROBE_ITERS", "3000"))
   def run():
-    rc = be.lib.cdll.crn_mfma_probe(int(key), iters, 256, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(_l0.stream()))
+    rc = probe.crn_mfma_probe(int(key), iters, 256, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(_l0.stream()))
     assert rc == 0, rc
 else:
   sys.argv = ["bench_conv.py", mode, key, "1", "2", math]

@@ -1,4 +1,5 @@
 import os, sys, ctypes
+os.environ.setdefault("CRN_TOOLS_LIB", "1")          # crn_pw_debug_stamps exists only in the tools build of the library
 sys.path.insert(0, os.getcwd())
 import torch as t
 from corenet_amd import views as V
