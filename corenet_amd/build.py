@@ -56,6 +56,11 @@ def build(verbose=True, force=False):
   with ThreadPoolExecutor(max_workers=8) as ex:
     list(ex.map(run, jobs))
   if jobs or not os.path.exists(LIB):
+    # the inline-assembly MFMA blocks of conv_bf3.hip hide their destination registers from the compiler's hazard recognizer: the
+    # wait states behind them are checked on the disassembly (tools/check_mfma_hazards.py)
+    chk = os.path.join(HERE, "..", "tools", "check_mfma_hazards.py")
+    if os.path.exists(chk):
+      run([sys.executable, chk, os.path.join(LIBDIR, "conv_bf3.o")])
     run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
   return LIB
 

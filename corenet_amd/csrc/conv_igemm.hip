@@ -28,6 +28,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 namespace {
 using namespace crnk;
@@ -552,7 +553,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_plain_kernel(float* y, int6
 // ray-traced skip path beside the encoder / decoder chain) must not share partial-sum storage.  Grown on demand;
 // hipFree synchronises the device, so a buffer is never released under a kernel that still uses it.
 constexpr int kSkSlots = 64;
-struct SkSlot { int dev; hipStream_t st; float* buf; size_t cap; bool used; };
+// pinned: the slot belongs to a stream whose launches are CAPTURED into HIP graphs (crn_splitk_reserve): a graph holds the
+// buffer's address, so a pinned slot that has to grow keeps its outgrown buffers (`retired`) until crn_splitk_release.
+struct SkSlot { int dev; hipStream_t st; float* buf; size_t cap; bool used; bool pinned; std::vector<float*>* retired; };
 SkSlot g_sk_slots[kSkSlots] = {};
 std::mutex g_sk_mu;                      // the table is shared by every host thread that launches (autograd worker, main)
 float* splitk_scratch(size_t floats, hipStream_t st) {
@@ -566,12 +569,19 @@ float* splitk_scratch(size_t floats, hipStream_t st) {
   for (int i = 0; i < kSlots && !sl; ++i)
     if (slots[i].used && slots[i].dev == dev && slots[i].st == st) sl = &slots[i];
   for (int i = 0; i < kSlots && !sl; ++i)
-    if (!slots[i].used) { slots[i] = Slot{dev, st, nullptr, 0, true}; sl = &slots[i]; }
+    if (!slots[i].used) { slots[i] = Slot{dev, st, nullptr, 0, true, false, nullptr}; sl = &slots[i]; }
   if (!sl) return nullptr;
   if (floats > sl->cap) {
     if (floats > ((size_t)256 << 20) / 4) return nullptr;       // larger outputs keep the atomic path
-    if (sl->buf) (void)hipFree(sl->buf);
-    sl->cap = std::max(floats, ((size_t)16 << 20) / 4);
+    if (sl->buf) {
+      if (sl->pinned) {
+        if (!sl->retired) sl->retired = new std::vector<float*>();
+        sl->retired->push_back(sl->buf);                       // a captured graph may still read / write it
+      } else {
+        (void)hipFree(sl->buf);
+      }
+    }
+    sl->cap = sl->pinned ? floats : std::max(floats, ((size_t)16 << 20) / 4);     // (a capture stream gets what was asked for)
     if (hipMalloc(&sl->buf, sl->cap * 4) != hipSuccess) { sl->buf = nullptr; sl->cap = 0; }
   }
   return sl->buf;
@@ -709,6 +719,16 @@ extern "C" int crn_splitk_reserve(int64_t floats, crnStream stream) {
     for (int i = 0; i < kSkSlots; ++i)
       if (g_sk_slots[i].used && g_sk_slots[i].dev == dev) want = std::max(want, g_sk_slots[i].cap);
   }
+  {
+    std::lock_guard<std::mutex> lock(g_sk_mu);               // mark (or create) the stream's slot as pinned first
+    SkSlot* sl = nullptr;
+    for (int i = 0; i < kSkSlots && !sl; ++i)
+      if (g_sk_slots[i].used && g_sk_slots[i].dev == dev && g_sk_slots[i].st == (hipStream_t)stream) sl = &g_sk_slots[i];
+    for (int i = 0; i < kSkSlots && !sl; ++i)
+      if (!g_sk_slots[i].used) { g_sk_slots[i] = SkSlot{dev, (hipStream_t)stream, nullptr, 0, true, false, nullptr}; sl = &g_sk_slots[i]; }
+    if (!sl) return CRN_ENOMEM;
+    sl->pinned = true;
+  }
   if (!want) return CRN_OK;
   return splitk_scratch(want, (hipStream_t)stream) ? CRN_OK : CRN_ENOMEM;
 }
@@ -722,6 +742,10 @@ extern "C" int crn_splitk_release(crnStream stream) {
     SkSlot& sl = g_sk_slots[i];
     if (sl.used && sl.dev == dev && sl.st == (hipStream_t)stream) {
       if (sl.buf) CRN_HIP(hipFree(sl.buf));
+      if (sl.retired) {
+        for (float* b : *sl.retired) (void)hipFree(b);
+        delete sl.retired;
+      }
       sl = SkSlot{};
     }
   }

@@ -14,6 +14,7 @@
 // same fixed point = the reference's connected-component answer.
 // HBM traffic: read grid once, write result once (+ 2 bits/voxel of bitmaps).
 #include "crn_common.h"
+#include <cstring>
 #include <algorithm>
 #include <mutex>
 #include <vector>
@@ -614,15 +615,19 @@ __global__ __launch_bounds__(1024) void fill_fused_kernel(const T* grid, T* out,
     __shared__ int s_go;
     unsigned* wp = &c->word[it & (kFusedIters - 1)];
     if (threadIdx.x == 0) {
-      __hip_atomic_fetch_add(wp, 1u + ((any || it == 0) ? 0x10000u : 0u), fused_relaxed ? __ATOMIC_RELAXED : __ATOMIC_RELEASE,
-                             __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned before = __hip_atomic_fetch_add(wp, 1u + ((any || it == 0) ? 0x10000u : 0u),
+                                                     fused_relaxed ? __ATOMIC_RELAXED : __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       int spins = 0;
       unsigned v;
       while (((v = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xFFFFu) < (unsigned)nslabs &&
              ++spins < (1 << 22))
         __builtin_amdgcn_s_sleep(2);
       if (!fused_relaxed) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      s_go = (v & 0xFFFFu) < (unsigned)nslabs ? -1 : (int)(v >> 16);
+      // an arrival count that was not below nslabs BEFORE this slab arrived, or that ends above it, is not of this round: words
+      // left behind by a launch that did not end (a fault killed it).  Give up like for a missing partner: the flag goes up, the
+      // last workgroup out redoes the grids alone and clears every control word of the launch.
+      const bool stale = (before & 0xFFFFu) >= (unsigned)nslabs || (v & 0xFFFFu) > (unsigned)nslabs;
+      s_go = ((v & 0xFFFFu) < (unsigned)nslabs || stale) ? -1 : (int)(v >> 16);
     }
     __syncthreads();
     const int go = s_go;
@@ -692,27 +697,36 @@ constexpr int CRN_EAGAIN = -1000;     // internal: use the multi-launch path
 // Control buffer of the single-launch path for one caller workspace: allocated and zeroed (on the call's stream) the
 // first time that workspace is seen or when it has to grow -- that call cannot be part of a stream capture, every
 // later one can.  Calls that share a workspace are ordered by the caller anyway (they share its bitmaps and halos).
+// A control buffer is NEVER freed while the process lives: a captured HIP graph keeps the address it saw, so a
+// workspace that grows gets a new buffer and the outgrown one stays allocated, and no entry is ever evicted (64 KiB per
+// distinct workspace address; torch's caching allocator hands the same few addresses out again and again).
 struct FillControl { const void* ws; char* buf; size_t bytes; };
 std::mutex g_fill_mu;
 std::vector<FillControl> g_fill_controls;
 char* fill_control(const void* ws, size_t bytes, hipStream_t st) {
   std::lock_guard<std::mutex> lock(g_fill_mu);
   FillControl* slot = nullptr;
-  for (auto& f : g_fill_controls) if (f.ws == ws) slot = &f;
-  if (slot && slot->bytes >= bytes) return slot->buf;
+  for (auto& f : g_fill_controls) if (f.ws == ws && f.bytes >= bytes) slot = &f;
+  if (slot) return slot->buf;
   const size_t want = std::max(bytes, (size_t)64 * 1024);
   char* buf = nullptr;
   if (hipMalloc(&buf, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   if (hipMemsetAsync(buf, 0, want, st) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(buf); return nullptr; }
-  if (slot) { (void)hipFree(slot->buf); slot->buf = buf; slot->bytes = want; }      // (hipFree waits for the device)
-  else {
-    if (g_fill_controls.size() >= 32) {          // a caller with a new workspace per call: forget the oldest one
-      (void)hipFree(g_fill_controls.front().buf);
-      g_fill_controls.erase(g_fill_controls.begin());
-    }
-    g_fill_controls.push_back({ws, buf, want});
-  }
+  g_fill_controls.push_back({ws, buf, want});          // (an outgrown entry of the same workspace stays: a graph may replay it)
   return buf;
+}
+// The cache-maintenance-free exchange (write-through stores, acknowledged, relaxed arrival) is outside what the HIP / LLVM memory
+// model promises; it rests on how gfx950 implements agent-scope atomics (written through / cache-bypassing) and on vmcnt covering
+// stores.  It is measured and tested on MI355X (bit-exact on every fixture incl. the serpentine grid's hundreds of rounds); on any
+// other device name the release / acquire form is used.  CRN_FILL_RELAXED=0 / 1 forces either.
+int fill_relaxed_default() {
+  static const int v = [] {
+    if (const char* e = getenv("CRN_FILL_RELAXED")) return atoi(e) != 0 ? 1 : 0;
+    int dev = 0; hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+    return strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+  }();
+  return v;
 }
 constexpr size_t kSweepLds = 144 * 1024;
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -778,7 +792,7 @@ int run_fill_fused(const T* grid, T* out, int N, int D, int H, int W, int WX, vo
   u64* halo = reinterpret_cast<u64*>(base + align256((size_t)N * sizeof(FusedCtl)) + 256);
   // rounds: bounded only to bound a launch's run time (tests: CRN_FILL_MAXROUNDS forces the failure path)
   static const int max_rounds = getenv("CRN_FILL_MAXROUNDS") ? std::max(2, atoi(getenv("CRN_FILL_MAXROUNDS"))) : (1 << 16);
-  static const int relaxed = (getenv("CRN_FILL_RELAXED") && atoi(getenv("CRN_FILL_RELAXED")) == 0) ? 0 : 1;
+  const int relaxed = fill_relaxed_default();
   const int64_t gstride = (int64_t)D * H * W;
   const int64_t hstride = (int64_t)nslabs * 2 * 2 * H * WX;
   for (int g0 = 0; g0 < N && !rescue_only; g0 += G) {

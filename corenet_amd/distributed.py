@@ -139,6 +139,7 @@ class GradientSync:
     if native and t.cuda.is_available() and (world_size > 1 or force):
       self.native = NativeComm(group=group) if dist.is_initialized() else NativeComm(0, 1)
     self.engine = None
+    self.needs_buffer_broadcast = False
     self._staged = False
     self.probe = False          # bench.py: HIP-event pairs around the wait for every bucket ...
     self.bucket_log = []        # ... one list of (start, end) per step, buckets in push order
@@ -153,9 +154,22 @@ class GradientSync:
     self._probe_evs = []
 
   def attach(self, engine):
-    """Carry the BatchRenorm buffers of `engine` on the first gradient bucket (see the class docstring)."""
+    """Carry the BatchRenorm buffers of `engine` on the first gradient bucket (see the class docstring).  The piggy-back
+    synchronises the ranks at the END of a step; the FIRST step after attach(), after load_state_dict() or after resuming from a
+    checkpoint on one rank starts from whatever each rank holds -- so the exchange owes one explicit broadcast of rank 0's buffers,
+    which CoreNet.train_step pays before that step's forward (`needs_buffer_broadcast`; DDP broadcast_buffers=True semantics,
+    pipeline.py:199-200)."""
     self.engine = engine
+    engine.exchange = self
+    self.needs_buffer_broadcast = True
     return self
+
+  def broadcast_buffers_once(self):
+    self.needs_buffer_broadcast = False
+    if self.engine is None or not self._active() or not dist.is_initialized():
+      return
+    src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+    broadcast_buffers(self.engine.store, src, group=self.group)
 
   def _active(self) -> bool:
     return self.world > 1 or (self.force and (dist.is_initialized() or self.native is not None))

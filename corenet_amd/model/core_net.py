@@ -149,6 +149,30 @@ class CoreNet(nn.Module):
 
   def _mark_dirty(self):
     self.engine.weights_dirty = True
+    self._packed_version = None              # whatever wrote the slabs: the next inference forward packs again
+    ex = getattr(self.engine, "exchange", None)
+    if ex is not None:                       # data parallel: the loaded BatchRenorm buffers of rank 0 go to every rank before the
+      ex.needs_buffer_broadcast = True       # next step (distributed.GradientSync.attach)
+
+  def close(self):
+    """Gives back what the inference / training graphs of this model hold outside torch's allocator: the captured graphs with their
+    private pools and the capture stream's split-K scratch.  Called by __del__; the model stays usable (it captures again)."""
+    eng = getattr(self, "engine", None)
+    if eng is None:
+      return
+    live = {id(g) for p in eng.plans.values() for g in list(p.graphs.values()) + [p.eval_graph] if g is not None}
+    _LIVE_GRAPHS[:] = [g for g in _LIVE_GRAPHS if id(g) not in live]
+    eng.release_graph_resources()
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+  def train(self, mode: bool = True):
+    self._packed_version = None              # mode switches re-derive the packed weights once (cheap, and never stale)
+    return super().train(mode)
 
   def _on_device(self):
     """Kernels go to the current stream of the CURRENT device: make that the model's device for the call, and pin
@@ -226,10 +250,12 @@ class CoreNet(nn.Module):
       # counters see every in-place torch write to a parameter (optimizers, load_state_dict, `p.add_()`); writes through
       # `.data` or raw pointers need `mark_weights_dirty()`.  (A training-mode forward re-derives them every call, as before:
       # an external optimizer steps between two of them.)
+      # `.data` / raw-pointer / custom-kernel writes bypass the counters and need `mark_weights_dirty()`; CRN_EVAL_WEIGHT_CHECK=N
+      # compares a device checksum of both slabs every N-th inference call (a host sync: a debugging aid, off by default)
       ver = (eng.store.params._version, eng.store.buffers._version)
-      if ver != self._packed_version:
+      if ver != self._packed_version or self._weights_moved():
         eng.weights_dirty = True
-        self._packed_version = ver
+      self._pending_version = ver              # becomes _packed_version once the forward below has packed
     else:
       eng.weights_dirty = True           # parameters may have been stepped by an external optimizer
       self._packed_version = None
@@ -242,8 +268,25 @@ class CoreNet(nn.Module):
         return _CoreNetFn.apply(self, image, v2s, off, *params)
       plan = eng.plan(B)
       if inference and image.is_cuda and _EVAL_GRAPH and plan.trace is None and plan.probes is None:
-        return self._forward_eval_graph(plan, image, v2s, off)
-      return plan.forward(image, v2s, off, training=self.training).clone()
+        out = self._forward_eval_graph(plan, image, v2s, off)
+      else:
+        out = plan.forward(image, v2s, off, training=self.training).clone()
+      if inference and not eng.weights_dirty:
+        self._packed_version = self._pending_version      # the packed forms now belong to this version of the slabs
+      return out
+
+  def _weights_moved(self) -> bool:
+    n = int(os.environ.get("CRN_EVAL_WEIGHT_CHECK", "0") or 0)
+    if n <= 0:
+      return False
+    self._eval_calls = getattr(self, "_eval_calls", 0) + 1
+    if self._eval_calls % n:
+      return False
+    st = self.engine.store
+    sig = (float(st.params.double().sum()), float(st.params.double().abs().sum()), float(st.buffers.double().sum()))
+    moved = getattr(self, "_weight_sig", None) is not None and sig != self._weight_sig
+    self._weight_sig = sig
+    return moved
 
   def mark_weights_dirty(self):
     """Parameters or buffers were written behind torch's back (`.data`, raw pointers): the next forward re-derives the packed
@@ -299,14 +342,15 @@ class CoreNet(nn.Module):
     ver = (self.engine.store.params._version, self.engine.store.buffers._version)     # (as in forward(): inference keeps its packs)
     if ver != self._packed_version:
       self.engine.weights_dirty = True
-      self._packed_version = ver
     plan = self.engine.plan(B)
     v2s = voxel_projection_matrix.to(t.float32).contiguous()
     offs = grid_offsets.to(t.float32).contiguous()
     C = self.engine.num_classes
     D, H, W = plan.logits.shape[2:]
     with t.no_grad():
-      plan.forward_encoder(image.contiguous(), training=False)
+      plan.forward_encoder(image.contiguous(), training=False)      # packs encoder AND decoder weights when they are dirty
+      if not self.engine.weights_dirty:
+        self._packed_version = ver
       stash = t.empty((n, B, C, D, H, W), dtype=plan.logits.dtype, device=plan.logits.device)
       for i in range(n):
         stash[i].copy_(plan.forward_decoder(v2s, offs[i], training=False))
@@ -343,6 +387,8 @@ class CoreNet(nn.Module):
       raise ValueError(f"grid of shape {tuple(grid.shape)}, expected {(B,) + tuple(eng.resolution)}")
     with self._on_device():
       plan = eng.plan(B)
+      if all_reduce is not None and getattr(all_reduce, "needs_buffer_broadcast", False):
+        all_reduce.broadcast_buffers_once()      # first step after attach() / load_state_dict(): DDP's broadcast_buffers
       if graph is None:
         graph = os.environ.get("CRN_GRAPH", "0") == "1"
       if all_reduce is not None and hasattr(all_reduce, "_active") and not all_reduce._active():

@@ -239,6 +239,7 @@ class Engine:
     self.adam_hyper: Optional[t.Tensor] = None
     self.dgrad_dirty = True
     self.weights_dirty = True
+    self.exchange = None           # distributed.GradientSync.attach(): the data-parallel exchange that carries this engine's buffers
     self._side = False             # created on first use (side_stream)
     self._capture = None           # created on first use (capture_stream)
     self._pack_ev = self._dgrad_packed = self._dec_packed = self._enc_late_packed = None
@@ -254,13 +255,23 @@ class Engine:
     after the other."""
     if self._capture is None:
       self._capture = t.cuda.Stream(device=self.device)
-      # the largest scratch the library ever uses (256 MB; larger reductions take the atomic path), once: a scratch that grew for a
-      # later capture would be freed under the graphs captured before
-      self.be.splitk_reserve(self._capture, floats=(256 << 20) // 4)
+    # (every call, i.e. before every capture:) as large as the largest split-K scratch any stream of this device has needed so far
+    # -- the eager runs that precede a capture have sized the main and the side stream's scratch for exactly these launches.  A
+    # capture stream's slot is pinned: if a later capture (a larger batch size) needs more, the outgrown buffer is kept for the
+    # graphs captured before (crn_splitk_reserve) and everything goes back in release_graph_resources().  (Round 4 reserved the
+    # library's maximum, 256 MB, for every engine that ever replayed an inference graph: ADVICE r4.)
+    self.be.splitk_reserve(self._capture, floats=0)
     return self._capture
 
   def release_graph_resources(self):
-    """Drops the capture stream's scratch (after the graphs captured on it were reset)."""
+    """Resets every graph captured for this engine's plans and gives the capture stream's scratch back (CoreNet.close())."""
+    for p in self.plans.values():
+      for g in list(p.graphs.values()) + ([p.eval_graph] if p.eval_graph is not None else []):
+        try:
+          g.reset()
+        except Exception:
+          pass
+      p.graphs, p.eval_graph, p.eval_eager = {}, None, 0
     if self._capture is not None:
       self.be.splitk_release(self._capture)
       self._capture = None

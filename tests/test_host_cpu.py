@@ -441,3 +441,77 @@ def test_mat_index_blocks_equal_tiles():
   for part in ((0, ct.index, ct.npad, 0), (0, G.stem_fwd().index, G.stem_fwd().npad, 0),
                (0, G.bias_index(16, 8, 128, True).astype(np.int64), 128, 0)):
     assert G.mat_index([part])[0].shape[0] == 0 and len(G.mat_index([part])[1]) == 1
+
+
+def test_gradient_bars_catch_a_glitched_scatter():
+  """Fault injection: the round-3/4 glitch made a few hundred of the 98 k elements of the 64^3 skip map's
+  gradient wrong by up to 6 % of the map's range, in ~90 % of the training steps, and every golden test passed.  Here the same
+  fault is put into the ORACLE's scatter (the gradient arriving at the compressed 64 x 64 map of rt_skip_5 is perturbed on a few
+  pixel clusters) and the per-tensor bars of tests/test_model_gpu.py::test_decoder_gradients_every_element_vs_oracle are
+  evaluated against the clean oracle run: the glitched run must fail them (and the clean run, compared with itself, passes)."""
+  import importlib
+  tm = importlib.import_module("test_model_gpu")
+  z = np.load(os.path.join(os.path.dirname(__file__), "golden", "model_h7_train_b2_nbt30k.npz"))
+  sd = O.make_state(0, 2, nbt=30000)
+  image, v2s, off, grid = O.synthetic_batch(2, 0, 2)
+
+  class Glitch(t.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+      return x.view_as(x)
+    @staticmethod
+    def backward(ctx, g):
+      if tuple(g.shape[1:]) != (12, 64, 64):        # only the 64^3 skip's compressed map
+        return g
+      gen = t.Generator().manual_seed(3)
+      g = g.clone()
+      rng = float(g.max() - g.min())
+      for _ in range(6):                            # six tiles' pixel windows, ~50 elements each: ~300 of 98 k
+        b, c = int(t.randint(0, g.shape[0], (1,), generator=gen)), int(t.randint(0, 12, (1,), generator=gen))
+        y0, x0 = int(t.randint(0, 56, (1,), generator=gen)), int(t.randint(0, 56, (1,), generator=gen))
+        g[b, c, y0:y0 + 7, x0:x0 + 7] += (t.rand(7, 7, generator=gen) * 2 - 1) * 0.06 * rng
+      return g
+
+  def run(glitch):
+    so = {k: v.clone() for k, v in sd.items()}
+    for k in so:
+      if so[k].dtype == t.float32 and "running" not in k: so[k].requires_grad_(True)
+    orig = O.ray_sample
+    if glitch:
+      O.ray_sample = lambda grid2d, *a, **kw: orig(Glitch.apply(grid2d), *a, **kw)
+    try:
+      O.iou_fgbg(grid, O.corenet_forward(so, image, v2s, off, training=True)).backward()
+    finally:
+      O.ray_sample = orig
+    return {k: v.grad for k, v in so.items() if v.dtype == t.float32 and v.requires_grad}
+
+  clean, bad = run(False), run(True)
+  names = tm.decoder_weight_names(clean)
+  bars = tm.decoder_gradient_bars(z, names, "bf16x3")          # the LOOSER of the two modes' bars
+  gmax = max(float(z[k]) for k in z.files if k.startswith("gmax::"))
+  flagged = {}
+  for n in names:
+    scale = max(float(clean[n].abs().max()), 1e-3 * gmax)
+    err = float((bad[n].double() - clean[n].double()).abs().max()) / scale
+    if err > bars[n]:
+      flagged[n] = err
+  print("tensors over their bar with the glitch injected:", {k: f"{v:.1e}" for k, v in flagged.items()})
+  assert "decoder.rt_skip_5.compress_channels.weight" in flagged, flagged
+
+
+def test_no_mfma_hazard_behind_the_inline_assembly_blocks():
+  """csrc/conv_bf3.hip issues the three products of an accumulator as one inline-asm block of MFMAs, which the compiler's hazard
+  recognizer cannot see into: the wait states between such an MFMA and the next access to its destination registers are checked on
+  the disassembly of the shipped objects (tools/check_mfma_hazards.py; the rules are LLVM's for the gfx940 family)."""
+  import importlib.util
+  from corenet_amd import build as B
+  if not os.path.exists(B.LIB):
+    B.build(verbose=False)
+  spec = importlib.util.spec_from_file_location("check_mfma_hazards", os.path.join(os.path.dirname(B.HERE), "tools", "check_mfma_hazards.py"))
+  chk = importlib.util.module_from_spec(spec); spec.loader.exec_module(chk)
+  total = 0
+  for obj in ("conv_bf3.o", "conv_e2d.o", "conv_igemm.o", "conv_inst_fwd_1_1.o", "conv_inst_wgrad_1_1.o"):
+    n, bad = chk.check(os.path.join(B.LIBDIR, obj))
+    assert not bad, (obj, bad[:3])
+    total += n
+  assert total > 5000          # (the split-bf16 decoder kernels alone hold ~5700 MFMAs)

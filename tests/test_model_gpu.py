@@ -240,6 +240,54 @@ def test_all_parameter_gradients_against_fp64_truth(math, fixture, B):
   assert max(bars) <= GRAD_BAR_CAP and outliers[0][0] <= GRAD_OUTLIER_CAP, outliers[:3]
 
 
+def decoder_gradient_bars(z, names, math):
+  """Per-tensor element-wise bars of the decoder's weight gradients, of the tensor's scale: max(8 x the reference's own fp32-vs-fp64
+  error on the fixture (`gnoise`), 2e-3), twice that for the split-bf16 mode (16 mantissa bits per product)."""
+  return {n: GRAD_MODE_FACTOR[math] * max(GRAD_NOISE_FACTOR * float(z["gnoise::" + n]), GRAD_ERR_FLOOR) for n in names}
+
+
+def decoder_weight_names(params):
+  return [n for n in params if n.startswith("decoder.") and n.endswith(".weight") and
+          (".c1." in n or ".t1." in n or "compress_channels" in n)]
+
+
+@pytest.mark.parametrize("math", MATHS)
+def test_decoder_gradients_every_element_vs_oracle(math):
+  """EVERY element of every decoder convolution's weight gradient (stage_k.c1 / t1, rt_skip_k.compress_channels: 22 tensors,
+  11.9 M elements) on the well-conditioned fixture's inputs (h7, B = 2, num_batches_tracked = 30000), against the oracle's
+  autograd run here on the host (fp32; the fixture generator asserts oracle == reference on exactly these inputs).  Decoder
+  tensors see no small-batch norm of the encoder, their conditioning is good (gnoise 2e-5 ... 6e-3 in the fixture), so the bar is
+  per tensor max(8 x gnoise, 2e-3) of the tensor's scale on ALL elements -- no quantile, no sub-sample, no outlier allowance.
+  This is the test the round-3/4 scatter glitch (a few hundred elements of the 64^3 skip-map gradient off by up to 6 % of its
+  range, DESIGN section 3e) has to get past: tests/test_host_cpu.py::test_gradient_bars_catch_a_glitched_scatter injects exactly
+  that fault into the oracle and asserts these bars flag it."""
+  from corenet_amd.model import losses
+  z = np.load(os.path.join(G, "model_h7_train_b2_nbt30k.npz"))
+  sd = O.make_state(0, 2, nbt=30000)
+  image, v2s, off, grid = O.synthetic_batch(2, 0, 2)
+  m = _model(2, sd, math).train()
+  losses.iou_fgbg(grid.cuda(), m(image.cuda(), v2s.cuda(), off.cuda())).backward()
+  so = {k: v.clone() for k, v in sd.items()}
+  for k in so:
+    if so[k].dtype == t.float32 and "running" not in k: so[k].requires_grad_(True)
+  O.iou_fgbg(grid, O.corenet_forward(so, image, v2s, off, training=True)).backward()
+  params = dict(m.named_parameters())
+  names = decoder_weight_names(params)
+  assert len(names) == 22, names
+  bars = decoder_gradient_bars(z, names, math)
+  gmax = max(float(z[k]) for k in z.files if k.startswith("gmax::"))
+  rows = []
+  for n in names:
+    got, want = params[n].grad.double().cpu(), so[n].grad.double()
+    scale = max(float(want.abs().max()), 1e-3 * gmax)
+    err = float((got - want).abs().max()) / scale
+    rows.append((err / bars[n], err, bars[n], n, got.numel()))
+  rows.sort(reverse=True)
+  print(f"[{math}] decoder weight gradients, every element vs the oracle: worst " +
+        ", ".join(f"{n} {e:.1e} (bar {b:.1e})" for _, e, b, n, _ in rows[:4]) + f"; {sum(r[4] for r in rows)} elements")
+  assert rows[0][0] <= 1.0, rows[:4]
+
+
 # element-wise bars of the five full gradients the fixtures store (oracle/gen_golden.py:87-90), by depth of the
 # tensor below the loss: last layer / its norm / the 64^3 skip compression (through stage_6) / the latent bias
 # (through the whole decoder; BatchRenorm over B=1 has zero gradient there).  The reference itself moves by
@@ -284,8 +332,15 @@ def test_train_forward_backward_golden(tag, nc, nbt, B, lossname):
     if n.endswith("conv.bias") or n.endswith("c1.bias") or ".t1.bias" in n and "stage_6" not in n:
       continue                     # biases in front of a train-mode BatchRenorm: true gradient is 0
     got = float(params[n].grad.double().norm())
-    if abs(got - want) > 0.25 * want + 1e-12:
-      bad.append((n, got, float(want)))
+    # B = 1 / nbt = 0 fixtures: statistics over ONE sample amplify rounding ~400x (the reference's own fp32 run is 5e-2 ... 2e-1 from
+    # fp64 in the encoder there): 25 % on the norm is all those fixtures can hold.  The well-conditioned fixture (B = 2,
+    # nbt = 30000) stores the reference's own fp32-vs-fp64 error per tensor (`gnoise`, of the tensor's scale): its norms are held to
+    # 10 x max(8 x gnoise, 2e-3) -- |norm error| <= (max / rms of the tensor, < 10 measured) x the element-wise bar
+    tol = 0.25
+    if "gnoise::" + n in z.files:
+      tol = min(0.25, 10.0 * max(8.0 * float(z["gnoise::" + n]), 2e-3))
+    if abs(got - want) > tol * want + 1e-12:
+      bad.append((n, got, float(want), tol))
   assert not bad, bad[:8]
   # running statistics were stepped like the reference's
   sdn = m.state_dict()
