@@ -32,12 +32,13 @@ import torch.distributed as dist  # noqa: E402
 # algorithmic work: per sample
 CONV6_FLOP = 2 * 64 ** 3 * 28 * 125 * 16          # stage_6 c1: Conv3d 28->16 k5 @64^3
 RAY64_BYTES = 64 ** 3 * 12 * 4 + 64 * 64 * 12 * 4  # ray-sample 64^3 x 12ch: output + map
+RAY64_IDX_BYTES = 64 ** 3 * 2                      # ... + the saved index tensor (uint16 per voxel) the scatter reads
 PEAK_F32_MFMA = 157.3e12                           # MI355X_MICROARCH.md: fp32 matrix peak
 PEAK_BF16_MFMA = 2500e12                           # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM = 8.0e12                                  # HBM3E spec peak
 # HBM bytes per launch come from separate rocprofv3 --pmc passes of this command (tools/pmc_traffic.sh); the record is
 # keyed by kernel name + grid, so both are named here, next to the kernel they describe
-TRAFFIC_FILES = {"bf16x3": "r04_pmc_traffic.json", "fp32": "r01_pmc_traffic.json"}
+TRAFFIC_FILES = {"bf16x3": "r05_pmc_traffic.json", "fp32": "r05_pmc_traffic_fp32.json"}
 CONV_BF3_TRAFFIC_KERNEL, CONV_BF3_THREADS = "conv_bf3_half_kernel<1, 1, 7, 1", 512
 
 
@@ -87,6 +88,44 @@ def synthetic_meshes(batch, dev):
   v2x = BE.view2voxel_matrices(t.full((batch, 3), 0.5), (128,) * 3)
   mv = t.cat([v2x[b:b + 1].expand(3, 4, 4) for b in range(batch)])
   return tris, nt, mv
+
+
+def load_traffic(math, B, C, want):
+  """HBM bytes per launch from the PMC passes of this same command (profiles/r05_pmc_traffic*.json; FETCH_SIZE / WRITE_SIZE
+  need their own rocprofv3 runs and cannot be read from inside the process).  Returns ({key: bytes}, file name)."""
+  traffic = {}
+  traffic_file = os.path.join("profiles", TRAFFIC_FILES[math])
+  try:
+    tj = json.load(open(os.path.join(ROOT, traffic_file)))
+  except (OSError, ValueError) as e:
+    print(f"bench.py: no HBM-traffic record ({traffic_file}: {e}); roofline.traffic = null", file=sys.stderr)
+    return traffic, traffic_file
+  if B == 4 and C == 2:
+    for k, v in tj.get("kernels", {}).items():
+      if math == "bf16x3":
+        # stage_6.c1 fwd is the only launch of conv_bf3_half_kernel<NSUB 1, unit-stride x, 5x5 plane> on 2048 tiles
+        if CONV_BF3_TRAFFIC_KERNEL in k and k.endswith(f"grid {2048 * CONV_BF3_THREADS}"):
+          traffic["conv"] = v["hbm_bytes"]
+      # stage_6.c1 fwd (fp32 engine): conv_fwd_kernel<8,1,xvec>, 2048 tiles x 1 N-block.  stage_5.t1 and stage_6.t1 fwd
+      # share that (kernel, grid); per step the dispatch order is s5.t1, s6.c1, s6.t1 -> every 3rd from 1
+      elif "conv_fwd_kernel<8, 1, 1>" in k and k.endswith(f"grid {2048 * 256}"):
+        pl = v.get("per_launch_hbm_bytes", [])
+        if len(pl) >= 3 and len(pl) % 3 == 0:
+          mine = pl[1::3]
+          traffic["conv"] = sum(mine) / len(mine)
+      if "ray_sample_fwd_kernel" in k and k.endswith("grid 262144"):        # 64^3 x 12 ch
+        traffic["ray"] = v["hbm_bytes"]
+      if "ray_scatter_kernel<4, 8" in k and k.endswith(f"grid {128 * 3 * 4 * 256}"):   # 64^3: (2 x 8 tiles x 8 z segments) x 3 channel groups x B of 256 threads
+        traffic["ray_bwd"] = v["hbm_bytes"]
+      if "fill_fused_kernel" in k:
+        traffic["fill"] = v["hbm_bytes"]
+    missing = [k for k in want if k not in traffic]
+    if missing:
+      # a kernel was renamed / re-gridded since the PMC passes were taken: say so instead of printing a stale or
+      # silently empty number (tools/pmc_traffic.sh regenerates the file)
+      print(f"bench.py: {traffic_file} has no record for {missing} (kernel names / grids changed?) -- "
+            f"re-run tools/pmc_traffic.sh; roofline.traffic = null for those", file=sys.stderr)
+  return traffic, traffic_file
 
 
 def host_threads():
@@ -201,9 +240,8 @@ def main():
   grid = grid.to(t.int32)
   # gradient exchange: overlapped buckets; rank 0's BatchRenorm buffers ride on the first bucket (what DDP's per-forward
   # buffer broadcast delivers, without the blocking collective in front of every step); one broadcast up front
-  sync = D.GradientSync(world).attach(model.engine)
+  sync = D.GradientSync(world).attach(model.engine)      # (owes one broadcast of rank 0's buffers: paid by the first step)
   sync.probe = world > 1
-  D.broadcast_buffers(model.engine.store)
   plan = model.engine.plan(B)
 
   def timed(mdl, pl):
@@ -290,39 +328,11 @@ def main():
   if rank != 0:
     return
   conv_s, ray_s = probes["conv3d_stage6_c1_fwd"], probes["ray_sample_fwd_64"]
-  # HBM bytes per launch from the PMC passes of this same command (profiles/*_pmc_traffic.json;
-  # FETCH_SIZE / WRITE_SIZE need their own rocprofv3 runs and cannot be read from inside the process)
-  traffic = {}
-  traffic_file = os.path.join("profiles", TRAFFIC_FILES[args.math])
-  try:
-    tj = json.load(open(os.path.join(ROOT, traffic_file)))
-  except (OSError, ValueError) as e:
-    tj = None
-    print(f"bench.py: no HBM-traffic record ({traffic_file}: {e}); roofline.traffic = null", file=sys.stderr)
-  if tj is not None:
-    if B == 4 and C == 2:
-      for k, v in tj.get("kernels", {}).items():
-        if args.math == "bf16x3":
-          # stage_6.c1 fwd is the only launch of conv_bf3_half_kernel<NSUB 1, unit-stride x, 5x5 plane> on 2048 tiles
-          if CONV_BF3_TRAFFIC_KERNEL in k and k.endswith(f"grid {2048 * CONV_BF3_THREADS}"):
-            traffic["conv"] = v["hbm_bytes"]
-        # stage_6.c1 fwd (fp32 engine): conv_fwd_kernel<8,1,xvec>, 2048 tiles x 1 N-block.  stage_5.t1 and stage_6.t1 fwd
-        # share that (kernel, grid); per step the dispatch order is s5.t1, s6.c1, s6.t1 -> every 3rd from 1
-        elif "conv_fwd_kernel<8, 1, 1>" in k and k.endswith(f"grid {2048 * 256}"):
-          pl = v.get("per_launch_hbm_bytes", [])
-          if len(pl) >= 3 and len(pl) % 3 == 0:
-            mine = pl[1::3]
-            traffic["conv"] = sum(mine) / len(mine)
-        if "ray_sample_fwd_kernel" in k and k.endswith("grid 262144"):        # 64^3 x 12 ch
-          traffic["ray"] = v["hbm_bytes"]
-        if "fill_fused_kernel" in k:
-          traffic["fill"] = v["hbm_bytes"]
-      missing = [k for k in ("conv", "ray", "fill") if k not in traffic]
-      if missing:
-        # a kernel was renamed / re-gridded since the PMC passes were taken: say so instead of printing a stale or
-        # silently empty number (tools/pmc_traffic.sh regenerates the file)
-        print(f"bench.py: {traffic_file} has no record for {missing} (kernel names / grids changed?) -- "
-              f"re-run tools/pmc_traffic.sh; roofline.traffic = null for those", file=sys.stderr)
+  traffic, traffic_file = load_traffic(args.math, B, C, ("conv", "ray", "ray_bwd", "fill"))
+  if fp32_side is not None:
+    t32, f32file = load_traffic("fp32", B, C, ("conv",))
+    fp32_side["roofline"]["traffic"] = t32.get("conv")
+    fp32_side["roofline"]["traffic_source"] = f"{f32file} (separate rocprofv3 --pmc passes of `bench.py --math fp32`; not measured in this run)"
   # ground-truth side: fill_voxels on 3 hollow shells per sample, whole call (one launch) timed with HIP
   # events; the kernel-only time is in profiles/
   ax = t.arange(128, device=dev, dtype=t.float32) - 63.5
@@ -372,6 +382,21 @@ def main():
     be.ray_sample_fwd(*ray_args, map_sC=1, map_sP=k5)
   e1.record(); t.cuda.synchronize()
   ray_burst_s = e0.elapsed_time(e1) / 20 * 1e-3
+  # ... and the scatter of the backward pass (from the saved index tensor the training-mode gather leaves), same form
+  gu6 = plan.dec[6]["gu"]
+  bwd_args = (gu6[:, gu6.shape[1] - k5:], gu6.stride(0), B, k5, 64, 64, 64, plan.ray_idx[5], plan.gsmap[5], plan.gsmap[5].stride(0),
+              64, 64, False) if plan.ray_idx is not None else None
+  ray_bwd_s = None
+  if bwd_args is not None:
+    be.ray_sample_fwd_idx(*ray_args, plan.ray_idx[5], map_sC=1, map_sP=k5)
+    gu6.normal_()
+    for _ in range(3):
+      be.ray_sample_bwd_idx(*bwd_args)
+    e0.record()
+    for _ in range(20):
+      be.ray_sample_bwd_idx(*bwd_args)
+    e1.record(); t.cuda.synchronize()
+    ray_bwd_s = e0.elapsed_time(e1) / 20 * 1e-3
   # forward-only (eval mode, running BatchRenorm statistics): SURVEY 8(d) asks for it next to the train step
   model.eval()
   with t.no_grad():
@@ -428,15 +453,28 @@ def main():
                                "frac": fill_bytes / fill_s / PEAK_HBM, "traffic": traffic.get("fill"),
                                "avg_launch_ms": fill_s * 1e3},
   }
+  if ray_bwd_s is not None:
+    out["roofline_ray_sample_bwd"] = {
+        "kernel": "ray_scatter_kernel<4,8,u16> (64^3 x 12 ch gradient -> 64 x 64 map, from the saved index tensor; 64-bit fixed-point LDS window)",
+        "bound": "hbm", "achieved": (RAY64_BYTES + RAY64_IDX_BYTES) * B / ray_bwd_s / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+        "frac": (RAY64_BYTES + RAY64_IDX_BYTES) * B / ray_bwd_s / PEAK_HBM, "traffic": traffic.get("ray_bwd"),
+        "avg_launch_ms": ray_bwd_s * 1e3, "note": "burst of 20 launches on the step's own buffers (the map gradient is zeroed by the caller)"}
   out["roofline_voxelize"] = {"kernel": f"voxelize_kernel ({3 * B} meshes x {vox_tris.shape[0] // (3 * B)} triangles -> 128^3, multiplier 8, whole call "
                                         "incl. the zero-initialisation of the grids)", "bound": "hbm",
                               "achieved": vox_bytes / vox_s / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                               "frac": vox_bytes / vox_s / PEAK_HBM, "traffic": None, "avg_launch_ms": vox_s * 1e3,
                               "note": "latency-bound rasterisation (one wavefront per triangle); off the model's critical path"}
-  for k in ("roofline_ray_sample", "roofline_fill_voxels"):
-    out[k]["traffic_source"] = out["roofline"]["traffic_source"]
+  for k in ("roofline_ray_sample", "roofline_ray_sample_bwd", "roofline_fill_voxels"):
+    if k in out:
+      out[k]["traffic_source"] = out["roofline"]["traffic_source"]
   if fp32_side is not None:
     out["fp32_math"] = fp32_side
+    # which of the numbers on this line is at the REFERENCE's arithmetic (fp32 end to end, model/losses.py:33): the
+    # headline `value` is the product default (split-bf16 products, 16 mantissa bits, error measured under `parity`), this block
+    # is the same step with every convolution on the fp32 MFMA engine, timed in the same run
+    out["reference_precision"] = {"dtype": "f32", "value": fp32_side["value"], "unit": "voxels/s",
+                                  "ms_per_step": fp32_side["ms_per_step"], "roofline": fp32_side["roofline"],
+                                  "note": "fp32_math leg: every convolution on v_mfma_f32_16x16x4_f32; the headline value is bf16x3"}
   if m9_side is not None:
     out["m7_m9"] = m9_side
   if world > 1:

@@ -109,8 +109,8 @@ _SIGS = {
     "crn_relu_mean_bwd": [vp, vp, i32, i32, i64, i64, vp, i64, i32, vp],
     "crn_linear_fwd": [vp, vp, vp, i32, i32, i32, vp, i32, vp],
     "crn_linear_bwd": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp],
-    "crn_stride2_gather": [vp, vp, i32, i32, i32, i32, vp],
-    "crn_stride2_scatter": [vp, vp, i32, i32, i32, i32, vp],
+    "crn_stride2_gather": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "crn_stride2_scatter": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "crn_fill_offset_channels": [vp, i32, i64, i64, i32, vp, vp],
     "crn_ray_sample_fwd": [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp],
     "crn_ray_sample_bwd": [vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp],

@@ -273,14 +273,14 @@ class HipBackend:
                             _lib.stream())
 
   def stride2_gather(self, x, y):
-    """y[b,c,i,j] = x[b,c,2i,2j] (contiguous tensors)."""
+    """y[b,c,i,j] = x[b,c,2i,2j] (contiguous tensors; y is ceil(x / 2) in both extents)."""
     B, Cn, h, w = y.shape
-    self.lib.crn_stride2_gather(ptr(x), ptr(y), B, Cn, h, w, _lib.stream())
+    self.lib.crn_stride2_gather(ptr(x), ptr(y), B, Cn, h, w, x.shape[2], x.shape[3], _lib.stream())
 
   def stride2_scatter(self, dy, dx):
     """dx[b,c,2i,2j] = dy[b,c,i,j], zeros elsewhere."""
     B, Cn, h, w = dy.shape
-    self.lib.crn_stride2_scatter(ptr(dy), ptr(dx), B, Cn, h, w, _lib.stream())
+    self.lib.crn_stride2_scatter(ptr(dy), ptr(dx), B, Cn, h, w, dx.shape[2], dx.shape[3], _lib.stream())
 
   def fill_offset_channels(self, x, B, sB, S, c0, offset):
     self.lib.crn_fill_offset_channels(ptr(x), B, sB, S, c0, ptr(offset), _lib.stream())

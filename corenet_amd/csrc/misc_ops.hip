@@ -570,22 +570,51 @@ __global__ __launch_bounds__(256) void stride2_scatter_kernel(const float* __res
   }
   *reinterpret_cast<f32x4*>(dx + (p * (2 * h) + io) * (int64_t)(2 * w) + 4 * j2) = v;
 }
+// any size (odd output widths, odd input extents: images other than 256 x 256): one thread per element
+__global__ __launch_bounds__(256) void stride2_gather_any_kernel(const float* __restrict__ x, float* __restrict__ y, int h, int w,
+                                                                 int hin, int win, int64_t planes) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= planes * h * w) return;
+  const int j = (int)(t % w);
+  const int64_t r = t / w;
+  const int i = (int)(r % h);
+  const int64_t p = r / h;
+  y[t] = x[(p * hin + 2 * i) * (int64_t)win + 2 * j];
+}
+__global__ __launch_bounds__(256) void stride2_scatter_any_kernel(const float* __restrict__ dy, float* __restrict__ dx, int h, int w,
+                                                                  int hin, int win, int64_t planes) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t >= planes * hin * win) return;
+  const int jo = (int)(t % win);
+  const int64_t r = t / win;
+  const int io = (int)(r % hin);
+  const int64_t p = r / hin;
+  dx[t] = ((io | jo) & 1) ? 0.f : dy[(p * h + (io >> 1)) * (int64_t)w + (jo >> 1)];
+}
 }  // namespace
 
-extern "C" int crn_stride2_gather(const float* x, float* y, int B, int C, int h, int w, crnStream s) {
+extern "C" int crn_stride2_gather(const float* x, float* y, int B, int C, int h, int w, int hin, int win, crnStream s) {
   CRN_ENTRY(s);
-  if (!x || !y || B < 1 || C < 1 || h < 1 || w < 2 || (w & 1) || (((uintptr_t)x) & 15) || (((uintptr_t)y) & 7)) return CRN_EINVAL;
-  const int64_t planes = (int64_t)B * C, n = planes * h * (w >> 1);
-  hipLaunchKernelGGL(stride2_gather_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)s, x, y, h, w, planes);
+  if (!x || !y || B < 1 || C < 1 || h < 1 || w < 1 || h != (hin + 1) / 2 || w != (win + 1) / 2) return CRN_EINVAL;
+  const int64_t planes = (int64_t)B * C;
+  if (hin == 2 * h && win == 2 * w && !(w & 1) && !(((uintptr_t)x) & 15) && !(((uintptr_t)y) & 7)) {
+    hipLaunchKernelGGL(stride2_gather_kernel, dim3(nblk(planes * h * (w >> 1))), dim3(256), 0, (hipStream_t)s, x, y, h, w, planes);
+  } else {
+    hipLaunchKernelGGL(stride2_gather_any_kernel, dim3(nblk(planes * h * w)), dim3(256), 0, (hipStream_t)s, x, y, h, w, hin, win, planes);
+  }
   CRN_CHECK_LAUNCH();
   return CRN_OK;
 }
 
-extern "C" int crn_stride2_scatter(const float* dy, float* dx, int B, int C, int h, int w, crnStream s) {
+extern "C" int crn_stride2_scatter(const float* dy, float* dx, int B, int C, int h, int w, int hin, int win, crnStream s) {
   CRN_ENTRY(s);
-  if (!dy || !dx || B < 1 || C < 1 || h < 1 || w < 2 || (w & 1) || (((uintptr_t)dx) & 15)) return CRN_EINVAL;
-  const int64_t planes = (int64_t)B * C, n = planes * (2 * h) * (w >> 1);
-  hipLaunchKernelGGL(stride2_scatter_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)s, dy, dx, h, w, planes);
+  if (!dy || !dx || B < 1 || C < 1 || h < 1 || w < 1 || h != (hin + 1) / 2 || w != (win + 1) / 2) return CRN_EINVAL;
+  const int64_t planes = (int64_t)B * C;
+  if (hin == 2 * h && win == 2 * w && !(w & 1) && !(((uintptr_t)dx) & 15)) {
+    hipLaunchKernelGGL(stride2_scatter_kernel, dim3(nblk(planes * (2 * h) * (w >> 1))), dim3(256), 0, (hipStream_t)s, dy, dx, h, w, planes);
+  } else {
+    hipLaunchKernelGGL(stride2_scatter_any_kernel, dim3(nblk(planes * hin * win)), dim3(256), 0, (hipStream_t)s, dy, dx, h, w, hin, win, planes);
+  }
   CRN_CHECK_LAUNCH();
   return CRN_OK;
 }

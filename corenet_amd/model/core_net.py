@@ -21,7 +21,7 @@ import torch as t
 from torch import nn
 
 from corenet_amd import _lib
-from corenet_amd.model.engine import Engine, IMAGE_HW
+from corenet_amd.model.engine import Engine, IMAGE_HW, check_image_hw
 
 
 @dataclasses.dataclass(frozen=True)
@@ -86,7 +86,7 @@ class _CoreNetFn(t.autograd.Function):
 
   @staticmethod
   def forward(ctx, model, image, v2s, offset, *params):
-    plan = model.engine.plan(image.shape[0])
+    plan = model.engine.plan(image.shape[0], image.shape[2:])
     logits = plan.forward(image, v2s, offset, training=model.training)
     ctx.model, ctx.plan, ctx.generation = model, plan, plan.generation
     return logits.clone()      # the plan's buffer is reused by the next forward
@@ -224,14 +224,11 @@ class CoreNet(nn.Module):
     return self
 
   def _check_image(self, image: t.Tensor):
-    """Argument checks of resnet50.py:198-199, plus the one this engine adds: its plans hold buffers for
-    IMAGE_HW images only (configs/models/*.json5 all train and evaluate at 256x256).  The reference's encoder is fully
-    convolutional (resnet50.py:176-186); here any other size raises instead of over-running (larger) or silently
-    under-filling (smaller) the plan's buffers."""
+    """Argument checks of resnet50.py:198-199.  The reference's encoder is fully convolutional (resnet50.py:176-186) and so is this
+    one: a plan (buffers + launch sequences) is built per (batch size, H, W) on first use.  One restriction is this engine's own: H
+    and W must be multiples of 4 (engine.check_image_hw); anything else raises before a kernel runs."""
     assert image.dtype == t.uint8 and image.dim() == 4 and image.shape[1] == 3
-    if tuple(image.shape[2:]) != IMAGE_HW:
-      raise ValueError(f"corenet_amd.CoreNet: image batch of {tuple(image.shape[2:])} pixels; this engine is built for "
-                       f"{IMAGE_HW[0]}x{IMAGE_HW[1]} inputs (resize before the call)")
+    check_image_hw(image.shape[2:])
 
   def forward(self, image: t.Tensor, voxel_projection_matrix: t.Tensor,
               voxel_sample_locations: t.Tensor) -> t.Tensor:
@@ -266,7 +263,7 @@ class CoreNet(nn.Module):
       if t.is_grad_enabled() and self.training:
         params = [self.get_parameter(k) for k in self._param_keys]
         return _CoreNetFn.apply(self, image, v2s, off, *params)
-      plan = eng.plan(B)
+      plan = eng.plan(B, image.shape[2:])
       if inference and image.is_cuda and _EVAL_GRAPH and plan.trace is None and plan.probes is None:
         out = self._forward_eval_graph(plan, image, v2s, off)
       else:
@@ -342,7 +339,7 @@ class CoreNet(nn.Module):
     ver = (self.engine.store.params._version, self.engine.store.buffers._version)     # (as in forward(): inference keeps its packs)
     if ver != self._packed_version:
       self.engine.weights_dirty = True
-    plan = self.engine.plan(B)
+    plan = self.engine.plan(B, image.shape[2:])
     v2s = voxel_projection_matrix.to(t.float32).contiguous()
     offs = grid_offsets.to(t.float32).contiguous()
     C = self.engine.num_classes
@@ -386,7 +383,7 @@ class CoreNet(nn.Module):
     if tuple(grid.shape) != (B,) + tuple(eng.resolution):
       raise ValueError(f"grid of shape {tuple(grid.shape)}, expected {(B,) + tuple(eng.resolution)}")
     with self._on_device():
-      plan = eng.plan(B)
+      plan = eng.plan(B, image.shape[2:])
       if all_reduce is not None and getattr(all_reduce, "needs_buffer_broadcast", False):
         all_reduce.broadcast_buffers_once()      # first step after attach() / load_state_dict(): DDP's broadcast_buffers
       if graph is None:

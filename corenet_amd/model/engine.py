@@ -34,7 +34,17 @@ from corenet_amd import views as V
 from corenet_amd.backend import Transform
 from corenet_amd.model import conv_geometry as G
 
-IMAGE_HW = (256, 256)   # the input size the plans' buffers are laid out for (all configs/models/*.json5; CoreNet checks it)
+IMAGE_HW = (256, 256)   # the default input size (all configs/models/*.json5); plans are built per (batch, H, W)
+
+
+def check_image_hw(hw):
+  """The encoder is fully convolutional (resnet50.py:176-186); this engine's stem reads a 2 x 2 space-to-depth view of the image and
+  its max-pool kernel pools whole 2 x 2 cells, so H and W must be multiples of 4 (the reference takes any size)."""
+  H, W = int(hw[0]), int(hw[1])
+  if H < 32 or W < 32 or H % 4 or W % 4 or H * W > 4096 * 4096:
+    raise ValueError(f"corenet_amd.CoreNet: image batch of {H}x{W} pixels; this engine takes H and W that are multiples of 4 and >= 32 "
+                     f"(256x256 in every shipped config)")
+  return H, W
 BN_EPS = 1e-3        # resnet50.py:63, reconstruction_decoder.py:44
 BN_MOMENTUM = 0.01   # batch_renorm.py:19
 
@@ -521,11 +531,14 @@ class Engine:
     self.dgrad_dirty = False
 
   # -------------------------------------------------------------------- plans
-  def plan(self, batch: int) -> "Plan":
-    p = self.plans.get(batch)
+  def plan(self, batch: int, hw=IMAGE_HW) -> "Plan":
+    """The plan (buffers + launch sequences) of one batch size and image size; (batch, 256, 256) is keyed by `batch` alone."""
+    hw = (int(hw[0]), int(hw[1]))
+    key = batch if hw == IMAGE_HW else (batch, hw[0], hw[1])
+    p = self.plans.get(key)
     if p is None:
-      p = Plan(self, batch)
-      self.plans[batch] = p
+      p = Plan(self, batch, hw)
+      self.plans[key] = p
     return p
 
   # ----------------------------------------------------------------- optimizer
@@ -577,8 +590,12 @@ def _no_exchange(grads: t.Tensor):
 class Plan:
   """Buffers + the explicit forward / backward sequences for one batch size."""
 
-  def __init__(self, eng: Engine, B: int):
+  def __init__(self, eng: Engine, B: int, hw=IMAGE_HW):
     self.eng, self.B = eng, B
+    H, W = check_image_hw(hw)
+    self.hw = (H, W)
+    self.stem_hw = (H // 2, W // 2)          # after the 7x7 / 2 stem (resnet50.py:122-124)
+    self.pool_hw = (H // 4, W // 4)          # after the 3x3 / 2 max-pool (:128-131): stage 2 runs here
     self.be = eng.be
     self.generation = 0            # bumped by every forward: CoreNet's autograd node checks it in backward
     self.graphs = {}               # captured training steps (CoreNet.train_step): loss name -> CUDAGraph
@@ -591,44 +608,47 @@ class Plan:
     self.dev = dev
     f = lambda *shape: t.zeros(*shape, dtype=eng.dtype, device=dev)
     # static inputs of the captured training step (a replayed graph reads fixed addresses)
-    self.in_image = t.zeros(B, 3, *IMAGE_HW, dtype=t.uint8, device=dev)
+    self.in_image = t.zeros(B, 3, H, W, dtype=t.uint8, device=dev)
     self.in_v2s = f(B, 4, 4)
     self.in_off = f(B, 3)
-    self.img = f(B, 3, *IMAGE_HW)
-    self.y1 = f(B, 64, 128, 128)
-    self.gy1 = f(B, 64, 128, 128); self.gy1b = f(B, 64, 128, 128)
-    self.p1 = f(B, 64, 64, 64)
-    self.p1_arg = t.zeros(B, 64, 64, 64, dtype=t.int32, device=dev)
+    self.img = f(B, 3, H, W)
+    self.y1 = f(B, 64, *self.stem_hw)
+    self.gy1 = f(B, 64, *self.stem_hw); self.gy1b = f(B, 64, *self.stem_hw)
+    self.p1 = f(B, 64, *self.pool_hw)
+    self.p1_arg = t.zeros(B, 64, *self.pool_hw, dtype=t.int32, device=dev)
     # encoder block buffers
     self.blocks = []
-    cin, hw = 64, 64
+    cin, (hi, wi) = 64, self.pool_hw
+    stage_hw = {}
     for name, blocks, filt, stride in ENC_STAGES:
       for bl in blocks:
         st = stride if bl == "a" else 1
-        ho = hw // st
-        blk = dict(prefix=f"encoder.{name}.{bl}.", cin=cin, f=filt, stride=st, hin=hw, h=ho,
+        ho, wo = (hi + st - 1) // st, (wi + st - 1) // st        # 1x1 stride-2 conv without padding: ceil (resnet50.py:94-97)
+        blk = dict(prefix=f"encoder.{name}.{bl}.", cin=cin, f=filt, stride=st, hin=hi, win=wi, h=ho, w=wo,
                    down=(bl == "a"), final=(bl == blocks[-1]), stage=name)
-        blk["ya"] = f(B, filt[0], ho, ho); blk["yb"] = f(B, filt[1], ho, ho); blk["yc"] = f(B, filt[2], ho, ho)
+        blk["ya"] = f(B, filt[0], ho, wo); blk["yb"] = f(B, filt[1], ho, wo); blk["yc"] = f(B, filt[2], ho, wo)
         if blk["down"]:
-          blk["ys"] = f(B, filt[2], ho, ho)
-        blk["out"] = f(B, filt[2], ho, ho)
+          blk["ys"] = f(B, filt[2], ho, wo)
+        blk["out"] = f(B, filt[2], ho, wo)
         # gradients
-        blk["gpre"] = f(B, filt[2], ho, ho); blk["gyc"] = f(B, filt[2], ho, ho)
-        blk["gab"] = f(B, filt[1], ho, ho); blk["gyb"] = f(B, filt[1], ho, ho)
-        blk["gaa"] = f(B, filt[0], ho, ho); blk["gya"] = f(B, filt[0], ho, ho)
+        blk["gpre"] = f(B, filt[2], ho, wo); blk["gyc"] = f(B, filt[2], ho, wo)
+        blk["gab"] = f(B, filt[1], ho, wo); blk["gyb"] = f(B, filt[1], ho, wo)
+        blk["gaa"] = f(B, filt[0], ho, wo); blk["gya"] = f(B, filt[0], ho, wo)
         if blk["down"]:
-          blk["gys"] = f(B, filt[2], ho, ho)
-          blk["gin"] = f(B, cin, hw, hw)
+          blk["gys"] = f(B, filt[2], ho, wo)
+          blk["gin"] = f(B, cin, hi, wi)
           if st == 2:
             # the stride-2 1x1 convs (op_a and the shortcut, resnet50.py:94-97) read a compacted copy of the
             # sub-sampled block input, and their data gradients meet in a compact buffer before they are
             # scattered back: plain tensors -> the pointwise kernel instead of strided views
-            blk["xs"] = f(B, cin, ho, ho); blk["gxs"] = f(B, cin, ho, ho)
+            blk["xs"] = f(B, cin, ho, wo); blk["gxs"] = f(B, cin, ho, wo)
         self.blocks.append(blk)
-        cin, hw = filt[2], ho
+        cin, hi, wi = filt[2], ho, wo
+      stage_hw[name] = (hi, wi)
+    self.stage_hw = stage_hw
     # stage-final pre-ReLU features + the 3 offset channels (Q6), and their grads
-    self.feat = {"stage2": f(B, 256 + 3, 64, 64), "stage3": f(B, 512 + 3, 32, 32),
-                 "stage4": f(B, 1024 + 3, 16, 16), "stage5": f(B, 2048 + 3, 8, 8)}
+    self.feat = {"stage2": f(B, 256 + 3, *stage_hw["stage2"]), "stage3": f(B, 512 + 3, *stage_hw["stage3"]),
+                 "stage4": f(B, 1024 + 3, *stage_hw["stage4"]), "stage5": f(B, 2048 + 3, *stage_hw["stage5"])}
     self.gfeat = {k: t.zeros_like(v) for k, v in self.feat.items()}
     self.avg = f(B, 2048); self.gavg = f(B, 2048)
     L = eng.latent
@@ -647,20 +667,20 @@ class Plan:
     self.logits = f(B, C, 128, 128, 128)
     self.glogits = f(B, C, 128, 128, 128)
     self.skip_src = {2: "stage5", 3: "stage4", 4: "stage3", 5: "stage2"}
-    self.skip_hw = {2: 8, 3: 16, 4: 32, 5: 64}
+    self.skip_hw = {k: stage_hw[self.skip_src[k]] for k in self.skip_src}      # (h, w) of the 2-D map each skip samples
     # compressed skip maps are channel-last [B][h][w][C]: the ray-sample gather then fetches four channels of a
     # pixel per load (crn_ray_sample_fwd); their gradients stay channel-major (scatter-add per channel plane)
-    self.smap = {k: f(B, self.skip_hw[k], self.skip_hw[k], sk[k]) for k in sk}
+    self.smap = {k: f(B, self.skip_hw[k][0], self.skip_hw[k][1], sk[k]) for k in sk}
     # the saved index tensors of the ray-sample backward (autograd keeps them in the reference: ray_traced_skip_connection.py:
     # 118-135): one uint16 per voxel of the 8^3 ... 64^3 skip grids, written by the training-mode gather, read by the scatter
     self.ray_idx = ({k: t.zeros(B, (2 * self.dec[k]["r"]) ** 3, dtype=t.int16, device=dev) for k in sk}
                     if hasattr(self.be, "ray_sample_fwd_idx") and os.environ.get("CRN_RAY_IDX", "1") != "0" and
-                    max(self.skip_hw.values()) ** 2 < 65535 else None)
-    gs_n = {k: B * sk[k] * self.skip_hw[k] ** 2 for k in sk}
+                    max(h * w for h, w in self.skip_hw.values()) < 65535 else None)
+    gs_n = {k: B * sk[k] * self.skip_hw[k][0] * self.skip_hw[k][1] for k in sk}
     self.gsmap_slab = f(sum(gs_n.values()))
     self.gsmap, o = {}, 0
     for k in sk:
-      self.gsmap[k] = self.gsmap_slab[o:o + gs_n[k]].view(B, sk[k], self.skip_hw[k], self.skip_hw[k]); o += gs_n[k]
+      self.gsmap[k] = self.gsmap_slab[o:o + gs_n[k]].view(B, sk[k], *self.skip_hw[k]); o += gs_n[k]
     self.layer_mats = f(4, B, 16)
     self.layer_scales = t.tensor([[128.0 / (2 * self.dec[k]["r"])] * 3 + [1.0] for k in (2, 3, 4, 5)],
                                  dtype=eng.dtype, device=dev).reshape(4, 1, 1, 4)
@@ -851,17 +871,17 @@ class Plan:
     d = self.dec[k]
     out = self.dec[k + 1]["u"]
     ft = self.feat[self.skip_src[k]]
-    hw, ro = self.skip_hw[k], 2 * d["r"]
+    (hh, ww), ro = self.skip_hw[k], 2 * d["r"]
     be.fill_offset_channels(ft, B, ft.stride(0), ft.shape[2] * ft.shape[3], ft.shape[1] - 3, self.offset)
     self._conv(eng.convs[f"decoder.rt_skip_{k}.compress_channels."], self.vw(ft), None,
                self.vw(self.smap[k].permute(0, 3, 1, 2)))
     if self.ray_idx is not None and self.training:
       self._probe(f"ray_sample_fwd_{ro}", lambda: be.ray_sample_fwd_idx(
-          self.smap[k], self.smap[k].stride(0), B, eng.skip_ch[k], hw, hw, self.layer_mats[k - 2],
+          self.smap[k], self.smap[k].stride(0), B, eng.skip_ch[k], hh, ww, self.layer_mats[k - 2],
           self.offset, out[:, d["cout"]:], out.stride(0), ro, ro, ro, self.ray_idx[k], map_sC=1, map_sP=eng.skip_ch[k]))
     else:
       self._probe(f"ray_sample_fwd_{ro}", lambda: be.ray_sample_fwd(
-          self.smap[k], self.smap[k].stride(0), B, eng.skip_ch[k], hw, hw, self.layer_mats[k - 2],
+          self.smap[k], self.smap[k].stride(0), B, eng.skip_ch[k], hh, ww, self.layer_mats[k - 2],
           self.offset, out[:, d["cout"]:], out.stride(0), ro, ro, ro, map_sC=1, map_sP=eng.skip_ch[k]))
 
   def _skip_fwd_async(self, stage: str):
@@ -917,8 +937,9 @@ class Plan:
     c1 = cv["encoder.stage1.conv."]
     self._conv(c1, self.s2d(self.img, 3, (1, 2, 2)), None, self.vw(self.y1))
     b1 = bn["encoder.stage1_part2.bn."]
-    self._stats(b1, self.y1, 128 * 128, 64 * 128 * 128, False, training)
-    be.maxpool_fwd(self.y1, b1.scale, b1.shift, B, 64, 128, 128, self.p1, self.p1_arg)
+    H1, W1 = self.stem_hw
+    self._stats(b1, self.y1, H1 * W1, 64 * H1 * W1, False, training)
+    be.maxpool_fwd(self.y1, b1.scale, b1.shift, B, 64, H1, W1, self.p1, self.p1_arg)
     cur = self.p1
     for blk in self.blocks:
       if eng._enc_late_pending and blk["stage"] != "stage2":
@@ -928,7 +949,8 @@ class Plan:
       if blk["final"] and self._skip_async_live:
         self._skip_fwd_async(blk["stage"])
     f5 = self.feat["stage5"]
-    be.relu_mean_fwd(f5, B, 2048, 64, f5.stride(0), self.avg)
+    S5 = f5.shape[2] * f5.shape[3]
+    be.relu_mean_fwd(f5, B, 2048, S5, f5.stride(0), self.avg)
 
   def forward_decoder(self, v2s: t.Tensor, offset: t.Tensor, training: bool) -> t.Tensor:
     """Offset channels, skip compression + ray sampling, 3D decoder (reconstruction_decoder.py:97-151)."""
@@ -979,7 +1001,7 @@ class Plan:
     eng, be, B = self.eng, self.be, self.B
     cv, bn = eng.convs, eng.bns
     p = blk["prefix"]
-    h = blk["h"]; S = h * h
+    h = blk["h"]; S = h * blk["w"]
     f1, f2, f3 = blk["f"]
     if blk["stride"] == 2:
       be.stride2_gather(cur, blk["xs"])
@@ -1144,9 +1166,10 @@ class Plan:
       t.cuda.current_stream().wait_event(self._skip_bwd_done)          # gfeat of all four stages
     f5, g5 = self.feat["stage5"], self.gfeat["stage5"]
     last = self.blocks[-1]
-    be.relu_mean_bwd(f5, self.gavg, B, 2048, 64, f5.stride(0), last["gpre"], 2048 * 64, False)
-    be.affine_add_relu(last["gpre"], None, None, g5, None, None, B, 2048, 64, 2048 * 64, g5.stride(0),
-                       None, 0, last["gpre"], 2048 * 64, False)
+    S5 = f5.shape[2] * f5.shape[3]
+    be.relu_mean_bwd(f5, self.gavg, B, 2048, S5, f5.stride(0), last["gpre"], 2048 * S5, False)
+    be.affine_add_relu(last["gpre"], None, None, g5, None, None, B, 2048, S5, 2048 * S5, g5.stride(0),
+                       None, 0, last["gpre"], 2048 * S5, False)
     g_in = None          # gradient wrt the block's output (post-ReLU), None for the last block
     for blk in reversed(self.blocks):
       g_in = self._block_bwd(blk, g_in)
@@ -1154,8 +1177,9 @@ class Plan:
         self._grads_ready(blk["prefix"], grad_hook)
     # stem: g_in = d p1
     b1 = bn["encoder.stage1_part2.bn."]
-    be.maxpool_bwd(g_in, self.p1_arg, B, 64, 128, 128, self.gy1)
-    S1 = 128 * 128
+    H1, W1 = self.stem_hw
+    be.maxpool_bwd(g_in, self.p1_arg, B, 64, H1, W1, self.gy1)
+    S1 = H1 * W1
     cs = cv["encoder.stage1.conv."]
     be.bn_bwd(self.y1, 64 * S1, self.gy1, 64 * S1, B, 64, S1, False, False, b1.gamma, b1.scale, b1.shift,
               b1.saved, self.gy1b, 64 * S1, b1.dgamma, b1.dbeta, dsum=cs.dbias, ndsum=cs.n_ref)
@@ -1171,19 +1195,19 @@ class Plan:
   def _ray_bwd(self, k: int, g_out: t.Tensor):
     """Scatter-add of the skip channels' gradient into the 2-D map gradient (ray_traced_skip_connection.py:135, autograd)."""
     d = self.dec[k]
-    ro, hw = 2 * d["r"], self.skip_hw[k]
+    ro, (hh, ww) = 2 * d["r"], self.skip_hw[k]
     if self.ray_idx is not None:
       self.be.ray_sample_bwd_idx(g_out[:, d["cout"]:], g_out.stride(0), self.B, self.eng.skip_ch[k], ro, ro, ro,
-                                 self.ray_idx[k], self.gsmap[k], self.gsmap[k].stride(0), hw, hw, False)
+                                 self.ray_idx[k], self.gsmap[k], self.gsmap[k].stride(0), hh, ww, False)
       return
     self.be.ray_sample_bwd(g_out[:, d["cout"]:], g_out.stride(0), self.B, self.eng.skip_ch[k], ro, ro, ro,
-                           self.layer_mats[k - 2], self.offset, self.gsmap[k], self.gsmap[k].stride(0), hw, hw, False)
+                           self.layer_mats[k - 2], self.offset, self.gsmap[k], self.gsmap[k].stride(0), hh, ww, False)
 
   def _skip_bwd(self, k: int, g_out: t.Tensor, on_side: bool):
     """Backward of the skip connection into decoder stage k+1 (g_out = gradient of that stage's concat buffer)."""
     eng, be, B = self.eng, self.be, self.B
     d = self.dec[k]
-    hw, ns = self.skip_hw[k], eng.skip_ch[k]
+    (hh, ww), ns = self.skip_hw[k], eng.skip_ch[k]
     if not on_side:                             # (asynchronous skip path: the caller ran the scatter on the main stream)
       self._ray_bwd(k, g_out)
     cs = eng.convs[f"decoder.rt_skip_{k}.compress_channels."]
@@ -1196,14 +1220,14 @@ class Plan:
                       boxes=(g.n_boxes, g.c_boxes), math=math)
     else:
       self._wgrad(cs, self.vw(ft), None, self.vw(self.gsmap[k]))
-    self._bias_grad(cs, self.gsmap[k], hw * hw, ns * hw * hw)
+    self._bias_grad(cs, self.gsmap[k], hh * ww, ns * hh * ww)
     self._dgrad(cs, self.vw(self.gsmap[k]), self.vw(self.gfeat[self.skip_src[k]]))
 
   def _block_bwd(self, blk, g_out: Optional[t.Tensor]) -> t.Tensor:
     eng, be, B = self.eng, self.be, self.B
     cv, bn = eng.convs, eng.bns
     p = blk["prefix"]
-    h = blk["h"]; S = h * h
+    h = blk["h"]; S = h * blk["w"]
     f1, f2, f3 = blk["f"]
     ba, bb, bc = bn[p + "op_a.bn."], bn[p + "op_b.bn."], bn[p + "op_c.bn."]
     gpre = blk["gpre"]

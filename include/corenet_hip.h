@@ -326,11 +326,11 @@ int crn_linear_bwd(const float* x, const float* w, const float* dy, int lddy, in
 /* dx[b,c,s] (+)= (x_pre>0) * davg[b,c] / S                                    */
 int crn_relu_mean_bwd(const float* x_pre, const float* davg, int B, int C, int64_t S, int64_t sB,
                       float* dx, int64_t sB_dx, int accumulate, crnStream s);
-/* Stride-2 sub-sampling of a contiguous [B][C][2h][2w] tensor, y[b,c,i,j] = x[b,c,2i,2j], and its adjoint
- * (dx[b,c,2i,2j] = dy[b,c,i,j], zeros elsewhere; every element of dx is written): the stride-2 1x1 convolutions of
- * the ResNet downscale blocks (resnet50.py:94-97) run on the compacted tensor.  w (the OUTPUT width) must be even. */
-int crn_stride2_gather(const float* x, float* y, int B, int C, int h, int w, crnStream s);
-int crn_stride2_scatter(const float* dy, float* dx, int B, int C, int h, int w, crnStream s);
+/* Stride-2 sub-sampling of a contiguous [B][C][hin][win] tensor, y[b,c,i,j] = x[b,c,2i,2j] with h = ceil(hin/2),
+ * w = ceil(win/2), and its adjoint (dx[b,c,2i,2j] = dy[b,c,i,j], zeros elsewhere; every element of dx is written): the
+ * stride-2 1x1 convolutions of the ResNet downscale blocks (resnet50.py:94-97) run on the compacted tensor.           */
+int crn_stride2_gather(const float* x, float* y, int B, int C, int h, int w, int hin, int win, crnStream s);
+int crn_stride2_scatter(const float* dy, float* dx, int B, int C, int h, int w, int hin, int win, crnStream s);
 /* fill channels [c0,c0+3) of a [B][Ctot][S] tensor with offset[b][j]
  * (reconstruction_decoder.py:108-110)                              */
 int crn_fill_offset_channels(float* x, int B, int64_t sB, int64_t S, int c0,

@@ -515,3 +515,42 @@ def test_no_mfma_hazard_behind_the_inline_assembly_blocks():
     assert not bad, (obj, bad[:3])
     total += n
   assert total > 5000          # (the split-bf16 decoder kernels alone hold ~5700 MFMAs)
+
+
+@pytest.mark.parametrize("hw", [(96, 160), (100, 68)])
+def test_engine_plan_other_image_sizes_fp64(hw):
+  """The encoder is fully convolutional (resnet50.py:176-186): a plan for another image size (96 x 160 is not square, 100 x 68
+  leaves odd extents from stage 3 on; 224 x 224 and 320 x 256 run on the GPU, tests/test_model_gpu.py) must reproduce the oracle's forward, loss gradient and running statistics like the 256 x 256 plan does (float64 over the
+  contract emulator: the host wiring -- buffer shapes, strides, stride-2 compaction, skip-map extents -- not the kernels)."""
+  from corenet_amd.model.engine import Engine, LOSS_KINDS
+  t.set_num_threads(min(8, os.cpu_count() or 1))
+  B, C = 1, 2
+  eng = Engine(C, device="cpu", backend=EmuBackend(), dtype=DT)
+  sd = O.make_state(0, C, nbt=30000)
+  for k, v in sd.items():
+    eng.store.view(k).copy_(v)
+  _, v2s, off, grid = O.synthetic_batch(B, 0, C)
+  image = t.randint(0, 256, (B, 3) + hw, generator=t.Generator().manual_seed(5), dtype=t.uint8)
+  plan = eng.plan(B, hw)
+  assert plan is not eng.plan(B) and plan is eng.plan(B, hw)
+  logits = plan.forward(image, v2s, off, training=True)
+  s = {k: (v.detach().clone().to(DT) if v.dtype == t.float32 else v.clone()) for k, v in sd.items()}
+  for k in s:
+    if s[k].dtype == DT and "running" not in k:
+      s[k].requires_grad_(True)
+  feats, avg = O.resnet50_features(O.preprocess_image_caffe(image).to(DT), s, True)
+  assert tuple(feats[3].shape[2:]) == plan.stage_hw["stage5"] and tuple(feats[0].shape[2:]) == plan.stage_hw["stage2"]
+  lo = O.decoder_forward(feats, avg, s, v2s, off, (128, 128, 128), True)
+  assert err(logits, lo.detach()) < 1e-6
+  O.iou_fgbg(grid, lo).backward()
+  plan.gt.copy_(grid.to(t.int32))
+  eng.be.loss_fwd_bwd(LOSS_KINDS["iou_fgbg"], plan.logits, plan.gt, B, C, 128 ** 3, plan.loss, plan.glogits, 1.0)
+  plan.backward(plan.glogits)
+  for k, v in s.items():
+    if v.grad is None or k.endswith("conv.bias") or k.endswith("c1.bias") or float(v.grad.abs().max()) < 1e-14:
+      continue
+    assert err(eng.store.view(k, grad=True), v.grad) < 1e-5, k
+  with pytest.raises(ValueError):
+    eng.plan(B, (250, 256))                       # not a multiple of 4
+  with pytest.raises(ValueError):
+    plan.forward(t.zeros(B, 3, 256, 256, dtype=t.uint8), v2s, off, training=False)     # a plan refuses other sizes

@@ -602,16 +602,17 @@ def test_stride2_gather_scatter(be):
   """crn_stride2_gather / crn_stride2_scatter (the compacted input of the ResNet downscale blocks' stride-2 1x1
   convs and the adjoint): exact copies; the scatter writes every element (zeros between the samples)."""
   g = t.Generator().manual_seed(2)
-  for shape in ((2, 5, 8, 8), (4, 256, 32, 32), (1, 3, 6, 10)):
-    B, C, h, w = shape
-    x = t.randn(B, C, 2 * h, 2 * w, generator=g)
-    y = t.full(shape, 9.0, device=DEV)
+  # (B, C, input h, input w): even extents with even / odd output widths (224 x 224 images reach 14 -> 7), odd input extents
+  for B, C, hin, win in ((2, 5, 16, 16), (4, 256, 64, 64), (1, 3, 12, 20), (2, 7, 14, 14), (2, 3, 7, 10), (1, 2, 9, 5)):
+    h, w = (hin + 1) // 2, (win + 1) // 2
+    x = t.randn(B, C, hin, win, generator=g)
+    y = t.full((B, C, h, w), 9.0, device=DEV)
     be.stride2_gather(x.to(DEV), y)
     assert t.equal(y.cpu(), x[:, :, ::2, ::2])
-    dy = t.randn(shape, generator=g)
-    dx = t.full((B, C, 2 * h, 2 * w), 9.0, device=DEV)
+    dy = t.randn(B, C, h, w, generator=g)
+    dx = t.full((B, C, hin, win), 9.0, device=DEV)
     be.stride2_scatter(dy.to(DEV), dx)
-    want = t.zeros(B, C, 2 * h, 2 * w); want[:, :, ::2, ::2] = dy
+    want = t.zeros(B, C, hin, win); want[:, :, ::2, ::2] = dy
     assert t.equal(dx.cpu(), want)
 
 

@@ -108,34 +108,65 @@ def test_bf16x3_mode_against_goldens_and_fp32_mode():
 
 
 @pytest.mark.parametrize("math", MATHS)
-@pytest.mark.parametrize("hw", [(224, 224), (512, 512), (256, 320)])
-def test_image_size_is_validated(math, hw):
-  """The plans hold buffers for 256x256 images (engine.IMAGE_HW): any other size raises ValueError on every entry point
-  BEFORE a kernel runs (a 512x512 batch would over-run the preprocess buffer, a 224x224 one would leave the rest of it
-  stale), and the model keeps working afterwards -- the logits of the next valid batch equal those of a fresh model."""
-  from corenet_amd import super_resolution as SR
+@pytest.mark.parametrize("hw", [(224, 224), (320, 256)])
+def test_other_image_sizes_match_oracle(math, hw):
+  """The reference encoder is fully convolutional (resnet50.py:176-186) and the decoder only sees the stage maps through the
+  ray-traced skips, so the model runs on any image size; here a plan is built per (batch, H, W).  224 x 224 (stage-5 map 7 x 7: odd
+  extents, 49 positions -- no multiple of 4, off every float4 fast path) and 320 x 256 (H != W) in eval mode against the oracle to
+  1e-4 on every voxel, and one training forward + backward (logits 1e-3, last layer's gradient and the 64^3 skip's compression
+  gradient element-wise); the 256 x 256 plan of the same model still gives what a fresh model gives."""
+  from corenet_amd.model import losses
+  sd = O.make_state(0, 2, nbt=30000)
+  m = _model(2, sd, math)
+  _, v2s, off, grid = O.synthetic_batch(2, 0, 2)
+  image = t.randint(0, 256, (2, 3) + hw, generator=t.Generator().manual_seed(hw[0]), dtype=t.uint8)
+  with t.no_grad():
+    want = O.corenet_forward({k: v.clone() for k, v in sd.items()}, image, v2s, off, training=False)
+    got = m.eval()(image.cuda(), v2s.cuda(), off.cuda())
+  e_eval = relerr(got, want)
+  so = {k: v.clone() for k, v in sd.items()}
+  for k in so:
+    if so[k].dtype == t.float32 and "running" not in k: so[k].requires_grad_(True)
+  lo = O.corenet_forward(so, image, v2s, off, training=True)
+  O.iou_fgbg(grid, lo).backward()
+  logits = m.train()(image.cuda(), v2s.cuda(), off.cuda())
+  losses.iou_fgbg(grid.cuda(), logits).backward()
+  e_train = relerr(logits, lo.detach())
+  params = dict(m.named_parameters())
+  e_g = {n: relerr(params[n].grad, so[n].grad) for n in ("decoder.stage_6.t1.weight", "decoder.rt_skip_5.compress_channels.weight",
+                                                           "decoder.rt_skip_2.compress_channels.weight")}
+  print(f"[{math} {hw}] eval logits {e_eval:.1e}, train logits {e_train:.1e}, gradients {', '.join(f'{k} {v:.1e}' for k, v in e_g.items())}")
+  assert e_eval < 1e-4 and e_train < 1e-3, (e_eval, e_train)
+  assert e_g["decoder.stage_6.t1.weight"] < 5e-4 and max(e_g.values()) < 2e-2, e_g
+  # the default-size plan of the same engine is untouched
+  i2, v2, o2, _ = O.synthetic_batch(2, 0, 2)
+  with t.no_grad():
+    a = m.eval()(i2.cuda(), v2.cuda(), o2.cuda())
+    bref = _model(2, sd, math).eval()(i2.cuda(), v2.cuda(), o2.cuda())
+  assert relerr(a, bref) < 1e-5
+
+
+@pytest.mark.parametrize("hw", [(250, 256), (256, 30), (255, 255)])
+def test_image_size_is_validated(hw):
+  """H and W must be multiples of 4 and >= 32 (engine.check_image_hw: the stem's 2 x 2 space-to-depth view, the pooling cells):
+  anything else raises ValueError on every entry point BEFORE a kernel runs or a buffer is allocated, and the model keeps working."""
   sd = O.make_state(0, 2, nbt=100)
-  m, mref = _model(2, sd, math), _model(2, sd, math)
+  m = _model(2, sd)
   image, v2s, off, grid = [x.cuda() for x in O.synthetic_batch(2, 0, 2)]
   bad = t.randint(0, 256, (2, 3) + hw, dtype=t.uint8, device="cuda")
-  guard = t.full((1 << 20,), 7.0, device="cuda")                   # (allocated right after the model's buffers)
   for mode in ("train", "eval"):
     getattr(m, mode)()
-    with pytest.raises(ValueError, match="256x256"):
+    with pytest.raises(ValueError, match="multiples of 4"):
       m(bad, v2s, off)
-  with pytest.raises(ValueError, match="256x256"):
+  with pytest.raises(ValueError, match="multiples of 4"):
     m.train().train_step(bad, v2s, off, grid.to(t.int32))
-  with pytest.raises(ValueError, match="256x256"):
+  with pytest.raises(ValueError, match="multiples of 4"):
     m.eval().multi_offset_pmf(bad, v2s, off[None])
   with pytest.raises(ValueError, match="grid"):
     m.train().train_step(image, v2s, off, grid[:, :64].to(t.int32))
   with pytest.raises(ValueError):
     m.engine.plan(2).forward_encoder(bad, training=False)          # the plan itself refuses, not only the module
-  t.cuda.synchronize()
-  assert bool((guard == 7.0).all())
-  m.eval(); mref.eval()
-  with t.no_grad():
-    assert relerr(m(image, v2s, off), mref(image, v2s, off)) < 1e-5
+  assert list(m.engine.plans.keys()) == [2]
 
 
 def test_forward_eval_b4_matches_oracle():
@@ -253,7 +284,7 @@ def decoder_weight_names(params):
 
 @pytest.mark.parametrize("math", MATHS)
 def test_decoder_gradients_every_element_vs_oracle(math):
-  """EVERY element of every decoder convolution's weight gradient (stage_k.c1 / t1, rt_skip_k.compress_channels: 22 tensors,
+  """EVERY element of every decoder convolution's weight gradient (stage_k.c1 / t1, rt_skip_k.compress_channels: 15 tensors,
   11.9 M elements) on the well-conditioned fixture's inputs (h7, B = 2, num_batches_tracked = 30000), against the oracle's
   autograd run here on the host (fp32; the fixture generator asserts oracle == reference on exactly these inputs).  Decoder
   tensors see no small-batch norm of the encoder, their conditioning is good (gnoise 2e-5 ... 6e-3 in the fixture), so the bar is
@@ -273,7 +304,7 @@ def test_decoder_gradients_every_element_vs_oracle(math):
   O.iou_fgbg(grid, O.corenet_forward(so, image, v2s, off, training=True)).backward()
   params = dict(m.named_parameters())
   names = decoder_weight_names(params)
-  assert len(names) == 22, names
+  assert len(names) == 15, names
   bars = decoder_gradient_bars(z, names, math)
   gmax = max(float(z[k]) for k in z.files if k.startswith("gmax::"))
   rows = []

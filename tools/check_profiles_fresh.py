@@ -1,0 +1,21 @@
+#!/usr/bin/env python
+"""Fails (exit 1) when a tracked profile of the current round is OLDER than the last commit that touched the kernels
+(corenet_amd/csrc/): round 4 shipped a profile that contradicted the code it was supposed to document.  Run after
+tools/refresh_profiles.sh and the commit of its output; hardware probes that do not depend on the library's kernels are exempt.
+usage: check_profiles_fresh.py [round prefix, default r05]"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+prefix = sys.argv[1] if len(sys.argv) > 1 else "r05"
+EXEMPT = ("lds_atomic_probe", "grid_barrier_probe")          # properties of the part, not of csrc/
+def ct(*paths):
+  out = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%ct", "--"] + list(paths), capture_output=True, text=True).stdout.strip()
+  return int(out) if out else 0
+kernels = ct("corenet_amd/csrc")
+stale = []
+for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+  if not f.startswith(prefix + "_") or any(e in f for e in EXEMPT):
+    continue
+  if ct(os.path.join("profiles", f)) < kernels:
+    stale.append(f)
+print(f"last csrc commit {kernels}; {len(stale)} stale profile(s) of {prefix}: {stale}")
+sys.exit(1 if stale else 0)

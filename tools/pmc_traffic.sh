@@ -29,7 +29,7 @@ out = {"command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, 
        "kernels": {}}
 for k in sorted(F, key=lambda k: -F[k] - W.get(k, 0)):
   name, grid = k
-  if not any(s in name for s in ("conv_fwd_kernel", "conv_wgrad_kernel", "conv_bf3", "ray_sample", "fill_fused", "pointwise")): continue
+  if not any(s in name for s in ("conv_fwd_kernel", "conv_wgrad_kernel", "conv_bf3", "ray_sample", "ray_scatter", "fill_fused", "pointwise")): continue
   f_kb = 2.0 * F[k]; w_kb = W.get(k, 0.0)
   out["kernels"][f"{name} grid {grid}"] = {"launches": nF[k], "FETCH_SIZE_KB_x2": round(f_kb, 1), "WRITE_SIZE_KB": round(w_kb, 1),
                                            "hbm_bytes": int((f_kb + w_kb) * 1024)}
