@@ -768,11 +768,29 @@ class Plan:
 
   conv_positions = None     # tools/layer_times.py: {layer name: logical output positions per sample} when tracing
 
+  @staticmethod
+  def _e2d_shape_ok(v: V.View, window) -> bool:
+    """The shapes crn_conv2d_bf3 covers (csrc/conv_e2d.hip): channel planes read in 16-byte pieces, 3 x 3 layers in tiles of 16 x 4 or
+    8 x 8 positions, 1 x 1 layers in runs of 64.  Every stage map of a 256 x 256 image qualifies; the 14 x 14 / 7 x 7 maps of a
+    224 x 224 image do not and take the fp32 engine."""
+    S = v.D * v.H * v.W
+    if S % 4:
+      return False
+    if tuple(window) == (1, 3, 3):
+      tw = 16 if v.W % 16 == 0 else 8
+      return v.D == 1 and v.W % tw == 0 and v.H % (64 // tw) == 0
+    return S % 64 == 0
+
+  @staticmethod
+  def _wg2d_shape_ok(v: V.View, window) -> bool:
+    """crn_conv_wgrad_2d_bf3: K = positions in steps of 32, 3 x 3 layers shift aligned 8-position groups."""
+    return (v.D * v.H * v.W) % 32 == 0 and (tuple(window) == (1, 1, 1) or v.W % 8 == 0)
+
   def _conv(self, cv: Conv, x: V.View, tr, y: V.View, accumulate=False):
     g = cv.fwd
     if self.trace is not None and self.conv_positions is not None:
       self.conv_positions[cv.name] = y.D * y.H * y.W
-    if cv.wop_f is not None and cv.wop_kind == "e2d":
+    if cv.wop_f is not None and cv.wop_kind == "e2d" and self._e2d_shape_ok(y, g.window):
       self._timed("fwd   " + cv.name, lambda: self.be.conv2d_bf3(
           x, tr, cv.wop_f, g.npad, cv.bias, 0, y, g.window, g.pad_lo, accumulate))
       return
@@ -782,7 +800,7 @@ class Plan:
 
   def _dgrad(self, cv: Conv, dy: V.View, dx: V.View, accumulate=False):
     g = cv.dgrad
-    if cv.wop_d is not None and cv.wop_kind == "e2d":
+    if cv.wop_d is not None and cv.wop_kind == "e2d" and self._e2d_shape_ok(dx, g.window):
       self._timed("dgrad " + cv.name, lambda: self.be.conv2d_bf3(
           dy, None, cv.wop_d, g.npad, None, 0, dx, g.window, g.pad_lo, accumulate))
       return
@@ -820,7 +838,7 @@ class Plan:
     beside the data-gradient chain; most layers below 32^3 / 64^2 cannot fill 256 CUs alone."""
     g = cv.fwd
     math = self._math(cv, "wgrad")
-    if (self.eng.encoder_e2d and self.eng.wgrad_2d and g.window in ((1, 1, 1), (1, 3, 3))
+    if (self.eng.encoder_e2d and self.eng.wgrad_2d and g.window in ((1, 1, 1), (1, 3, 3)) and self._wg2d_shape_ok(dy, g.window)
         and (cv.name.startswith("encoder.stage") and not cv.name.startswith("encoder.stage1")
              or cv.name.startswith("decoder.rt_skip"))):
       math = "bf16x3_2d"          # both operands straight from HBM, K = positions (csrc/conv_e2d.hip)
@@ -1214,7 +1232,8 @@ class Plan:
     ft = self.feat[self.skip_src[k]]
     if on_side:                                 # already on the weight-gradient stream: no hand-over event
       g = cs.fwd
-      math = "bf16x3_2d" if (eng.encoder_e2d and eng.wgrad_2d) else self._math(cs, "wgrad")
+      math = ("bf16x3_2d" if (eng.encoder_e2d and eng.wgrad_2d and self._wg2d_shape_ok(self.vw(self.gsmap[k]), g.window))
+              else self._math(cs, "wgrad"))
       with _lib.roctx_range("wgrad " + cs.name):
         be.conv_wgrad(self.vw(ft), None, self.vw(self.gsmap[k]), cs.gwf, g.npad, g.window, g.pad_lo, False,
                       boxes=(g.n_boxes, g.c_boxes), math=math)

@@ -124,6 +124,13 @@ def test_other_image_sizes_match_oracle(math, hw):
     want = O.corenet_forward({k: v.clone() for k, v in sd.items()}, image, v2s, off, training=False)
     got = m.eval()(image.cuda(), v2s.cuda(), off.cuda())
   e_eval = relerr(got, want)
+  # the default-size plan of the same engine is its own set of buffers: same logits as a fresh model
+  i2, v2, o2, _ = O.synthetic_batch(2, 0, 2)
+  with t.no_grad():
+    a = m(i2.cuda(), v2.cuda(), o2.cuda())
+    bref = _model(2, sd, math).eval()(i2.cuda(), v2.cuda(), o2.cuda())
+    again = m(image.cuda(), v2s.cuda(), off.cuda())
+  assert relerr(a, bref) < 1e-5 and t.equal(again, got)
   so = {k: v.clone() for k, v in sd.items()}
   for k in so:
     if so[k].dtype == t.float32 and "running" not in k: so[k].requires_grad_(True)
@@ -138,12 +145,6 @@ def test_other_image_sizes_match_oracle(math, hw):
   print(f"[{math} {hw}] eval logits {e_eval:.1e}, train logits {e_train:.1e}, gradients {', '.join(f'{k} {v:.1e}' for k, v in e_g.items())}")
   assert e_eval < 1e-4 and e_train < 1e-3, (e_eval, e_train)
   assert e_g["decoder.stage_6.t1.weight"] < 5e-4 and max(e_g.values()) < 2e-2, e_g
-  # the default-size plan of the same engine is untouched
-  i2, v2, o2, _ = O.synthetic_batch(2, 0, 2)
-  with t.no_grad():
-    a = m.eval()(i2.cuda(), v2.cuda(), o2.cuda())
-    bref = _model(2, sd, math).eval()(i2.cuda(), v2.cuda(), o2.cuda())
-  assert relerr(a, bref) < 1e-5
 
 
 @pytest.mark.parametrize("hw", [(250, 256), (256, 30), (255, 255)])
@@ -404,7 +405,7 @@ def test_backward_matches_oracle_cosine(math):
       continue
     cos = float((a @ b) / (a.norm() * b.norm() + 1e-300))
     worst = min(worst, cos)
-    assert cos > 0.98, (n, cos)
+    assert cos > 0.995, (n, cos)        # measured: worst 0.9983 (bf16x3) / 0.9986 (fp32) at B = 1, nbt = 0 (round 5)
   print("worst gradient cosine vs oracle:", worst)
 
 
