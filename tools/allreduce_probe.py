@@ -12,6 +12,9 @@ from corenet_amd import distributed as D
 from corenet_amd.model.engine import param_specs, ParamStore, GRAD_BUCKET_LABELS
 
 rank, local, world = D.init_from_env()
+DRY = os.environ.get("CRN_DIST_BACKEND") == "gloo"      # tools/scale_probe.sh dry run: the ranks share one GPU, no RCCL
+if DRY:
+  local = local % t.cuda.device_count()
 t.cuda.set_device(local)
 specs = param_specs(2)
 off, n = {}, 0
@@ -26,7 +29,7 @@ for lo in los:
   sizes.append(hi - lo); hi = lo
 sizes.append(n)                                     # the whole slab in one piece
 buf = t.randn(n, device="cuda")
-native = D.NativeComm() if world > 1 or os.environ.get("CRN_PROBE_NATIVE") else None
+native = D.NativeComm() if (world > 1 and not DRY) or os.environ.get("CRN_PROBE_NATIVE") else None
 
 def timeit(fn, x):
   for _ in range(3): fn(x)
