@@ -1049,6 +1049,7 @@ struct Bf3WgGeom {
   int tilesD, tilesH, tilesW, ntiles, tiles_per_split;
   unsigned magic_pw2, magic_PH, magic_kw, magic_KHW;
   int dbg;
+  int inherit;             // tiles inherit the kd - 1 patch planes they share with the tile below (CRN_BF3_WG_INHERIT=0: off)
 };
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -1118,15 +1119,35 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
   float tsc[kCK], tsh[kCK];
   unsigned inmask = 0;
   int b = 0, d0 = 0, h0 = 0, w0 = 0;
+  // Tiles are walked D-first: the next tile of a workgroup is the one ABOVE the current one (same b, h, w), whose patch shares
+  // kd - 1 of its PD = TDT + kd - 1 planes with it.  Those planes stay in LDS -- converted, split, transformed -- and move down
+  // by TDT planes with an LDS-to-LDS copy; only the TDT new planes are loaded, transformed and split (round 5: the x traffic
+  // of stage_6.c1 was 3.75 x the tensor -- every tile re-read its 5^3 halo -- and half of a tile's staging instructions went
+  // into planes the workgroup had staged one tile earlier).  ubase / ucount: the unit range a tile stages.
+  int ubase = 0;                                               // units of the planes the tile inherits (0: a full patch)
+#define ucount (g.nunits - ubase)
+  // (the 32-column instances on stride-2 dy views without the software pipeline sit at 250-252 registers: the extra state of
+  // the inherited planes would spill their staging registers -- a correctness hazard with loads in flight -- so they stage full patches)
+  constexpr bool kInherit = !(NSUB == 2 && DM == 2 && !PIPE);
+  auto tile_reuses = [&](int tl) { return kInherit && g.inherit && tl > tbeg && (tl % g.tilesD) != 0; };
   auto tile_origin = [&](int tl) {
     int tile = tl;
-    const int twi = tile % g.tilesW; tile /= g.tilesW;
-    const int thi = tile % g.tilesH; tile /= g.tilesH;
-    const int tdi = tile % g.tilesD; tile /= g.tilesD;
-    b = tile; d0 = tdi * TDT; h0 = thi * 8; w0 = twi * TWT;
+    if constexpr (kInherit) {
+      const int tdi = tile % g.tilesD; tile /= g.tilesD;
+      const int twi = tile % g.tilesW; tile /= g.tilesW;
+      const int thi = tile % g.tilesH; tile /= g.tilesH;
+      b = tile; d0 = tdi * TDT; h0 = thi * 8; w0 = twi * TWT;
+      ubase = tile_reuses(tl) ? (g.PD - TDT) * g.PH * g.pw2 : 0;
+    } else {
+      const int twi = tile % g.tilesW; tile /= g.tilesW;
+      const int thi = tile % g.tilesH; tile /= g.tilesH;
+      const int tdi = tile % g.tilesD; tile /= g.tilesD;
+      b = tile; d0 = tdi * TDT; h0 = thi * 8; w0 = twi * TWT;
+    }
   };
   auto unit_of = [&](int jx, int& pos, unsigned& sp, bool& in) -> bool {
-    int u = tid + jx * kThreads;
+    const int ul = tid + jx * kThreads;                         // index inside the tile's unit range
+    int u = ubase + ul;
     asm volatile("" : "+v"(u));
     const int row = mdiv(u, g.magic_pw2), pp = u - row * g.pw2;
     const int pdz = mdiv(row, g.magic_PH), phy = row - pdz * g.PH;
@@ -1134,7 +1155,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
     in = (unsigned)gd < (unsigned)g.x.D && (unsigned)gh < (unsigned)g.x.H && (unsigned)gw < (unsigned)g.x.W;
     sp = (unsigned)gd * (unsigned)g.x.sD + (unsigned)gh * (unsigned)g.x.sH + (unsigned)gw;
     pos = row * g.PW + 2 * pp;
-    return u < g.nunits;
+    return ul < ucount;
   };
   // dy unit: (position pair pq of the 256 of a tile, octet o of the NB columns); thread -> (o = jd, pq = tid & 255) ...
   // 512 threads: pair = tid & 255, octet = (tid >> 8) + 2 * jd
@@ -1152,6 +1173,8 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
     inmask = 0;
 #pragma unroll
     for (int jx = 0; jx < kNUX; ++jx) {
+      // (no branch around these loads -- registers with loads in flight must not meet a control-flow merge: the units a tile
+      // does not stage get the out-of-range offset, which costs an instruction slot and no traffic)
       int pos; unsigned sp; bool in;
       const bool ld = unit_of(jx, pos, sp, in) && in;
       if (ld) inmask |= 1u << jx;
@@ -1174,9 +1197,20 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
     }
   };
   auto stage_commit = [&]() {
+    if (ubase) {
+      // inherited planes: [TDT, PD) of the previous patch become [0, PD - TDT) of this one (disjoint ranges: kd - 1 <= TDT)
+      const int n16 = (g.PD - TDT) * g.PHW, src = TDT * g.PHW * 16;
+      for (int i = tid; i < n16; i += kThreads) {
+        const bf16x8 hv = *reinterpret_cast<const bf16x8*>(Xhi + src + (size_t)i * 16);
+        const bf16x8 lv = *reinterpret_cast<const bf16x8*>(Xlo + src + (size_t)i * 16);
+        *reinterpret_cast<bf16x8*>(Xhi + (size_t)i * 16) = hv;
+        *reinterpret_cast<bf16x8*>(Xlo + (size_t)i * 16) = lv;
+      }
+      __syncthreads();                                           // the new planes overwrite what was just copied from
+    }
 #pragma unroll
     for (int jx = 0; jx < kNUX; ++jx) {
-      if (jx * kThreads < g.nunits) {
+      if (jx * kThreads < ucount) {
         int pos; unsigned sp; bool in;
         if (unit_of(jx, pos, sp, in)) {
           float v0[kCK], v1[kCK];
@@ -1328,6 +1362,8 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
       }
     }
 }
+
+#undef ucount
 
 template <int NSUB, int DM, int TPW, int TWT>
 int launch_bf3_wgrad(const Bf3WgGeom& g, dim3 grid, size_t lds, hipStream_t st) {
@@ -1663,6 +1699,8 @@ extern "C" int crn_conv_wgrad_bf3(const crnView* x, const crnInTransform* tr, co
   g.tiles_per_split = crn_cdiv(g.ntiles, splits);
   splits = crn_cdiv(g.ntiles, g.tiles_per_split);
   g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
+  static const int inherit_env = getenv("CRN_BF3_WG_INHERIT") ? atoi(getenv("CRN_BF3_WG_INHERIT")) : 1;
+  g.inherit = inherit_env;
   dim3 grid((unsigned)cblocks, (unsigned)nblocks, (unsigned)splits);
   static const bool dbg = getenv("CRN_DEBUG") != nullptr;
   if (dbg)

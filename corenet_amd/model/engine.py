@@ -226,6 +226,8 @@ class Engine:
     self.defer_reduce = os.environ.get("CRN_DEFER_REDUCE", "1") != "0"
     # decoder data gradients leave the two sums of the following BatchRenorm backward (crn_conv_fwd_bf3_slabs_bnbwd)
     self.bn_bwd_fuse = os.environ.get("CRN_BN_BWD_FUSE", "1") != "0"
+    # ... except for these layers (measured per layer, profiles/r05_bn_bwd_fuse.txt; CRN_BN_BWD_FUSE_SKIP overrides, comma separated)
+    self.bn_bwd_fuse_skip = frozenset(x for x in os.environ.get("CRN_BN_BWD_FUSE_SKIP", "").split(",") if x)
     self.fuse_tail = os.environ.get("CRN_FUSE_TAIL", "1") != "0"
     # fp32 is the only dtype of the HIP kernels; float64 exists so that the CPU
     # contract emulator (tests/) can check the host wiring far below fp32 noise.
@@ -815,7 +817,7 @@ class Plan:
     eng, be = self.eng, self.be
     gvw = self.vw(g)
     fusable = (eng.bn_bwd_fuse and hasattr(be, "conv_dgrad_bn_bwd") and cv.wop_kind == "slab" and cv.wop_d is not None
-               and self._math(cv, "dgrad") == "bf16x3")
+               and self._math(cv, "dgrad") == "bf16x3" and cv.name not in eng.bn_bwd_fuse_skip)
     if not fusable:
       if eng.defer_reduce:
         be.splitk_defer()                        # g is read next by the norm's backward, which adds up the splits
