@@ -15,7 +15,7 @@ def cat(n):
   for key, c in (("conv_e2d", "encoder bf16x3 fwd/dgrad"), ("wgrad1x1_bf3", "encoder bf16x3 wgrad"), ("wgrad3x3_bf3", "encoder bf16x3 wgrad"),
                  ("bf3_operands", "weight pack / grad un-pack"), ("conv_bf3_wgrad", "conv bf16x3 wgrad"), ("conv_bf3", "conv bf16x3 fwd/dgrad"), ("conv_wgrad", "conv fp32 wgrad"),
                  ("conv_fwd", "conv fp32 fwd/dgrad"), ("pointwise", "conv fp32 1x1"), ("splitk", "split-K reduce"), ("bn_", "BatchRenorm"),
-                 ("copy_tiles", "weight pack / grad un-pack"), ("copy_mats", "weight pack / grad un-pack"), ("ray_sample", "ray sample"), ("loss_", "loss"), ("adam", "adam"),
+                 ("copy_tiles", "weight pack / grad un-pack"), ("copy_mats", "weight pack / grad un-pack"), ("ray_sample", "ray sample"), ("ray_scatter", "ray sample"), ("ray_project", "ray sample"), ("loss_", "loss"), ("adam", "adam"),
                  ("affine_add_relu", "residual add"), ("relu_bwd", "residual add"), ("maxpool", "stem pool"), ("Fill", "memset/zero"),
                  ("zero_", "memset/zero"), ("copyBuffer", "copies"), ("elementwise", "torch elementwise")):
     if key in n: return c
