@@ -11,11 +11,15 @@ def ct(*paths):
   out = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%ct", "--"] + list(paths), capture_output=True, text=True).stdout.strip()
   return int(out) if out else 0
 kernels = ct("corenet_amd/csrc")
+# profiles of ONE kernel family are compared with that family's source, everything else with all of csrc/
+FAMILY = (("_ray_", "corenet_amd/csrc/ray_sample.hip"), ("_mfma_neighbour", "corenet_amd/csrc/ray_sample.hip"),
+          ("_voxelize", "corenet_amd/csrc/voxelize.hip"))
 stale = []
 for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
   if not f.startswith(prefix + "_") or any(e in f for e in EXEMPT):
     continue
-  if ct(os.path.join("profiles", f)) < kernels:
+  src = next((path for key, path in FAMILY if key in f), None)
+  if ct(os.path.join("profiles", f)) < (ct(src) if src else kernels):
     stale.append(f)
 print(f"last csrc commit {kernels}; {len(stale)} stale profile(s) of {prefix}: {stale}")
 sys.exit(1 if stale else 0)
