@@ -696,6 +696,15 @@ class Plan:
     use_side = self.side is not None
     self._side_ev, self._side_i = [], 0
     self._side_done = t.cuda.Event() if use_side else None
+    # Every hand-over to the side stream costs the data-gradient chain an event record (a marker packet between two dependent
+    # launches: ~3.5 us).  The encoder's weight gradients are therefore handed over one bottleneck at a time (3-4 convolutions behind
+    # ONE event) and a gradient bucket's un-pack rides on the hand-over in front of it: 7.58 -> 7.44 ms per step
+    # (profiles/r05_wgrad_handover.txt; per conv 0, per 1 / 2 / 3 / 6 blocks, per bucket 99; CRN_WG_BATCH_DEC=1: decoder stages too)
+    self.wg_batch = int(os.environ.get("CRN_WG_BATCH", "1")) if use_side else 0      # bottlenecks per hand-over (0: per conv)
+    self.wg_batch_dec = os.environ.get("CRN_WG_BATCH_DEC", "0") == "1"
+    self._handed_over = False
+    self._wg_pending = []
+    self._wg_blocks = 0
     # the ray-traced skip path (offset channels -> 1x1 compress -> ray sample; backward: scatter -> compress gradients)
     # hangs off the encoder's stage outputs and joins the main chain only at the consuming decoder stage (backward: at the
     # start of the encoder's backward pass): it runs on the side stream beside the encoder / decoder chain
@@ -848,6 +857,19 @@ class Plan:
       self._timed("wgrad " + cv.name, lambda: self.be.conv_wgrad(
           x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes), math=math))
       return
+    if self.wg_batch and (cv.name.startswith("encoder.") or self.wg_batch_dec):
+      # the encoder's small weight gradients are handed to the side stream one bottleneck at a time (_flush_wgrads): ONE event on
+      # the data-gradient chain per block instead of one per convolution
+      self._wg_pending.append((cv, x, tr, dy, math))
+      return
+    if self._handed_over:
+      # the side stream already waits for an event recorded after dy became final (the skip path's hand-over, just before this
+      # call, with nothing launched on the main stream in between): no second marker on the data-gradient chain
+      self._handed_over = False
+      self._side_i = max(self._side_i, 1)
+      with t.cuda.stream(self.side), _lib.pinned_stream(self.side), _lib.roctx_range("wgrad " + cv.name):
+        self.be.conv_wgrad(x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes), math=math)
+      return
     if self._side_i == len(self._side_ev):
       self._side_ev.append(t.cuda.Event())
     ev = self._side_ev[self._side_i]; self._side_i += 1
@@ -856,8 +878,29 @@ class Plan:
       self.side.wait_event(ev)
       self.be.conv_wgrad(x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes), math=math)
 
+  def _flush_wgrads(self, then=None):
+    """Launches the weight gradients collected since the last flush on the side stream, behind ONE event of the main stream;
+    `then` (a gradient bucket's un-pack + hook) runs behind them in the same hand-over."""
+    if not self._wg_pending and then is None:
+      return
+    if self._side_i == len(self._side_ev):
+      self._side_ev.append(t.cuda.Event())
+    ev = self._side_ev[self._side_i]; self._side_i += 1
+    ev.record()
+    with t.cuda.stream(self.side), _lib.pinned_stream(self.side):
+      self.side.wait_event(ev)
+      for cv, x, tr, dy, math in self._wg_pending:
+        g = cv.fwd
+        with _lib.roctx_range("wgrad " + cv.name):
+          self.be.conv_wgrad(x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes), math=math)
+      if then is not None:
+        then()
+    self._wg_pending = []
+    self._wg_blocks = 0
+
   def _join_side(self):
     """Main stream waits for every weight gradient issued on the side stream."""
+    self._flush_wgrads()
     if self.side is not None and self._side_i:
       self._side_done.record(self.side)
       t.cuda.current_stream().wait_event(self._side_done)
@@ -1000,8 +1043,10 @@ class Plan:
       r, S = d["r"], d["r"] ** 3
       p = f"decoder.stage_{k}."
       b1_, b2_ = bn[p + "b1."], bn[p + "b2."]
-      if skip_async and k > 2:
-        t.cuda.current_stream().wait_event(self._skip_ev[k - 1][1])      # the skip channels of this stage's input
+      if skip_async and k == 3:
+        # the skip paths run on the side stream in the order of the encoder's stages (64^3 first, 8^3 last): the event behind the
+        # LAST one -- the 8^3 skip into this stage -- covers all four; one marker on the decoder's chain instead of four
+        t.cuda.current_stream().wait_event(self._skip_ev[2][1])
       self._stats(b1_, d["u"], S, d["cin"] * S, True, training)
       if training and eng.defer_reduce:
         be.splitk_defer()                      # (stages 2-4 split K: the statistics below add the partial sums up)
@@ -1077,6 +1122,7 @@ class Plan:
     weight gradients and hand the slice to `hook` (an async all-reduce).  Both go to the side stream behind
     the bucket's weight gradients, so the data-gradient chain on the main stream never waits for them."""
     if hook is None:
+      self._flush_wgrads()
       return
     eng = self.eng
     i = [b[0] for b in eng.grad_buckets].index(label)
@@ -1088,6 +1134,8 @@ class Plan:
       hook(eng.store.grads[lo:hi])
     if self.side is None or self.trace is not None:
       return run()
+    if self.wg_batch:
+      return self._flush_wgrads(then=run)          # (its event also covers the bucket's bias / norm gradients on the main stream)
     self._bucket_ev[i].record()                  # bias / norm gradients of the bucket are written on the main stream
     with t.cuda.stream(self.side), _lib.pinned_stream(self.side):
       self.side.wait_event(self._bucket_ev[i])
@@ -1128,11 +1176,11 @@ class Plan:
           # MFMAs of a neighbour wave with idle cycles between them made VALU results of the scatter's waves go missing
           # (tools/mfma_neighbour.py).  The convolutions issue their three products as one block of adjacent
           # MFMAs now (mfma3, csrc/conv_bf3.hip): beside them the scatter is exact in 82 of 82 steps and in 660 of 660
-          # two-kernel runs; test_run_to_run_gradient_spread_default_mode watches it.
+          # two-kernel runs; test_run_to_run_gradient_spread_default_mode watches it.  (Round 5: the scatter has no projection left.)
           ray_side = self.ray_side
           if not ray_side:
             self._ray_bwd(k, g_out)
-          self._skip_bwd_ev[k].record()
+          self._skip_bwd_ev[k].record()             # (also the hand-over event of this stage's transposed-conv weight gradient below)
           with t.cuda.stream(self.side), _lib.pinned_stream(self.side):
             self.side.wait_event(self._skip_bwd_ev[k])
             if ray_side:
@@ -1140,12 +1188,14 @@ class Plan:
             self._skip_bwd(k, g_out, on_side=True)
             if k == 2:
               self._skip_bwd_done.record(self.side)
+          self._handed_over = True                   # nothing was launched on the main stream since that event
         else:
           self._skip_bwd(k, g_out, on_side=False)
       ct = cv[p + "t1."]
       gv = self.s2d(g_out, d["cout"], (2, 2, 2))
       tr2 = Transform(b2_.scale, b2_.shift, pre_relu=True)
       self._wgrad(ct, self.vw(d["w"]), tr2, gv)
+      self._handed_over = False
       if k == 6:   # gradient of the logits comes from the loss kernel; below it is a bn_bwd output
         self._bias_grad(ct, g_out, So, ctot * So)
       cc = cv[p + "c1."]
@@ -1166,6 +1216,8 @@ class Plan:
                   b1_.gamma, b1_.scale, b1_.shift, b1_.saved, d["gu"], d["cin"] * S, b1_.dgamma, b1_.dbeta,
                   dsum=cprev.dbias, ndsum=cprev.n_ref)
       g_out = d["gu"]
+      if self.wg_batch_dec:
+        self._flush_wgrads()
       if k == 3:
         self._grads_ready("decoder.stage_3.", grad_hook)
     # stage_1 / stage_0
@@ -1193,6 +1245,9 @@ class Plan:
     g_in = None          # gradient wrt the block's output (post-ReLU), None for the last block
     for blk in reversed(self.blocks):
       g_in = self._block_bwd(blk, g_in)
+      self._wg_blocks += 1
+      if self._wg_blocks >= self.wg_batch:
+        self._flush_wgrads()
       if blk["prefix"] in GRAD_BUCKET_LABELS:
         self._grads_ready(blk["prefix"], grad_hook)
     # stem: g_in = d p1
