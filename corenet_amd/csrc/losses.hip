@@ -12,7 +12,8 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kNQ = 5;   // per-sample sums: I_fg, U_fg, I_ag, U_ag, X
+constexpr int kNQ = 6;   // per-sample sums: I_fg, U_fg, I_ag, U_ag, X, and the number of labels outside [0, C) (the status word: it
+                         // travels with the partial sums, so no memset -- a launch of its own on the step's chain -- precedes pass 1)
 
 // per-voxel softmax over CT (>= C) classes held in registers
 template <int CT>
@@ -35,19 +36,18 @@ struct Soft {
 
 template <int CT>
 __global__ __launch_bounds__(kThreads) void loss_pass1_kernel(const float* logits, const int32_t* gt,
-                                                              const float* weights, int C, int64_t S, double* part,
-                                                              int* bad_label) {
+                                                              const float* weights, int C, int64_t S, double* part) {
   __shared__ double red[kThreads / 64];
   const int b = blockIdx.y;
   const float* lb = logits + (int64_t)b * C * S;
   const int32_t* gb = gt + (int64_t)b * S;
   const float* wb = weights ? weights + (int64_t)b * S : nullptr;
-  double q[kNQ] = {0, 0, 0, 0, 0};
+  double q[kNQ] = {0, 0, 0, 0, 0, 0};
   for (int64_t v = blockIdx.x * (int64_t)kThreads + threadIdx.x; v < S; v += (int64_t)gridDim.x * kThreads) {
     Soft<CT> sm;
     sm.compute(lb + v, S, C);
     int g = gb[v];
-    if (g < 0 || g >= C) { *bad_label = 1; g = 0; }     // F.one_hot / cross_entropy raise (losses.py:36,131); no OOB read here
+    if (g < 0 || g >= C) { q[5] += 1.0; g = 0; }       // F.one_hot / cross_entropy raise (losses.py:36,131); no OOB read here
     const float w = wb ? wb[v] : 1.f;                   // per-voxel loss weights (losses.py:47-49,99-102,134-136)
     float pfg = 0.f;
 #pragma unroll
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kThreads) void loss_pass1_kernel(const float* logit
 // a pair are summed in a fixed order: lane-strided, then the wave tree), thread 0 combines them.  (A single wave
 // walking all B*5 pairs one after the other took 25 us of the step's critical path.)
 __global__ __launch_bounds__(1024) void loss_finalize_kernel(const double* part, int nblk, int B, int64_t S, int kind,
-                                                            float grad_scale, float* loss, float* coef) {
+                                                            float grad_scale, float* loss, float* coef, int* bad_label) {
   __shared__ double sums[64 * kNQ];                      // B <= 64
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int pair = wave; pair < B * kNQ; pair += (int)(blockDim.x >> 6)) {     // 16 waves: 20 sums in two rounds
@@ -89,9 +89,10 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const double* part,
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
-  double iou_fg = 0.0, iou_ag = 0.0, xs = 0.0;
+  double iou_fg = 0.0, iou_ag = 0.0, xs = 0.0, nbad = 0.0;
   for (int b = 0; b < B; ++b) {
     const double* q = sums + b * kNQ;
+    nbad += q[5];
     // losses.py:57,110: union==0 -> divide by 1
     const float ifg = (float)q[0], ufg = (float)q[1] == 0.f ? 1.f : (float)q[1];
     const float iag = (float)q[2], uag = (float)q[3] == 0.f ? 1.f : (float)q[3];
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const double* part,
     case 3: L = X; kx = 1.f; break;
     case 4: L = (1.f + Lfg) * (1.f + X); kfg = 1.f + X; kx = 1.f + Lfg; break;
   }
+  *bad_label = nbad > 0.0 ? 1 : 0;
   loss[0] = L;
   coef[0] = L; coef[1] = kfg * grad_scale / B; coef[2] = kag * grad_scale / B;
   coef[3] = kx * grad_scale / (float)((double)B * (double)S);
@@ -214,15 +216,14 @@ extern "C" int crn_loss_fwd_bwd(int kind, const float* logits, const int32_t* gt
   double* part = reinterpret_cast<double*>(workspace);
   float* coef = reinterpret_cast<float*>(part + (size_t)B * 512 * kNQ);
   int* bad_label = reinterpret_cast<int*>(coef + 4 + 4 * B + (16 - (4 + 4 * B) % 16) % 16);   // crn_loss_status reads it
-  CRN_HIP(hipMemsetAsync(bad_label, 0, sizeof(int), st));
   dim3 grid(nblk, B);
-#define CRN_LOSS_P1(CT) hipLaunchKernelGGL(loss_pass1_kernel<CT>, grid, dim3(kThreads), 0, st, logits, gt, weights, C, S, part, bad_label)
+#define CRN_LOSS_P1(CT) hipLaunchKernelGGL(loss_pass1_kernel<CT>, grid, dim3(kThreads), 0, st, logits, gt, weights, C, S, part)
   if (C <= 2) CRN_LOSS_P1(2); else if (C <= 4) CRN_LOSS_P1(4); else if (C <= 8) CRN_LOSS_P1(8);
   else if (C <= 16) CRN_LOSS_P1(16); else CRN_LOSS_P1(32);
 #undef CRN_LOSS_P1
   CRN_CHECK_LAUNCH();
   if (B > 64) return CRN_EINVAL;
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nblk, B, S, kind, grad_scale, loss, coef);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nblk, B, S, kind, grad_scale, loss, coef, bad_label);
   CRN_CHECK_LAUNCH();
   if (dlogits) {
 #define CRN_LOSS_P2(CT) hipLaunchKernelGGL(loss_pass2_kernel<CT>, grid, dim3(kThreads), 0, st, logits, gt, weights, C, S, coef, dlogits)

@@ -1155,7 +1155,14 @@ class Plan:
     if not eng._gpacked_zeroed:
       be.zero(eng.gpacked)
     eng._gpacked_zeroed = False
-    be.zero(self.gsmap_slab)                       # the four skip-map gradients: one launch instead of four memsets
+    skips_on_side = self.async_skip and self.side is not None and self.trace is None and self.ray_side
+    if skips_on_side:
+      # the four skip-map gradients are written and read on the side stream only (scatter -> compress gradients): zeroed there,
+      # off the step's chain (a memset is a launch of its own)
+      with t.cuda.stream(self.side), _lib.pinned_stream(self.side):
+        be.zero(self.gsmap_slab)
+    else:
+      be.zero(self.gsmap_slab)                     # the four skip-map gradients: one launch instead of four memsets
     if grad_hook is None and self.side is not None and self.trace is None:
       grad_hook = _no_exchange                     # un-pack the finished buckets on the side stream all the same
     L = eng.latent
