@@ -6,7 +6,8 @@ usage: check_profiles_fresh.py [round prefix, default r05]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prefix = sys.argv[1] if len(sys.argv) > 1 else "r05"
-EXEMPT = ("lds_atomic_probe", "grid_barrier_probe")          # properties of the part, not of csrc/
+EXEMPT = ("lds_atomic_probe", "grid_barrier_probe",           # properties of the part, not of csrc/
+          "defer_wgrad_experiment", "wgrad_handover")         # host-side schedule experiments (corenet_amd/model/engine.py), dated in the file
 def ct(*paths):
   out = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%ct", "--"] + list(paths), capture_output=True, text=True).stdout.strip()
   return int(out) if out else 0
