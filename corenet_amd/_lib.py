@@ -112,6 +112,7 @@ _SIGS = {
     "crn_stride2_gather": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "crn_stride2_scatter": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "crn_fill_offset_channels": [vp, i32, i64, i64, i32, vp, vp],
+    "crn_decoder_inputs": [vp, vp, i32, i32, C.POINTER(C.c_float), vp, vp, vp],
     "crn_ray_sample_fwd": [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp],
     "crn_ray_sample_bwd": [vp, i64, i32, i32, i32, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp],
     "crn_ray_sample_fwd_idx": [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp, vp, i64, i32, i32, i32, vp, vp],

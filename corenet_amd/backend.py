@@ -282,6 +282,12 @@ class HipBackend:
     B, Cn, h, w = dy.shape
     self.lib.crn_stride2_scatter(ptr(dy), ptr(dx), B, Cn, h, w, dx.shape[2], dx.shape[3], _lib.stream())
 
+  def decoder_inputs(self, v2s, offset, scales, layer_mats, offset_out):
+    """layer_mats[s][b] = v2s[b] . scale(scales[s]) and offset_out = offset in one launch (crn_decoder_inputs)."""
+    n = len(scales)
+    arr = (C.c_float * n)(*[float(v) for v in scales])
+    self.lib.crn_decoder_inputs(ptr(v2s), ptr(offset), v2s.shape[0], n, arr, ptr(layer_mats), ptr(offset_out), _lib.stream())
+
   def fill_offset_channels(self, x, B, sB, S, c0, offset):
     self.lib.crn_fill_offset_channels(ptr(x), B, sB, S, c0, ptr(offset), _lib.stream())
 

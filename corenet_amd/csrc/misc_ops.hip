@@ -152,6 +152,20 @@ __global__ void fill_offset_kernel(float* x, int64_t sB, int64_t S, int c0, cons
   x[b * sB + (int64_t)(c0 + j) * S + s] = offset[b * 3 + j];
 }
 
+// layer matrices of the ray-traced skips, layer_mats[s][b] = v2s[b] . scale(f_s, f_s, f_s) (reconstruction_decoder.py:111-116: a
+// column scaling, exact), and a copy of the sampling offset -- the decoder's per-call inputs in ONE launch (three torch launches
+// in rounds 1-4: a multiply and two device-to-device copies at the head of every step)
+__global__ void decoder_inputs_kernel(const float* v2s, const float* offset, int B, int nscales, float f0, float f1, float f2, float f3,
+                                      float* layer_mats, float* offset_out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  const float f[4] = {f0, f1, f2, f3};
+  if (e < nscales * B * 16) {
+    const int s = e / (B * 16), r = e - s * B * 16;
+    layer_mats[e] = (r & 3) == 3 ? v2s[r] : v2s[r] * f[s];
+  }
+  if (e < B * 3) offset_out[e] = offset[e];
+}
+
 __global__ void gather_kernel(const float* src, const int32_t* idx, float* dst, int64_t n) {
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     const int32_t i = idx[e];
@@ -433,6 +447,18 @@ extern "C" int crn_fill_offset_channels(float* x, int B, int64_t sB, int64_t S, 
   CRN_ENTRY(s);
   const int64_t total = (int64_t)B * 3 * S;
   hipLaunchKernelGGL(fill_offset_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)s, x, sB, S, c0, offset, total);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_decoder_inputs(const float* v2s, const float* offset, int B, int nscales, const float* scales, float* layer_mats,
+                                  float* offset_out, crnStream s) {
+  CRN_ENTRY(s);
+  if (!v2s || !offset || !scales || !layer_mats || !offset_out || B < 1 || nscales < 1 || nscales > 4) return CRN_EINVAL;
+  float f[4] = {1.f, 1.f, 1.f, 1.f};
+  for (int i = 0; i < nscales; ++i) f[i] = scales[i];          // (host array)
+  hipLaunchKernelGGL(decoder_inputs_kernel, dim3(nblk((int64_t)nscales * B * 16)), dim3(256), 0, (hipStream_t)s, v2s, offset, B, nscales,
+                     f[0], f[1], f[2], f[3], layer_mats, offset_out);
   CRN_CHECK_LAUNCH();
   return CRN_OK;
 }

@@ -684,6 +684,7 @@ class Plan:
     for k in sk:
       self.gsmap[k] = self.gsmap_slab[o:o + gs_n[k]].view(B, sk[k], *self.skip_hw[k]); o += gs_n[k]
     self.layer_mats = f(4, B, 16)
+    self._layer_scale_list = [128.0 / (2 * self.dec[k]["r"]) for k in (2, 3, 4, 5)]
     self.layer_scales = t.tensor([[128.0 / (2 * self.dec[k]["r"])] * 3 + [1.0] for k in (2, 3, 4, 5)],
                                  dtype=eng.dtype, device=dev).reshape(4, 1, 1, 4)
     self.offset = f(B, 3)
@@ -923,6 +924,10 @@ class Plan:
   def _decoder_inputs(self, v2s: t.Tensor, offset: t.Tensor):
     """Sampling offset and the layer matrices v2s @ scale(128 / r) of the four skip grids (reconstruction_decoder.py:111-116)."""
     B = self.B
+    if (hasattr(self.be, "decoder_inputs") and v2s.dtype == self.layer_mats.dtype and offset.dtype == self.offset.dtype
+        and v2s.is_contiguous() and offset.is_contiguous() and v2s.device == self.layer_mats.device):
+      self.be.decoder_inputs(v2s, offset, self._layer_scale_list, self.layer_mats, self.offset)      # one launch
+      return
     self.offset.copy_(offset)
     v = v2s.to(self.layer_mats.dtype).reshape(1, B, 4, 4)
     self.layer_mats.copy_((v * self.layer_scales).reshape(4, B, 16))    # exact: column scaling

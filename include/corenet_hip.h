@@ -336,6 +336,12 @@ int crn_stride2_scatter(const float* dy, float* dx, int B, int C, int h, int w, 
 int crn_fill_offset_channels(float* x, int B, int64_t sB, int64_t S, int c0,
                              const float* offset, crnStream s);
 
+/* The decoder's per-call inputs in one launch: layer_mats[s][b] = v2s[b] . scale(f_s, f_s, f_s) for the nscales <= 4 skip grids
+ * (reconstruction_decoder.py:111-116: layer_matrix = v2s . scale(resolution / grid); columns 0-2 of the row-major 4x4 times f_s,
+ * exact) and offset_out = offset.  v2s [B][16], offset [B][3] device; scales: HOST array of nscales floats.                   */
+int crn_decoder_inputs(const float* v2s, const float* offset, int B, int nscales, const float* scales,
+                       float* layer_mats, float* offset_out, crnStream s);
+
 /* ---------------- ray-traced skip connection --------------------------------
  * Gather part of SampleGrid2d.forward (ray_traced_skip_connection.py:91-144):
  * per voxel centre (x,y,z)+off: p = M*(.,1); u=(px/pw)/2+.5; ix=(int)(u*W);

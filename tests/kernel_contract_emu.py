@@ -301,6 +301,12 @@ class EmuBackend:
     dx.zero_()
     dx[:, :, ::2, ::2] = dy
 
+  def decoder_inputs(self, v2s, offset, scales, layer_mats, offset_out):
+    B = v2s.shape[0]
+    sc = t.tensor([[float(s)] * 3 + [1.0] for s in scales], dtype=layer_mats.dtype).reshape(len(scales), 1, 1, 4)
+    layer_mats.copy_((v2s.to(layer_mats.dtype).reshape(1, B, 4, 4) * sc).reshape(len(scales), B, 16))
+    offset_out.copy_(offset)
+
   def fill_offset_channels(self, x, B, sB, S, c0, offset):
     t.as_strided(x, (B, 3, S), (sB, S, 1), x.storage_offset() + c0 * S).copy_(
         offset.view(B, 3, 1).expand(B, 3, S))

@@ -616,6 +616,21 @@ def test_stride2_gather_scatter(be):
     assert t.equal(dx.cpu(), want)
 
 
+def test_decoder_inputs_one_launch(be):
+  """crn_decoder_inputs: the four layer matrices v2s . scale(128 / r) (reconstruction_decoder.py:111-116) and the offset copy of a
+  call in one launch -- bit for bit what the torch expression of the contract gives (a column scaling is exact)."""
+  g = t.Generator().manual_seed(3)
+  for B in (1, 4, 7):
+    v2s, off = t.randn(B, 4, 4, generator=g), t.rand(B, 3, generator=g)
+    scales = [8.0, 4.0, 2.0, 1.0]
+    want_m, want_o = t.zeros(4, B, 16), t.zeros(B, 3)
+    EMU.decoder_inputs(v2s, off, scales, want_m, want_o)
+    lm, oo = t.full((4, B, 16), 9.0, device=DEV), t.full((B, 3), 9.0, device=DEV)
+    be.decoder_inputs(v2s.to(DEV), off.to(DEV), scales, lm, oo)
+    assert t.equal(lm.cpu(), want_m) and t.equal(oo.cpu(), want_o)
+    assert t.equal(want_m[1].view(B, 4, 4)[:, :, 3], v2s[:, :, 3]) and t.equal(want_m[1].view(B, 4, 4)[:, :, :3], v2s[:, :, :3] * 4.0)
+
+
 # ------------------------------------------------------------------ ray-traced skip
 def test_ray_sample_golden_and_edge(be, golden_dir):
   import os
