@@ -206,14 +206,14 @@ class HipBackend:
                                     ptr(scale), ptr(shift), ptr(saved), ptr(ws), n, _lib.stream())
 
   def bn_stats_tail(self, x, B, Cn, S, sB, gamma, beta, rmean, rvar, nbt, eps, momentum, training, scale, shift, saved,
-                    r, rscale, rshift, sB_r, y_pre, sB_pre, y, sB_y, relu):
+                    r, rscale, rshift, sB_r, y_pre, sB_pre, y, sB_y, relu, y2=None, W=0):
     """bn_stats(x) + affine_add_relu(x, scale, shift, r, rscale, rshift, ...) in one call (one launch where a workgroup
-    owns a channel in registers: crn_batch_renorm_stats_tail)."""
+    owns a channel in registers: crn_batch_renorm_stats_tail); y2: also the stride-2 compaction of y (rows of width W)."""
     ws, n = self._bn_ws(Cn, x.device)
     self.lib.crn_batch_renorm_stats_tail(ptr(x), B, Cn, S, sB, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), ptr(nbt),
                                          eps, momentum, int(training), ptr(scale), ptr(shift), ptr(saved), ptr(ws), n,
                                          ptr(r), ptr(rscale), ptr(rshift), sB_r, ptr(y_pre), sB_pre, ptr(y), sB_y,
-                                         int(relu), _lib.stream())
+                                         int(relu), ptr(y2), int(W), _lib.stream())
 
   def bn_bwd(self, x, sB_x, dy, sB_dy, B, Cn, S, pre_relu, post_relu, gamma, scale, shift, saved,
              dx, sB_dx, dgamma, dbeta, accumulate=False, dsum=None, ndsum=0):

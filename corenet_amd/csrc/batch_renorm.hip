@@ -203,9 +203,13 @@ __global__ __launch_bounds__(kThreads) void bn_owner_stats_kernel(
 // known to this workgroup the moment the statistics are finalized, so y = relu(x*scale + shift + residual) (the
 // arithmetic of affine_add_relu_kernel, expression for expression) is written from here: 16 launches fewer per forward
 // and one read of x instead of two.
+// y2: the stride-2 compaction of y (y2[b,c,i,j] = y[b,c,2i,2j], crn_stride2_gather) for the down-sampling block that reads this
+// block's output next (resnet50.py:94-97): written from the same registers, one launch less on the forward chain.  W = row width of
+// the channel plane (a multiple of 4: a float4 never straddles rows), W2 = ceil(W / 2), H2 = ceil(H / 2).
 struct BnTail {
   const float* r; const float* rscale; const float* rshift; int64_t sBr;
   float* y_pre; int64_t sBpre; float* y; int64_t sBy; int relu;
+  float* y2; int64_t sBy2; int W, W2, H2;
 };
 template <int NV, bool TAIL = false>
 __global__ __launch_bounds__(kThreads) void bn_owner_stats_reg_kernel(
@@ -281,6 +285,14 @@ __global__ __launch_bounds__(kThreads) void bn_owner_stats_reg_kernel(
             for (int i = 0; i < 4; ++i) q[i] = fmaxf(q[i], 0.f);
           }
           *reinterpret_cast<f32x4*>(tail.y + (int64_t)b * tail.sBy + o) = q;
+          if (tail.y2) {
+            const int s = s4 * 4, row = s / tail.W, col = s - row * tail.W;
+            if (!(row & 1)) {
+              typedef float f32x2 __attribute__((ext_vector_type(2)));
+              float* d2 = tail.y2 + (int64_t)b * tail.sBy2 + ((int64_t)c * tail.H2 + (row >> 1)) * tail.W2 + (col >> 1);
+              *reinterpret_cast<f32x2*>(d2) = (f32x2){q[0], q[2]};
+            }
+          }
         }
       }
     }
@@ -792,14 +804,22 @@ extern "C" int crn_batch_renorm_stats_tail(const float* x, int B, int C, int64_t
                                            double* ws, size_t ws_bytes,
                                            const float* r, const float* rscale, const float* rshift, int64_t sB_r,
                                            float* y_pre, int64_t sB_pre, float* y, int64_t sB_y, int relu,
-                                           crnStream stream) {
+                                           float* y2, int W, crnStream stream) {
   if (!y && !y_pre) return CRN_EINVAL;      // (no CRN_ENTRY: a pending split-K sum of x is taken over below)
-  const BnTail tail{r, rscale, rshift, sB_r, y_pre, sB_pre, y, sB_y, relu};
+  if (y2 && (!y || W < 1 || S % W || sB_y != (int64_t)C * S)) return CRN_EINVAL;
+  const int H = y2 ? (int)(S / W) : 0, H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  const bool y2_fused = y2 && W % 4 == 0 && (((uintptr_t)y2) & 7) == 0;      // (a float4 inside one row, 8-byte stores)
+  const BnTail tail{r, rscale, rshift, sB_r, y_pre, sB_pre, y, sB_y, relu, y2_fused ? y2 : nullptr, (int64_t)C * H2 * W2, W, W2, H2};
   bool done = false;
   const int rc = bn_stats_impl(x, B, C, S, sB, 0, gamma, beta, running_mean, running_var, nbt, eps, momentum, training,
                                scale, shift, saved, ws, ws_bytes, stream, &tail, &done);
-  if (rc != CRN_OK || done) return rc;
-  return crn_affine_add_relu_impl(x, scale, shift, r, rscale, rshift, B, C, S, sB, sB_r, y_pre, sB_pre, y, sB_y, relu, stream);
+  if (rc != CRN_OK) return rc;
+  if (!done) {
+    const int rc2 = crn_affine_add_relu_impl(x, scale, shift, r, rscale, rshift, B, C, S, sB, sB_r, y_pre, sB_pre, y, sB_y, relu, stream);
+    if (rc2 != CRN_OK) return rc2;
+  }
+  if (y2 && !(done && y2_fused)) return crn_stride2_gather(y, y2, B, C, H2, W2, H, W, stream);
+  return CRN_OK;
 }
 
 extern "C" int crn_batch_renorm_eval_affine(const float* params, const float* buffers, const int32_t* table,

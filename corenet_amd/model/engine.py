@@ -644,6 +644,8 @@ class Plan:
             # sub-sampled block input, and their data gradients meet in a compact buffer before they are
             # scattered back: plain tensors -> the pointwise kernel instead of strided views
             blk["xs"] = f(B, cin, ho, wo); blk["gxs"] = f(B, cin, ho, wo)
+        if st == 2 and self.blocks:
+          self.blocks[-1]["xs_next"] = blk          # the block in front writes this block's compacted input with its tail
         self.blocks.append(blk)
         cin, hi, wi = filt[2], ho, wo
       stage_hw[name] = (hi, wi)
@@ -1074,7 +1076,8 @@ class Plan:
     h = blk["h"]; S = h * blk["w"]
     f1, f2, f3 = blk["f"]
     if blk["stride"] == 2:
-      be.stride2_gather(cur, blk["xs"])
+      if not blk.pop("xs_filled", False):            # (filled by the tail launch of the block in front: crn_batch_renorm_stats_tail)
+        be.stride2_gather(cur, blk["xs"])
       xin = self.vw(blk["xs"])
     else:
       xin = self.vw(cur)
@@ -1109,9 +1112,13 @@ class Plan:
     self._conv(cv[p + "op_c.conv."], self.vw(blk["yb"]), Transform(bb.scale, bb.shift, post_relu=True),
                self.vw(blk["yc"]))
     if fused_tail:
+      nxt = blk.get("xs_next") if os.environ.get("CRN_FUSE_GATHER", "1") != "0" else None
       with _lib.roctx_range("bn_stats_tail C%d S%d" % (bc.C, S)):
         be.bn_stats_tail(blk["yc"], B, f3, S, f3 * S, bc.gamma, bc.beta, bc.rmean, bc.rvar, bc.nbt, BN_EPS, BN_MOMENTUM,
-                         True, bc.scale, bc.shift, bc.saved, res, rsc, rsh, f3 * S, pre, sB_pre, blk["out"], f3 * S, True)
+                         True, bc.scale, bc.shift, bc.saved, res, rsc, rsh, f3 * S, pre, sB_pre, blk["out"], f3 * S, True,
+                         y2=nxt["xs"] if nxt is not None else None, W=blk["w"])
+      if nxt is not None:
+        nxt["xs_filled"] = True
     else:
       self._stats(bc, blk["yc"], S, f3 * S, False, training)
       if blk["down"]:

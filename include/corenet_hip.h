@@ -235,13 +235,17 @@ size_t crn_batch_renorm_workspace_bytes(int C);
 /* crn_batch_renorm_stats (pre_relu = 0) followed by crn_affine_add_relu(x, scale, shift, r, rscale, rshift, ...) -- the tail
  * of a ResNet bottleneck (resnet50.py:71-78: bn of the last conv + shortcut + ReLU) -- as ONE call: where a workgroup owns
  * a channel with all of it in registers (training, B*S <= 16384: every bottleneck of the encoder) the tail is written by
- * the statistics launch itself, otherwise by a second launch.  Same results as the two calls, bit for bit.            */
+ * the statistics launch itself, otherwise by a second launch.  Same results as the two calls, bit for bit.
+ * y2 (may be NULL): additionally the stride-2 compaction of y, y2[b,c,i,j] = y[b,c,2i,2j] (what crn_stride2_gather(y, ...) gives:
+ * the input of the down-sampling block that follows, resnet50.py:94-97), W = row width of a channel plane (S = H * W; y dense
+ * [B][C][H][W]); written from the same registers when W is a multiple of 4, by a gather launch otherwise.               */
 int crn_batch_renorm_stats_tail(const float* x, int B, int C, int64_t S, int64_t sB,
                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
                                 const int64_t* num_batches_tracked, float eps, float momentum, int training,
                                 float* scale, float* shift, float* saved, double* workspace, size_t workspace_bytes,
                                 const float* r, const float* rscale, const float* rshift, int64_t sB_r,
-                                float* y_pre, int64_t sB_pre, float* y, int64_t sB_y, int relu, crnStream s);
+                                float* y_pre, int64_t sB_pre, float* y, int64_t sB_y, int relu,
+                                float* y2, int W, crnStream s);
 
 /* Eval mode (batch_renorm.py:59: (x - running_mean) / sqrt(running_var + eps) * weight + bias) for all
  * BatchRenorm instances of a model at once: n channels, table [n][5] = offsets of (weight, bias) in `params`,

@@ -537,6 +537,21 @@ def test_bottleneck_tail_fused_equals_two_launches(be, B, C, S, shortcut, second
   EMU.affine_add_relu(xc, sc, sh, rc, rsc.cpu() if rsc is not None else None, rsh.cpu() if rsh is not None else None,
                       B, C, S, C * S, C * S, None, 0, want, C * S, True)
   close(outs[1][5], want, 2e-5, "tail vs emulator")
+  # the stride-2 compaction of y for the down-sampling block that follows (y2 argument): equals crn_stride2_gather of y, whichever
+  # path wrote it (the tail launch itself for planes with W % 4 == 0, a gather launch otherwise)
+  for W in ([64, 16] if S in (4096, 256) else [6, 4] if S == 36 else [128]):
+    W = W if S % W == 0 else None
+    if W is None:
+      continue
+    H = S // W
+    rm, rv = rm0.clone(), rv0.clone()
+    sc2, sh2, sv2 = t.zeros(C, device=dev), t.zeros(C, device=dev), t.zeros(4 * C, device=dev)
+    y = t.full((B, C, S), -7.0, device=dev)
+    y2 = t.full((B, C, (H + 1) // 2, (W + 1) // 2), -7.0, device=dev)
+    be.bn_stats_tail(x, B, C, S, C * S, gamma, beta, rm, rv, nb, 1e-3, 0.01, True, sc2, sh2, sv2, r, rsc, rsh, C * S,
+                     None, 0, y, C * S, True, y2=y2, W=W)
+    assert t.equal(y, outs[1][5]), W
+    assert t.equal(y2, y.view(B, C, H, W)[:, :, ::2, ::2]), (W, float((y2 - y.view(B, C, H, W)[:, :, ::2, ::2]).abs().max()))
 
 
 @pytest.mark.parametrize("m,B,C,dims", [(1, 3, 2, (5, 6, 7)), (2, 2, 14, (4, 5, 6)), (3, 1, 5, (3, 4, 5)), (2, 1, 2, (16, 16, 16))])
