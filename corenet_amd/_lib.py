@@ -97,7 +97,7 @@ _SIGS = {
     "crn_batch_renorm_stats_tail": [vp, i32, i32, i64, i64, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, sz,
                                     vp, vp, vp, i64, vp, i64, vp, i64, i32, vp, i32, vp],
     "crn_batch_renorm_bwd_head": [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i64, vp, vp, vp, vp, vp, i64,
-                                  vp, vp, i32, vp, i32, vp, sz, vp],
+                                  vp, vp, i32, vp, i32, vp, sz, vp, i32, vp],
     "crn_batch_renorm_bwd": [vp, i64, vp, i64, i32, i32, i64, i32, i32, vp, vp, vp, vp, vp, i64,
                              vp, vp, i32, vp, i32, vp, sz, vp],
     "crn_affine_add_relu": [vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i64, vp, i64, vp, i64, i32, vp],

@@ -224,13 +224,14 @@ class HipBackend:
                                   ptr(dsum), int(ndsum), ptr(ws), n, _lib.stream())
 
   def bn_bwd_head(self, x, sB_x, dy, sB_dy, g, sB_g, act, sB_act, g2, sB_g2, B, Cn, S, gamma, scale, shift, saved,
-                  dx, sB_dx, dgamma, dbeta, accumulate=False, dsum=None, ndsum=0):
-    """relu_bwd_add(g, act, g2 -> dy) + bn_bwd(x, dy -> dx) in one call (crn_batch_renorm_bwd_head)."""
+                  dx, sB_dx, dgamma, dbeta, accumulate=False, dsum=None, ndsum=0, g_compact=None, W=0):
+    """relu_bwd_add(g, act, g2 -> dy) + bn_bwd(x, dy -> dx) in one call (crn_batch_renorm_bwd_head); g_compact: g in the
+    compact form of a stride-2 data gradient (g = stride2_scatter(g_compact), planes with rows of width W)."""
     ws, n = self._bn_ws(Cn, x.device)
     self.lib.crn_batch_renorm_bwd_head(ptr(x), sB_x, ptr(dy), sB_dy, ptr(g), sB_g, ptr(act), sB_act, ptr(g2), sB_g2,
                                        B, Cn, S, ptr(gamma), ptr(scale), ptr(shift), ptr(saved), ptr(dx), sB_dx,
                                        ptr(dgamma), ptr(dbeta), int(accumulate), ptr(dsum), int(ndsum), ptr(ws), n,
-                                       _lib.stream())
+                                       ptr(g_compact), int(W), _lib.stream())
 
   def bn_eval_affine(self, params, buffers, table, eps, scale, shift):
     self.lib.crn_batch_renorm_eval_affine(ptr(params), ptr(buffers), ptr(table), table.shape[0], eps,

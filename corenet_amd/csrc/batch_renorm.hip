@@ -305,7 +305,11 @@ __global__ __launch_bounds__(kThreads) void bn_owner_stats_reg_kernel(
 //   dy = (act > 0 ? g : 0) + g2      (the arithmetic of relu_bwd_add_kernel; g2 may be absent),
 // and stored to `dy` on the way (the shortcut's norm and the block's input gradient read it later): 15 launches fewer
 // per backward.
-struct BnHead { const float* g; int64_t sBg; const float* act; int64_t sBact; const float* g2; int64_t sBg2; };
+// gc != nullptr: g is given in its compact form -- it is the data gradient of a stride-2 1x1 convolution, non-zero only at even
+// (row, column) (crn_stride2_scatter(gc) would expand it: g[2i][2j] = gc[i][j], zeros elsewhere): read from there, the expanded
+// tensor is never written.  W = row width of the full plane (a multiple of 4), W2 = ceil(W / 2), H2 = ceil(H / 2).
+struct BnHead { const float* g; int64_t sBg; const float* act; int64_t sBact; const float* g2; int64_t sBg2;
+                const float* gc; int64_t sBgc; int W, W2, H2; };
 template <int NV, bool HEAD = false>
 __global__ __launch_bounds__(kThreads) void bn_owner_bwd_reg_kernel(
     const float* x, int64_t sBx, const float* dy, int64_t sBdy, int B, int S4, int C, int pre_relu,
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(kThreads) void bn_owner_bwd_reg_kernel(
   __shared__ float redf[kThreads / 64];
   crn_kernargs_now(x, sBx, dy, sBdy, B, S4, C, pre_relu, post_relu, gamma, scale, shift, saved, dx, sBdx, dgamma, dbeta,
                    accumulate, dsum, ndsum, part, splits);
-  if (HEAD) crn_kernargs_now(head.g, head.sBg, head.act, head.sBact, head.g2, head.sBg2);
+  if (HEAD) crn_kernargs_now(head.g, head.sBg, head.act, head.sBact, head.g2, head.sBg2, head.gc, head.sBgc, head.W, head.W2, head.H2);
   const int c = blockIdx.x, total4 = B * S4;
   // every per-channel scalar of the kernel is loaded here, next to x and dy: one round trip to memory, not three
   const float sc = scale[c], sh = shift[c], mu = saved[c], rstd = saved[C + c];
@@ -334,7 +338,17 @@ __global__ __launch_bounds__(kThreads) void bn_owner_bwd_reg_kernel(
     xv[k] = ok ? *reinterpret_cast<const f32x4*>(x + (int64_t)b * sBx + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
     if (HEAD) {
       const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const f32x4 g = ok ? *reinterpret_cast<const f32x4*>(head.g + (int64_t)b * head.sBg + o) : z;
+      f32x4 g = z;
+      if (ok && head.gc) {
+        const int s = s4 * 4, row = s / head.W, col = s - row * head.W;
+        if (!(row & 1)) {
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          const f32x2 v = *reinterpret_cast<const f32x2*>(head.gc + (int64_t)b * head.sBgc + ((int64_t)c * head.H2 + (row >> 1)) * head.W2 + (col >> 1));
+          g[0] = v[0]; g[2] = v[1];
+        }
+      } else if (ok) {
+        g = *reinterpret_cast<const f32x4*>(head.g + (int64_t)b * head.sBg + o);
+      }
       const f32x4 a = ok ? *reinterpret_cast<const f32x4*>(head.act + (int64_t)b * head.sBact + o) : z;
       const f32x4 g2 = (ok && head.g2) ? *reinterpret_cast<const f32x4*>(head.g2 + (int64_t)b * head.sBg2 + o) : z;
       f32x4 d;
@@ -852,6 +866,15 @@ static int bn_bwd_impl(const float* x, int64_t sB_x, const float* dy, int64_t sB
     const int rcf = crn_splitk_flush(st);          // (dy is formed here: nothing pending can be meant for this call)
     if (rcf != CRN_OK) return rcf;
     const bool hv = vec_ok(S, {head->sBg, head->sBact, head->g2 ? head->sBg2 : 0}, {head->g, head->act, head->g2});
+    BnHead expanded = *head;
+    if (head->gc && !(reg_form && hv && head->W % 4 == 0 && (((uintptr_t)head->gc) & 7) == 0)) {
+      // the launch below reads the expanded gradient: expand it into the caller's buffer first
+      const int H = (int)(S / head->W);
+      const int rcs = crn_stride2_scatter(head->gc, const_cast<float*>(head->g), B, C, head->H2, head->W2, H, head->W, stream);
+      if (rcs != CRN_OK) return rcs;
+      expanded.gc = nullptr;
+      head = &expanded;
+    }
     if (reg_form && hv) {
       const int per = (int)crn_cdiv((int64_t)B * S / 4, kThreads);
 #define CRN_BN_BWD_HEAD(NV)                                                                                         \
@@ -998,9 +1021,11 @@ extern "C" int crn_batch_renorm_bwd_head(const float* x, int64_t sB_x, float* dy
                                          int B, int C, int64_t S, const float* gamma, const float* scale,
                                          const float* shift, const float* saved, float* dx, int64_t sB_dx,
                                          float* dgamma, float* dbeta, int accumulate, float* dsum, int ndsum,
-                                         double* ws, size_t ws_bytes, crnStream stream) {
+                                         double* ws, size_t ws_bytes, const float* g_compact, int W, crnStream stream) {
   if (!g || !act || !dy) return CRN_EINVAL;
-  const BnHead head{g, sB_g, act, sB_act, g2, sB_g2};
+  if (g_compact && (W < 1 || S % W || sB_g != (int64_t)C * S)) return CRN_EINVAL;
+  const int H = g_compact ? (int)(S / W) : 0, H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+  const BnHead head{g, sB_g, act, sB_act, g2, sB_g2, g_compact, (int64_t)C * H2 * W2, W, W2, H2};
   return bn_bwd_impl(x, sB_x, dy, sB_dy, B, C, S, 0, 0, gamma, scale, shift, saved, dx, sB_dx, dgamma, dbeta,
                      accumulate, dsum, ndsum, ws, ws_bytes, stream, &head);
 }

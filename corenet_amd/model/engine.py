@@ -706,6 +706,7 @@ class Plan:
     self.wg_batch = int(os.environ.get("CRN_WG_BATCH", "1")) if use_side else 0      # bottlenecks per hand-over (0: per conv)
     self.wg_batch_dec = os.environ.get("CRN_WG_BATCH_DEC", "0") == "1"
     self._handed_over = False
+    self._g_compact = None
     self._wg_pending = []
     self._wg_blocks = 0
     # the ray-traced skip path (offset channels -> 1x1 compress -> ray sample; backward: scatter -> compress gradients)
@@ -1331,6 +1332,12 @@ class Plan:
     # op_c's norm itself on the HIP backend (crn_batch_renorm_bwd_head), by a launch of its own otherwise
     # (g_out None: gpre already holds d pre -- last block of the encoder)
     fused_head = g_out is not None and hasattr(be, "bn_bwd_head") and eng.fuse_tail
+    # g_out may still be in the compact form the down-sampling block behind this one left it in (below): the fused head reads
+    # it from there, anything else gets it expanded first
+    gc, self._g_compact = self._g_compact, None
+    if gc is not None and not fused_head:
+      be.stride2_scatter(gc, g_out)
+      gc = None
     if blk["final"]:
       act, sB_act, g2, sB_g2 = (self.feat[blk["stage"]], self.feat[blk["stage"]].stride(0),
                                 self.gfeat[blk["stage"]], self.gfeat[blk["stage"]].stride(0))
@@ -1339,7 +1346,8 @@ class Plan:
     # conv bias gradients = sum(dx) of the following norm, fused into bn_bwd (dsum)
     if fused_head:
       be.bn_bwd_head(blk["yc"], f3 * S, gpre, f3 * S, g_out, f3 * S, act, sB_act, g2, sB_g2, B, f3, S, bc.gamma, bc.scale,
-                     bc.shift, bc.saved, blk["gyc"], f3 * S, bc.dgamma, bc.dbeta, dsum=cc.dbias, ndsum=cc.n_ref)
+                     bc.shift, bc.saved, blk["gyc"], f3 * S, bc.dgamma, bc.dbeta, dsum=cc.dbias, ndsum=cc.n_ref,
+                     g_compact=gc, W=blk["w"])
     else:
       if g_out is not None:
         be.relu_bwd_add(g_out, act, g2, B, f3, S, f3 * S, sB_act, sB_g2, gpre, f3 * S)
@@ -1373,7 +1381,10 @@ class Plan:
       self._dgrad(ca, self.vw(blk["gya"]), gv)
       self._dgrad(csn, self.vw(blk["gys"]), gv, accumulate=True)
       if blk["stride"] == 2:
-        be.stride2_scatter(blk["gxs"], gin)           # every element of gin is written (zeros between the samples)
+        if hasattr(be, "bn_bwd_head") and eng.fuse_tail and os.environ.get("CRN_FUSE_GATHER", "1") != "0":
+          self._g_compact = blk["gxs"]                # expanded by its reader: the norm backward at the head of the block in front
+        else:
+          be.stride2_scatter(blk["gxs"], gin)         # every element of gin is written (zeros between the samples)
       return gin
     # identity block: d in = d pre + dgrad(op_a)
     self._dgrad(ca, self.vw(blk["gya"]), self.vw(gpre), accumulate=True)

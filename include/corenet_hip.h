@@ -286,14 +286,18 @@ int crn_batch_renorm_bwd_apply(const float* x, int64_t sB_x, const float* dy, in
 /* crn_relu_bwd_add(g, act, g2 -> dy) followed by crn_batch_renorm_bwd(x, dy, pre_relu = post_relu = 0, ...) -- the backward
  * of a bottleneck's tail and of its last norm -- as ONE call: dy = (act > 0 ? g : 0) + g2 (g2 may be NULL) is formed and
  * stored by the norm's backward launch where a workgroup owns a channel in registers (B*S <= 16384), by a launch of its
- * own otherwise.  Same results as the two calls, bit for bit.                                                        */
+ * own otherwise.  Same results as the two calls, bit for bit.
+ * g_compact (may be NULL): g is the data gradient of the stride-2 1x1 convolutions of the down-sampling block behind this one
+ * (resnet50.py:94-97), given in its compact form [B][C][ceil(H/2)][ceil(W/2)] (g = crn_stride2_scatter(g_compact), rows of width W,
+ * S = H * W): the register form reads it from there and never touches `g`; otherwise the call expands it into `g` (which must
+ * then be a dense [B][C][S] buffer) first.                                                                            */
 int crn_batch_renorm_bwd_head(const float* x, int64_t sB_x, float* dy, int64_t sB_dy,
                               const float* g, int64_t sB_g, const float* act, int64_t sB_act,
                               const float* g2 /* may be NULL */, int64_t sB_g2,
                               int B, int C, int64_t S, const float* gamma, const float* scale, const float* shift,
                               const float* saved, float* dx, int64_t sB_dx, float* dgamma, float* dbeta,
                               int accumulate, float* dsum, int ndsum,
-                              double* workspace, size_t workspace_bytes, crnStream s);
+                              double* workspace, size_t workspace_bytes, const float* g_compact, int W, crnStream s);
 
 /* y = act( x*scale[c]+shift[c] [+ r*rscale[c]+rshift[c]] ) ; optional second
  * output y_pre (before the final ReLU).  Encoder block tails

@@ -537,6 +537,25 @@ def test_bottleneck_tail_fused_equals_two_launches(be, B, C, S, shortcut, second
   EMU.affine_add_relu(xc, sc, sh, rc, rsc.cpu() if rsc is not None else None, rsh.cpu() if rsh is not None else None,
                       B, C, S, C * S, C * S, None, 0, want, C * S, True)
   close(outs[1][5], want, 2e-5, "tail vs emulator")
+  # the gradient g in the COMPACT form of a stride-2 data gradient (g_compact argument of crn_batch_renorm_bwd_head): equals the call
+  # on crn_stride2_scatter(g_compact), whichever path expands it (the register kernel on the fly, or a scatter launch into `g`)
+  for W in ([64, 16] if S in (4096, 256) else [6, 4] if S == 36 else [128]):
+    if S % W:
+      continue
+    H = S // W
+    gcmp = t.randn(B, C, (H + 1) // 2, (W + 1) // 2, generator=t.Generator().manual_seed(9)).to(dev)
+    gfull = t.zeros(B, C, H, W, device=dev); gfull[:, :, ::2, ::2] = gcmp
+    act, sBa = outs[1][5], C * S
+    res = []
+    for compact in (False, True):
+      dpre = t.full((B, C, S), 3.0, device=dev); dx = t.zeros(B, C, S, device=dev)
+      dg, db, ds = t.zeros(C, device=dev), t.zeros(C, device=dev), t.zeros(C, device=dev)
+      gbuf = gfull.clone() if not compact else t.full((B, C, H, W), 5.0, device=dev)      # (compact: a buffer the call may expand into)
+      be.bn_bwd_head(x, C * S, dpre, C * S, gbuf, C * S, act, sBa, None, 0, B, C, S, gamma, outs[1][0], outs[1][1], outs[1][2],
+                     dx, C * S, dg, db, dsum=ds, ndsum=C, g_compact=gcmp if compact else None, W=W)
+      res.append((dpre, dx, dg, db))
+    for a, b_, nm in zip(res[0], res[1], ("d pre", "dx", "dgamma", "dbeta")):
+      assert t.equal(a, b_), (W, nm, float((a - b_).abs().max()))
   # the stride-2 compaction of y for the down-sampling block that follows (y2 argument): equals crn_stride2_gather of y, whichever
   # path wrote it (the tail launch itself for planes with W % 4 == 0, a gather launch otherwise)
   for W in ([64, 16] if S in (4096, 256) else [6, 4] if S == 36 else [128]):
