@@ -1044,7 +1044,15 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
 #define CRN_FWD_CASE(M, N) if (best.MSUB == M && NSUB == N) rc = crn_launch_fwd_##M##_##N(g, xvec, grid, lds_bytes, st);
   CRN_FWD_CONFIGS(CRN_FWD_CASE)
 #undef CRN_FWD_CASE
-  if (rc == CRN_OK && g.mode == 3) rc = crn_splitk_reduce(yreal, scratch, splits, accumulate, st);
+  if (rc == CRN_OK && g.mode == 3) {
+    // the next BatchRenorm launch over y adds the partial sums up itself when the caller armed it (crn_splitk_defer) -- like the
+    // pointwise and the split-bf16 paths above: the encoder's fp32 3x3 layers and decoder stage 2 lose their reduction launch
+    if (armed && !accumulate && plain_view(yreal) && yreal.sB == (int64_t)yreal.C * yreal.D * yreal.H * yreal.W) {
+      crn_splitk_set_pending(yreal, scratch, splits, st);
+      return rc;
+    }
+    rc = crn_splitk_reduce(yreal, scratch, splits, accumulate, st);
+  }
   return rc;
 }
 
