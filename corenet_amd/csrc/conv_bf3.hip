@@ -70,6 +70,7 @@ struct Bf3Geom {
   int UP;                  // wave-specialised kernel: staging units per patch plane (PH * pw2)
   unsigned magic_UP;
   int dbg;
+  int rowskip;             // 4 x 4 window planes with tap boxes: a tap group = a window row, rows outside the box are skipped
   int half_last;           // the last chunk has <= 4 real channels: 8 taps x 4 channels per MFMA (conv_bf3_kernel, plane_half)
   long long* stamps;       // tuning aid (CRN_BF3_STAMPS=1): shader-clock stamps of workgroup 0, 4 per staging step
   // fused sums of the BatchRenorm backward whose output gradient this launch writes (crn_conv_fwd_bf3_slabs_bnbwd)
@@ -385,17 +386,20 @@ __device__ __forceinline__ void conv_bf3_body(const Bf3Geom& g) {
 
   const auto nbox = box_union(g.n_box, g.n_groups, g.y.C, n0, min(n0 + NB, g.y.C) - 1, g.kd, g.kh, g.kw);
   // zd range of a chunk that can hold non-zero weights (tap boxes of transposed convolutions)
-  auto chunk_zrange = [&](int c0, int& z0, int& z1) {
+  // (hr: the window ROWS zh of that range that can hold non-zero weights, h0 | h1 << 8 -- for 4 x 4 window planes a row is one
+  // group of four taps, and a group outside the box multiplies zeros only: `plane` skips it, g.rowskip)
+  auto chunk_zrange = [&](int c0, int& z0, int& z1, int& hr) {
     const TapBox tb = box_intersect(nbox, box_union(g.c_box, g.c_groups, g.x.C, c0, min(c0 + kCK, g.x.C) - 1,
                                                     g.kd, g.kh, g.kw));
     z0 = tb.d0; z1 = tb.d1;
     if (tb.h1 <= tb.h0 || tb.w1 <= tb.w0) z1 = z0;
+    hr = tb.h0 | (tb.h1 << 8);
   };
   // first (chunk, slab) step with work at or after `chunk`
-  auto first_step = [&](int chunk, int& zd, int& z1) -> int {
+  auto first_step = [&](int chunk, int& zd, int& z1, int& hr) -> int {
     for (; chunk < cend; ++chunk) {
       int z0;
-      chunk_zrange(chunk * kCK, z0, z1);
+      chunk_zrange(chunk * kCK, z0, z1, hr);
       if (z1 > z0) { zd = ZS == 1 ? z0 : 0; return chunk; }
     }
     return cend;
@@ -405,8 +409,8 @@ __device__ __forceinline__ void conv_bf3_body(const Bf3Geom& g) {
   int step_no = 0;
   const bool stamp = g.stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
   auto mark = [&](int i) { if (stamp && step_no < 24) g.stamps[step_no * 8 + i] = (long long)__builtin_amdgcn_s_memtime(); };
-  int zd = 0, zend = 0;
-  int chunk = first_step(cbeg, zd, zend);
+  int zd = 0, zend = 0, hrow = 0;
+  int chunk = first_step(cbeg, zd, zend, hrow);
   bool first = true;
   bool fresh = true;                                     // the patch of `chunk` is in registers, not yet in LDS
   if (chunk < cend) {
@@ -420,8 +424,8 @@ __device__ __forceinline__ void conv_bf3_body(const Bf3Geom& g) {
   while (chunk < cstop) {
     const int c0 = chunk * kCK;
     // next step
-    int nchunk = chunk, nzd = zd + ZS, nzend = zend;
-    if (nzd >= zend) nchunk = first_step(chunk + 1, nzd, nzend);
+    int nchunk = chunk, nzd = zd + ZS, nzend = zend, nhrow = hrow;
+    if (nzd >= zend) nchunk = first_step(chunk + 1, nzd, nzend, nhrow);
     mark(0);
     wait_loads2d(pv);
     if constexpr (WS) wait_loads2d(wq); else wait_loads2d(wv);
@@ -446,8 +450,10 @@ __device__ __forceinline__ void conv_bf3_body(const Bf3Geom& g) {
       // groups, so the compiler keeps the next group's LDS reads in flight under this group's MFMAs
       auto plane = [&](int z, const bf16x8* bh0, const bf16x8* bl0) {
         const int zoff = z * g.PHW;
+        const int rlo = hrow & 255, rhi = hrow >> 8;
 #pragma unroll
         for (int gq = 0; gq < NG; ++gq) {
+          if (NG == 4 && g.rowskip && (gq < rlo || gq >= rhi)) continue;   // (workgroup-uniform: a scalar branch)
           const int off = toff[gq] + zoff;
           bf16x8 bh[NSUB], bl[NSUB], ah[kMSUB], al[kMSUB];
 #pragma unroll
@@ -516,8 +522,8 @@ __device__ __forceinline__ void conv_bf3_body(const Bf3Geom& g) {
         if constexpr (kHalf) plane_half(zd, Bhi, Blo);
         else plane(zd, Bhi, Blo);
       } else {
-        int z0, z1;
-        chunk_zrange(c0, z0, z1);
+        int z0, z1, hr_;
+        chunk_zrange(c0, z0, z1, hr_);
         const int zlo = max(zd, z0), zhi = min(zd + ZS, zend);
 #pragma unroll 1
         for (int z = zlo; z < zhi; ++z) {
@@ -531,7 +537,7 @@ __device__ __forceinline__ void conv_bf3_body(const Bf3Geom& g) {
     mark(6);
     ++step_no;
     fresh = nchunk != chunk;
-    chunk = nchunk; zd = nzd; zend = nzend;
+    chunk = nchunk; zd = nzd; zend = nzend; hrow = nhrow;
   }
   };
   const int chalf = (HALF && cend * kCK >= g.x.C) ? cend - 1 : cend;
@@ -1600,6 +1606,8 @@ int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w
     fuse->nparts = (int)tiles_bn;
   }
   g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
+  static const bool rowskip_off = getenv("CRN_BF3_ROWSKIP") != nullptr && atoi(getenv("CRN_BF3_ROWSKIP")) == 0;
+  g.rowskip = (!rowskip_off && kh == 4 && kw == 4 && (g.n_groups > 0 || g.c_groups > 0)) ? 1 : 0;
   static const bool half_off = getenv("CRN_BF3_HALF") != nullptr && atoi(getenv("CRN_BF3_HALF")) == 0;
   g.half_last = (!half_off && x->C % kCK >= 1 && x->C % kCK <= 4 && ZS == 1) ? 1 : 0;
 #ifdef CRN_TOOLS

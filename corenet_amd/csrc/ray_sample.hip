@@ -219,7 +219,7 @@ __device__ __forceinline__ unsigned long long to_fixed(float v, float s) {
   const float hf = floorf(t * 5.9604644775390625e-08f);                  // 2^-24
   const float lf = __builtin_fmaf(hf, -16777216.f, t);                   // exact
   const long long hi = (long long)(int)hf;
-  return (unsigned long long)((hi << 24) + (long long)(unsigned)lf);
+  return (unsigned long long)(hi * 16777216LL + (long long)(unsigned)lf);       // (hi may be negative: no shift of a signed value)
 }
 
 template <int CN, int ZS, typename IT, bool DET>
