@@ -103,6 +103,9 @@ _SIGS = {
     "crn_affine_add_relu": [vp, vp, vp, vp, vp, vp, i32, i32, i64, i64, i64, vp, i64, vp, i64, i32, vp],
     "crn_relu_bwd_add": [vp, vp, vp, i32, i32, i64, i64, i64, i64, vp, i64, vp],
     "crn_preprocess_caffe": [vp, i32, i32, i32, vp, vp],
+    "crn_stem_conv_fwd": [vp, i32, i32, i32, vp, vp, vp, vp, sz, vp],
+    "crn_stem_conv_wgrad": [vp, i32, i32, i32, vp, vp, vp],
+    "crn_batch_renorm_finalize": [vp, i32, i32, C.c_double, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp],
     "crn_bn_relu_maxpool_fwd": [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp],
     "crn_bn_relu_maxpool_bwd": [vp, vp, i32, i32, i32, i32, vp, vp],
     "crn_relu_mean_fwd": [vp, i32, i32, i64, i64, vp, vp],
@@ -137,6 +140,7 @@ _SIZE_FNS = {
     "crn_batch_renorm_workspace_bytes": [i32],
     "crn_loss_workspace_bytes": [i32, i32],
     "crn_fill_voxels_workspace_bytes": [i32, i32, i32, i32],
+    "crn_stem_conv_parts": [i32, i32, i32],
 }
 _PTR_FNS = {
     "crn_loss_status_ptr": [vp, i32],

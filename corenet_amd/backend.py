@@ -173,6 +173,13 @@ class HipBackend:
                                   window[0], window[1], window[2], pad_lo[0], pad_lo[1], pad_lo[2],
                                   int(zero_first), _lib.stream())
       return
+    if math == "stem":             # the encoder's stem on its own kernel (csrc/stem_conv.hip); x: the 2x2 space-to-depth view of the image
+      rc = self.lib._crn_stem_conv_wgrad(x.storage.data_ptr() + 4 * x.offset, x.B, 2 * x.H, 2 * x.W,
+                                         dy.storage.data_ptr() + 4 * dy.offset, ptr(dw), _lib.stream())
+      if rc == 0:
+        return
+      if rc != -1:                 # CRN_EINVAL: a shape it does not cover, or deterministic mode -> the generic engine below
+        raise _lib.HipError(f"crn_stem_conv_wgrad failed with status {rc}")
     self.lib.crn_conv_wgrad(C.byref(_cview(x)), _ctr(tr), C.byref(_cview(dy)), ptr(dw), npad,
                             window[0], window[1], window[2], pad_lo[0], pad_lo[1], pad_lo[2],
                             int(zero_first), _ctapboxes(boxes), _lib.stream())
@@ -204,6 +211,21 @@ class HipBackend:
     self.lib.crn_batch_renorm_stats(ptr(x), B, Cn, S, sB, int(pre_relu), ptr(gamma), ptr(beta),
                                     ptr(rmean), ptr(rvar), ptr(nbt), eps, momentum, int(training),
                                     ptr(scale), ptr(shift), ptr(saved), ptr(ws), n, _lib.stream())
+
+  def stem_conv_fwd(self, img: t.Tensor, w_packed: t.Tensor, bias, y: t.Tensor, stats: bool) -> int:
+    """ZeroPad2d(3) + Conv2d(3 -> 64, 7x7, stride 2) on its own kernel (crn_stem_conv_fwd); stats: the partial sums of the
+    BatchRenorm that follows come out of the same launch -> the number of parts for bn_finalize (0 without)."""
+    B, _, H, W = img.shape
+    parts = int(self.lib.crn_stem_conv_parts(B, H, W)) if stats else 0
+    ws, n = self._bn_ws(64, img.device) if stats else (None, 0)
+    self.lib.crn_stem_conv_fwd(ptr(img), B, H, W, ptr(w_packed), ptr(bias), ptr(y), ptr(ws), n, _lib.stream())
+    return parts
+
+  def bn_finalize(self, parts: int, Cn: int, count: float, gamma, beta, rmean, rvar, nbt, eps, momentum, scale, shift, saved):
+    """Second half of bn_stats from the partial sums the producing launch left in this stream's BatchRenorm workspace."""
+    ws, _ = self._bn_ws(Cn, scale.device)
+    self.lib.crn_batch_renorm_finalize(ptr(ws), parts, Cn, float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
+                                       ptr(nbt), eps, momentum, ptr(scale), ptr(shift), ptr(saved), _lib.stream())
 
   def bn_stats_tail(self, x, B, Cn, S, sB, gamma, beta, rmean, rvar, nbt, eps, momentum, training, scale, shift, saved,
                     r, rscale, rshift, sB_r, y_pre, sB_pre, y, sB_y, relu, y2=None, W=0):

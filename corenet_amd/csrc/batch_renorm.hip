@@ -807,6 +807,20 @@ extern "C" int crn_batch_renorm_stats(const float* x, int B, int C, int64_t S, i
                        scale, shift, saved, ws, ws_bytes, stream, nullptr, nullptr);
 }
 
+// The second half of crn_batch_renorm_stats alone: the partial sums ws[(c * nparts + i) * 2 + {0, 1}] = sum(x), sum(x^2)
+// of part i came out of the launch that produced x (crn_stem_conv_fwd); count = elements per channel.
+extern "C" int crn_batch_renorm_finalize(const double* ws, int nparts, int C, double count,
+                                         const float* gamma, const float* beta, float* running_mean,
+                                         float* running_var, const int64_t* nbt, float eps, float momentum,
+                                         float* scale, float* shift, float* saved, crnStream stream) {
+  CRN_ENTRY(stream);
+  if (!ws || nparts < 1 || nparts > kMaxParts || C < 1 || !(count >= 1.0)) return CRN_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(crn_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, ws, nparts, C, count,
+                     gamma, beta, running_mean, running_var, nbt, eps, momentum, 1, scale, shift, saved);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
 int crn_affine_add_relu_impl(const float* x, const float* scale, const float* shift, const float* r, const float* rscale,
                              const float* rshift, int B, int C, int64_t S, int64_t sB_x, int64_t sB_r, float* y_pre,
                              int64_t sB_pre, float* y, int64_t sB_y, int relu, crnStream stream);

@@ -597,6 +597,10 @@ class Plan:
     H, W = check_image_hw(hw)
     self.hw = (H, W)
     self.stem_hw = (H // 2, W // 2)          # after the 7x7 / 2 stem (resnet50.py:122-124)
+    # the stem's own kernels (csrc/stem_conv.hip: H even, W a multiple of 8, <= 4096 workgroup partial sums); CRN_STEM=0: the
+    # generic engine on the space-to-depth view, as before round 5
+    parts = int(eng.be.lib.crn_stem_conv_parts(B, H, W)) if hasattr(eng.be, "stem_conv_fwd") else 0
+    self.stem_fast = os.environ.get("CRN_STEM", "1") != "0" and 0 < parts <= 4096
     self.pool_hw = (H // 4, W // 4)          # after the 3x3 / 2 max-pool (:128-131): stage 2 runs here
     self.be = eng.be
     self.generation = 0            # bumped by every forward: CoreNet's autograd node checks it in backward
@@ -853,6 +857,8 @@ class Plan:
     beside the data-gradient chain; most layers below 32^3 / 64^2 cannot fill 256 CUs alone."""
     g = cv.fwd
     math = self._math(cv, "wgrad")
+    if self.stem_fast and cv.name == "encoder.stage1.conv.":
+      math = "stem"               # (falls back to the generic engine by itself where it does not apply)
     if (self.eng.encoder_e2d and self.eng.wgrad_2d and g.window in ((1, 1, 1), (1, 3, 3)) and self._wg2d_shape_ok(dy, g.window)
         and (cv.name.startswith("encoder.stage") and not cv.name.startswith("encoder.stage1")
              or cv.name.startswith("decoder.rt_skip"))):
@@ -1006,10 +1012,20 @@ class Plan:
     be.preprocess(image_u8, self.img)
     # stem (resnet50.py:122-131)
     c1 = cv["encoder.stage1.conv."]
-    self._conv(c1, self.s2d(self.img, 3, (1, 2, 2)), None, self.vw(self.y1))
     b1 = bn["encoder.stage1_part2.bn."]
     H1, W1 = self.stem_hw
-    self._stats(b1, self.y1, H1 * W1, 64 * H1 * W1, False, training)
+    if self.stem_fast:
+      # the stem on its own kernel (csrc/stem_conv.hip); in training the partial sums of its norm come out of the same launch
+      parts = [0]
+      def stem():
+        parts[0] = be.stem_conv_fwd(self.img, c1.wf, c1.bias, self.y1, training)
+      self._timed("fwd   " + c1.name, stem)
+      if training:
+        be.bn_finalize(parts[0], 64, B * H1 * W1, b1.gamma, b1.beta, b1.rmean, b1.rvar, b1.nbt, BN_EPS, BN_MOMENTUM,
+                       b1.scale, b1.shift, b1.saved)
+    else:
+      self._conv(c1, self.s2d(self.img, 3, (1, 2, 2)), None, self.vw(self.y1))
+      self._stats(b1, self.y1, H1 * W1, 64 * H1 * W1, False, training)
     be.maxpool_fwd(self.y1, b1.scale, b1.shift, B, 64, H1, W1, self.p1, self.p1_arg)
     cur = self.p1
     for blk in self.blocks:

@@ -314,6 +314,26 @@ int crn_relu_bwd_add(const float* dy, const float* y_pre, const float* dy2,
                      int B, int C, int64_t S, int64_t sB_dy, int64_t sB_pre, int64_t sB_dy2,
                      float* dx, int64_t sB_dx, crnStream s);
 
+/* ---------------- the encoder's stem on its own kernels ----------------------
+ * ZeroPad2d(3) + Conv2d(3 -> 64, 7x7, stride 2) of resnet50.py:122-124 on the preprocessed image img [B,3,H,W]
+ * (H even, W % 8 == 0; CRN_EINVAL otherwise: the caller keeps crn_conv_fwd / crn_conv_wgrad on the 2x2 space-to-depth
+ * view), y / dy [B,64,H/2,W/2] dense.  w_packed / dw_packed: the layer's packed weights / weight gradient as
+ * crn_conv_fwd / crn_conv_wgrad see them ([12][16][64], conv_geometry.stem_fwd), bias [64] or NULL.
+ * stats_ws != NULL: the forward also leaves sum(y), sum(y^2) per channel and workgroup in
+ * stats_ws[(n * parts + i) * 2 + {0,1}], parts = crn_stem_conv_parts(B, H, W) (0: shape not covered), for
+ * crn_batch_renorm_finalize -- the BatchRenorm of resnet50.py:125 without a statistics pass over y.
+ * crn_stem_conv_wgrad ADDS to dw_packed (atomics); CRN_EINVAL in deterministic mode.                              */
+size_t crn_stem_conv_parts(int B, int H, int W);
+int crn_stem_conv_fwd(const float* img, int B, int H, int W, const float* w_packed, const float* bias,
+                      float* y, double* stats_ws /* may be NULL */, size_t ws_bytes, crnStream s);
+int crn_stem_conv_wgrad(const float* img, int B, int H, int W, const float* dy, float* dw_packed, crnStream s);
+/* scale / shift / saved / running statistics of a BatchRenorm (batch_renorm.py:41-57, training mode) from partial sums
+ * ws[(c * nparts + i) * 2 + {0,1}] = sum(x), sum(x^2) of part i; count = elements per channel.                   */
+int crn_batch_renorm_finalize(const double* ws, int nparts, int C, double count,
+                              const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              const int64_t* nbt, float eps, float momentum,
+                              float* scale, float* shift, float* saved, crnStream s);
+
 /* ---------------- encoder odds and ends -------------------------------------
  * preprocess_image_caffe (resnet50.py:189-204): u8 RGB -> f32 BGR + means.    */
 int crn_preprocess_caffe(const uint8_t* img, int B, int H, int W, float* out, crnStream s);

@@ -390,6 +390,68 @@ def test_conv_stem_and_strided(be):
   close(gw.view(w.shape), wr.grad, 3e-5, "1x1 s2 wgrad")
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 64, 64), (4, 256, 256), (1, 56, 72), (3, 36, 40)])
+def test_stem_conv_own_kernels(be, B, H, W):
+  """csrc/stem_conv.hip (ZeroPad2d(3) + Conv2d 7x7 / 2, resnet50.py:122-124): forward against the CPU fp32 convolution, the
+  BatchRenorm partial sums it leaves against the statistics pass (scale / shift / saved / running statistics), the weight
+  gradient in the packed layout against autograd -- tiles cut by the image border included (56 x 72, 36 x 40)."""
+  from corenet_amd import views as V
+  from corenet_amd.model import conv_geometry as G
+  g = t.Generator().manual_seed(11)
+  x = t.randn(B, 3, H, W, generator=g) * 50.0; w = t.randn(64, 3, 7, 7, generator=g) * 0.1; b = t.randn(64, generator=g)
+  geo = G.stem_fwd(w.shape, 3)
+  wf = EMU_pack(w, geo).to(DEV); bp = EMU_pack(b, None, G.bias_index(64, 1, geo.npad)).to(DEV)
+  xg = x.to(DEV); H1, W1 = H // 2, W // 2
+  assert int(be.lib.crn_stem_conv_parts(B, H, W)) == B * ((H1 + 3) // 4) * ((W1 + 31) // 32)
+  assert int(be.lib.crn_stem_conv_parts(B, H + 1, W)) == 0 and int(be.lib.crn_stem_conv_parts(B, H, W + 4)) == 0
+  yg = t.full((B, 64, H1, W1), float("nan"), device=DEV)
+  parts = be.stem_conv_fwd(xg, wf, bp, yg, True)
+  ref = t.nn.functional.conv2d(t.nn.functional.pad(x, [3, 3, 3, 3]), w, b, stride=2)
+  close(yg, ref, 2e-5, "stem fwd")
+  # the generic engine on the space-to-depth view computes the same thing
+  y2 = t.zeros_like(yg)
+  be.conv_fwd(V.space_to_depth_view(V.view_of(xg), (1, 2, 2)), None, wf, geo.npad, bp, 0, V.view_of(y2), geo.window, geo.pad_lo, 0)
+  close(yg, y2, 2e-5, "stem fwd vs generic engine")
+  # statistics: finalize from the launch's partial sums == the statistics pass over y
+  def bn_state():
+    gg = t.Generator().manual_seed(5)
+    return [v.to(DEV) for v in (t.rand(64, generator=gg) + 0.5, t.randn(64, generator=gg), t.randn(64, generator=gg),
+                                t.rand(64, generator=gg) + 0.5)] + [t.tensor([20000], dtype=t.int64, device=DEV)]
+  outs = []
+  for fused in (True, False):
+    gamma, beta, rm, rv, nbt = bn_state()
+    sc, sh, sv = t.zeros(64, device=DEV), t.zeros(64, device=DEV), t.zeros(4 * 64, device=DEV)
+    if fused:
+      parts = be.stem_conv_fwd(xg, wf, bp, yg, True)
+      be.bn_finalize(parts, 64, B * H1 * W1, gamma, beta, rm, rv, nbt, 1e-5, 0.01, sc, sh, sv)
+    else:
+      be.bn_stats(yg, B, 64, H1 * W1, 64 * H1 * W1, False, gamma, beta, rm, rv, nbt, 1e-5, 0.01, True, sc, sh, sv)
+    outs.append((sc, sh, sv, rm, rv))
+  for a, c, nm in zip(outs[0], outs[1], ("scale", "shift", "saved", "running_mean", "running_var")):
+    close(a, c.cpu(), 2e-6, "stem statistics " + nm)
+  # without statistics (eval): same y
+  y3 = t.zeros_like(yg)
+  assert be.stem_conv_fwd(xg, wf, bp, y3, False) == 0
+  assert t.equal(y3, yg)
+  # weight gradient, added to the packed gradient
+  dy = t.randn(ref.shape, generator=g)
+  dwg = t.zeros(wf.numel(), device=DEV)
+  be.conv_wgrad(V.space_to_depth_view(V.view_of(xg), (1, 2, 2)), None, V.view_of(dy.to(DEV)), dwg, geo.npad, geo.window,
+                geo.pad_lo, False, math="stem")
+  wr = w.clone().requires_grad_(True)
+  t.nn.functional.conv2d(t.nn.functional.pad(x, [3, 3, 3, 3]), wr, None, stride=2).backward(dy)
+  gw = t.zeros(w.numel()); EMU.scatter(dwg.cpu(), t.as_tensor(geo.index), gw)
+  close(gw.view(w.shape), wr.grad, 3e-5, "stem wgrad")
+  # every packed slot that is no real tap stays zero
+  mask = t.as_tensor(geo.index) < 0
+  assert float(dwg.cpu()[mask].abs().max()) == 0.0
+  # a second call accumulates
+  be.conv_wgrad(V.space_to_depth_view(V.view_of(xg), (1, 2, 2)), None, V.view_of(dy.to(DEV)), dwg, geo.npad, geo.window,
+                geo.pad_lo, False, math="stem")
+  gw2 = t.zeros(w.numel()); EMU.scatter(dwg.cpu(), t.as_tensor(geo.index), gw2)
+  close(gw2.view(w.shape), 2 * wr.grad, 3e-5, "stem wgrad accumulates")
+
+
 def test_conv_1to4(be):
   from corenet_amd import views as V
   from corenet_amd.model import conv_geometry as G

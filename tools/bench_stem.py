@@ -24,3 +24,17 @@ a.record()
 for _ in range(iters): run()
 b.record(); t.cuda.synchronize()
 print(f"stem fwd {os.environ.get('CRN_FWD_FORCE')} splits {os.environ.get('CRN_FWD_SPLITS')}: {a.elapsed_time(b) / iters * 1e3:.1f} us")
+# the stem's own kernels (csrc/stem_conv.hip)
+def timeit(fn, label):
+  for _ in range(3): fn()
+  t.cuda.synchronize(); a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+  a.record()
+  for _ in range(iters): fn()
+  b.record(); t.cuda.synchronize()
+  print(f"{label}: {a.elapsed_time(b) / iters * 1e3:.1f} us")
+timeit(lambda: be.stem_conv_fwd(img, wf, bias, y, False), "stem_conv_fwd (no statistics)")
+timeit(lambda: be.stem_conv_fwd(img, wf, bias, y, True), "stem_conv_fwd + BatchRenorm partial sums")
+dy = t.randn(4, 64, 128, 128).cuda(); dw = t.zeros(wf.numel()).cuda()
+timeit(lambda: be.conv_wgrad(xv, None, V.view_of(dy), dw, g.npad, g.window, g.pad_lo, False), "generic wgrad")
+timeit(lambda: be.conv_wgrad(xv, None, V.view_of(dy), dw, g.npad, g.window, g.pad_lo, False, math="stem"),
+       f"stem_conv_wgrad (CRN_STEM_WG_BLOCKS={os.environ.get('CRN_STEM_WG_BLOCKS')})")
