@@ -67,6 +67,8 @@ _SIGS = {
                                    vp, sz, i32, vp],
     "crn_conv_wgrad_bf3": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32,
                            i32, i32, i32, i32, i32, i32, i32, vp],
+    "crn_conv_wgrad_bf3_boxes": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32,
+                                 i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "crn_conv_wgrad": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32,
                        i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "crn_bf3_operands": [vp, vp, i32, i64, vp, vp],

@@ -169,9 +169,9 @@ class HipBackend:
                                      window[2], pad_lo[1], pad_lo[2], int(zero_first), _lib.stream())
       return
     if math == "bf16x3":
-      self.lib.crn_conv_wgrad_bf3(C.byref(_cview(x)), _ctr(tr), C.byref(_cview(dy)), ptr(dw), npad,
-                                  window[0], window[1], window[2], pad_lo[0], pad_lo[1], pad_lo[2],
-                                  int(zero_first), _lib.stream())
+      self.lib.crn_conv_wgrad_bf3_boxes(C.byref(_cview(x)), _ctr(tr), C.byref(_cview(dy)), ptr(dw), npad,
+                                        window[0], window[1], window[2], pad_lo[0], pad_lo[1], pad_lo[2],
+                                        int(zero_first), _ctapboxes(boxes), _lib.stream())
       return
     if math == "stem":             # the encoder's stem on its own kernel (csrc/stem_conv.hip); x: the 2x2 space-to-depth view of the image
       rc = self.lib._crn_stem_conv_wgrad(x.storage.data_ptr() + 4 * x.offset, x.B, 2 * x.H, 2 * x.W,

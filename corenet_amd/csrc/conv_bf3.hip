@@ -1056,6 +1056,10 @@ struct Bf3WgGeom {
   unsigned magic_pw2, magic_PH, magic_kw, magic_KHW;
   int dbg;
   int inherit;             // tiles inherit the kd - 1 patch planes they share with the tile below (CRN_BF3_WG_INHERIT=0: off)
+  // tap boxes of the output columns (crnTapBoxes, transposed convolutions): a workgroup whose columns share a (d, h) tap range
+  // deals only the window rows inside it to its waves (boxskip; kw == 4: two tap pairs per row)
+  int boxskip, n_groups;
+  signed char n_box[8][6];
 };
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -1100,10 +1104,28 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
   const int k1 = kk * 8 + j;                                   // K index inside the 32-position block (second read: +4)
   // A (input patch): virtual column quad q = (tap of the pair: q >> 1, channel half: q & 1)
   const int abase = (((k1 / TWT) * g.PW + (k1 % TWT) + g.lead) << 4) + ((q & 1) << 3);
+  // Tap pairs of this wave.  Plain: pairs wave * TPW .. + TPW - 1.  boxskip: the window rows (zd, zh) inside the tap box of the
+  // workgroup's columns are dealt round-robin -- pair list index wave + 8 ti = (row, half) -- so that every wave multiplies
+  // ceil(rows * 2 / 8) pairs instead of TPW (a 7^3 stride-2 transposed convolution: 9 / 12 / 12 / 16 of 16 rows hold real taps)
+  int bx_d0 = 0, bx_h0 = 0, bx_nh = 1, bx_np = 0, tpwe = TPW;
+  if (!PIPE && g.boxskip) {
+    const TapBox tb = box_union(g.n_box, g.n_groups, g.dy.C, n0, min(n0 + NB, g.dy.C) - 1, g.kd, g.kh, g.kw);
+    bx_d0 = tb.d0; bx_h0 = tb.h0; bx_nh = max(tb.h1 - tb.h0, 1);
+    bx_np = max(tb.d1 - tb.d0, 0) * max(tb.h1 - tb.h0, 0) * 2;
+    tpwe = min(TPW, (bx_np + 7) >> 3);
+  }
+  auto pair_of = [&](int ti) -> int {                          // tap pair index of this wave's slot ti (-1: none)
+    if (!(!PIPE && g.boxskip)) return wave * TPW + ti;
+    const int idx = wave + 8 * ti;
+    if (idx >= bx_np) return -1;
+    const int row = idx >> 1, zd = bx_d0 + row / bx_nh, zh = bx_h0 + row % bx_nh;
+    return ((zd * g.kh + zh) * g.kw >> 1) + (idx & 1);
+  };
   int toffL[TPW];
 #pragma unroll
   for (int ti = 0; ti < TPW; ++ti) {
-    int tp = 2 * (wave * TPW + ti) + (q >> 1);
+    const int pr = pair_of(ti);
+    int tp = 2 * max(pr, 0) + (q >> 1);
     if (tp >= g.T) tp = 0;                                     // rows of taps past the window are never stored
     const int zd = mdiv(tp, g.magic_KHW), r = tp - zd * g.KHW;
     const int zh = mdiv(r, g.magic_kw), zw = r - zh * g.kw;
@@ -1295,6 +1317,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
         }
 #pragma unroll
         for (int ti = 0; ti < TPW; ++ti) {
+          if (ti >= tpwe) continue;                            // (workgroup-uniform: boxskip)
           const char* xa = Xhi + abase + toffL[ti] + kbx;
           const bf16x8 ah = cat(trd(xa), trd(xa + 64));
           const bf16x8 al = cat(trd(xa + xlo), trd(xa + xlo + 64));
@@ -1359,8 +1382,9 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = kk * 4 + r;
-      const int tp = 2 * (wave * TPW + ti) + (m >> 3), c = c0 + (m & 7);
-      if (tp >= g.T || c >= g.x.C) continue;
+      const int pr = pair_of(ti);
+      const int tp = 2 * pr + (m >> 3), c = c0 + (m & 7);
+      if (pr < 0 || ti >= tpwe || tp >= g.T || c >= g.x.C) continue;
 #pragma unroll
       for (int ns = 0; ns < NSUB; ++ns) {
         const int n = n0 + ns * 16 + i16;
@@ -1667,9 +1691,20 @@ int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w
 
 // Weight gradient on the split-bf16 MFMA engine; same contract as crn_conv_wgrad (dw zeroed by the caller or
 // zero_first).  Returns CRN_EINVAL for shapes it does not cover.
+extern "C" int crn_conv_wgrad_bf3_boxes(const crnView* x, const crnInTransform* tr, const crnView* dy, float* dw, int Npad,
+                                        int kd, int kh, int kw, int pd, int ph, int pw, int zero_first,
+                                        const crnTapBoxes* boxes, crnStream stream);
 extern "C" int crn_conv_wgrad_bf3(const crnView* x, const crnInTransform* tr, const crnView* dy, float* dw, int Npad,
                                   int kd, int kh, int kw, int pd, int ph, int pw, int zero_first, crnStream stream) {
+  return crn_conv_wgrad_bf3_boxes(x, tr, dy, dw, Npad, kd, kh, kw, pd, ph, pw, zero_first, nullptr, stream);
+}
+// ... with the tap boxes of the output columns (transposed convolutions, conv_geometry.convt_fwd): window rows that hold only
+// structural zeros for a workgroup's columns are not multiplied (their dw entries stay what they were: zero)
+extern "C" int crn_conv_wgrad_bf3_boxes(const crnView* x, const crnInTransform* tr, const crnView* dy, float* dw, int Npad,
+                                        int kd, int kh, int kw, int pd, int ph, int pw, int zero_first,
+                                        const crnTapBoxes* boxes, crnStream stream) {
   CRN_ENTRY(stream);
+  if (boxes && (boxes->n_groups < 0 || boxes->n_groups > 8 || boxes->c_groups < 0 || boxes->c_groups > 8)) return CRN_EINVAL;
   if (!x || !dy || !dw || Npad <= 0 || (Npad & 15) || x->B != dy->B || kd < 1 || kh < 1 || kw < 1) return CRN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (!even_view(*x)) return CRN_EINVAL;
@@ -1709,6 +1744,10 @@ extern "C" int crn_conv_wgrad_bf3(const crnView* x, const crnInTransform* tr, co
   g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
   static const int inherit_env = getenv("CRN_BF3_WG_INHERIT") ? atoi(getenv("CRN_BF3_WG_INHERIT")) : 1;
   g.inherit = inherit_env;
+  static const bool boxskip_off = getenv("CRN_BF3_WG_BOXSKIP") != nullptr && atoi(getenv("CRN_BF3_WG_BOXSKIP")) == 0;
+  if (boxes && !boxskip_off && boxes->n_groups > 0 && dy->C % boxes->n_groups == 0 && kw == 4) {
+    g.boxskip = 1; g.n_groups = boxes->n_groups; memcpy(g.n_box, boxes->n_box, sizeof(g.n_box));
+  }
   dim3 grid((unsigned)cblocks, (unsigned)nblocks, (unsigned)splits);
   static const bool dbg = getenv("CRN_DEBUG") != nullptr;
   if (dbg)

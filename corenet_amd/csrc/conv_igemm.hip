@@ -369,12 +369,22 @@ int launch_pw2(const Pw2Geom& g, dim3 grid, hipStream_t st) {
 // MFMA row block and spent 67 / 76 / 47 us (forward / data gradient / weight gradient) on 1.1 M multiply-adds per
 // sample; these three loops are bandwidth bound on the 4.4 MB of weights instead.
 constexpr int kDenseB = 8;      // samples per launch
-// many output columns, few input channels: one thread per column
+// many output columns, few input channels: a workgroup owns 64 columns, its four waves split the input channels (one
+// thread per column and 256 columns per workgroup left 192 CUs idle and walked the 67 rows in three batches of loads:
+// 25 us for 4.4 MB of weights); the weight rows of a thread are in flight before the inputs are staged
 __global__ __launch_bounds__(256) void dense_cols_kernel(const float* x, int64_t xsB, int64_t xsC, crnInTransform tr,
                                                          const float* w, int Npad, int N, int C, int B,
                                                          const float* bias, int bias_sB, float* y, int64_t ysB,
                                                          int64_t ysC, int accumulate) {
   extern __shared__ float xs[];                        // [B][C] transformed inputs
+  __shared__ float red[3][kDenseB][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  const int cq = (C + 3) >> 2, cbeg = wave * cq, cend = min(C, cbeg + cq);
+  const bool col = n < N;
+  float wv[32];
+#pragma unroll
+  for (int u = 0; u < 32; ++u) wv[u] = (col && cbeg + u < cend) ? w[(int64_t)(cbeg + u) * Npad + n] : 0.f;
   for (int i = threadIdx.x; i < B * C; i += blockDim.x) {
     const int b = i / C, c = i - b * C;
     float v = x[b * xsB + c * xsC];
@@ -386,27 +396,32 @@ __global__ __launch_bounds__(256) void dense_cols_kernel(const float* x, int64_t
     xs[i] = v;
   }
   __syncthreads();
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
   float acc[kDenseB];
 #pragma unroll
   for (int b = 0; b < kDenseB; ++b) acc[b] = 0.f;
-  // the loads of 32 rows are issued together (one after the other they cost a memory latency each: 42 us for 67 rows)
-  for (int c = 0; c < C; c += 32) {
-    float wv[32];
+  for (int c = cbeg; c < cend; c += 32) {
+    if (c > cbeg) {
 #pragma unroll
-    for (int u = 0; u < 32; ++u) wv[u] = c + u < C ? w[(int64_t)(c + u) * Npad + n] : 0.f;
+      for (int u = 0; u < 32; ++u) wv[u] = (col && c + u < cend) ? w[(int64_t)(c + u) * Npad + n] : 0.f;
+    }
 #pragma unroll
     for (int u = 0; u < 32; ++u)
 #pragma unroll
       for (int b = 0; b < kDenseB; ++b)
-        if (b < B && c + u < C) acc[b] += xs[b * C + c + u] * wv[u];
+        if (b < B && c + u < cend) acc[b] += xs[b * C + c + u] * wv[u];
   }
+  if (wave) {
+#pragma unroll
+    for (int b = 0; b < kDenseB; ++b) red[wave - 1][b][lane] = acc[b];
+  }
+  __syncthreads();
+  if (wave || !col) return;
 #pragma unroll
   for (int b = 0; b < kDenseB; ++b)
     if (b < B) {
       float* d = y + b * ysB + n * ysC;
-      const float v = acc[b] + (bias ? bias[(int64_t)b * bias_sB + n] : 0.f);
+      const float v = ((acc[b] + red[0][b][lane]) + (red[1][b][lane] + red[2][b][lane])) +
+                      (bias ? bias[(int64_t)b * bias_sB + n] : 0.f);
       *d = accumulate ? *d + v : v;
     }
 }
@@ -793,7 +808,7 @@ extern "C" int crn_conv_fwd(const crnView* x, const crnInTransform* tr, const fl
       x->B <= kDenseB) {
     const crnInTransform trv = tr ? *tr : crnInTransform{nullptr, nullptr, 0, 0};
     if (y->C >= 1024 && x->C <= 2048) {              // wide output: a thread per column
-      hipLaunchKernelGGL(dense_cols_kernel, dim3((unsigned)crn_cdiv(y->C, 256)), dim3(256), (size_t)x->B * x->C * 4, st,
+      hipLaunchKernelGGL(dense_cols_kernel, dim3((unsigned)crn_cdiv(y->C, 64)), dim3(256), (size_t)x->B * x->C * 4, st,
                          x->base, x->sB, x->sC, trv, w, Npad, y->C, x->C, x->B, bias, bias_sB, y->base, y->sB, y->sC,
                          accumulate);
       CRN_CHECK_LAUNCH();

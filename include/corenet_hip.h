@@ -154,6 +154,11 @@ int crn_conv_wgrad(const crnView* x, const crnInTransform* tr, const crnView* dy
 int crn_conv_wgrad_bf3(const crnView* x, const crnInTransform* tr, const crnView* dy,
                        float* dw, int Npad, int kd, int kh, int kw, int pd, int ph, int pw,
                        int zero_first, crnStream stream);
+/* ... with the tap boxes of the output columns (transposed convolutions): window rows that are structural zeros for all
+ * columns of a workgroup are not multiplied (4^3 windows; their dw entries are not touched).                        */
+int crn_conv_wgrad_bf3_boxes(const crnView* x, const crnInTransform* tr, const crnView* dy, float* dw, int Npad,
+                             int kd, int kh, int kw, int pd, int ph, int pw, int zero_first,
+                             const crnTapBoxes* boxes /* may be NULL */, crnStream stream);
 
 /* Encoder engine (csrc/conv_e2d.hip): the ResNet-50 encoder's stride-1 Conv2d 1x1 / 3x3 layers (resnet50.py:49-115;
  * the stride of a down-sampling block is applied by crn_stride2_gather before its first 1x1) at batch sizes where

@@ -31,6 +31,8 @@ LAYERS = {  # name: (kind, wshape, pad, in dims)
     "s4t1": ("convT", (64, 32, 7, 7, 7), 3, (16, 16, 16)),
     "s3c1": ("conv", (128, 224, 5, 5, 5), 2, (8, 8, 8)),
     "s3t1": ("convT", (128, 64, 7, 7, 7), 3, (8, 8, 8)),
+    "s2c1": ("conv", (256, 259, 3, 3, 3), 1, (4, 4, 4)),
+    "s2t1": ("convT", (256, 128, 3, 3, 3), 1, (4, 4, 4)),
 }
 mode, key = sys.argv[1], sys.argv[2]
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 10
