@@ -510,11 +510,11 @@ def test_no_mfma_hazard_behind_the_inline_assembly_blocks():
   spec = importlib.util.spec_from_file_location("check_mfma_hazards", os.path.join(os.path.dirname(B.HERE), "tools", "check_mfma_hazards.py"))
   chk = importlib.util.module_from_spec(spec); spec.loader.exec_module(chk)
   total = 0
-  for obj in ("conv_bf3.o", "conv_e2d.o", "conv_igemm.o", "conv_inst_fwd_1_1.o", "conv_inst_wgrad_1_1.o"):
+  for obj in ("conv_bf3.o", "conv_e2d.o", "conv_igemm.o", "stem_conv.o", "conv_inst_fwd_1_1.o", "conv_inst_wgrad_1_1.o"):
     n, bad = chk.check(os.path.join(B.LIBDIR, obj))
     assert not bad, (obj, bad[:3])
     total += n
-  assert total > 5000          # (the split-bf16 decoder kernels alone hold ~5700 MFMAs)
+  assert total > 5000          # (the split-bf16 decoder kernels alone hold ~4100 MFMAs, the stem's two kernels ~700)
 
 
 @pytest.mark.parametrize("hw", [(96, 160), (100, 68)])
