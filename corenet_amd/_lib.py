@@ -63,6 +63,8 @@ _SIGS = {
                                C.POINTER(CrnView), i32, i32, i32, i32, i32, i32, i32, vp, vp],
     "crn_conv_fwd_bf3_slabs_bnbwd": [C.POINTER(CrnView), C.POINTER(CrnInTransform), vp, i32, vp, i32,
                                      C.POINTER(CrnView), i32, i32, i32, i32, i32, i32, i32, vp, C.POINTER(CrnBnBwdFuse), vp],
+    "crn_conv_fwd_bf3_slabs_stats": [C.POINTER(CrnView), C.POINTER(CrnInTransform), vp, i32, vp, i32,
+                                     C.POINTER(CrnView), i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, sz, C.POINTER(C.c_int), vp],
     "crn_batch_renorm_bwd_apply": [vp, i64, vp, i64, i32, i32, i64, i32, vp, vp, vp, vp, vp, i64, vp, vp, i32, vp, i32,
                                    vp, sz, i32, vp],
     "crn_conv_wgrad_bf3": [C.POINTER(CrnView), C.POINTER(CrnInTransform), C.POINTER(CrnView), vp, i32,

@@ -108,6 +108,17 @@ class HipBackend:
                           pad_lo[0], pad_lo[1], pad_lo[2], splits, int(accumulate), _ctapboxes(boxes),
                           _lib.stream())
 
+  def conv_fwd_stats(self, x: View, tr: Optional[Transform], wslab: t.Tensor, npad: int, bias, bias_sB: int, y: View, window,
+                     pad_lo, boxes, Cn: int, pre_relu: bool) -> int:
+    """conv_fwd(math="bf16x3", wslab) that also leaves the partial sums of the BatchRenorm behind it in this stream's
+    BatchRenorm workspace (crn_conv_fwd_bf3_slabs_stats) -> number of parts for bn_finalize, 0: run bn_stats."""
+    ws, n = self._bn_ws(Cn, y.storage.device)
+    parts = C.c_int(0)
+    self.lib.crn_conv_fwd_bf3_slabs_stats(C.byref(_cview(x)), _ctr(tr), ptr(wslab), npad, ptr(bias), bias_sB,
+                                          C.byref(_cview(y)), window[0], window[1], window[2], pad_lo[0], pad_lo[1], pad_lo[2],
+                                          0, _ctapboxes(boxes), int(pre_relu), ptr(ws), n, C.byref(parts), _lib.stream())
+    return parts.value
+
   def conv_dgrad_bn_bwd(self, dyv: View, wslab: t.Tensor, npad: int, gv: View, g: t.Tensor, window, pad_lo, boxes,
                         x, sB_x, B, Cn, S, pre_relu, gamma, scale, shift, saved, dx, sB_dx, dgamma, dbeta,
                         dsum=None, ndsum=0) -> bool:

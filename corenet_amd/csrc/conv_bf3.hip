@@ -583,6 +583,13 @@ __device__ __forceinline__ void conv_bf3_body(const Bf3Geom& g) {
             bn_s1[ns] += v[r];
             bn_s2[ns] += v[r] * ((xr - bn_mu[ns]) * bn_rstd[ns]);
           }
+        } else if (g.bn_ws) {                    // forward statistics of the norm BEHIND this conv: sum(y), sum(y^2) (of max(y, 0))
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float yr = g.bn_pre_relu ? fmaxf(v[r], 0.f) : v[r];
+            bn_s1[ns] += yr;
+            bn_s2[ns] += yr * yr;
+          }
         }
       } else {
 #pragma unroll
@@ -596,7 +603,7 @@ __device__ __forceinline__ void conv_bf3_body(const Bf3Geom& g) {
       }
     }
   }
-  if (g.bn_x) bn_bwd_sums_store<NSUB>(g, smem, bn_s1, bn_s2, wave, kk, i16, n0, tid);
+  if (g.bn_ws) bn_bwd_sums_store<NSUB>(g, smem, bn_s1, bn_s2, wave, kk, i16, n0, tid);
   if (g.mode == 4) {      // fused split-K reduction by the last workgroup of the tile (see conv_fwd_kernel, mode 4)
     __threadfence();
     int* s_last = reinterpret_cast<int*>(smem);           // the channel tables are dead by now
@@ -998,6 +1005,13 @@ __global__ __launch_bounds__(kWsThreads) void conv_bf3_ws_kernel(Bf3Geom g) {
             bn_s1[ns] += v[r];
             bn_s2[ns] += v[r] * ((xr - bn_mu[ns]) * bn_rstd[ns]);
           }
+        } else if (g.bn_ws) {                    // forward statistics of the norm BEHIND this conv: sum(y), sum(y^2) (of max(y, 0))
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float yr = g.bn_pre_relu ? fmaxf(v[r], 0.f) : v[r];
+            bn_s1[ns] += yr;
+            bn_s2[ns] += yr * yr;
+          }
         }
       } else {
 #pragma unroll
@@ -1011,7 +1025,7 @@ __global__ __launch_bounds__(kWsThreads) void conv_bf3_ws_kernel(Bf3Geom g) {
       }
     }
   }
-  if (g.bn_x) bn_bwd_sums_store<NSUB>(g, smem, bn_s1, bn_s2, wave, kk, i16, n0, tid);
+  if (g.bn_ws) bn_bwd_sums_store<NSUB>(g, smem, bn_s1, bn_s2, wave, kk, i16, n0, tid);
 }
 
 // MEASURED AND REMOVED: a "sliding" variant of the kernel above (K = 4 (zd, zw) tap pairs x 8 channels, the zh taps
@@ -1507,6 +1521,23 @@ extern "C" int crn_conv_fwd_bf3_slabs_bnbwd(const crnView* x, const crnInTransfo
   if (!wslab || !fuse || !fuse->x || !fuse->saved || !fuse->ws) return CRN_EINVAL;
   return conv_fwd_bf3_impl(x, tr, nullptr, wslab, Npad, bias, bias_sB, y, kd, kh, kw, pd, ph, pw, accumulate, boxes, stream, fuse);
 }
+// ... leaving the partial sums of the BatchRenorm BEHIND the convolution (reconstruction_decoder.py:56-60: conv -> ReLU -> norm):
+// sum(y'), sum(y'^2) per channel and workgroup, y' = max(y, 0) with pre_relu, in ws[(n * nparts + i) * 2 + {0, 1}] for
+// crn_batch_renorm_finalize -- the norm's statistics pass over y is not needed.  *nparts = 0 when the launch could not produce
+// them (split reduction, strided y, ws too small): the caller runs crn_batch_renorm_stats; y is written either way.
+extern "C" int crn_conv_fwd_bf3_slabs_stats(const crnView* x, const crnInTransform* tr, const void* wslab, int Npad,
+                                            const float* bias, int bias_sB, const crnView* y,
+                                            int kd, int kh, int kw, int pd, int ph, int pw,
+                                            int accumulate, const crnTapBoxes* boxes, int pre_relu, double* ws, size_t ws_bytes,
+                                            int* nparts, crnStream stream) {
+  if (!wslab || !ws || !nparts) return CRN_EINVAL;
+  crnBnBwdFuse f{};
+  f.pre_relu = pre_relu; f.ws = ws; f.ws_bytes = ws_bytes;
+  const int rc = conv_fwd_bf3_impl(x, tr, nullptr, wslab, Npad, bias, bias_sB, y, kd, kh, kw, pd, ph, pw, accumulate, boxes, stream, &f);
+  *nparts = f.nparts;
+  return rc;
+}
+
 namespace {
 int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w, const void* wslab, int Npad,
                       const float* bias, int bias_sB, const crnView* y, int kd, int kh, int kw, int pd, int ph, int pw,

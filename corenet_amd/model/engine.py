@@ -601,6 +601,7 @@ class Plan:
     # generic engine on the space-to-depth view, as before round 5
     parts = int(eng.be.lib.crn_stem_conv_parts(B, H, W)) if hasattr(eng.be, "stem_conv_fwd") else 0
     self.stem_fast = os.environ.get("CRN_STEM", "1") != "0" and 0 < parts <= 4096
+    self.dec_stats_fused = os.environ.get("CRN_DEC_STATS_FUSE", "1") != "0" and hasattr(eng.be, "conv_fwd_stats")
     self.pool_hw = (H // 4, W // 4)          # after the 3x3 / 2 max-pool (:128-131): stage 2 runs here
     self.be = eng.be
     self.generation = 0            # bumped by every forward: CoreNet's autograd node checks it in backward
@@ -1017,6 +1018,8 @@ class Plan:
     if self.stem_fast:
       # the stem on its own kernel (csrc/stem_conv.hip); in training the partial sums of its norm come out of the same launch
       parts = [0]
+      if self.trace is not None and self.conv_positions is not None:
+        self.conv_positions[c1.name] = H1 * W1
       def stem():
         parts[0] = be.stem_conv_fwd(self.img, c1.wf, c1.bias, self.y1, training)
       self._timed("fwd   " + c1.name, stem)
@@ -1074,9 +1077,25 @@ class Plan:
       self._stats(b1_, d["u"], S, d["cin"] * S, True, training)
       if training and eng.defer_reduce:
         be.splitk_defer()                      # (stages 2-4 split K: the statistics below add the partial sums up)
-      self._probe(f"conv3d_stage{k}_c1_fwd", lambda: self._conv(
-          cv[p + "c1."], self.vw(d["u"]), Transform(b1_.scale, b1_.shift, pre_relu=True), self.vw(d["w"])))
-      self._stats(b2_, d["w"], S, d["cmid"] * S, True, training)
+      cc = cv[p + "c1."]
+      parts = [0]
+      if (training and self.dec_stats_fused and cc.wop_kind == "slab" and cc.wop_f is not None and self._math(cc, "fwd") == "bf16x3"
+          and self.trace is None):
+        # the partial sums of the norm behind c1 come out of c1's launch where it does not split its reduction (stages 5-6 at the
+        # bench batch): crn_conv_fwd_bf3_slabs_stats + crn_batch_renorm_finalize instead of a statistics pass over w
+        gq = cc.fwd
+        def c1_stats():
+          parts[0] = be.conv_fwd_stats(self.vw(d["u"]), Transform(b1_.scale, b1_.shift, pre_relu=True), cc.wop_f, gq.npad, cc.bias, 0,
+                                       self.vw(d["w"]), gq.window, gq.pad_lo, (gq.n_boxes, gq.c_boxes), d["cmid"], True)
+        self._probe(f"conv3d_stage{k}_c1_fwd", lambda: self._timed("fwd   " + cc.name, c1_stats))
+      else:
+        self._probe(f"conv3d_stage{k}_c1_fwd", lambda: self._conv(
+            cc, self.vw(d["u"]), Transform(b1_.scale, b1_.shift, pre_relu=True), self.vw(d["w"])))
+      if parts[0] > 0:
+        be.bn_finalize(parts[0], d["cmid"], B * S, b2_.gamma, b2_.beta, b2_.rmean, b2_.rvar, b2_.nbt, BN_EPS, BN_MOMENTUM,
+                       b2_.scale, b2_.shift, b2_.saved)
+      else:
+        self._stats(b2_, d["w"], S, d["cmid"] * S, True, training)
       out = self.dec[k + 1]["u"] if k < 6 else self.logits
       ov = self.s2d(out, d["cout"], (2, 2, 2))
       self._conv(cv[p + "t1."], self.vw(d["w"]), Transform(b2_.scale, b2_.shift, pre_relu=True), ov)

@@ -119,6 +119,15 @@ int crn_conv_fwd_bf3_slabs_bnbwd(const crnView* x, const crnInTransform* tr, con
                                  int accumulate, const crnTapBoxes* boxes /* may be NULL */, crnBnBwdFuse* fuse,
                                  crnStream stream);
 
+/* ... or the partial sums of the BatchRenorm BEHIND the convolution (reconstruction_decoder.py:56-60): sum(y'), sum(y'^2) per
+ * channel and workgroup, y' = max(y, 0) with pre_relu, in ws[(n * *nparts + i) * 2 + {0,1}] for crn_batch_renorm_finalize.
+ * *nparts = 0 when the launch could not produce them (as above): the caller runs crn_batch_renorm_stats.          */
+int crn_conv_fwd_bf3_slabs_stats(const crnView* x, const crnInTransform* tr, const void* wslab, int Npad,
+                                 const float* bias, int bias_sB, const crnView* y,
+                                 int kd, int kh, int kw, int pd, int ph, int pw,
+                                 int accumulate, const crnTapBoxes* boxes /* may be NULL */, int pre_relu,
+                                 double* ws, size_t ws_bytes, int* nparts, crnStream stream);
+
 /* A convolution that splits its reduction writes partial sums to the library's scratch and adds them up in a
  * second launch.  crn_splitk_defer(1) arms, for the NEXT convolution call of this host thread (crn_conv2d_bf3, or
  * the 1x1 path of crn_conv_fwd), the following shortcut: if that call splits and does not accumulate, the sum is

@@ -352,6 +352,50 @@ def EMU_pack(w, geom, index=None):
   return out
 
 
+@pytest.mark.parametrize("key", ["s6c1", "s5c1", "s3c1"])
+def test_conv_fwd_leaves_the_statistics_of_the_norm_behind_it(be, key):
+  """crn_conv_fwd_bf3_slabs_stats: the same y as crn_conv_fwd_bf3_slabs, and finalize(partial sums of the launch) == the statistics
+  pass over max(y, 0) (scale / shift / saved / running statistics); a launch that splits its reduction reports 0 parts."""
+  from corenet_amd import views as V
+  from corenet_amd.backend import Transform
+  from corenet_amd.model import conv_geometry as G
+  # (s5c1 at B = 4: 256 tiles, the launch does not split -- the wave-specialised kernel; at B = 2 it would)
+  shapes = {"s6c1": ((16, 28, 5, 5, 5), (32, 32, 64), 2), "s5c1": ((32, 56, 5, 5, 5), (32, 32, 32), 4), "s3c1": ((128, 224, 5, 5, 5), (8, 8, 8), 2)}
+  wshape, dims, B = shapes[key]
+  cout, cin = wshape[0], wshape[1]
+  g = t.Generator().manual_seed(17)
+  x = t.randn((B, cin) + dims, generator=g).to(DEV); w = t.randn(wshape, generator=g) * 0.05; bias = t.randn(cout, generator=g)
+  fwd = G.conv_fwd(wshape, 2)
+  wf = EMU_pack(w, fwd).to(DEV); bp = EMU_pack(bias, None, G.bias_index(cout, 1, fwd.npad)).to(DEV)
+  ns = G.slab_entries(fwd)
+  desc, blocks = G.operand_table([(0, 0, fwd, True)])
+  slab = t.zeros(ns * 32, dtype=t.uint8, device=DEV)
+  be.bf3_operands(wf, (t.as_tensor(desc).to(DEV), blocks), slab)
+  sc, sh = (t.rand(cin, generator=g) + 0.5).to(DEV), t.randn(cin, generator=g).to(DEV)
+  tr = Transform(sc, sh, pre_relu=True)
+  S = dims[0] * dims[1] * dims[2]
+  y0 = t.zeros((B, cout) + dims, device=DEV); y1 = t.full((B, cout) + dims, float("nan"), device=DEV)
+  be.conv_fwd(V.view_of(x), tr, wf, fwd.npad, bp, 0, V.view_of(y0), fwd.window, fwd.pad_lo, 0, math="bf16x3", wslab=slab)
+  def bn_state():
+    gg = t.Generator().manual_seed(5)
+    return [v.to(DEV) for v in (t.rand(cout, generator=gg) + 0.5, t.randn(cout, generator=gg), t.randn(cout, generator=gg),
+                                t.rand(cout, generator=gg) + 0.5)] + [t.tensor([20000], dtype=t.int64, device=DEV)]
+  gamma, beta, rm, rv, nbt = bn_state()
+  s1, h1, v1 = t.zeros(cout, device=DEV), t.zeros(cout, device=DEV), t.zeros(4 * cout, device=DEV)
+  parts = be.conv_fwd_stats(V.view_of(x), tr, slab, fwd.npad, bp, 0, V.view_of(y1), fwd.window, fwd.pad_lo, None, cout, True)
+  assert t.equal(y0, y1)
+  if key == "s3c1":
+    assert parts == 0                                # 8^3 maps: the launch splits its reduction
+    return
+  assert parts > 0
+  be.bn_finalize(parts, cout, B * S, gamma, beta, rm, rv, nbt, 1e-3, 0.01, s1, h1, v1)
+  gamma2, beta2, rm2, rv2, nbt2 = bn_state()
+  s2, h2, v2 = t.zeros(cout, device=DEV), t.zeros(cout, device=DEV), t.zeros(4 * cout, device=DEV)
+  be.bn_stats(y0, B, cout, S, cout * S, True, gamma2, beta2, rm2, rv2, nbt2, 1e-3, 0.01, True, s2, h2, v2)
+  for a, c, nm in ((s1, s2, "scale"), (h1, h2, "shift"), (v1, v2, "saved"), (rm, rm2, "running_mean"), (rv, rv2, "running_var")):
+    close(a, c, 3e-6, f"{key} statistics {nm}")
+
+
 def test_conv_stem_and_strided(be):
   """7x7/2 stem on the space-to-depth view and the stride-2 1x1 convs (views)."""
   from corenet_amd import views as V
