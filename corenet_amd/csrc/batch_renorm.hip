@@ -875,7 +875,18 @@ static int bn_bwd_impl(const float* x, int64_t sB_x, const float* dy, int64_t sB
   hipStream_t st = (hipStream_t)stream;
   if (B < 1 || C < 1 || S < 1 || B > 64) return CRN_EINVAL;
   const bool v = vec_ok(S, {sB_x, sB_dy, sB_dx}, {x, dy, dx});
-  const bool reg_form = owner_form(S, C, B) && v && (int64_t)B * S <= 16384;
+  // The register-resident owner kernel keeps 16 float4 of x and of dy per thread when a channel has up to 16384 elements: 359
+  // registers, i.e. a workgroup that only fits on a CU with NO wave of a weight-gradient kernel (206-250 registers x 2 waves per
+  // SIMD) on it.  In the decoder's backward those run beside the data-gradient chain all the time: stage 4's two norms (64 / 112
+  // channels = workgroups) took 125-150 us each inside the step against ~35 us alone.  The two-pass form (50 / 46 registers, many
+  // workgroups) slots in beside them: step 7.30 -> 7.19 ms.  Applies to the pre-ReLU norms (the decoder's; the encoder's run
+  // beside small weight gradients).  CRN_BN_BWD_DEC16: 0 the register form as before, 1 the streaming owner kernel, 2 (default)
+  // two passes, 3 two passes for every norm of that size; CRN_BN_BWD_DEC_MIN: elements per channel from which it applies.
+  static const int dec16 = getenv("CRN_BN_BWD_DEC16") ? atoi(getenv("CRN_BN_BWD_DEC16")) : 2;
+  static const int dec_min = getenv("CRN_BN_BWD_DEC_MIN") ? atoi(getenv("CRN_BN_BWD_DEC_MIN")) : 8192;
+  const bool big_dec = dec16 && (pre_relu || dec16 == 3) && !head && (int64_t)B * S > dec_min;
+  const bool owner_ok = owner_form(S, C, B) && !(big_dec && dec16 >= 2);
+  const bool reg_form = owner_ok && v && (int64_t)B * S <= 16384 && !big_dec;
   if (head) {
     const int rcf = crn_splitk_flush(st);          // (dy is formed here: nothing pending can be meant for this call)
     if (rcf != CRN_OK) return rcf;
@@ -931,7 +942,7 @@ static int bn_bwd_impl(const float* x, int64_t sB_x, const float* dy, int64_t sB
     CRN_CHECK_LAUNCH();
     return CRN_OK;
   }
-  if (owner_form(S, C, B)) {
+  if (owner_ok) {
     if (v)
       hipLaunchKernelGGL(bn_owner_bwd_kernel<true>, dim3(C), dim3(kThreads), 0, st, x, sB_x, dy, sB_dy, B, S, C, pre_relu,
                          post_relu, gamma, scale, shift, saved, dx, sB_dx, dgamma, dbeta, accumulate, dsum, ndsum);

@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
 
   XLoad<1>::T pv[kNUX][kCK];
   DT dv[NSUB][kCK];
-  unsigned xco[kCK], dco[NSUB][kCK];
+  unsigned dco[NSUB][kCK];
   float tsc[kCK], tsh[kCK];
   unsigned inmask = 0;
   int b = 0, d0 = 0, h0 = 0, w0 = 0;
@@ -1222,7 +1222,10 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
       if (ld) inmask |= 1u << jx;
 #pragma unroll
       for (int cl = 0; cl < kCK; ++cl) {
-        const unsigned off = (ld && c0 + cl < g.x.C) ? (xco[cl] + sp) * 4u : 0x80000000u;
+        // (x is a plain view here -- even_view, checked on the host: the channel offset is workgroup-uniform scalar arithmetic,
+        // not eight registers filled from the LDS table)
+        const unsigned xc = (unsigned)min(c0 + cl, g.x.C - 1) * (unsigned)g.x.sC;
+        const unsigned off = (ld && c0 + cl < g.x.C) ? (xc + sp) * 4u : 0x80000000u;
         XLoad<1>::load(pv[jx][cl], xrs, off);
       }
     }
@@ -1233,7 +1236,10 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
 #pragma unroll
       for (int cl = 0; cl < kCK; ++cl) {
         const int n = oct * 8 + cl;
-        const unsigned off = (in && n0 + n < g.ncols && n0 + n < g.dy.C) ? (dco[jd][cl] + sp) * 4u : 0x80000000u;
+        unsigned dc;
+        if constexpr (DM == 1) dc = (unsigned)min(n0 + n, g.dy.C - 1) * (unsigned)g.dy.sC;   // (plain dy view: no table, 16 registers less)
+        else dc = dco[jd][cl];
+        const unsigned off = (in && n0 + n < g.ncols && n0 + n < g.dy.C) ? (dc + sp) * 4u : 0x80000000u;
         XLoad<DM>::load(dv[jd][cl], drs, off);
       }
     }
@@ -1303,11 +1309,15 @@ __global__ __launch_bounds__(kThreads) void conv_bf3_wgrad_kernel(Bf3WgGeom g) {
   // the workgroup's 8 input channels and this thread's dy columns never change: their offsets and the BatchRenorm
   // scale / shift live in registers (read from LDS per load, every staged load waited for an LDS round trip first)
 #pragma unroll
-  for (int cl = 0; cl < kCK; ++cl) { xco[cl] = choff[cl]; tsc[cl] = tscale[cl]; tsh[cl] = tshift[cl]; }
+  for (int cl = 0; cl < kCK; ++cl) {        // (uniform addresses: scalar loads into SGPRs, not 16 registers filled from the LDS tables)
+    const int c = min(c0 + cl, g.x.C - 1);
+    tsc[cl] = g.tr.scale ? g.tr.scale[c] : 1.f;
+    tsh[cl] = g.tr.scale ? g.tr.shift[c] : 0.f;
+  }
 #pragma unroll
   for (int jd = 0; jd < NSUB; ++jd)
 #pragma unroll
-    for (int cl = 0; cl < kCK; ++cl) dco[jd][cl] = dchoff[((tid >> 8) + 2 * jd) * 8 + cl];
+    for (int cl = 0; cl < kCK; ++cl) dco[jd][cl] = DM == 1 ? 0u : dchoff[((tid >> 8) + 2 * jd) * 8 + cl];
   if (tbeg < tend) { tile_origin(tbeg); stage_issue(); }
   for (int tl = tbeg; tl < tend; ++tl) {
     wait_loads2d(pv);
@@ -1413,7 +1423,8 @@ template <int NSUB, int DM, int TPW, int TWT>
 int launch_bf3_wgrad(const Bf3WgGeom& g, dim3 grid, size_t lds, hipStream_t st) {
   // software-pipelined LDS reads: measured per variant (profiles/r03_wgrad_pipe_ab.txt); CRN_BF3_WG_PIPE = 0 / 1 forces
   static const int force = getenv("CRN_BF3_WG_PIPE") ? atoi(getenv("CRN_BF3_WG_PIPE")) : -1;
-  const bool pipe = force >= 0 ? force != 0 : (NSUB == 1 || (TPW == 8 && TWT == 16));
+  static const int force2 = getenv("CRN_BF3_WG_PIPE2") ? atoi(getenv("CRN_BF3_WG_PIPE2")) : -1;   // ... of the 32-column instances only
+  const bool pipe = (NSUB == 2 && force2 >= 0) ? force2 != 0 : force >= 0 ? force != 0 : (NSUB == 1 || (TPW == 8 && TWT == 16));
   auto k = pipe ? conv_bf3_wgrad_kernel<NSUB, DM, TPW, TWT, true> : conv_bf3_wgrad_kernel<NSUB, DM, TPW, TWT, false>;
   if (lds > 65536) CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, grid, dim3(kThreads), lds, st, g);
