@@ -486,9 +486,11 @@ def test_stem_conv_own_kernels(be, B, H, W):
   t.nn.functional.conv2d(t.nn.functional.pad(x, [3, 3, 3, 3]), wr, None, stride=2).backward(dy)
   gw = t.zeros(w.numel()); EMU.scatter(dwg.cpu(), t.as_tensor(geo.index), gw)
   close(gw.view(w.shape), wr.grad, 3e-5, "stem wgrad")
-  # every packed slot that is no real tap stays zero
-  mask = t.as_tensor(geo.index) < 0
-  assert float(dwg.cpu()[mask].abs().max()) == 0.0
+  # every packed slot that is no real tap stays zero (the own kernel; in deterministic mode the call falls back to the generic
+  # engine, which also fills the window slots of the space-to-depth form that hold no tap -- the un-pack ignores them)
+  if os.environ.get("CRN_DETERMINISTIC", "0") != "1":
+    mask = t.as_tensor(geo.index) < 0
+    assert float(dwg.cpu()[mask].abs().max()) == 0.0
   # a second call accumulates
   be.conv_wgrad(V.space_to_depth_view(V.view_of(xg), (1, 2, 2)), None, V.view_of(dy.to(DEV)), dwg, geo.npad, geo.window,
                 geo.pad_lo, False, math="stem")
