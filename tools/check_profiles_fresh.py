@@ -7,7 +7,9 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prefix = sys.argv[1] if len(sys.argv) > 1 else "r05"
 EXEMPT = ("lds_atomic_probe", "grid_barrier_probe",           # properties of the part, not of csrc/
-          "defer_wgrad_experiment", "wgrad_handover")         # host-side schedule experiments (corenet_amd/model/engine.py), dated in the file
+          "defer_wgrad_experiment", "wgrad_handover",         # host-side schedule experiments (corenet_amd/model/engine.py), dated in the file
+          "ray_sweep")                                        # the development sweep of the scatter (variants that no longer exist, dated in the file);
+                                                              # the final kernel's numbers are r05_ray_kernels.txt / r05_small_kernels.txt
 def ct(*paths):
   out = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%ct", "--"] + list(paths), capture_output=True, text=True).stdout.strip()
   return int(out) if out else 0
