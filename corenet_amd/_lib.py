@@ -132,6 +132,7 @@ _SIGS = {
     "crn_adam_set_hyper": [vp, f32, f32, f32, f32, f32, i32, vp],
     "crn_adam_step_hyper": [vp, vp, vp, vp, i64, vp, vp],
     "crn_fill_voxels": [vp, vp, i32, i32, i32, i32, i32, vp, sz, vp],
+    "crn_fill_voxels_strided": [vp, C.POINTER(i64), vp, C.POINTER(i64), i32, i32, i32, i32, i32, vp, sz, vp],
     "crn_fill_voxels_cpu": [vp, vp, i32, i32, i32, i32, i32, i32],
     "crn_voxelize_mesh": [vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp],
     "crn_batch_renorm_eval_affine": [vp, vp, vp, i32, f32, vp, vp, vp],

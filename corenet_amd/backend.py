@@ -391,8 +391,15 @@ class HipBackend:
     N, D, H, W = grid.shape
     n = self.lib.crn_fill_voxels_workspace_bytes(N, D, H, W)
     ws = self.workspace("fill", n, grid.device)
-    self.lib.crn_fill_voxels(ptr(grid), ptr(out), _DTYPE_CODE[grid.dtype], N, D, H, W, ptr(ws), n,
-                             _lib.stream())
+    if grid.is_contiguous() and out.is_contiguous():
+      self.lib.crn_fill_voxels(ptr(grid), ptr(out), _DTYPE_CODE[grid.dtype], N, D, H, W, ptr(ws), n,
+                               _lib.stream())
+    else:      # strided views on either side (the reference's packed accessors, fill_voxels_gpu.cu:146-163)
+      import ctypes as C
+      gs = (C.c_int64 * 4)(*grid.stride())
+      os_ = (C.c_int64 * 4)(*out.stride())
+      self.lib.crn_fill_voxels_strided(ptr(grid), gs, ptr(out), os_, _DTYPE_CODE[grid.dtype], N, D, H, W,
+                                       ptr(ws), n, _lib.stream())
 
   def voxelize_mesh(self, tri, tri_mesh, view2voxel, M, D, H, W, sub_side, mult, conservative,
                     depth_mult, grid):

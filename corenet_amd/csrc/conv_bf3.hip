@@ -1663,10 +1663,17 @@ int conv_fwd_bf3_impl(const crnView* x, const crnInTransform* tr, const float* w
   g.vec_store = (g.mw >= 4 && yo.sW == 1 && (yo.W & 3) == 0 && (yo.sH & 3) == 0 && (yo.sD & 3) == 0 && (yo.sB & 3) == 0 &&
                  (yo.sC & 3) == 0 && (((uintptr_t)yo.base) & 15) == 0 && yo.chan_off == nullptr) ? 1 : 0;
   const int64_t tiles_bn = tiles;
+  // two users of this epilogue, each behind its own switch: the BatchRenorm BACKWARD sums of a data gradient
+  // (fuse->x = the norm's input; CRN_BN_BWD_FUSE=0) and the forward STATISTICS of the next norm (fuse->x == nullptr:
+  // crn_conv_fwd_bf3_slabs_stats; CRN_DEC_STATS_FUSE=0), which knows nothing of x / sB_x / ndsum
   static const bool bn_fuse_off = getenv("CRN_BN_BWD_FUSE") != nullptr && atoi(getenv("CRN_BN_BWD_FUSE")) == 0;
-  if (fuse && !bn_fuse_off && splits == 1 && g.vec_store && y->sW == 1 && tiles_bn <= 0x7fffffff &&
-      fuse->ws_bytes >= (size_t)y->C * (size_t)tiles_bn * 2 * sizeof(double) && fuse->ndsum <= kThreads &&
-      (fuse->sB_x & 3) == 0 && (((uintptr_t)fuse->x) & 15) == 0 && (((int64_t)y->D * y->H * y->W) & 3) == 0) {
+  static const bool stats_fuse_off = getenv("CRN_DEC_STATS_FUSE") != nullptr && atoi(getenv("CRN_DEC_STATS_FUSE")) == 0;
+  const bool stats_mode = fuse && fuse->x == nullptr;
+  const bool mode_ok = fuse && (stats_mode ? !stats_fuse_off
+                                           : (!bn_fuse_off && fuse->ndsum <= kThreads && (fuse->sB_x & 3) == 0 &&
+                                              (((uintptr_t)fuse->x) & 15) == 0));
+  if (mode_ok && splits == 1 && g.vec_store && y->sW == 1 && tiles_bn <= 0x7fffffff &&
+      fuse->ws_bytes >= (size_t)y->C * (size_t)tiles_bn * 2 * sizeof(double) && (((int64_t)y->D * y->H * y->W) & 3) == 0) {
     g.bn_x = fuse->x; g.bn_sB = fuse->sB_x; g.bn_S = (int64_t)y->D * y->H * y->W; g.bn_saved = fuse->saved;
     g.bn_pre_relu = fuse->pre_relu; g.bn_ws = fuse->ws; g.bn_dsum = fuse->dsum; g.bn_ndsum = fuse->dsum ? fuse->ndsum : 0;
     fuse->nparts = (int)tiles_bn;
@@ -1785,7 +1792,9 @@ extern "C" int crn_conv_wgrad_bf3_boxes(const crnView* x, const crnInTransform* 
   splits = crn_cdiv(g.ntiles, g.tiles_per_split);
   g.dbg = getenv("CRN_DBG_MODE") ? atoi(getenv("CRN_DBG_MODE")) : 0;
   static const int inherit_env = getenv("CRN_BF3_WG_INHERIT") ? atoi(getenv("CRN_BF3_WG_INHERIT")) : 1;
-  g.inherit = inherit_env;
+  // the in-LDS plane copy [TDT, PD) -> [0, PD - TDT) runs on all threads at once: only disjoint ranges (kd - 1 <= TDT) may
+  // inherit (every model layer; a (7,3,3) window over 4-plane tiles would race -- ADVICE r5), others stage full patches
+  g.inherit = (inherit_env && kd - 1 <= TDT) ? 1 : 0;
   static const bool boxskip_off = getenv("CRN_BF3_WG_BOXSKIP") != nullptr && atoi(getenv("CRN_BF3_WG_BOXSKIP")) == 0;
   if (boxes && !boxskip_off && boxes->n_groups > 0 && dy->C % boxes->n_groups == 0 && kw == 4) {
     g.boxskip = 1; g.n_groups = boxes->n_groups; memcpy(g.n_box, boxes->n_box, sizeof(g.n_box));

@@ -588,6 +588,12 @@ float* splitk_scratch(size_t floats, hipStream_t st) {
   if (!sl) return nullptr;
   if (floats > sl->cap) {
     if (floats > ((size_t)256 << 20) / 4) return nullptr;       // larger outputs keep the atomic path
+    // a stream that is being captured cannot allocate (hipMalloc would fail the capture): the launch keeps the atomic path
+    // (crn_splitk_reserve sizes the scratch BEFORE a capture, so this only catches a launch that needs more
+    // than any eager run before it did)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap != hipStreamCaptureStatusNone) return nullptr;
     if (sl->buf) {
       if (sl->pinned) {
         if (!sl->retired) sl->retired = new std::vector<float*>();

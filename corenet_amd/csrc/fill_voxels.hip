@@ -23,6 +23,18 @@ namespace {
 
 typedef unsigned long long u64;
 
+// Element strides of a [N][D][H][W] tensor (crn_fill_voxels_strided: the reference op takes packed accessors with
+// strides, fill_voxels_gpu.cu:146-163).  SV = false instantiations never read it (contiguous grids, 16-byte paths).
+struct FillView { long long sN, sD, sH, sW; };
+template <bool SV> __device__ __forceinline__ long long fv_grid(const FillView& v, long long n, long long DHW) {
+  return SV ? n * v.sN : n * DHW;
+}
+// element offset of (row = z*H + y, x) inside a grid
+template <bool SV> __device__ __forceinline__ long long fv_at(const FillView& v, long long row, int x, int H, int W) {
+  if (SV) { const long long z = row / H, y = row - z * H; return z * v.sD + y * v.sH + (long long)x * v.sW; }
+  return row * W + x;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void fill_pack_kernel(const T* grid, u64* E, u64* R, int D, int H, int W,
                                                         int WX, int64_t nwords) {
@@ -70,12 +82,13 @@ __device__ __forceinline__ u64 fill_up(u64 e, u64 r) { return (((e + r) ^ e) & e
 // until a whole sweep changes nothing, then unpack.  Every update only sets bits (monotone closure), words are written
 // with single 8-byte stores, and the workgroup barrier between sweeps orders them: any interleaving inside a sweep
 // reads valid lower bounds and the fixed point is the reference's connected components.  No host round trip.
-template <typename T>
-__global__ __launch_bounds__(1024) void fill_global_kernel(const T* grid, T* out, u64* E, u64* R, int D, int H, int W, int WX) {
+template <typename T, bool SV>
+__global__ __launch_bounds__(1024) void fill_global_kernel(const T* grid, T* out, u64* E, u64* R, int D, int H, int W, int WX,
+                                                          FillView vi, FillView vo) {
   const int n = blockIdx.x;
   const int64_t rows = (int64_t)D * H, nw = rows * WX;
-  const T* g = grid + (int64_t)n * rows * W;
-  T* o = out + (int64_t)n * rows * W;
+  const T* g = grid + fv_grid<SV>(vi, n, rows * W);
+  T* o = out + fv_grid<SV>(vo, n, rows * W);
   u64* e = E + (int64_t)n * nw;
   u64* r = R + (int64_t)n * nw;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -84,7 +97,7 @@ __global__ __launch_bounds__(1024) void fill_global_kernel(const T* grid, T* out
     const int64_t row = wi / WX;
     const int y = (int)(row % H), z = (int)(row / H);
     const int x = k * 64 + lane;
-    const bool empty = x < W && !(g[row * W + x] > (T)0);
+    const bool empty = x < W && !(g[fv_at<SV>(vi, row, x, H, W)] > (T)0);
     const u64 eb = __ballot(empty);
     if (lane == 0) { e[wi] = eb; r[wi] = (y == 0 || z == 0) ? eb : (k == 0 ? (eb & 1ull) : 0ull); }
   }
@@ -123,7 +136,7 @@ __global__ __launch_bounds__(1024) void fill_global_kernel(const T* grid, T* out
     const int64_t row = wi / WX;
     const int x = k * 64 + lane;
     const u64 outside = e[wi] & r[wi];
-    if (x < W) o[row * W + x] = ((outside >> lane) & 1ull) ? (T)0 : (T)1;
+    if (x < W) o[fv_at<SV>(vo, row, x, H, W)] = ((outside >> lane) & 1ull) ? (T)0 : (T)1;
   }
 }
 
@@ -239,8 +252,9 @@ struct FusedCtl { unsigned word[kFusedIters]; unsigned depart[kFusedIters]; unsi
 // as a kernel of its own for tests (CRN_FILL_RESCUE=1).
 // One grid, one workgroup (any size): pack -> sweep the slabs of the grid through LDS until a whole pass changes
 // nothing -> unpack.  sm: (2 * zs + 2) planes of LDS.
-template <typename T, int WX>
-__device__ void rescue_grid(const T* gsrc, T* gdst, u64* Eg, u64* Rg, int D, int H, int W, int zs, int nslabs, u64* sm) {
+template <typename T, int WX, bool SV>
+__device__ void rescue_grid(const T* gsrc, T* gdst, u64* Eg, u64* Rg, int D, int H, int W, int zs, int nslabs, u64* sm,
+                            const FillView& vi, const FillView& vo) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int rowsz = H * WX;
   const int64_t gwords = (int64_t)D * rowsz;
@@ -250,7 +264,7 @@ __device__ void rescue_grid(const T* gsrc, T* gdst, u64* Eg, u64* Rg, int D, int
     const int y = (int)(row % H), z = (int)(row / H);
     const int x = k * 64 + lane;
     bool empty = false;
-    if (x < W) empty = !(gsrc[row * W + x] > (T)0);
+    if (x < W) empty = !(gsrc[fv_at<SV>(vi, row, x, H, W)] > (T)0);
     const u64 e = __ballot(empty);
     if (lane == 0) {
       Eg[wi] = e;
@@ -288,19 +302,19 @@ __device__ void rescue_grid(const T* gsrc, T* gdst, u64* Eg, u64* Rg, int D, int
     const int64_t row = wi / WX;
     const int x = k * 64 + lane;
     const u64 outside = Eg[wi] & Rg[wi];
-    if (x < W) gdst[row * W + x] = ((outside >> lane) & 1ull) ? (T)0 : (T)1;
+    if (x < W) gdst[fv_at<SV>(vo, row, x, H, W)] = ((outside >> lane) & 1ull) ? (T)0 : (T)1;
   }
   __syncthreads();
 }
 
-template <typename T, int WX>
+template <typename T, int WX, bool SV>
 __global__ __launch_bounds__(512) void fill_rescue_kernel(const T* grid, T* out, u64* E, u64* R, int D, int H, int W,
-                                                          int zs, int nslabs) {
+                                                          int zs, int nslabs, FillView vi, FillView vo) {
   extern __shared__ __attribute__((aligned(16))) u64 sm[];
   const int n = blockIdx.x;
   const int64_t gwords = (int64_t)D * H * WX;
-  rescue_grid<T, WX>(grid + (int64_t)n * D * H * W, out + (int64_t)n * D * H * W, E + n * gwords, R + n * gwords, D, H, W, zs,
-                     nslabs, sm);
+  rescue_grid<T, WX, SV>(grid + fv_grid<SV>(vi, n, (int64_t)D * H * W), out + fv_grid<SV>(vo, n, (int64_t)D * H * W),
+                         E + n * gwords, R + n * gwords, D, H, W, zs, nslabs, sm, vi, vo);
 }
 
 // ---- wave-level plane closure (single-launch path) --------------------------------------------
@@ -455,10 +469,10 @@ __device__ int relax_slab_waves(const u64* El, u64* Rl, int nz, int H) {
 // `raised` flag, and the last workgroup to leave the launch redoes its grids alone (rescue_grid).
 
 
-template <typename T, int WX>
+template <typename T, int WX, bool SV>
 __global__ __launch_bounds__(1024) void fill_fused_kernel(const T* grid, T* out, int D, int H, int W, int zs,
                                                          int nslabs, u64* halo, FusedCtl* ctl, u64* E, u64* R,
-                                                         int max_rounds, int fused_relaxed) {
+                                                         int max_rounds, int fused_relaxed, FillView vi, FillView vo) {
   extern __shared__ __attribute__((aligned(16))) u64 sm[];
   const int slab = blockIdx.x % nslabs, n = blockIdx.x / nslabs;
   const int z0 = slab * zs, nz = min(zs, D - z0);
@@ -466,13 +480,13 @@ __global__ __launch_bounds__(1024) void fill_fused_kernel(const T* grid, T* out,
   u64* El = sm;                          // [nz][H][WX]
   u64* Rl = sm + (size_t)zs * rowsz;     // [nz+2][H][WX], plane 0 / nz+1 = halos
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-  const T* gsrc = grid + ((int64_t)n * D + z0) * H * W;
+  const T* gsrc = SV ? grid + n * vi.sN + z0 * vi.sD : grid + ((int64_t)n * D + z0) * H * W;
   const int nrows = nz * H;
   // load + pack, 16-byte path (4-byte voxels, W a multiple of 64, aligned slab): the slab is one flat array; a lane
   // loads 4 consecutive voxels, 8 lanes = 32 voxels = one 32-bit piece of a row bitmap, assembled with three DPP
   // OR steps -- a quarter of the load instructions of the one-voxel-per-lane path below, whose load phase was
   // bound by the rate of (coalesced) dword load instructions, not by HBM (33 us for 100 MB)
-  const bool vec4 = sizeof(T) == 4 && (W & 63) == 0 && ((reinterpret_cast<uintptr_t>(gsrc) & 15) == 0);
+  const bool vec4 = !SV && sizeof(T) == 4 && (W & 63) == 0 && ((reinterpret_cast<uintptr_t>(gsrc) & 15) == 0);
   if (vec4) {
     constexpr int NV = 8;
     typedef T __attribute__((ext_vector_type(4))) T4;
@@ -513,7 +527,7 @@ __global__ __launch_bounds__(1024) void fill_fused_kernel(const T* grid, T* out,
     for (int j = 0; j < RW; ++j)
 #pragma unroll
       for (int k = 0; k < WX; ++k)
-        vals[j][k] = gsrc[(int64_t)min(r0 + j, nrows - 1) * W + min(k * 64 + lane, W - 1)];
+        vals[j][k] = gsrc[fv_at<SV>(vi, min(r0 + j, nrows - 1), min(k * 64 + lane, W - 1), H, W)];
     bool emp[RW][WX];
 #pragma unroll
     for (int j = 0; j < RW; ++j)
@@ -537,7 +551,7 @@ __global__ __launch_bounds__(1024) void fill_fused_kernel(const T* grid, T* out,
 
   FusedCtl* c = ctl + n;
   u64* hb = halo + (int64_t)n * nslabs * 2 * 2 * rowsz;       // [parity][slab][lo/hi][rowsz]
-  T* gdst = out + ((int64_t)n * D + z0) * H * W;
+  T* gdst = SV ? out + n * vo.sN + z0 * vo.sD : out + ((int64_t)n * D + z0) * H * W;
   // unpack + store from the LDS bitmaps (an in-place call overwrites its input only here)
   auto store_slab = [&]() {
     // 16-byte path (same condition as the load): the slab is one flat array of 64-voxel words, word w = El[w]; 16 lanes
@@ -572,7 +586,7 @@ __global__ __launch_bounds__(1024) void fill_fused_kernel(const T* grid, T* out,
       for (int k = 0; k < WX; ++k) {
         const int x = k * 64 + lane;
         const u64 outside = El[r0 * WX + k] & Rl[rowsz + r0 * WX + k];
-        if (x < W) gdst[(int64_t)r0 * W + x] = ((outside >> lane) & 1ull) ? (T)0 : (T)1;
+        if (x < W) gdst[fv_at<SV>(vo, r0, x, H, W)] = ((outside >> lane) & 1ull) ? (T)0 : (T)1;
       }
     }
   };
@@ -683,8 +697,8 @@ __global__ __launch_bounds__(1024) void fill_fused_kernel(const T* grid, T* out,
   const int64_t gwords = (int64_t)D * rowsz;
   const int nsl = (D + zs - 1) / zs;
   for (int g = 0; g < G; ++g)
-    rescue_grid<T, WX>(grid + (int64_t)g * D * H * W, out + (int64_t)g * D * H * W, E + g * gwords, R + g * gwords, D, H, W, zs,
-                       nsl, sm);
+    rescue_grid<T, WX, SV>(grid + fv_grid<SV>(vi, g, (int64_t)D * H * W), out + fv_grid<SV>(vo, g, (int64_t)D * H * W),
+                           E + g * gwords, R + g * gwords, D, H, W, zs, nsl, sm, vi, vo);
   unsigned* cw = reinterpret_cast<unsigned*>(ctl);
   for (int i = threadIdx.x; i < (int)(G * sizeof(FusedCtl) / 4); i += blockDim.x)
     __hip_atomic_store(cw + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -732,35 +746,36 @@ constexpr size_t kSweepLds = 144 * 1024;
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 inline size_t fused_offset(int64_t nwords) { return 2 * align256((size_t)nwords * 8) + 4096 * sizeof(int) + 256; }
 
-template <typename T, int WX>
+template <typename T, int WX, bool SV>
 int launch_fused(const T* grid, T* out, int G, int D, int H, int W, int zs, int nslabs, size_t lds, u64* halo,
-                 FusedCtl* ctl, u64* E, u64* R, int max_rounds, int relaxed, hipStream_t st) {
-  auto k = fill_fused_kernel<T, WX>;
+                 FusedCtl* ctl, u64* E, u64* R, int max_rounds, int relaxed, hipStream_t st, FillView vi, FillView vo) {
+  auto k = fill_fused_kernel<T, WX, SV>;
   if (lds > 65536) CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k, dim3(G * nslabs), dim3(1024), lds, st, grid, out, D, H, W, zs, nslabs, halo, ctl, E, R, max_rounds, relaxed);
+  hipLaunchKernelGGL(k, dim3(G * nslabs), dim3(1024), lds, st, grid, out, D, H, W, zs, nslabs, halo, ctl, E, R, max_rounds, relaxed,
+                     vi, vo);
   CRN_CHECK_LAUNCH();
   return CRN_OK;
 }
 
-template <typename T, int WX>
-int launch_rescue(const T* grid, T* out, u64* E, u64* R, int N, int D, int H, int W, hipStream_t st) {
+template <typename T, int WX, bool SV>
+int launch_rescue(const T* grid, T* out, u64* E, u64* R, int N, int D, int H, int W, hipStream_t st, FillView vi, FillView vo) {
   const size_t plane = (size_t)H * WX * 8;
   int zs = (int)std::min<size_t>((size_t)D, (kSweepLds / plane - 2) / 2);
   if (zs < 1) return CRN_EINVAL;
   const int nslabs = (D + zs - 1) / zs;
   zs = (D + nslabs - 1) / nslabs;
   const size_t lds = (size_t)(2 * zs + 2) * plane;
-  auto k = fill_rescue_kernel<T, WX>;
+  auto k = fill_rescue_kernel<T, WX, SV>;
   if (lds > 65536) CRN_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k, dim3(N), dim3(512), lds, st, grid, out, E, R, D, H, W, zs, nslabs);
+  hipLaunchKernelGGL(k, dim3(N), dim3(512), lds, st, grid, out, E, R, D, H, W, zs, nslabs, vi, vo);
   CRN_CHECK_LAUNCH();
   return CRN_OK;
 }
 
 // ONE launch per call (per G grids): the single-launch kernel carries its own rescue path (its last workgroup out);
 // nothing here waits for the GPU.  CRN_FILL_RESCUE=1 (tests): run the rescue body alone, one workgroup per grid.
-template <typename T>
-int run_fill_fused(const T* grid, T* out, int N, int D, int H, int W, int WX, void* ws, hipStream_t st) {
+template <typename T, bool SV>
+int run_fill_fused(const T* grid, T* out, int N, int D, int H, int W, int WX, void* ws, hipStream_t st, FillView vi, FillView vo) {
   static const bool off = getenv("CRN_FILL_MULTI") != nullptr;
   static const bool rescue_only = getenv("CRN_FILL_RESCUE") != nullptr;
   if (off) return CRN_EAGAIN;
@@ -793,38 +808,39 @@ int run_fill_fused(const T* grid, T* out, int N, int D, int H, int W, int WX, vo
   // rounds: bounded only to bound a launch's run time (tests: CRN_FILL_MAXROUNDS forces the failure path)
   static const int max_rounds = getenv("CRN_FILL_MAXROUNDS") ? std::max(2, atoi(getenv("CRN_FILL_MAXROUNDS"))) : (1 << 16);
   const int relaxed = fill_relaxed_default();
-  const int64_t gstride = (int64_t)D * H * W;
+  const int64_t gstride = SV ? vi.sN : (int64_t)D * H * W, ostride = SV ? vo.sN : (int64_t)D * H * W;
   const int64_t hstride = (int64_t)nslabs * 2 * 2 * H * WX;
   for (int g0 = 0; g0 < N && !rescue_only; g0 += G) {
     const int Gn = std::min(G, N - g0);
     int rc = CRN_EINVAL;
-#define CRN_FUSED(K) case K: rc = launch_fused<T, K>(grid + g0 * gstride, out + g0 * gstride, Gn, D, H, W, zs, nslabs, lds, \
-                                                     halo + g0 * hstride, ctl + g0, E + g0 * (int64_t)D * H * WX, R + g0 * (int64_t)D * H * WX, max_rounds, relaxed, st); break;
+#define CRN_FUSED(K) case K: rc = launch_fused<T, K, SV>(grid + g0 * gstride, out + g0 * ostride, Gn, D, H, W, zs, nslabs, lds, \
+                                                     halo + g0 * hstride, ctl + g0, E + g0 * (int64_t)D * H * WX, R + g0 * (int64_t)D * H * WX, max_rounds, relaxed, st, vi, vo); break;
     switch (WX) { CRN_FUSED(1) CRN_FUSED(2) CRN_FUSED(3) CRN_FUSED(4) CRN_FUSED(5) CRN_FUSED(6) CRN_FUSED(7) CRN_FUSED(8) }
 #undef CRN_FUSED
     if (rc != CRN_OK) return rc;
   }
   if (!rescue_only) return CRN_OK;
   int rc = CRN_EINVAL;
-#define CRN_RESCUE(K) case K: rc = launch_rescue<T, K>(grid, out, E, R, N, D, H, W, st); break;
+#define CRN_RESCUE(K) case K: rc = launch_rescue<T, K, SV>(grid, out, E, R, N, D, H, W, st, vi, vo); break;
   switch (WX) { CRN_RESCUE(1) CRN_RESCUE(2) CRN_RESCUE(3) CRN_RESCUE(4) CRN_RESCUE(5) CRN_RESCUE(6) CRN_RESCUE(7) CRN_RESCUE(8) }
 #undef CRN_RESCUE
   return rc;
 }
 
-template <typename T>
-int run_fill(const T* grid, T* out, int N, int D, int H, int W, void* ws, hipStream_t st) {
+template <typename T, bool SV>
+int run_fill(const T* grid, T* out, int N, int D, int H, int W, void* ws, hipStream_t st, FillView vi = FillView{},
+             FillView vo = FillView{}) {
   const int WX = (W + 63) / 64;
   const int64_t nwords = (int64_t)N * D * H * WX;
   if (WX <= 8) {
-    const int rc = run_fill_fused<T>(grid, out, N, D, H, W, WX, ws, st);
+    const int rc = run_fill_fused<T, SV>(grid, out, N, D, H, W, WX, ws, st, vi, vo);
     if (rc != CRN_EAGAIN) return rc;
   }
   // any other size (rows wider than 512 voxels, planes beyond the LDS budget, CRN_FILL_MULTI=1): one persistent
   // workgroup per grid on bitmaps in the workspace -- still a single asynchronous launch, no host wait
   u64* E = reinterpret_cast<u64*>(ws);
   u64* R = reinterpret_cast<u64*>(reinterpret_cast<char*>(ws) + align256((size_t)nwords * 8));
-  hipLaunchKernelGGL(fill_global_kernel<T>, dim3(N), dim3(1024), 0, st, grid, out, E, R, D, H, W, WX);
+  hipLaunchKernelGGL((fill_global_kernel<T, SV>), dim3(N), dim3(1024), 0, st, grid, out, E, R, D, H, W, WX, vi, vo);
   CRN_CHECK_LAUNCH();
   return CRN_OK;
 }
@@ -847,13 +863,38 @@ extern "C" int crn_fill_voxels(const void* grid, void* out, int dtype, int N, in
   if (!grid || !out || N < 1 || D < 1 || H < 1 || W < 1) return CRN_EINVAL;
   if (workspace_bytes < crn_fill_voxels_workspace_bytes(N, D, H, W)) return CRN_ENOMEM;
   switch (dtype) {
-    case 0: return run_fill<float>((const float*)grid, (float*)out, N, D, H, W, workspace, st);
-    case 1: return run_fill<uint8_t>((const uint8_t*)grid, (uint8_t*)out, N, D, H, W, workspace, st);
-    case 2: return run_fill<int32_t>((const int32_t*)grid, (int32_t*)out, N, D, H, W, workspace, st);
-    case 3: return run_fill<double>((const double*)grid, (double*)out, N, D, H, W, workspace, st);
-    case 4: return run_fill<int64_t>((const int64_t*)grid, (int64_t*)out, N, D, H, W, workspace, st);
-    case 5: return run_fill<int16_t>((const int16_t*)grid, (int16_t*)out, N, D, H, W, workspace, st);
-    case 6: return run_fill<int8_t>((const int8_t*)grid, (int8_t*)out, N, D, H, W, workspace, st);
+    case 0: return run_fill<float, false>((const float*)grid, (float*)out, N, D, H, W, workspace, st);
+    case 1: return run_fill<uint8_t, false>((const uint8_t*)grid, (uint8_t*)out, N, D, H, W, workspace, st);
+    case 2: return run_fill<int32_t, false>((const int32_t*)grid, (int32_t*)out, N, D, H, W, workspace, st);
+    case 3: return run_fill<double, false>((const double*)grid, (double*)out, N, D, H, W, workspace, st);
+    case 4: return run_fill<int64_t, false>((const int64_t*)grid, (int64_t*)out, N, D, H, W, workspace, st);
+    case 5: return run_fill<int16_t, false>((const int16_t*)grid, (int16_t*)out, N, D, H, W, workspace, st);
+    case 6: return run_fill<int8_t, false>((const int8_t*)grid, (int8_t*)out, N, D, H, W, workspace, st);
+  }
+  return CRN_EINVAL;
+}
+
+// Strided views of both tensors (element strides, any sign-free layout torch can produce): the reference op reads and
+// writes through packed accessors (fill_voxels_gpu.cu:146-163), so `fill_inside_voxels_gpu(grid[:, ::2], inplace=True)`
+// mutates the caller's view.  One launch like the contiguous entry; voxels move one per lane (no 16-byte paths).
+extern "C" int crn_fill_voxels_strided(const void* grid, const int64_t* grid_strides, void* out, const int64_t* out_strides,
+                                       int dtype, int N, int D, int H, int W, void* workspace, size_t workspace_bytes,
+                                       crnStream stream) {
+  CRN_ENTRY(stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (!grid || !out || !grid_strides || !out_strides || N < 1 || D < 1 || H < 1 || W < 1) return CRN_EINVAL;
+  for (int i = 0; i < 4; ++i) if (grid_strides[i] < 0 || out_strides[i] < 0) return CRN_EINVAL;
+  if (workspace_bytes < crn_fill_voxels_workspace_bytes(N, D, H, W)) return CRN_ENOMEM;
+  const FillView vi{grid_strides[0], grid_strides[1], grid_strides[2], grid_strides[3]};
+  const FillView vo{out_strides[0], out_strides[1], out_strides[2], out_strides[3]};
+  switch (dtype) {
+    case 0: return run_fill<float, true>((const float*)grid, (float*)out, N, D, H, W, workspace, st, vi, vo);
+    case 1: return run_fill<uint8_t, true>((const uint8_t*)grid, (uint8_t*)out, N, D, H, W, workspace, st, vi, vo);
+    case 2: return run_fill<int32_t, true>((const int32_t*)grid, (int32_t*)out, N, D, H, W, workspace, st, vi, vo);
+    case 3: return run_fill<double, true>((const double*)grid, (double*)out, N, D, H, W, workspace, st, vi, vo);
+    case 4: return run_fill<int64_t, true>((const int64_t*)grid, (int64_t*)out, N, D, H, W, workspace, st, vi, vo);
+    case 5: return run_fill<int16_t, true>((const int16_t*)grid, (int16_t*)out, N, D, H, W, workspace, st, vi, vo);
+    case 6: return run_fill<int8_t, true>((const int8_t*)grid, (int8_t*)out, N, D, H, W, workspace, st, vi, vo);
   }
   return CRN_EINVAL;
 }

@@ -199,7 +199,7 @@ struct ScatterArgs {
   const float* dout; int64_t dout_sB; int C, D, H, W;
   const void* idx;
   float* dmap; int64_t dmap_sB; int h, w;
-  unsigned wrecip;                 // ceil(2^32 / w): iy = umulhi(po, wrecip) is exact for po < 2^16
+  unsigned wrecip;                 // ceil(2^32 / w), w >= 2 (the host re-shapes width-1 maps): iy = umulhi(po, wrecip) is exact for po < 2^16
   int zseg, tilesX, tilesY, kTX, kTY, win_floats;      // win_floats: entries (8 bytes each) of the LDS window
   unsigned long long* detmap; const float* scale_p;
   int dbg;                         // tools build only (CRN_RAY_DBG): 1 no LDS adds, 2 no window write-out, 4 every plane = plane z0
@@ -431,6 +431,10 @@ int ray_project(const float* matrix, const float* offset, int B, int D, int H, i
 template <typename IT>
 int ray_scatter(const float* dout, int64_t dout_sB, int B, int C, int D, int H, int W, const IT* idx, float* dmap,
                 int64_t dmap_sB, int h, int w, int zero_first, hipStream_t st) {
+  // A map of width 1 (the stage-5 map of a 64 x 32 image): ceil(2^32 / 1) does not fit wrecip's 32 bits.  The kernel only
+  // ever splits the FLAT pixel index po = iy * w + ix of a [C][h][w] map, so a [h][1] map is scattered as the [1][h] map it
+  // is in memory (iy = 0, ix = po): same addresses, and every reciprocal fits (h = w = 1 has po = 0 only).
+  if (w == 1 && h > 1) { w = h; h = 1; }
   if (zero_first) {
     if (dmap_sB == (int64_t)C * h * w) {
       CRN_HIP(hipMemsetAsync(dmap, 0, (size_t)B * C * h * w * 4, st));

@@ -155,14 +155,27 @@ class GradientSync:
 
   def attach(self, engine):
     """Carry the BatchRenorm buffers of `engine` on the first gradient bucket (see the class docstring).  The piggy-back
-    synchronises the ranks at the END of a step; the FIRST step after attach(), after load_state_dict() or after resuming from a
-    checkpoint on one rank starts from whatever each rank holds -- so the exchange owes one explicit broadcast of rank 0's buffers,
-    which CoreNet.train_step pays before that step's forward (`needs_buffer_broadcast`; DDP broadcast_buffers=True semantics,
-    pipeline.py:199-200)."""
+    synchronises the ranks at the END of a step; the FIRST step after attach() starts from whatever each rank holds -- so the
+    exchange owes one explicit broadcast of rank 0's buffers, which CoreNet.train_step pays before that step's forward
+    (`needs_buffer_broadcast`; DDP broadcast_buffers=True semantics, pipeline.py:199-200).
+
+    COLLECTIVE, like wrapping a module in DistributedDataParallel: every rank of the group calls attach() (the flag it sets
+    gates a collective in train_step, so it must be set on all ranks or on none).  Nothing rank-local ever sets that flag:
+    a `load_state_dict()` / `mark_weights_dirty()` on ONE rank after attach() does not ask for a broadcast (it used
+    to, and the other ranks then went straight to their bucket all-reduces -- mismatched collectives, a hang).  What happens
+    instead is what the piggy-back does every step: rank 0's buffers, as stepped by its next forward, reach every rank with
+    the first bucket of that step (a reload on rank 0 wins one step late; a reload on another rank is overwritten, as under
+    DDP).  Ranks that all reload after attach() and want DDP's "before the next forward" exactly call
+    `request_buffer_broadcast()` -- on every rank."""
     self.engine = engine
     engine.exchange = self
     self.needs_buffer_broadcast = True
     return self
+
+  def request_buffer_broadcast(self):
+    """COLLECTIVE (call on every rank of the group, or on none): the next train_step broadcasts rank 0's BatchRenorm buffers
+    before its forward, as after attach()."""
+    self.needs_buffer_broadcast = True
 
   def broadcast_buffers_once(self):
     self.needs_buffer_broadcast = False

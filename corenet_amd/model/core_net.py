@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import contextlib
 import os
+import sys
 import dataclasses
 import math
 from typing import Any, Dict, Optional, Tuple
@@ -60,6 +61,11 @@ def _release_graphs():
       _LIVE_GRAPHS.pop().reset()
     except Exception:
       pass
+  try:                                # graphs of models the garbage collector dropped (Engine.orphan_graph_resources)
+    from corenet_amd.model.engine import Engine
+    Engine.drain_orphans()
+  except Exception:
+    pass
 
 
 import atexit  # noqa: E402
@@ -150,13 +156,16 @@ class CoreNet(nn.Module):
   def _mark_dirty(self):
     self.engine.weights_dirty = True
     self._packed_version = None              # whatever wrote the slabs: the next inference forward packs again
-    ex = getattr(self.engine, "exchange", None)
-    if ex is not None:                       # data parallel: the loaded BatchRenorm buffers of rank 0 go to every rank before the
-      ex.needs_buffer_broadcast = True       # next step (distributed.GradientSync.attach)
+    # (data parallel: a rank-local reload never raises the exchange's broadcast flag -- that flag gates a collective and
+    # is only set by the collective calls GradientSync.attach() / request_buffer_broadcast(); see attach())
 
   def close(self):
     """Gives back what the inference / training graphs of this model hold outside torch's allocator: the captured graphs with their
-    private pools and the capture stream's split-K scratch.  Called by __del__; the model stays usable (it captures again)."""
+    private pools and the capture stream's split-K scratch (a `hipFree`, i.e. a device-wide wait).  EXPLICIT: call it (or use the
+    model as a context manager) when a process builds and drops many models; the model stays usable (it captures again).  The
+    garbage collector never does this (`__del__` used to -- a device synchronisation on whatever thread the collector
+    runs, possibly at interpreter shutdown): a model that is simply dropped parks its graphs and capture stream on a list that the
+    next graph capture of any model in the process releases (Engine.orphan_graph_resources / drain_orphans)."""
     eng = getattr(self, "engine", None)
     if eng is None:
       return
@@ -164,9 +173,22 @@ class CoreNet(nn.Module):
     _LIVE_GRAPHS[:] = [g for g in _LIVE_GRAPHS if id(g) not in live]
     eng.release_graph_resources()
 
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *exc):
+    self.close()
+    return False
+
   def __del__(self):
+    # references only: no graph reset, no hipFree from the collector (see close()); at interpreter shutdown nothing at all
+    # (the atexit hook above has reset the live graphs already)
     try:
-      self.close()
+      eng = getattr(self, "engine", None)
+      if eng is not None and not sys.is_finalizing():
+        live = {id(g) for p in eng.plans.values() for g in list(p.graphs.values()) + [p.eval_graph] if g is not None}
+        _LIVE_GRAPHS[:] = [g for g in _LIVE_GRAPHS if id(g) not in live]
+        eng.orphan_graph_resources()
     except Exception:
       pass
 
@@ -385,7 +407,7 @@ class CoreNet(nn.Module):
     with self._on_device():
       plan = eng.plan(B, image.shape[2:])
       if all_reduce is not None and getattr(all_reduce, "needs_buffer_broadcast", False):
-        all_reduce.broadcast_buffers_once()      # first step after attach() / load_state_dict(): DDP's broadcast_buffers
+        all_reduce.broadcast_buffers_once()      # first step after attach() / request_buffer_broadcast(): DDP's broadcast_buffers
       if graph is None:
         graph = os.environ.get("CRN_GRAPH", "0") == "1"
       if all_reduce is not None and hasattr(all_reduce, "_active") and not all_reduce._active():

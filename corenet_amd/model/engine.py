@@ -195,6 +195,9 @@ class Conv:
   wop_kind: str = ""                 # slab images for the decoder's bf16x3 engine ("slab"); None: not used
 
 
+_ORPHANS = []      # (backend, graphs, capture stream) of engines dropped by the garbage collector: Engine.orphan_graph_resources
+
+
 class Engine:
   """Builds and runs the forward/backward plan for a fixed per-GPU batch size."""
 
@@ -260,11 +263,35 @@ class Engine:
     self._dgrad_pack_pending = False   # ... the data-gradient weights;
     self._gpacked_zeroed = False       # the packed gradient slab was zeroed (on the side stream) for the next backward
 
+  def orphan_graph_resources(self):
+    """What `CoreNet.__del__` does instead of release_graph_resources(): hand the engine's graphs and capture stream to a
+    module-level list WITHOUT touching the HIP runtime (no graph reset, no hipFree from the garbage collector: ADVICE r5).
+    The next capture_stream() of any engine -- an ordinary call on the thread that drives the GPU -- releases them."""
+    graphs = [g for p in self.plans.values() for g in list(p.graphs.values()) + [p.eval_graph] if g is not None]
+    for p in self.plans.values():
+      p.graphs, p.eval_graph, p.eval_eager = {}, None, 0
+    if graphs or self._capture is not None:
+      _ORPHANS.append((self.be, graphs, self._capture))
+    self._capture = None
+
+  @staticmethod
+  def drain_orphans():
+    while _ORPHANS:
+      be, graphs, stream = _ORPHANS.pop()
+      for g in graphs:
+        try:
+          g.reset()
+        except Exception:
+          pass
+      if stream is not None:
+        be.splitk_release(stream)
+
   def capture_stream(self):
     """The ONE stream every HIP graph of this engine is captured on (fused training steps, inference forwards of every batch
     size): a capture stream owns a split-K scratch slot (>= 16 MB, 64 per process) and a BatchRenorm workspace, so one per
     captured graph would leak both.  Replays run on the caller's stream; graphs of one engine are replayed one
     after the other."""
+    Engine.drain_orphans()       # scratch slots / graphs of models the garbage collector dropped since the last capture
     if self._capture is None:
       self._capture = t.cuda.Stream(device=self.device)
     # (every call, i.e. before every capture:) as large as the largest split-K scratch any stream of this device has needed so far

@@ -468,6 +468,12 @@ int crn_adam_step_hyper(float* param, const float* grad, float* exp_avg, float* 
 int crn_fill_voxels(const void* grid, void* out, int dtype, int N, int D, int H, int W,
                     void* workspace, size_t workspace_bytes, crnStream s);
 size_t crn_fill_voxels_workspace_bytes(int N, int D, int H, int W);
+/* The same operator on strided views: the reference reads `grid` and writes `result` through packed accessors
+ * (cc/fill_voxels_gpu.cu:146-163), so non-contiguous tensors -- and in-place calls on them -- need no copy.
+ * grid_strides / out_strides: 4 host int64 element strides (N, D, H, W), all >= 0; same workspace, same single
+ * asynchronous launch, voxels move one per lane.                                                              */
+int crn_fill_voxels_strided(const void* grid, const int64_t* grid_strides, void* out, const int64_t* out_strides,
+                            int dtype, int N, int D, int H, int W, void* workspace, size_t workspace_bytes, crnStream s);
 /* crn_fill_voxels never waits for the GPU (the reference op is asynchronous too,
  * fill_voxels_gpu.cu:158-165): ONE kernel launch per call (per 256-CU load of
  * grids); a workgroup that gives up raises a device-side flag and the last

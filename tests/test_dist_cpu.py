@@ -82,11 +82,26 @@ def _train_worker(rank, world, port, out):
   sync = D.GradientSync(world).attach(model.engine)
   before = model.engine.store.params.clone()
   buf0 = model.engine.store.buffers.clone()
+  assert sync.needs_buffer_broadcast              # attach() is collective: every rank owes (and enters) the start-up broadcast
   loss = model.train_step(image, v2s, off, grid.to(t.int32), "iou_fgbg", world_size=world, all_reduce=sync)
-  t.save({"p": model.engine.store.params.clone(), "g": model.engine.store.grads.clone(), "before": before,
-          "buf": model.engine.store.buffers.clone(), "buf_before": buf0,
-          "loss": float(loss), "pushed": list(sync.pushed), "buckets": [(lo, hi) for _, lo, hi in model.engine.grad_buckets]},
-         os.path.join(out, f"t{rank}.pt"))
+  assert not sync.needs_buffer_broadcast
+  rec = {"p": model.engine.store.params.clone(), "g": model.engine.store.grads.clone(), "before": before,
+         "buf": model.engine.store.buffers.clone(), "buf_before": buf0,
+         "loss": float(loss), "pushed": list(sync.pushed), "buckets": [(lo, hi) for _, lo, hi in model.engine.grad_buckets]}
+  # ONE rank reloads state after attach() (a checkpoint resumed on rank 0 only).  Nothing rank-local may gate a
+  # collective: the next step must run its bucket all-reduces on both ranks (no hang), and rank 0's reloaded statistics --
+  # stepped by its forward -- reach rank 1 with that step's first bucket.
+  if rank == 0:
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    for k in sd:
+      if k.endswith("running_mean"):
+        sd[k] += 0.25
+    model.load_state_dict(sd)
+  assert not sync.needs_buffer_broadcast          # a rank-local reload does not raise the collective flag
+  sync.pushed.clear()
+  model.train_step(image, v2s, off, grid.to(t.int32), "iou_fgbg", world_size=world, all_reduce=sync)
+  rec.update(buf2=model.engine.store.buffers.clone(), p2=model.engine.store.params.clone(), pushed2=list(sync.pushed))
+  t.save(rec, os.path.join(out, f"t{rank}.pt"))
   dist.barrier(); dist.destroy_process_group()
 
 
@@ -104,4 +119,9 @@ def test_two_rank_overlapped_train_step(tmp_path):
   assert t.equal(a["buf"], b["buf"]) and not t.equal(a["buf"], a["buf_before"])         # rank 0's stepped statistics everywhere
   moved = (a["p"] - a["before"]).abs()
   assert float(moved.max()) > 1e-5 and float(moved.max()) <= 4e-4 * 1.01      # one Adam step of lr 4e-4
+  # second step, after rank 0 alone reloaded its state: every bucket exchanged on both ranks, rank 0's (shifted, then stepped)
+  # running statistics on both
+  assert a["pushed2"] == a["pushed"] and b["pushed2"] == b["pushed"]
+  assert t.equal(a["buf2"], b["buf2"]) and t.equal(a["p2"], b["p2"])
+  assert float((a["buf2"] - a["buf"]).abs().max()) > 0.2
 

@@ -269,6 +269,29 @@ def test_fill_inside_voxels_cpu_operator():
   assert fv.fill_inside_voxels_cpu(t.zeros(0, 4, 4, 4)).shape == (0, 4, 4, 4)
 
 
+def test_get_module_is_shaped_like_corenet_cpp():
+  """`corenet.cc.fill_voxels.get_module()` returns the extension module `corenet_cpp` and its two callers are written
+  against that object (cc/fill_voxels.py:98-107: `get_module().fill_inside_voxels_cpu(grid)`,
+  `get_module().fill_inside_voxels_gpu(grid, inplace)`; cc/module.cc:18-29).  The same two statements run verbatim on
+  what `corenet_amd.cc.fill_voxels.get_module()` returns; the C-ABI library is its `.lib`."""
+  from reference_known_answers import fill_grids
+  from corenet_amd.cc import fill_voxels as fv
+  from corenet_amd import _lib
+  mod = fv.get_module()
+  assert mod is fv.get_module(verbose=True)                      # one module object per process, like the reference's global
+  assert callable(mod.fill_inside_voxels_gpu) and callable(mod.fill_inside_voxels_cpu)
+  assert mod.lib is _lib.lib()
+  g1, g2, e1, e2 = fill_grids()
+  grid = t.tensor(np.stack([g1, g2]))
+  np.testing.assert_array_equal(mod.fill_inside_voxels_cpu(grid).numpy(), np.stack([e1, e2]))   # cc/fill_voxels.py:99
+  with pytest.raises(ValueError):
+    mod.fill_inside_voxels_gpu(grid, False)                      # :107 on a CPU tensor: the op's own ValueError
+  with pytest.raises(ValueError):
+    mod.fill_inside_voxels_gpu(grid, inplace=True)
+  with pytest.raises(ValueError):
+    mod.fill_inside_voxels_cpu(grid[0])                          # rank 3
+
+
 def test_tap_boxes_cover_every_real_weight():
   """crnTapBoxes contract (include/corenet_hip.h): for output group g (forward geometry) / input group g
   (data-gradient geometry) every packed weight with a tap OUTSIDE the box is a structural zero (index -1),

@@ -1007,6 +1007,185 @@ def test_ray_scatter_beside_mfma_neighbours(be, neighbour):
   assert not bad, (neighbour, len(bad), bad[:5])
 
 
+def _scatter_vs_index_put(be, gy, m, off, res, C, hw, tag):
+  """crn_ray_sample_bwd_idx against the oracle's autograd index_put_ (ray_traced_skip_connection.py:135) on gradients that hold
+  inf / NaN / zeros / extreme magnitudes: non-finite POSITIONS equal (and of the same kind), finite elements within 2e-5 of
+  what the pixel's contributions sum to in absolute value (index_put_ of |gy|: the conditioning-aware scale of each pixel)."""
+  B = gy.shape[0]
+  cmap = t.zeros(B, C, hw, hw).requires_grad_(True)
+  with np.errstate(all="ignore"):
+    O.ray_sample(cmap, m, off, (res,) * 3).backward(gy)
+    want = cmap.grad.clone()
+    fin = t.where(t.isfinite(gy), gy.abs(), t.zeros_like(gy))
+    cm2 = t.zeros(B, C, hw, hw).requires_grad_(True)
+    O.ray_sample(cm2, m, off, (res,) * 3).backward(fin)
+    wabs = cm2.grad
+  md, od = m.reshape(B, 16).to(DEV), off.to(DEV)
+  idx = t.zeros(B, res ** 3, dtype=t.int16, device=DEV)
+  be.ray_project(md, od, B, res, res, res, hw, hw, idx)
+  for zero_first in (True, False):
+    dmap = t.full((B, C, hw, hw), 0.0 if not zero_first else 9.0, device=DEV)
+    be.ray_sample_bwd_idx(gy.to(DEV), C * res ** 3, B, C, res, res, res, idx, dmap, C * hw * hw, hw, hw, zero_first)
+    got = dmap.cpu()
+    assert t.equal(t.isnan(got), t.isnan(want)), (tag, int(t.isnan(got).sum()), int(t.isnan(want).sum()))
+    assert t.equal(t.isposinf(got), t.isposinf(want)) and t.equal(t.isneginf(got), t.isneginf(want)), tag
+    f = t.isfinite(want)
+    err = (got[f].double() - want[f].double()).abs()
+    bar = 2e-5 * wabs[f].double() + 1e-44
+    assert bool((err <= bar).all()), (tag, zero_first, float((err / bar).max()))
+  return want
+
+
+def test_ray_scatter_fallback_branches(be):
+  """The branches of ray_scatter_kernel beside its fixed-point window (csrc/ray_sample.hip): a workgroup whose largest |gradient| is
+  inf / NaN, or below 2^-83, or zero, adds to HBM in float -- the reference's autograd `index_put_(accumulate=True)`
+  (ray_traced_skip_connection.py:135) propagates non-finite values and loses nothing of tiny ones.  (i) one +inf, one -inf and one
+  NaN element (in different tiles, and a pixel that receives +inf and -inf), (ii) an all-zero 64^3 gradient, (iii) gradients of
+  magnitude 1e-30, (iv) mixed tiles: one 32 x 8-column tile of magnitude 1e+20 among tiles of 1e-20, (v) one huge tile among zeros;
+  64^3 x 12 (the tiled form) and a 16^3 x 48 map (8 x 8 tiles), canonical and shifted cameras."""
+  for res, C, hw in ((64, 12, 64), (16, 48, 16)):
+    g = t.Generator().manual_seed(res)
+    B = 2
+    cams, offs = _ray_cameras(res)
+    m, off = cams[:B], offs[:B]
+    shape = (B, C, res, res, res)
+    base = t.randn(shape, generator=g)
+    # (i) non-finite elements
+    gy = base.clone()
+    gy[0, 1, 3, 5, 7] = float("inf"); gy[0, 2, res - 2, res - 3, res - 4] = float("-inf"); gy[1, 0, res // 2, 9, 11] = float("nan")
+    gy[1, 3, 2, 4, 4] = float("inf"); gy[1, 3, 3, 4, 4] = float("-inf")      # neighbours in z: the same pixel or adjacent ones
+    want = _scatter_vs_index_put(be, gy, m, off, res, C, hw, f"non-finite {res}")
+    assert int((~t.isfinite(want)).sum()) >= 3
+    # (ii) all zeros (M = 0: nothing to scale by)
+    w0 = _scatter_vs_index_put(be, t.zeros(shape), m, off, res, C, hw, f"zeros {res}")
+    assert float(w0.abs().max()) == 0.0
+    # (iii) tiny gradients: 1e-30 is below the window's 2^-83 floor, nothing may be flushed to zero
+    wt = _scatter_vs_index_put(be, base * 1e-30, m, off, res, C, hw, f"tiny {res}")
+    assert float(wt.abs().max()) > 1e-30
+    # (iv) / (v) one tile huge, its neighbours tiny / zero: per-workgroup scales differ by 2^133
+    tx, ty = (32, 8) if res >= 64 else (8, 8)
+    for other in (1e-20, 0.0):
+      gm = base * other
+      gm[:, :, :8, ty:2 * ty, tx % res:(tx % res) + tx] = base[:, :, :8, ty:2 * ty, tx % res:(tx % res) + tx] * 1e20
+      _scatter_vs_index_put(be, gm, m, off, res, C, hw, f"mixed {other} {res}")
+
+
+def test_ray_scatter_width_one_map(be):
+  """A skip map of width 1 (the stage-5 map of a 64 x 32 image, which check_image_hw accepts): ceil(2^32 / w) does not fit the
+  16-bit path's reciprocal; the host scatters the [h][1] map as the [1][h] map it is in memory.  Gather indices bit
+  for bit, scatter against index_put_, for (h, w) = (2, 1), (8, 1), (1, 1) and (1, 8)."""
+  res, C, B = 8, 96, 2
+  cams, offs = _ray_cameras(res)
+  m, off = cams[:B], offs[:B]
+  g = t.Generator().manual_seed(3)
+  for h, w in ((2, 1), (8, 1), (1, 1), (1, 8)):
+    cmap = t.randn(B, C, h, w, generator=g).requires_grad_(True)
+    gy = t.randn(B, C, res, res, res, generator=g)
+    O.ray_sample(cmap, m, off, (res,) * 3).backward(gy)
+    md, od = m.reshape(B, 16).to(DEV), off.to(DEV)
+    idx = t.zeros(B, res ** 3, dtype=t.int16, device=DEV)
+    be.ray_project(md, od, B, res, res, res, h, w, idx)
+    assert t.equal(idx.cpu().to(t.int64).view(B, res, res, res) & 0xFFFF, EmuBackend.ray_indices_u16(m.reshape(B, 16), off, B, res, res, res, h, w))
+    dmap = t.full((B, C, h, w), 4.0, device=DEV)
+    be.ray_sample_bwd_idx(gy.to(DEV), C * res ** 3, B, C, res, res, res, idx, dmap, C * h * w, h, w, True)
+    close(dmap, cmap.grad, 2e-5, f"scatter into a {h} x {w} map")
+    dm2 = t.zeros(B, C, h, w, device=DEV)
+    be.ray_sample_bwd(gy.to(DEV), C * res ** 3, B, C, res, res, res, md, od, dm2, C * h * w, h, w, True)
+    close(dm2, cmap.grad, 2e-5, f"plain backward into a {h} x {w} map")
+
+
+@pytest.mark.parametrize("mode", [1, 44, 48])
+def test_side_stream_victims_beside_mfma_probe(be, mode):
+  """Round 4's glitch made VALU results of a wave go missing when dependent-MFMA chains ran on the same SIMD; the
+  only victim ever seen was the old scatter's projection.  The other kernels the plan runs on the side stream beside split-bf16
+  convolutions get the same treatment here: the two-pass BatchRenorm backward (bn_bwd_partial / bn_bwd_apply_kernel), the loss's
+  second pass (loss_pass2_kernel), Adam from device scalars (adam_hyper_kernel) and crn_ray_project (which still evaluates the
+  loop-free projection), each on a side stream BESIDE the probe's failing family on the main stream, 30 runs, against the CPU
+  contract (kernel_contract_emu) computed once: BatchRenorm / loss gradients 2e-5, Adam 1e-6, indices bit for bit."""
+  if _SELF:
+    return
+  import ctypes
+  from corenet_amd import _lib
+  probe = _probe_lib()
+  sink = t.zeros(16, device=DEV)
+  g = t.Generator().manual_seed(mode)
+  # BatchRenorm backward, decoder shape (two-pass form): [2, 16, 64^3]
+  B, C, S = 2, 16, 64 ** 3
+  x = t.randn(B, C, S, generator=g) * 2 + 0.4; gy = t.randn(B, C, S, generator=g)
+  gamma, beta = t.rand(C, generator=g) + 0.5, t.randn(C, generator=g)
+  rm0, rv0 = t.randn(C, generator=g), t.rand(C, generator=g) * 3 + 0.1
+  nb = t.tensor([30000], dtype=t.int64)
+  def bn_state(dev, bk):
+    sc, sh, sv = t.zeros(C, device=dev), t.zeros(C, device=dev), t.zeros(4 * C, device=dev)
+    bk.bn_stats(x.to(dev), B, C, S, C * S, True, gamma.to(dev), beta.to(dev), rm0.clone().to(dev), rv0.clone().to(dev), nb.to(dev),
+                1e-3, 0.01, True, sc, sh, sv)
+    return sc, sh, sv
+  sc, sh, sv = bn_state("cpu", EMU)
+  dx_w, dg_w, db_w = t.zeros(B, C, S), t.zeros(C), t.zeros(C)
+  EMU.bn_bwd(x, C * S, gy, C * S, B, C, S, True, False, gamma, sc, sh, sv, dx_w, C * S, dg_w, db_w)
+  xd, gyd, gammad = x.to(DEV), gy.to(DEV), gamma.to(DEV)
+  scd, shd, svd = bn_state(DEV, be)
+  dx, dg, db = t.zeros(B, C, S, device=DEV), t.zeros(C, device=DEV), t.zeros(C, device=DEV)
+  # loss: iou_fgbg and xent_times_iou_agnostic on [2, C, 64^3]
+  Sl = 64 ** 3
+  loss_cases = []
+  for Cn, kind in ((2, 0), (14, 4)):
+    logits = t.randn(2, Cn, Sl, generator=g) * 2; gt = t.randint(0, Cn, (2, Sl), generator=g)
+    lw, dlw = t.zeros(1), t.zeros(2, Cn, Sl)
+    EMU.loss_fwd_bwd(kind, logits, gt.to(t.int32), 2, Cn, Sl, lw, dlw, 1.0)
+    loss_cases.append((kind, Cn, logits.to(DEV), gt.to(t.int32).to(DEV), float(lw), dlw, t.zeros(1, device=DEV), t.zeros(2, Cn, Sl, device=DEV)))
+  # Adam from device scalars
+  n = 1 << 22
+  p0, gr = t.randn(n, generator=g), t.randn(n, generator=g)
+  m0, v0 = t.randn(n, generator=g) * 0.1, t.rand(n, generator=g) * 0.01
+  pw, mw, vw, hy = p0.clone(), m0.clone(), v0.clone(), t.zeros(8)
+  EMU.adam_set_hyper(hy, 4e-4, 0.9, 0.999, 1e-4, 0.5, 7)
+  EMU.adam_step_hyper(pw, gr, mw, vw, n, hy)
+  hyd = t.zeros(8, device=DEV)
+  be.adam_set_hyper(hyd, 4e-4, 0.9, 0.999, 1e-4, 0.5, 7)
+  grd = gr.to(DEV)
+  # projection
+  res = 64
+  cams, offs = _ray_cameras(res)
+  mc, oc = cams[:2], offs[:2]
+  want_idx = EmuBackend.ray_indices_u16(mc.reshape(2, 16), oc, 2, res, res, res, res, res)
+  mcd, ocd = mc.reshape(2, 16).to(DEV), oc.to(DEV)
+  idx = t.zeros(2, res ** 3, dtype=t.int16, device=DEV)
+  side = t.cuda.Stream()
+  bad = []
+  for i in range(30):
+    dx.zero_(); dg.zero_(); db.zero_(); idx.zero_()
+    pd, md_, vd = p0.to(DEV), m0.to(DEV), v0.to(DEV)
+    for c in loss_cases:
+      c[6].zero_(); c[7].zero_()
+    t.cuda.synchronize()
+    ev = t.cuda.Event(); ev.record()
+    assert probe.crn_mfma_probe(mode, 6000, 256, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(_lib.stream())) == 0
+    with t.cuda.stream(side), _lib.pinned_stream(side):
+      side.wait_event(ev)
+      if i % 2: t.cuda._sleep(20000)
+      be.ray_project(mcd, ocd, 2, res, res, res, res, res, idx)
+      be.bn_bwd(xd, C * S, gyd, C * S, B, C, S, True, False, gammad, scd, shd, svd, dx, C * S, dg, db)
+      for kind, Cn, lg, gtd, _, _, lossd, dld in loss_cases:
+        be.loss_fwd_bwd(kind, lg, gtd, 2, Cn, Sl, lossd, dld, 1.0)
+      be.adam_step_hyper(pd, grd, md_, vd, n, hyd)
+    t.cuda.synchronize()
+    def rel(a, b):
+      return float((a.cpu().double() - b.double()).abs().max()) / (float(b.abs().max()) + 1e-30)
+    errs = {"bn dx": rel(dx, dx_w), "bn dgamma": rel(dg, dg_w), "bn dbeta": rel(db, db_w), "adam p": rel(pd, pw), "adam m": rel(md_, mw),
+            "adam v": rel(vd, vw)}
+    for kind, Cn, _, _, lv, dlw, lossd, dld in loss_cases:
+      errs[f"loss{kind} dl"] = rel(dld, dlw)
+      errs[f"loss{kind} value"] = abs(float(lossd) - lv) / max(1.0, abs(lv)) * 2.0     # (bar 1e-5: scaled onto the 2e-5 bar)
+    bars = {k: (1e-6 if k.startswith("adam") else 2e-5) for k in errs}
+    off_ = {k: v for k, v in errs.items() if not v <= bars[k]}
+    if not t.equal(idx.cpu().to(t.int64).view(2, res, res, res) & 0xFFFF, want_idx):
+      off_["ray_project"] = 1.0
+    if off_:
+      bad.append((i, off_))
+  assert not bad, (mode, len(bad), bad[:3])
+
+
 @pytest.mark.parametrize("Cin,N,hw", [(2048, 96, 8), (256, 12, 64), (96, 20, 16)])
 def test_pointwise_conv_channel_last_output(be, Cin, N, hw):
   """1x1 conv writing a channel-last view (compress_channels -> skip map), with and without split-K, against
@@ -1301,6 +1480,62 @@ def test_fill_any_size_bit_exact(be, shape):
     gi = t.tensor(g).to(t.uint8).to(DEV)
     be.fill_voxels(gi, gi)
     np.testing.assert_array_equal(gi.cpu().numpy(), want.astype(np.uint8))
+
+
+def test_fill_strided_views_like_packed_accessors(be):
+  """The reference op reads and writes through packed accessors (fill_voxels_gpu.cu:146-163), so a non-contiguous tensor is
+  filled where it lies: `crn_fill_voxels_strided` (no `.contiguous()` copy).  Permuted, sliced and step-2 views, out of place
+  (fresh contiguous result, input untouched) and in place (the caller's view is mutated, the elements between its strides are
+  not), through `get_module()` like cc/fill_voxels.py:102-107; 128-wide rows (the contiguous twin would take the 16-byte
+  path), a grid that needs the any-size kernel (W > 512) and the in-launch rescue path (subprocess, CRN_FILL_MAXROUNDS)."""
+  if _SELF:
+    return
+  import fill_oracle_c, subprocess, sys, os
+  from corenet_amd.cc import fill_voxels as fv
+  mod = fv.get_module()
+  rng = np.random.RandomState(11)
+  base = (rng.rand(3, 40, 36, 140) < 0.42).astype(np.float32)
+  views = [lambda x: x.permute(0, 1, 3, 2), lambda x: x.permute(0, 3, 2, 1), lambda x: x[:, ::2, 1:, ::3],
+           lambda x: x[1:, :, :, 5:133], lambda x: x.permute(1, 0, 2, 3)]
+  for dt in (t.float32, t.uint8, t.int64):
+    for mk in views:
+      full = t.tensor(base).to(dt).to(DEV)
+      v = mk(full)
+      assert not v.is_contiguous()
+      want = fill_oracle_c.fill(v.cpu().contiguous().numpy().astype(np.float32))
+      keep = full.clone()
+      out = mod.fill_inside_voxels_gpu(v, False)
+      assert out.is_contiguous() and out.data_ptr() != full.data_ptr() and t.equal(full, keep)
+      np.testing.assert_array_equal(out.cpu().numpy(), want.astype(out.cpu().numpy().dtype))
+      r = mod.fill_inside_voxels_gpu(v, True)
+      assert r.data_ptr() == v.data_ptr() and r.stride() == v.stride()
+      np.testing.assert_array_equal(v.cpu().numpy(), want.astype(out.cpu().numpy().dtype))
+      # the elements the view does not cover are untouched
+      mask = t.zeros_like(full, dtype=t.bool); mk(mask)[...] = True
+      assert t.equal(full[~mask], keep[~mask])
+  wide = (rng.rand(2, 4, 520, 6) < 0.4).astype(np.float32)          # viewed as W = 520: the any-size kernel
+  wv = t.tensor(wide).to(DEV).permute(0, 1, 3, 2)
+  np.testing.assert_array_equal(fv.fill_inside_voxels_gpu(wv).cpu().numpy(), fill_oracle_c.fill(wv.cpu().contiguous().numpy()))
+  ex = t.tensor(base[:1, :1]).to(DEV).expand(2, 40, 36, 140)          # stride-0 dimensions: readable, not writable in place
+  np.testing.assert_array_equal(fv.fill_inside_voxels_gpu(ex).cpu().numpy(), fill_oracle_c.fill(ex.cpu().contiguous().numpy()))
+  with pytest.raises(ValueError):
+    fv.fill_inside_voxels_gpu(ex, inplace=True)
+  if _SELF:
+    return
+  code = ("import sys, numpy as np, torch as t; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+          "import fill_oracle_c; from corenet_amd.cc import fill_voxels as fv;"
+          "rng = np.random.RandomState(5);\n"
+          "for shape in ((3, 40, 70, 33), (2, 64, 128, 128)):\n"
+          "  g = (rng.rand(*shape) < 0.4).astype(np.float32); x = t.tensor(g).cuda().permute(0, 1, 3, 2)\n"
+          "  want = fill_oracle_c.fill(x.cpu().contiguous().numpy())\n"
+          "  assert (fv.fill_inside_voxels_gpu(x).cpu().numpy() == want).all(), shape\n"
+          "  fv.fill_inside_voxels_gpu(x, inplace=True); assert (x.cpu().numpy() == want).all(), shape\n"
+          "print('path ok')"
+          % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+  for var, val in (("CRN_FILL_MULTI", "1"), ("CRN_FILL_RESCUE", "1"), ("CRN_FILL_MAXROUNDS", "3")):
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{var: val}), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "path ok" in r.stdout, (var, r.stderr[-2000:])
 
 
 def test_fill_is_asynchronous_graph_capturable(be):

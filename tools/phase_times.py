@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Elapsed time of the phases of one training step on the main stream (HIP events between the phases, no profiler):
 together with the per-phase kernel time of a rocprofv3 trace this shows where the main stream idles.
-usage: phase_times.py [steps]"""
+usage: phase_times.py [steps] [classes]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch as t
@@ -9,11 +9,14 @@ import bench
 from corenet_amd.model.core_net import CoreNet, CoreNetConfig, DecoderConfig
 from corenet_amd.model.engine import LOSS_KINDS
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-m = CoreNet(CoreNetConfig(DecoderConfig((128, 128, 128), 2, 2, 64, 0.75)), device="cuda", decoder_math="bf16x3")
+NC = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+LOSS = "iou_fgbg" if NC == 2 else "xent_times_iou_agnostic"
+m = CoreNet(CoreNetConfig(DecoderConfig((128, 128, 128), NC, 2, 64, 0.75)), device="cuda", decoder_math="bf16x3")
 m.train()
-image, v2s, off, grid = [x.cuda() for x in bench.synthetic_batch(4, 0, 2)]
+image, v2s, off, grid = [x.cuda() for x in bench.synthetic_batch(4, 0, NC)]
 grid = grid.to(t.int32)
-for _ in range(3): m.train_step(image, v2s, off, grid, "iou_fgbg")
+print(f"C={NC} B=4 {LOSS}")
+for _ in range(3): m.train_step(image, v2s, off, grid, LOSS)
 eng = m.engine; plan = eng.plan(4)
 plan.in_image.copy_(image); plan.in_v2s.copy_(v2s); plan.in_off.copy_(off); plan.gt.copy_(grid)
 names = ["enc fwd", "dec fwd", "loss", "backward", "adam"]
@@ -27,7 +30,7 @@ for s in range(steps):
   e[0].record()
   plan.forward_encoder(plan.in_image, True); e[1].record()
   plan.forward_decoder(plan.in_v2s, plan.in_off, True); e[2].record()
-  eng.be.loss_fwd_bwd(LOSS_KINDS["iou_fgbg"], plan.logits, plan.gt, plan.B, eng.num_classes, 128 ** 3, plan.loss, plan.glogits, 1.0)
+  eng.be.loss_fwd_bwd(LOSS_KINDS[LOSS], plan.logits, plan.gt, plan.B, eng.num_classes, 128 ** 3, plan.loss, plan.glogits, 1.0)
   e[3].record()
   orig_join = plan._join_side
   def timed_join():
