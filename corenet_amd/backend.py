@@ -162,6 +162,27 @@ class HipBackend:
     desc, blocks = table
     self.lib.crn_bf3_operands(ptr(packed), ptr(desc), desc.shape[0], blocks, ptr(out), _lib.stream())
 
+  def bf3_gather_image(self, src: t.Tensor, table: t.Tensor, out: t.Tensor, host_table=None):
+    """out (bytes) <- bf16 hi / lo entries of src gathered through `table` (int32 [n, 10] on the device:
+    conv_geometry.convt_par_*_table)."""
+    self.lib.crn_bf3_gather_image(ptr(src), ptr(table), table.shape[0], ptr(out), _lib.stream())
+
+  def convt_par_fwd(self, x: t.Tensor, tr: Optional[Transform], wimg: t.Tensor, bias: Optional[t.Tensor], y: t.Tensor, cout: int,
+                    host_table=None):
+    """ConvTranspose3d(16 -> cout, k 7, stride 2, padding 3, output_padding 1) of T(x) into channels [0, cout) of y
+    (csrc/convt_par.hip).  x [B,16,D,H,W] dense inside a sample, y [B,>=cout,2D,2H,2W]."""
+    B, cin, D, H, W = x.shape
+    assert cin == 16 and x[0].is_contiguous() and y[0].is_contiguous() and tuple(y.shape[2:]) == (2 * D, 2 * H, 2 * W)
+    self.lib.crn_convt_s2k7_fwd_bf3(ptr(x), x.stride(0), B, D, H, W, _ctr(tr), ptr(wimg), ptr(bias), ptr(y), y.stride(0),
+                                    y.stride(1), cout, _lib.stream())
+
+  def convt_par_dgrad(self, dy: t.Tensor, cout: int, wimg: t.Tensor, dx: t.Tensor, accumulate: bool = False, host_table=None):
+    """Data gradient of the same layer: dy [B,>=cout,2D,2H,2W] (channels [0, cout)) -> dx [B,16,D,H,W]."""
+    B, cin, D, H, W = dx.shape
+    assert cin == 16 and dx[0].is_contiguous() and dy[0].is_contiguous() and tuple(dy.shape[2:]) == (2 * D, 2 * H, 2 * W)
+    self.lib.crn_convt_s2k7_dgrad_bf3(ptr(dy), dy.stride(0), dy.stride(1), cout, B, D, H, W, ptr(wimg), ptr(dx), dx.stride(0),
+                                      int(accumulate), _lib.stream())
+
   def conv2d_bf3(self, x: View, tr: Optional[Transform], wop: t.Tensor, npad: int, bias: Optional[t.Tensor],
                  bias_sB: int, y: View, window, pad_lo, accumulate: bool = False):
     """The encoder engine (csrc/conv_e2d.hip): 1x1 / 3x3 stride-1 convs on operand blocks from bf3_operands."""

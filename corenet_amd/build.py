@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcorenet_hip.so")
 SOURCES = ["conv_igemm.hip", "conv_bf3.hip", "conv_e2d.hip", "batch_renorm.hip", "ray_sample.hip", "misc_ops.hip", "losses.hip", "fill_voxels.hip",
-           "voxelize.hip", "comm_rccl.hip", "stem_conv.hip", "fill_voxels_cpu.cpp"]
+           "voxelize.hip", "comm_rccl.hip", "stem_conv.hip", "convt_par.hip", "fill_voxels_cpu.cpp"]
 # conv engine tile configurations (conv_kernels.h CRN_FWD_CONFIGS / CRN_WG_CONFIGS): one object each
 CONV_CONFIGS = [(8, 1), (4, 2), (4, 1), (2, 4), (2, 2), (2, 1), (1, 4), (1, 2), (1, 1)]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",

@@ -358,3 +358,63 @@ def operand_table(layers):
     rows.append((src, dst, g.cin, g.taps, g.npad, blocks, g.window[1] * g.window[2] if slab else 0))
     blocks += ((slab_entries(g) if slab else operand_entries(g)) + 255) // 256
   return np.asarray(rows, dtype=np.int64).reshape(-1, 7), blocks
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Weight images of the parity-walk kernels of decoder stage_6.t1 (csrc/convt_par.hip, ConvTranspose3d 16 -> C, k 7, stride 2,
+# padding 3; reconstruction_decoder.py:89-95).  A table row = 8 source indices into the flat parameter slab (-1: zero) and
+# the two destination entries (16-byte units) of their bf16 hi / lo parts: crn_bf3_gather_image.  Image = the steps of the
+# kernel's walk in order, per step hi[rows][4 taps][32 columns] then lo[...]; + 4 KiB of slack (a 3-row step is followed
+# by a 4-row one at most: the kernels never read past a step, the slack only keeps every piece inside the buffer).
+def _ct_table(rows_of_step):
+  tab, off16 = [], 0
+  for rows, entry in rows_of_step:                  # rows: window rows of the step; entry(zi_h, kk, col) -> 8 indices
+    hi0, lo0 = off16, off16 + rows * 128
+    for zi in range(rows):
+      for kk in range(4):
+        for col in range(32):
+          e = (zi * 4 + kk) * 32 + col
+          tab.append(list(entry(zi, kk, col)) + [hi0 + e, lo0 + e])
+    off16 += rows * 256
+  return np.asarray(tab, np.int32), off16 * 16 + 4096
+
+
+def convt_par_fwd_table(wshape, wofs: int = 0):
+  """Forward walk: (rd, rh) x 8-channel chunk of the 16 inputs x window plane zd < 3 + rd; rows zh < 3 + rh; column =
+  rw * 16 + n; tap k = 5 - 2 z + r per dimension (convt_fwd above)."""
+  Cc, N, ks = wshape[0], wshape[1], wshape[2]
+  assert Cc == 16 and ks == 7 and N <= 16
+  steps = []
+  for pp in range(4):
+    rd, rh = pp >> 1, pp & 1
+    for ch in range(2):
+      for zd in range(3 + rd):
+        def entry(zh, kk, col, rd=rd, rh=rh, ch=ch, zd=zd):
+          rw, n = col >> 4, col & 15
+          kd, kh, kw = 5 - 2 * zd + rd, 5 - 2 * zh + rh, 5 - 2 * kk + rw
+          if n >= N or kw < 0:
+            return [-1] * 8
+          return [wofs + (((ch * 8 + j) * N + n) * ks + kd) * ks * ks + kh * ks + kw for j in range(8)]
+        steps.append((3 + rh, entry))
+  return _ct_table(steps)
+
+
+def convt_par_dgrad_table(wshape, wofs: int = 0):
+  """Data-gradient walk: (rd, rh) x 8-channel half of n x window plane z in [1 - rd, 4); rows z in [1 - rh, 4); column =
+  rw * 16 + c; tap k = 2 z - 1 + r (convt_dgrad above); the 8 bf16 of an entry are 8 output channels n."""
+  Cc, N, ks = wshape[0], wshape[1], wshape[2]
+  assert Cc == 16 and ks == 7 and N <= 16
+  steps = []
+  for pp in range(4):
+    rd, rh = pp >> 1, pp & 1
+    for nh in range((N + 7) // 8):
+      for zd in range(1 - rd, 4):
+        def entry(zi, kk, col, rd=rd, rh=rh, nh=nh, zd=zd):
+          rw, c = col >> 4, col & 15
+          zh = 1 - rh + zi
+          kd, kh, kw = 2 * zd - 1 + rd, 2 * zh - 1 + rh, 2 * kk - 1 + rw
+          if kw < 0:
+            return [-1] * 8
+          return [(wofs + ((c * N + nh * 8 + j) * ks + kd) * ks * ks + kh * ks + kw) if nh * 8 + j < N else -1 for j in range(8)]
+        steps.append((3 + rh, entry))
+  return _ct_table(steps)

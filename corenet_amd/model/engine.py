@@ -193,6 +193,8 @@ class Conv:
   wop_f: Optional[t.Tensor] = None   # forward / data-gradient weights pre-split to bf16 hi + lo and pre-arranged
   wop_d: Optional[t.Tensor] = None   # (slices of eng.wop): MFMA operand blocks for the encoder engine ("e2d"),
   wop_kind: str = ""                 # slab images for the decoder's bf16x3 engine ("slab"); None: not used
+  ct_f: Optional[t.Tensor] = None    # step-ordered weight images of the parity-walk kernels (csrc/convt_par.hip; decoder stage_6.t1
+  ct_d: Optional[t.Tensor] = None    # with more than 8 classes): forward / data gradient
 
 
 _ORPHANS = []      # (backend, graphs, capture stream) of engines dropped by the garbage collector: Engine.orphan_graph_resources
@@ -460,11 +462,34 @@ class Engine:
                               s.view(name + "bias", grad=True), nref)
     self._build_operands(reg, idx_parts)
 
+  def _build_ct_images(self):
+    """Weight images of the parity-walk kernels of decoder stage_6.t1 (ConvTranspose3d 16 -> C, k 7, stride 2: csrc/convt_par.hip),
+    gathered straight from the flat parameter slab after every weight pack (crn_bf3_gather_image).  Used with more than 8 classes
+    (m7 / m9): the walk multiplies 16 columns per parity, with the 2 classes of h7 the generic engine's one 16-column block for
+    all 8 parities executes fewer MFMAs (CRN_CT_PAR=0 turns the kernels off, CRN_CT_PAR_MIN sets the class threshold)."""
+    self.ct_tables = {}
+    name = "decoder.stage_6.t1."
+    if (self.decoder_math != "bf16x3" or self.device.type != "cuda" or os.environ.get("CRN_CT_PAR", "1") == "0"
+        or name not in self.convs or not hasattr(self.be, "convt_par_fwd")):
+      return
+    shape = tuple(self.store.off[name + "weight"][1])
+    if shape[0] != 16 or shape[1] > 16 or shape[1] < int(os.environ.get("CRN_CT_PAR_MIN", "9")) or tuple(shape[2:]) != (7, 7, 7):
+      return
+    if tuple(self.resolution) != (128, 128, 128):
+      return
+    wofs = self.store.offset(name + "weight")
+    for kind, fn, field in (("dec", G.convt_par_fwd_table, "ct_f"), ("bwd", G.convt_par_dgrad_table, "ct_d")):
+      tab, nbytes = fn(shape, wofs)
+      img = t.zeros(nbytes, dtype=t.uint8, device=self.device)
+      setattr(self.convs[name], field, img)
+      self.ct_tables[kind] = (t.as_tensor(tab, device=self.device), img, None)
+
   def _build_operands(self, reg, idx_parts):
     """Operand blocks of the encoder engine: which layers, where in eng.wop, and the layer tables of the
     conversion launches that follow each weight pack (conv_geometry.operand_table)."""
     self.wop = None
     self.op_tables = {}
+    self._build_ct_images()
     if self.decoder_math != "bf16x3":
       return
     groups = {"enc_early": [], "enc_late": [], "dec": [], "bwd": []}
@@ -516,6 +541,9 @@ class Engine:
     for k in groups:
       if k in self.op_tables:
         self.be.bf3_operands(self.packed, self.op_tables[k], self.wop)
+      if k in self.ct_tables:
+        tab, img, _ = self.ct_tables[k]
+        self.be.bf3_gather_image(self.store.params, tab, img)
 
   def _tiles_dev(self, parts):
     """Device tables of one pack / un-pack: the parts that are plain transposes as LDS blocks (conv_geometry.mat_index,
@@ -1124,8 +1152,17 @@ class Plan:
       else:
         self._stats(b2_, d["w"], S, d["cmid"] * S, True, training)
       out = self.dec[k + 1]["u"] if k < 6 else self.logits
-      ov = self.s2d(out, d["cout"], (2, 2, 2))
-      self._conv(cv[p + "t1."], self.vw(d["w"]), Transform(b2_.scale, b2_.shift, pre_relu=True), ov)
+      ct = cv[p + "t1."]
+      if ct.ct_f is not None and self._math(ct, "fwd") == "bf16x3":
+        # the logits layer with > 8 classes: parity-walk kernel (csrc/convt_par.hip)
+        if self.trace is not None and self.conv_positions is not None:
+          self.conv_positions[ct.name] = S
+        self._timed("fwd   " + ct.name, lambda: be.convt_par_fwd(
+            d["w"], Transform(b2_.scale, b2_.shift, pre_relu=True), ct.ct_f, ct.bias, out, d["cout"],
+            host_table=eng.ct_tables["dec"][2]))
+      else:
+        ov = self.s2d(out, d["cout"], (2, 2, 2))
+        self._conv(ct, self.vw(d["w"]), Transform(b2_.scale, b2_.shift, pre_relu=True), ov)
       if k < 6 and not skip_async:
         self._skip_fwd(k)
     if training:
@@ -1286,7 +1323,13 @@ class Plan:
       # A data gradient is the output gradient of the norm in front of its conv: where the launch does not split its
       # reduction (stages 5-6 at the bench batch) it also leaves that norm's two backward sums, and the norm's backward
       # is its second pass alone (_dgrad_bn_bwd)
-      if not self._dgrad_bn_bwd(ct, gv, d["gv2"], d["w"], d["cmid"], S, b2_, d["gw"], cc):
+      if ct.ct_d is not None and self._math(ct, "dgrad") == "bf16x3":
+        self._timed("dgrad " + ct.name, lambda: be.convt_par_dgrad(g_out, d["cout"], ct.ct_d, d["gv2"], False,
+                                                                     host_table=eng.ct_tables["bwd"][2]))
+        ct_done = False
+      else:
+        ct_done = self._dgrad_bn_bwd(ct, gv, d["gv2"], d["w"], d["cmid"], S, b2_, d["gw"], cc)
+      if not ct_done:
         be.bn_bwd(d["w"], d["cmid"] * S, d["gv2"], d["cmid"] * S, B, d["cmid"], S, True, False,
                   b2_.gamma, b2_.scale, b2_.shift, b2_.saved, d["gw"], d["cmid"] * S, b2_.dgamma, b2_.dbeta,
                   dsum=cc.dbias, ndsum=cc.n_ref)

@@ -460,6 +460,23 @@ int crn_adam_set_hyper(float* hyper, float lr, float beta1, float beta2, float e
 int crn_adam_step_hyper(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                         int64_t n, const float* hyper, crnStream s);
 
+/* Decoder stage_6.t1 -- ConvTranspose3d(16 -> Cout <= 16, k 7, stride 2, padding 3, output_padding 1), the layer that writes the
+ * logits (model/reconstruction_decoder.py:89-95) -- on its own parity-walk kernels of the split-bf16 MFMA engine
+ * (csrc/convt_par.hip): the input patch of a 4 x 8 x 16 tile stays in LDS while the workgroup walks the 8 output parities over
+ * exactly the window rows that hold weights.  Same arithmetic as crn_conv_fwd_bf3 on the layer's window-correlation form.
+ * wimg: the weights as a step-ordered image of bf16 hi / lo entries, built by crn_bf3_gather_image from any fp32 array that
+ * holds the reference weight [16][Cout][7][7][7] (e.g. the flat parameter slab) through a device table of int32 [n][10] rows
+ * (8 source indices, -1 = zero; destination entry of the hi part; of the lo part: corenet_amd/model/conv_geometry.py
+ * convt_par_fwd_table / convt_par_dgrad_table).
+ * fwd:   x [B][16][D][H][W] (dense inside a sample, batch stride x_sB) with the input transform tr -> y [B][..][2D][2H][2W]
+ *        channels [0, Cout) (+ bias[n]), strides y_sB / y_sC.  D % 4 == H % 8 == W % 16 == 0.
+ * dgrad: dy [B][..][2D][2H][2W] channels [0, Cout) -> dx [B][16][D][H][W] (accumulate: dx +=).                              */
+int crn_bf3_gather_image(const float* src, const int32_t* table, int n_entries, void* dst, crnStream s);
+int crn_convt_s2k7_fwd_bf3(const float* x, int64_t x_sB, int B, int D, int H, int W, const crnInTransform* tr,
+                           const void* wimg, const float* bias, float* y, int64_t y_sB, int64_t y_sC, int Cout, crnStream s);
+int crn_convt_s2k7_dgrad_bf3(const float* dy, int64_t dy_sB, int64_t dy_sC, int Cout, int B, int D, int H, int W,
+                             const void* wimg, float* dx, int64_t dx_sB, int accumulate, crnStream s);
+
 /* ---------------- ground-truth side -------------------------------------------
  * fill_inside_voxels_gpu (cc/fill_voxels_gpu.cu:136-171, module.cc:18-29):
  * grid [N][D][H][W] of dtype (0 f32, 1 u8, 2 i32, 3 f64, 4 i64, 5 i16, 6 i8),

@@ -117,6 +117,42 @@ class EmuBackend:
       ent = t.stack([hi, lo], dim=-2).reshape(-1)                                          # ... [hi 8 | lo 8]
       o16[dst * 16:dst * 16 + ent.numel()] = ent.view(t.int16)
 
+  def bf3_gather_image(self, src, table, out, host_table=None):
+    tab = table.cpu().long()
+    v = t.where(tab[:, :8] >= 0, src.float()[tab[:, :8].clamp(min=0)], t.zeros(()))
+    hi = v.to(t.bfloat16)
+    lo = (v - hi.float()).to(t.bfloat16)
+    o16 = out.view(t.int16).view(-1, 8)
+    o16[tab[:, 8]] = hi.view(t.int16)
+    o16[tab[:, 9]] = lo.view(t.int16)
+
+  @staticmethod
+  def _ct_weights(wimg, host_table, cout):
+    """The [16, cout, 7, 7, 7] weights a parity-walk image holds (hi + lo), via the table that built it (source offset 0)."""
+    tab = t.as_tensor(host_table).long()
+    ent = wimg.view(t.int16).view(-1, 8).view(t.bfloat16).float()
+    v = ent[tab[:, 8]] + ent[tab[:, 9]]
+    w = t.zeros(16 * cout * 343)
+    m = tab[:, :8] >= 0
+    w[tab[:, :8][m]] = v[m]
+    return w.view(16, cout, 7, 7, 7)
+
+  def convt_par_fwd(self, x, tr, wimg, bias, y, cout, host_table=None):
+    w = self._ct_weights(wimg, host_table, cout)
+    xt = x.float()
+    if tr is not None:
+      if tr.pre_relu: xt = xt.relu()
+      xt = xt * tr.scale.view(1, -1, 1, 1, 1) + tr.shift.view(1, -1, 1, 1, 1)
+      if tr.post_relu: xt = xt.relu()
+    b = bias[:cout].float() if bias is not None else None
+    y[:, :cout] = t.nn.functional.conv_transpose3d(xt, w, b, stride=2, padding=3, output_padding=1).to(y.dtype)
+
+  def convt_par_dgrad(self, dy, cout, wimg, dx, accumulate=False, host_table=None):
+    w = self._ct_weights(wimg, host_table, cout)
+    g = t.nn.functional.conv3d(dy[:, :cout].float(), w, stride=2, padding=3)          # the adjoint of the transposed conv
+    if accumulate: dx += g.to(dx.dtype)
+    else: dx.copy_(g)
+
   def conv2d_bf3(self, x, tr, wop, npad, bias, bias_sB, y, window, pad_lo, accumulate=False):
     T = window[1] * window[2]
     n = (x.C // 32) * T * (npad // 16) * 64 * 16
