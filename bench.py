@@ -38,7 +38,9 @@ PEAK_BF16_MFMA = 2500e12                           # MI355X_MICROARCH.md: dense 
 PEAK_HBM = 8.0e12                                  # HBM3E spec peak
 # HBM bytes per launch come from separate rocprofv3 --pmc passes of this command (tools/pmc_traffic.sh); the record is
 # keyed by kernel name + grid, so both are named here, next to the kernel they describe
-TRAFFIC_FILES = {"bf16x3": "r05_pmc_traffic.json", "fp32": "r05_pmc_traffic_fp32.json"}
+TRAFFIC_FILES = {"bf16x3": "r06_pmc_traffic.json", "fp32": "r06_pmc_traffic_fp32.json", "bf16x3_c14": "r06_pmc_traffic_c14.json"}
+# decoder stage_6.t1 forward (ConvTranspose3d 16 -> C, k 7, stride 2 @64^3 -> 128^3; reconstruction_decoder.py:89-95): real FLOP per sample and class
+CONVT6_FLOP_PER_CLASS = 2.0 * 64 ** 3 * 16 * 343
 CONV_BF3_TRAFFIC_KERNEL, CONV_BF3_THREADS = "conv_bf3_half_kernel<1, 1, 7, 1", 512
 
 
@@ -100,6 +102,12 @@ def load_traffic(math, B, C, want):
   except (OSError, ValueError) as e:
     print(f"bench.py: no HBM-traffic record ({traffic_file}: {e}); roofline.traffic = null", file=sys.stderr)
     return traffic, traffic_file
+  if B == 4 and C == 14:
+    for k, v in tj.get("kernels", {}).items():
+      if "convt_par_fwd_kernel" in k and k.endswith(f"grid {2048 * 512}"):
+        traffic["convt"] = v["hbm_bytes"]
+    if "convt" in want and "convt" not in traffic:
+      print(f"bench.py: {traffic_file} has no record of convt_par_fwd_kernel -- re-run tools/pmc_traffic.sh; traffic = null", file=sys.stderr)
   if B == 4 and C == 2:
     for k, v in tj.get("kernels", {}).items():
       if math == "bf16x3":
@@ -188,6 +196,63 @@ def parity_check(state, batch, classes, dev, headline_math):
           "note": "north_star: logits within 1e-3 relative; eval mode (running statistics), B = the bench batch"}
 
 
+def super_resolution_leg(state, batch_cpu, dev, math, reps=5):
+  """h7 at 256^3 (BASELINE configs[4]) = x2 super-resolution, super_resolution.py:92-112: 8 native passes at shifted sampling
+  offsets, interleaved.  Timed: the drop-in with encoder reuse (the encoder does not depend on the offset in eval mode: 1 encoder
+  + 8 decoder passes, softmax + interleave in one kernel) and the reference's schedule on the same kernels (8 full forwards).
+  Parity: pmf of sample 0 against the oracle's 8-pass result on the same weights and image, every one of its 2 x 256^3 values."""
+  from corenet_amd import super_resolution as SR
+  from corenet_amd.geometry import transformations as T
+  from corenet_amd.model.core_net import CoreNet, CoreNetConfig, DecoderConfig
+  from oracle import corenet_oracle as O
+  image, _, off, _ = batch_cpu
+  B = image.shape[0]
+  m = CoreNet(CoreNetConfig(DecoderConfig((128, 128, 128), 2, 2, 64, 0.75)), device=dev, decoder_math=math)
+  m.load_state_dict(state); m.eval()
+
+  class _State: pass
+  st = _State(); st.model = m
+  sr = SR.super_resolution_from_state(st)
+  cam = canonical_camera()[None].expand(B, 4, 4).contiguous().to(dev)
+  v2v = T.scale([256.0] * 3)[None].expand(B, 4, 4).contiguous().to(dev)      # view -> voxel of the 256^3 output grid
+  go, img = off.to(dev), image.to(dev)
+  e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+  for _ in range(2):
+    pmf = sr(img, cam, v2v, go, (256, 256, 256))
+  e0.record()
+  for _ in range(reps):
+    pmf = sr(img, cam, v2v, go, (256, 256, 256))
+  e1.record(); t.cuda.synchronize()
+  reuse_s = e0.elapsed_time(e1) / reps * 1e-3
+  native = sr.get_native_offsets((256, 256, 256), go)                             # [8, B, 3]
+  vs = cam @ (v2v @ T.scale([0.5] * 3).to(dev)).inverse()
+  with t.no_grad():
+    for _ in range(2):
+      for n in range(8):
+        m(img, vs, native[n])
+    e0.record()
+    for _ in range(reps):
+      for n in range(8):
+        m(img, vs, native[n])
+    e1.record(); t.cuda.synchronize()
+  eight_s = e0.elapsed_time(e1) / reps * 1e-3
+  with t.no_grad():                                                              # the oracle's 8 passes on sample 0
+    t.set_num_threads(host_threads())
+    want = t.empty(2, 256, 256, 256)
+    for n in range(8):
+      iz, iy, ix = n // 4, (n // 2) % 2, n % 2
+      lg = O.corenet_forward({k: v.clone() for k, v in state.items()}, image[:1], vs[:1].cpu(), native[n, :1].cpu(), training=False)
+      want[:, iz::2, iy::2, ix::2] = lg.softmax(1)[0]
+  err = float((pmf[0].cpu() - want).abs().max())
+  del m
+  return {"config": "h7 at 256^3: x2 super-resolution (8 sampling offsets interleaved), C=2, B=%d, eval mode, decoder_math=%s" % (B, math),
+          "ms_per_batch": reuse_s * 1e3, "value": B * 256 ** 3 / reuse_s, "unit": "output voxels/s",
+          "schedule": "encoder once + 8 decoder passes + fused softmax/interleave (CoreNet.multi_offset_pmf)",
+          "eight_full_forwards_ms": eight_s * 1e3, "speedup_vs_eight_full_forwards": eight_s / reuse_s,
+          "parity": {"max_abs_pmf_err_vs_oracle_8_pass": err, "values_compared": 2 * 256 ** 3, "sample": 0, "tolerance": 1e-3,
+                     "note": "pmf in [0, 1]: absolute error; oracle = oracle/corenet_oracle.py forward per offset + softmax + interleave (super_resolution.py:105-112)"}}
+
+
 def cpu_baseline_fill(shells_cpu, seconds_budget=5.0):
   """fill_voxels on the host: the library's own C++ twin (crn_fill_voxels_cpu, csrc/fill_voxels_cpu.cpp; one
   host thread per grid), same 12 x 128^3 shells as the GPU leg (SURVEY 8(d) last row)."""
@@ -218,6 +283,7 @@ def main():
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-fp32-side", action="store_true", help="skip the fp32-math run printed beside the headline (profiling)")
   ap.add_argument("--no-m9-side", action="store_true", help="skip the 14-class (m7 / m9) step printed beside the headline")
+  ap.add_argument("--no-sr-side", action="store_true", help="skip the x2 super-resolution (h7 at 256^3) leg")
   args = ap.parse_args()
 
   from corenet_amd import distributed as D
@@ -317,14 +383,29 @@ def main():
       return m14.train_step(i14, v14, o14, g14, "xent_times_iou_agnostic", lr=4e-4, adam_eps=1e-4)
     for _ in range(args.warmup):
       step14()
+    pl14 = m14.engine.plan(B)
+    pl14.probes = {"conv3d_stage6_t1_fwd": []}         # HIP events around the logits layer's forward launch, inside the timed steps
     t.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(args.steps):
       l14 = step14()
     t.cuda.synchronize(); dt14 = time.perf_counter() - t0
+    t1s = sum(a.elapsed_time(b) for a, b in pl14.probes["conv3d_stage6_t1_fwd"]) / max(1, len(pl14.probes["conv3d_stage6_t1_fwd"])) * 1e-3
+    pl14.probes = None
+    peak14 = PEAK_BF16_MFMA / 3 if args.math == "bf16x3" else PEAK_F32_MFMA
+    tr14, tr14_file = load_traffic(args.math + "_c14", B, 14, ("convt",)) if args.math == "bf16x3" else ({}, None)
+    walk = m14.engine.convs["decoder.stage_6.t1."].ct_kind == "par"
     m9_side = {"config": "m7/m9: C=14, xent_times_iou_agnostic, B=%d/GPU, decoder_math=%s" % (B, args.math),
                "ms_per_step": dt14 / args.steps * 1e3, "value": B * 128 ** 3 * args.steps / dt14, "unit": "voxels/s",
-               "loss": float(l14)}
-    del m14
+               "loss": float(l14),
+               "roofline": {"kernel": ("convt_par_fwd_kernel (stage_6.t1 ConvTranspose3d 16->14 k7 s2 @64^3 -> 128^3, fwd: the patch of a tile "
+                                       "resident in LDS, the 8 output parities walked over exactly their window rows, split-bf16 MFMA)"
+                                       if walk else "stage_6.t1 forward on the generic engine"),
+                            "bound": "mfma", "achieved": CONVT6_FLOP_PER_CLASS * 14 * B / t1s / 1e12, "peak": peak14 / 1e12,
+                            "unit": "TFLOP/s", "frac": CONVT6_FLOP_PER_CLASS * 14 * B / t1s / peak14, "traffic": tr14.get("convt"),
+                            "traffic_source": f"{tr14_file} (separate rocprofv3 --pmc passes of `bench.py --classes 14`; not measured in this run)",
+                            "avg_launch_ms": t1s * 1e3,
+                            "note": "achieved counts the layer's real 2*M*K*N (16 x 343 taps x 14 classes per coarse voxel)"}}
+    del m14, pl14
   if rank != 0:
     return
   conv_s, ray_s = probes["conv3d_stage6_c1_fwd"], probes["ray_sample_fwd_64"]
@@ -486,6 +567,8 @@ def main():
     out["cpu_baseline"] = cpu_baseline(state0, batch_cpu, loss_name)
     del model, plan
     out["parity"] = parity_check(state0, batch_cpu, C, dev, args.math)
+    if C == 2 and not args.no_sr_side:
+      out["super_resolution_x2"] = super_resolution_leg(state0, batch_cpu, dev, args.math)
     out["cpu_baseline_fill_voxels"] = cpu_baseline_fill(shells.cpu())
   print(json.dumps(out))
 

@@ -77,6 +77,9 @@ _SIGS = {
     "crn_bf3_gather_image": [vp, vp, i32, vp, vp],
     "crn_convt_s2k7_fwd_bf3": [vp, i64, i32, i32, i32, i32, C.POINTER(CrnInTransform), vp, vp, vp, i64, i64, i32, vp],
     "crn_convt_s2k7_dgrad_bf3": [vp, i64, i64, i32, i32, i32, i32, i32, vp, vp, i64, i32, vp],
+    "crn_convt_s2k7_c2_fwd_bf3": [vp, i64, i32, i32, i32, i32, C.POINTER(CrnInTransform), vp, vp, vp, i64, i64, i32, vp],
+    "crn_convt_s2k7_c2_dgrad_bf3": [vp, i64, i64, i32, i32, i32, i32, i32, vp, vp, i64, i32, vp],
+    "crn_convt_s2k7_wgrad_bf3": [vp, i64, i32, i32, i32, i32, C.POINTER(CrnInTransform), vp, i64, i64, i32, vp, i32, i32, vp],
     "crn_splitk_defer": [i32],
     "crn_splitk_reserve": [i64, vp],
     "crn_splitk_release": [vp],

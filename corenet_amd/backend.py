@@ -168,20 +168,22 @@ class HipBackend:
     self.lib.crn_bf3_gather_image(ptr(src), ptr(table), table.shape[0], ptr(out), _lib.stream())
 
   def convt_par_fwd(self, x: t.Tensor, tr: Optional[Transform], wimg: t.Tensor, bias: Optional[t.Tensor], y: t.Tensor, cout: int,
-                    host_table=None):
+                    host_table=None, resident: bool = False):
     """ConvTranspose3d(16 -> cout, k 7, stride 2, padding 3, output_padding 1) of T(x) into channels [0, cout) of y
-    (csrc/convt_par.hip).  x [B,16,D,H,W] dense inside a sample, y [B,>=cout,2D,2H,2W]."""
+    (csrc/convt_par.hip).  x [B,16,D,H,W] dense inside a sample, y [B,>=cout,2D,2H,2W].  resident: the two-class kernel whose
+    weights stay in LDS (image from conv_geometry.convt_res_*_table instead of convt_par_*_table)."""
     B, cin, D, H, W = x.shape
     assert cin == 16 and x[0].is_contiguous() and y[0].is_contiguous() and tuple(y.shape[2:]) == (2 * D, 2 * H, 2 * W)
-    self.lib.crn_convt_s2k7_fwd_bf3(ptr(x), x.stride(0), B, D, H, W, _ctr(tr), ptr(wimg), ptr(bias), ptr(y), y.stride(0),
-                                    y.stride(1), cout, _lib.stream())
+    fn = self.lib.crn_convt_s2k7_c2_fwd_bf3 if resident else self.lib.crn_convt_s2k7_fwd_bf3
+    fn(ptr(x), x.stride(0), B, D, H, W, _ctr(tr), ptr(wimg), ptr(bias), ptr(y), y.stride(0), y.stride(1), cout, _lib.stream())
 
-  def convt_par_dgrad(self, dy: t.Tensor, cout: int, wimg: t.Tensor, dx: t.Tensor, accumulate: bool = False, host_table=None):
+  def convt_par_dgrad(self, dy: t.Tensor, cout: int, wimg: t.Tensor, dx: t.Tensor, accumulate: bool = False, host_table=None,
+                      resident: bool = False):
     """Data gradient of the same layer: dy [B,>=cout,2D,2H,2W] (channels [0, cout)) -> dx [B,16,D,H,W]."""
     B, cin, D, H, W = dx.shape
     assert cin == 16 and dx[0].is_contiguous() and dy[0].is_contiguous() and tuple(dy.shape[2:]) == (2 * D, 2 * H, 2 * W)
-    self.lib.crn_convt_s2k7_dgrad_bf3(ptr(dy), dy.stride(0), dy.stride(1), cout, B, D, H, W, ptr(wimg), ptr(dx), dx.stride(0),
-                                      int(accumulate), _lib.stream())
+    fn = self.lib.crn_convt_s2k7_c2_dgrad_bf3 if resident else self.lib.crn_convt_s2k7_dgrad_bf3
+    fn(ptr(dy), dy.stride(0), dy.stride(1), cout, B, D, H, W, ptr(wimg), ptr(dx), dx.stride(0), int(accumulate), _lib.stream())
 
   def conv2d_bf3(self, x: View, tr: Optional[Transform], wop: t.Tensor, npad: int, bias: Optional[t.Tensor],
                  bias_sB: int, y: View, window, pad_lo, accumulate: bool = False):
@@ -200,6 +202,16 @@ class HipBackend:
       self.lib.crn_conv_wgrad_2d_bf3(C.byref(_cview(x)), _ctr(tr), C.byref(_cview(dy)), ptr(dw), npad, window[1],
                                      window[2], pad_lo[1], pad_lo[2], int(zero_first), _lib.stream())
       return
+    if math == "ct_par":           # decoder stage_6.t1 with > 8 classes: the parity-walk weight gradient (csrc/convt_par.hip); x: the plain view
+      xs, ds = x.storage, dy.storage     # of the layer's input, dy: the space-to-depth view of the output gradient tensor
+      rc = self.lib._crn_convt_s2k7_wgrad_bf3(xs.data_ptr() + 4 * (x.offset - xs.storage_offset()), x.sB, x.B, x.D, x.H, x.W, _ctr(tr),
+                                              ds.data_ptr(), ds.stride(0), ds.stride(1), dy.C // 8, ptr(dw), npad, int(zero_first),
+                                              _lib.stream())
+      if rc == 0:
+        return
+      if rc != -1:                 # CRN_EINVAL: deterministic mode or a shape it does not cover -> the generic split-bf16 engine
+        raise _lib.HipError(f"crn_convt_s2k7_wgrad_bf3 failed with status {rc}")
+      math = "bf16x3"
     if math == "bf16x3":
       self.lib.crn_conv_wgrad_bf3_boxes(C.byref(_cview(x)), _ctr(tr), C.byref(_cview(dy)), ptr(dw), npad,
                                         window[0], window[1], window[2], pad_lo[0], pad_lo[1], pad_lo[2],

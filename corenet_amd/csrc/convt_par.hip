@@ -379,6 +379,444 @@ __global__ __launch_bounds__(kT) void convt_par_dgrad_kernel(CtGeom g) {
   }
 }
 
+// ------------------------------------------------------------------ weight gradient ----------------------------
+// dW[c, n, k] = sum over (b, q) of T(x)[b, c, q + z - 1] * dy[b, n, 2 q + r],  k = 5 - 2 z + r: per output parity r a GEMM
+// D_z[c][n] = X_z^T . dY_r with K = positions, like conv_bf3_wgrad_kernel (conv_bf3.hip) -- 32 positions per MFMA, both
+// operands read out of position-major LDS images with the transposing ds_read_b64_tr_b16 -- but cut the way the layer is:
+// a workgroup owns ONE (rd, rh) pair (blockIdx.x), both rw (2 x 16 columns), ALL 16 input channels (the MFMA's 16 rows = 2
+// chunks x 8 channels of one tap instead of 2 taps x 8 channels) and a slice of the 2 x 8 x 16 position tiles (blockIdx.y).
+// So dy is read once in total (each pair's workgroups load only their own fine rows, 16-byte loads that serve both rw), the
+// taps are exactly the (3 + rd)(3 + rh) 4 of the pair's box, dealt round-robin to the 8 waves, and nothing is multiplied for
+// columns of another parity (the generic kernel's 16-column blocks straddle parities at 14 classes: 956 us at B = 4).
+// Partial sums go to the layer's packed gradient [c][64 window taps][Npad] (parity-major columns, conv_geometry.convt_fwd)
+// with fire-and-forget atomics, like the generic kernel: the un-pack is unchanged.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+constexpr int WTD = 2, WPD = WTD + 3, WNP = WPD * PHW;       // weight-gradient tile: 2 x 8 x 16 positions = 8 K blocks of 32
+constexpr int kWgPos = WTD * TH * TW;                        // 256
+constexpr size_t kLdsWg = kLdsTab + (size_t)4 * WNP * 16 + (size_t)2 * kWgPos * 32 * 2;
+
+struct CtWgGeom {
+  const float* x; long long x_sB; int B, D, H, W;
+  const float* scale; const float* shift; int pre_relu, post_relu;
+  const float* dy; long long dy_sB, dy_sC; int Cout;
+  float* dw; int Npad;
+  int tilesD, tilesH, tilesW, ntiles, tiles_per_split;
+};
+
+template <int TPW>
+__device__ __forceinline__ void convt_par_wgrad_body(const CtWgGeom& g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tscale = reinterpret_cast<float*>(smem);
+  float* tshift = tscale + 16;
+  char* Xhi = smem + kLdsTab;                                // [2 chunks][WNP] entries of 8 bf16
+  char* Xlo = Xhi + (size_t)2 * WNP * 16;
+  char* Yhi = Xlo + (size_t)2 * WNP * 16;                    // [256 positions][32 columns] bf16
+  char* Ylo = Yhi + (size_t)kWgPos * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, kk = lane >> 4;
+  const int pp = blockIdx.x, rd = pp >> 1, rh = pp & 1, dz = 3 + rd, dh = 3 + rh;
+  const int ntaps = dz * dh * 4;
+  const int tbeg = min((int)blockIdx.y * g.tiles_per_split, g.ntiles), tend = min(tbeg + g.tiles_per_split, g.ntiles);
+
+  if (tid < 16) {
+    tscale[tid] = g.scale ? g.scale[tid] : 1.f;
+    tshift[tid] = g.scale ? g.shift[tid] : 0.f;
+  }
+  // transposing reads: lane = row j of the [4 K][16 M] block of its 16-lane group, column quad q (conv_bf3_wgrad_kernel)
+  const int j = i16 >> 2, q = i16 & 3;
+  const int k1 = kk * 8 + j;                                 // K index inside the 32-position block (second read: + 4)
+  // A (input patch): column quad q = (chunk q >> 1, channel half q & 1) of the 16 input channels
+  const int abase = (((k1 >> 4) * PW + (k1 & 15)) << 4) + ((q & 1) << 3) + (q >> 1) * (WNP * 16);
+  // TPW = taps per wave = ceil(ntaps / 8): 36 / 48 / 48 / 64 taps -> 5 / 6 / 6 / 8 (compile time: the tap loop is straight-line
+  // code and software-pipelined).  Wave w multiplies taps w + 8 ti; with 36 taps waves 4-7 have no fifth one: they multiply the
+  // clamped last tap once more and drop the result (an eighth of that pair's MFMAs, no branch in the loop)
+  int toffL[TPW];
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti) {
+    const int tp = min(wave + 8 * ti, ntaps - 1);
+    const int zw = tp & 3, zr = tp >> 2, zh = zr % dh, zd = zr / dh;
+    toffL[ti] = ((zd * PH + zh) * PW + zw) << 4;
+  }
+  const int ybase = k1 * 64 + (q << 3);
+  constexpr int xlo = 2 * WNP * 16, ylo = kWgPos * 64;
+
+  f32x4 acc[TPW][2];
+#pragma unroll
+  for (int ti = 0; ti < TPW; ++ti) { acc[ti][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[ti][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  // staging units.  x: (patch row, 16-byte quad) x 16 channels, threads 0 .. 329; dy: (position pair, 8-channel half of n) of
+  // the pair's fine rows -- one 16-byte load = 2 positions x 2 rw --, threads 256 .. 511
+  constexpr int kXUnits = WPD * PH * 6;                      // 330
+  const int xu = tid < kXUnits ? tid : 0;
+  const int xrow = xu / 6, xquad = xu - xrow * 6;
+  const int xpz = xrow / PH, xpy = xrow - xpz * PH;
+  const int du = (tid - 256) & 255, dpq = du & 127, doct = du >> 7;
+  const int dp = dpq * 2, dwp = dp & 15, dhp = (dp >> 4) & 7, ddp = dp >> 7;
+  f32x4 pv[16], dv[8];
+  bool xin = false;
+  int b = 0, d0 = 0, h0 = 0, w0 = 0;
+  const int OH = 2 * g.H, OW = 2 * g.W;
+  auto tile_origin = [&](int tl) {
+    int tile = tl;
+    const int twi = tile % g.tilesW; tile /= g.tilesW;
+    const int thi = tile % g.tilesH; tile /= g.tilesH;
+    const int tdi = tile % g.tilesD; tile /= g.tilesD;
+    b = tile; d0 = tdi * WTD; h0 = thi * TH; w0 = twi * TW;
+  };
+  auto stage_issue = [&]() {
+    const crn_rsrc xrs = make_rsrc(g.x + (long long)b * g.x_sB);
+    const crn_rsrc drs = make_rsrc(g.dy + (long long)b * g.dy_sB);
+    const int gd = d0 + xpz - 1, gh = h0 + xpy - 1, gw = w0 - 4 + 4 * xquad;
+    xin = tid < kXUnits && (unsigned)gd < (unsigned)g.D && (unsigned)gh < (unsigned)g.H && (unsigned)gw < (unsigned)g.W;
+    const unsigned sp = ((unsigned)gd * (unsigned)g.H + (unsigned)gh) * (unsigned)g.W + (unsigned)gw;
+    const unsigned sC = (unsigned)g.D * (unsigned)g.H * (unsigned)g.W;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) crn_bload4(pv[c], xrs, xin ? ((unsigned)c * sC + sp) * 4u : 0x80000000u);
+    const unsigned od = 2 * (d0 + ddp) + rd, oh = 2 * (h0 + dhp) + rh, ow = 2 * (w0 + dwp);
+    const unsigned dsp = (od * (unsigned)OH + oh) * (unsigned)OW + ow;
+#pragma unroll
+    for (int cl = 0; cl < 8; ++cl) {
+      const int n = doct * 8 + cl;
+      crn_bload4(dv[cl], drs, (tid >= 256 && n < g.Cout) ? ((unsigned)n * (unsigned)g.dy_sC + dsp) * 4u : 0x80000000u);
+    }
+  };
+  auto stage_commit = [&]() {
+    if (tid < kXUnits) {
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(tscale + ch * 8), s1 = *reinterpret_cast<const f32x4*>(tscale + ch * 8 + 4);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tshift + ch * 8), t1 = *reinterpret_cast<const f32x4*>(tshift + ch * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int pl = 4 * xquad + e - 3;
+          if (pl < 0 || pl >= PW) continue;
+          float v[8];
+#pragma unroll
+          for (int cl = 0; cl < 8; ++cl) {
+            float a = pv[ch * 8 + cl][e];
+            if (g.scale && xin) {
+              const float sc = cl < 4 ? s0[cl & 3] : s1[cl & 3], sh = cl < 4 ? t0[cl & 3] : t1[cl & 3];
+              if (g.pre_relu) a = fmaxf(a, 0.f);
+              a = a * sc + sh;
+              if (g.post_relu) a = fmaxf(a, 0.f);
+            }
+            v[cl] = a;
+          }
+          bf16x8 h, l;
+          split8(v, h, l);
+          *reinterpret_cast<bf16x8*>(Xhi + ((size_t)ch * WNP + xrow * PW + pl) * 16) = h;
+          *reinterpret_cast<bf16x8*>(Xlo + ((size_t)ch * WNP + xrow * PW + pl) * 16) = l;
+        }
+      }
+    }
+    if (tid >= 256) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {                            // element e = (position e >> 1 of the pair, rw e & 1)
+        float v[8];
+#pragma unroll
+        for (int cl = 0; cl < 8; ++cl) v[cl] = dv[cl][e];
+        bf16x8 h, l;
+        split8(v, h, l);
+        const size_t o = (size_t)(dp + (e >> 1)) * 64 + (size_t)((e & 1) * 16 + doct * 8) * 2;
+        *reinterpret_cast<bf16x8*>(Yhi + o) = h;
+        *reinterpret_cast<bf16x8*>(Ylo + o) = l;
+      }
+    }
+  };
+  auto trd = [&](const char* p) -> bf16x4 { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p)); };
+  auto cat = [](bf16x4 a, bf16x4 c) -> bf16x8 { return __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7); };
+
+  if (tbeg < tend) { tile_origin(tbeg); stage_issue(); }
+  for (int tl = tbeg; tl < tend; ++tl) {
+    crn_wait_loads4n(pv);
+    crn_wait_loads4n(dv);
+    __syncthreads();
+    stage_commit();
+    __syncthreads();
+    if (tl + 1 < tend) { tile_origin(tl + 1); stage_issue(); }
+    // Software-pipelined over (K block kb, tap ti): the transposing reads of the NEXT unit's A fragments (at the last tap of a K
+    // block: the next block's B fragments too) are issued before the MFMAs of the current one -- two waves per SIMD cannot hide an LDS
+    // round trip per MFMA pair otherwise (conv_bf3_wgrad_kernel, profiles/r03_wgrad_pipe_ab.txt)
+    auto kbx_of = [&](int kb) { return (((kb >> 2) * PH + (kb & 3) * 2) * PW) << 4; };      // K block kb = (plane, H row pair)
+    bf16x8 bh[2][2], bl[2][2], ah[2], al[2];
+    auto ldB = [&](int kb, int qb) {
+      const char* yb = Yhi + ybase + kb * (32 * 64);
+#pragma unroll
+      for (int ns = 0; ns < 2; ++ns) {
+        bh[qb][ns] = cat(trd(yb + ns * 32), trd(yb + ns * 32 + 4 * 64));
+        bl[qb][ns] = cat(trd(yb + ylo + ns * 32), trd(yb + ylo + ns * 32 + 4 * 64));
+      }
+    };
+    auto ldA = [&](int kbx, int ti, int qa) {
+      const char* xa = Xhi + abase + toffL[ti] + kbx;
+      ah[qa] = cat(trd(xa), trd(xa + 64));
+      al[qa] = cat(trd(xa + xlo), trd(xa + xlo + 64));
+    };
+    auto block = [&](int kb, auto QB_) {
+      constexpr int qb = decltype(QB_)::value;
+      const int kbx = kbx_of(kb);
+#pragma unroll
+      for (int ti = 0; ti < TPW; ++ti) {
+        const int qa = (TPW & 1) ? ((qb * TPW + ti) & 1) : (ti & 1);       // A buffers alternate across the whole stream
+        if (ti + 1 < TPW) ldA(kbx, ti + 1, qa ^ 1);
+        else { const int kn = min(kb + 1, 7); ldB(kn, qb ^ 1); ldA(kbx_of(kn), 0, qa ^ 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(acc[ti][0], ah[qa], al[qa], bh[qb][0], bl[qb][0]);
+        mfma3(acc[ti][1], ah[qa], al[qa], bh[qb][1], bl[qb][1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    ldB(0, 0);
+    ldA(kbx_of(0), 0, 0);
+#pragma unroll 1
+    for (int kb = 0; kb < 8; kb += 2) {
+      block(kb, std::integral_constant<int, 0>());
+      block(kb + 1, std::integral_constant<int, 1>());
+    }
+  }
+
+  // D row m = 4 kk + r = input channel c, column i16 = n of block ns = rw; packed gradient [c][(zd * 4 + zh) * 4 + zw][Npad]
+  if (i16 < g.Cout) {
+#pragma unroll
+    for (int ti = 0; ti < TPW; ++ti) {
+      const int tp = wave + 8 * ti;
+      if (tp >= ntaps) continue;                               // (the clamped duplicate of waves 4-7 at 36 taps)
+      const int zw = tp & 3, zr = tp >> 2, zh = zr % dh, zd = zr / dh;
+#pragma unroll
+      for (int ns = 0; ns < 2; ++ns) {
+        if (zw == 3 && ns == 0) continue;                      // (k = 5 - 2 z + r < 0: no such tap for rw = 0)
+        const int col = ((rd * 2 + rh) * 2 + ns) * g.Cout + i16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = kk * 4 + r;
+          atomicAdd(g.dw + ((long long)c * 64 + (zd * 4 + zh) * 4 + zw) * g.Npad + col, acc[ti][ns][r]);
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kT) void convt_par_wgrad_kernel(CtWgGeom g) {
+  crn_kernarg_touch(g);
+  switch (blockIdx.x) {                                      // the (rd, rh) pair: 36 / 48 / 48 / 64 taps
+    case 0: convt_par_wgrad_body<5>(g); break;
+    case 3: convt_par_wgrad_body<8>(g); break;
+    default: convt_par_wgrad_body<6>(g); break;
+  }
+}
+
+// ------------------------------------------------------------------ two classes: resident weights ----------------------
+// With 2 classes (h7) the 8 parities x 2 classes are ONE 16-column block and the whole layer's weights -- 2 chunks x 4^3 taps
+// x 16 columns, 64 KB as bf16 hi / lo -- fit in LDS next to the tile's patch.  The generic engine re-stages a 4 KB weight slab
+// and meets at two barriers for every 16 MFMA triples of a wave there (forward 151 us, data gradient 159 us + the fused sums;
+// 0.18 / 0.11 of the roof).  Here a PERSISTENT workgroup (one per CU) loads the weights once by LDS-DMA and walks its tiles:
+// per tile two barriers around the patch commit, the next tile's loads in flight under this tile's 112-128 triples per wave.
+//   forward       : chunk = 8 of the 16 input channels, columns (rd, rh, rw, n); the pixel-shuffle store pairs the rw = 0 / 1
+//                   lanes with one DPP exchange so that every lane writes 16 bytes.
+//   data gradient : chunk = rd, the 8 channels of an entry are (rh, rw, n) of dy -- one 16-byte load = 2 positions x 2 rw --,
+//                   columns = the 16 input channels; rd = 0 has no tap on window plane 0.
+constexpr int RPW = 19, RPHW = PH * RPW, RNP = PD * RPHW;    // (19 columns: patch + weights stay under 160 KiB)
+constexpr int kResW = 2 * 4 * 4 * 4 * 16;                    // entries of the hi (or lo) half of the resident weights
+constexpr size_t kLdsRes = kLdsTab + (size_t)4 * RNP * 16 + (size_t)2 * kResW * 16;
+
+template <bool DGRAD>
+__global__ __launch_bounds__(kT) void convt_res_kernel(CtGeom g, int ntiles, int tiles_per_wg) {
+  crn_kernarg_touch(g);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* tscale = reinterpret_cast<float*>(smem);
+  float* tshift = tscale + 16;
+  bf16x8* Ahi = reinterpret_cast<bf16x8*>(smem + kLdsTab);   // [2 chunks][RNP]
+  bf16x8* Alo = Ahi + 2 * RNP;
+  bf16x8* Bhi = Alo + 2 * RNP;                               // [chunk][zd][zh][tap][16 columns]
+  bf16x8* Blo = Bhi + kResW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, kk = lane >> 4;
+  {
+    const crn_rsrc wrs = make_rsrc(reinterpret_cast<const float*>(g.wimg));
+    const unsigned lds_w = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(Bhi);
+#pragma unroll
+    for (int jp = 0; jp < 8; ++jp) {                         // 64 pieces of 1 KiB: the image IS the LDS layout (hi, then lo)
+      const int piece = wave * 8 + jp;
+      const unsigned m = __builtin_amdgcn_readfirstlane(lds_w + (unsigned)piece * 1024u);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                   :: "s"(m), "v"((unsigned)piece * 1024u + (unsigned)lane * 16u), "s"(wrs) : "memory");
+    }
+  }
+  if (!DGRAD && tid < 16) {
+    tscale[tid] = g.scale ? g.scale[tid] : 1.f;
+    tshift[tid] = g.scale ? g.shift[tid] : 0.f;
+  }
+  const int tbeg = min((int)blockIdx.x * tiles_per_wg, ntiles), tend = min(tbeg + tiles_per_wg, ntiles);
+  int b = 0, d0 = 0, h0 = 0, w0 = 0;
+  auto tile_origin = [&](int tl) {
+    int tile = tl;
+    const int twi = tile % g.tilesW; tile /= g.tilesW;
+    const int thi = tile % g.tilesH; tile /= g.tilesH;
+    const int tdi = tile % g.tilesD; tile /= g.tilesD;
+    b = tile; d0 = tdi * TD; h0 = thi * TH; w0 = twi * TW;
+  };
+  const int OD = 2 * g.D, OH = 2 * g.H, OW = 2 * g.W;
+  // ---- staging ----
+  // forward: unit = (patch row, 16-byte quad from w0 - 4), 16 channels; 462 units.  data gradient: unit = (chunk rd, patch row,
+  // position pair), loads (rh, n); rows of chunk 1 (rd = 1: 7 planes) first, then chunk 0 (planes 1 .. 6): 1430 units, 3 per thread
+  constexpr int kNL = DGRAD ? 12 : 16;
+  f32x4 pv[kNL];
+  bool xin = false;
+  constexpr int kFUnits = PD * PH * 6, kDRows1 = PD * PH, kDUnits = (PD + PD - 1) * PH * 10;
+  auto stage_issue = [&]() {
+    if constexpr (!DGRAD) {
+      const crn_rsrc xrs = make_rsrc(g.x + (long long)b * g.x_sB);
+      const int u = tid < kFUnits ? tid : 0;
+      const int row = u / 6, quad = u - row * 6;
+      const int pz = row / PH, py = row - pz * PH;
+      const int gd = d0 + pz - 1, gh = h0 + py - 1, gw = w0 - 4 + 4 * quad;
+      xin = tid < kFUnits && (unsigned)gd < (unsigned)g.D && (unsigned)gh < (unsigned)g.H && (unsigned)gw < (unsigned)g.W;
+      const unsigned sp = ((unsigned)gd * (unsigned)g.H + (unsigned)gh) * (unsigned)g.W + (unsigned)gw;
+      const unsigned sC = (unsigned)g.D * (unsigned)g.H * (unsigned)g.W;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) crn_bload4(pv[c], xrs, xin ? ((unsigned)c * sC + sp) * 4u : 0x80000000u);
+    } else {
+      const crn_rsrc yrs = make_rsrc(g.y + (long long)b * g.y_sB);
+#pragma unroll
+      for (int jx = 0; jx < 3; ++jx) {
+        const int u = min(tid + jx * kT, kDUnits - 1);
+        const int r = u / 10, pair = u - r * 10;
+        const int rd = r < kDRows1 ? 1 : 0, rr = rd ? r : r - kDRows1 + PH;           // patch row (plane * PH + py)
+        const int pz = rr / PH, py = rr - pz * PH;
+        const int od = 2 * (d0 - 2 + pz) + rd, ow = 2 * w0 - 4 + 4 * pair;
+        const bool inz = tid + jx * kT < kDUnits && (unsigned)od < (unsigned)OD && (unsigned)ow < (unsigned)OW;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                          // e = (rh, n)
+          const int rh = e >> 1, n = e & 1;
+          const int oh = 2 * (h0 - 2 + py) + rh;
+          const bool in = inz && (unsigned)oh < (unsigned)OH && n < g.Cout;
+          crn_bload4(pv[jx * 4 + e], yrs, in ? ((unsigned)n * (unsigned)g.y_sC + ((unsigned)od * (unsigned)OH + (unsigned)oh) * (unsigned)OW + (unsigned)ow) * 4u
+                                             : 0x80000000u);
+        }
+      }
+    }
+  };
+  auto stage_commit = [&]() {
+    if constexpr (!DGRAD) {
+      if (tid < kFUnits) {
+        const int row = tid / 6, quad = tid - row * 6;
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(tscale + ch * 8), s1 = *reinterpret_cast<const f32x4*>(tscale + ch * 8 + 4);
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(tshift + ch * 8), t1 = *reinterpret_cast<const f32x4*>(tshift + ch * 8 + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int pl = 4 * quad + e - 3;
+            if (pl < 0 || pl >= RPW) continue;
+            float v[8];
+#pragma unroll
+            for (int cl = 0; cl < 8; ++cl) {
+              float a = pv[ch * 8 + cl][e];
+              if (g.scale && xin) {
+                const float sc = cl < 4 ? s0[cl & 3] : s1[cl & 3], sh = cl < 4 ? t0[cl & 3] : t1[cl & 3];
+                if (g.pre_relu) a = fmaxf(a, 0.f);
+                a = a * sc + sh;
+                if (g.post_relu) a = fmaxf(a, 0.f);
+              }
+              v[cl] = a;
+            }
+            bf16x8 h, l;
+            split8(v, h, l);
+            Ahi[ch * RNP + row * RPW + pl] = h;
+            Alo[ch * RNP + row * RPW + pl] = l;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int jx = 0; jx < 3; ++jx) {
+        const int u = tid + jx * kT;
+        if (u < kDUnits) {
+          const int r = u / 10, pair = u - r * 10;
+          const int rd = r < kDRows1 ? 1 : 0, rr = rd ? r : r - kDRows1 + PH;
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            if (2 * pair + px >= RPW) continue;
+            float v[8];
+#pragma unroll
+            for (int jc = 0; jc < 8; ++jc) {                  // channel jc of the entry = (rh, rw, n)
+              const int rh = jc >> 2, rw = (jc >> 1) & 1, n = jc & 1;
+              v[jc] = pv[jx * 4 + rh * 2 + n][2 * px + rw];
+            }
+            bf16x8 h, l;
+            split8(v, h, l);
+            Ahi[rd * RNP + rr * RPW + 2 * pair + px] = h;
+            Alo[rd * RNP + rr * RPW + 2 * pair + px] = l;
+          }
+        }
+      }
+    }
+  };
+
+  const int sd = wave >> 1, sh0 = (wave & 1) * 4;
+  const unsigned pa = (unsigned)((sd * PH + sh0) * RPW + i16 + kk);
+  const float bsv = (!DGRAD && g.bias) ? g.bias[i16 & 1] : 0.f;      // (2 classes: column = parity * 2 + n)
+  if (tbeg < tend) { tile_origin(tbeg); stage_issue(); }
+  for (int tl = tbeg; tl < tend; ++tl) {
+#pragma unroll
+    for (int i = 0; i < kNL; ++i) asm volatile("s_waitcnt vmcnt(0)" : "+v"(pv[i]));
+    __syncthreads();                                         // nobody reads the previous tile's patch any more (first trip: the tables and weights are in LDS)
+    stage_commit();
+    __syncthreads();
+    const int cb = b, cd0 = d0, ch0 = h0, cw0 = w0;
+    if (tl + 1 < tend) { tile_origin(tl + 1); stage_issue(); }
+    f32x4 acc[4];
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) acc[ms] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll 1
+      for (int zd = DGRAD ? 1 - c : 0; zd < 4; ++zd) {
+        const bf16x8* Ah = Ahi + c * RNP + zd * RPHW;
+        const bf16x8* Al = Alo + c * RNP + zd * RPHW;
+        const bf16x8* bh0 = Bhi + (c * 4 + zd) * 256;
+        const bf16x8* bl0 = Blo + (c * 4 + zd) * 256;
+#pragma unroll
+        for (int zh = 0; zh < 4; ++zh) {
+          const bf16x8 bh = bh0[(zh * 4 + kk) * 16 + i16], bl = bl0[(zh * 4 + kk) * 16 + i16];
+          bf16x8 ah[4], al[4];
+#pragma unroll
+          for (int ms = 0; ms < 4; ++ms) { ah[ms] = Ah[pa + (unsigned)((ms + zh) * RPW)]; al[ms] = Al[pa + (unsigned)((ms + zh) * RPW)]; }
+#pragma unroll
+          for (int ms = 0; ms < 4; ++ms) mfma3(acc[ms], ah[ms], al[ms], bh, bl);
+        }
+      }
+    }
+    if constexpr (DGRAD) {
+      float* dxb = const_cast<float*>(g.x) + (long long)cb * g.x_sB + (long long)i16 * ((long long)g.D * g.H * g.W);
+#pragma unroll
+      for (int ms = 0; ms < 4; ++ms) {
+        float* dst = dxb + ((long long)(cd0 + sd) * g.H + (ch0 + sh0 + ms)) * g.W + cw0 + 4 * kk;
+        f32x4 v = acc[ms];
+        if (g.accumulate) v += *reinterpret_cast<const f32x4*>(dst);
+        *reinterpret_cast<f32x4*>(dst) = v;
+      }
+    } else {
+      // column i16 = ((rd * 2 + rh) * 2 + rw) * 2 + n.  The lane pair (rw 0, rw 1) = (lane, lane ^ 2) holds the two interleaved
+      // halves of the same 8 output floats: rw 0 keeps positions 0, 1 and takes the partner's, rw 1 keeps 2, 3 -- one 16-byte store each
+      const int rw = (i16 >> 1) & 1, n = i16 & 1, rh = (i16 >> 2) & 1, rd = i16 >> 3;
+      if (n < g.Cout) {
+        float* yb = g.y + (long long)cb * g.y_sB + (long long)n * g.y_sC;
+#pragma unroll
+        for (int ms = 0; ms < 4; ++ms) {
+          const f32x4 a = acc[ms] + bsv;
+          const float s0 = rw ? a[0] : a[2], s1 = rw ? a[1] : a[3];           // what the partner needs
+          const float p0 = __shfl_xor(s0, 2), p1 = __shfl_xor(s1, 2);
+          const f32x4 v = rw ? (f32x4){p0, a[2], p1, a[3]} : (f32x4){a[0], p0, a[1], p1};
+          const int od = 2 * (cd0 + sd) + rd, oh = 2 * (ch0 + sh0 + ms) + rh, ow = 2 * (cw0 + 4 * kk) + 4 * rw;
+          *reinterpret_cast<f32x4*>(yb + ((long long)od * OH + oh) * OW + ow) = v;
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ weight image -------------------------------
 // dst entry (16 B) table[e][8] = 8 bf16 hi of src[table[e][0..7]] (index < 0: 0), entry table[e][9] their lo parts
 __global__ __launch_bounds__(256) void bf3_gather_image_kernel(const float* src, const int* table, int n, char* dst) {
@@ -448,6 +886,89 @@ extern "C" int crn_convt_s2k7_dgrad_bf3(const float* dy, int64_t dy_sB, int64_t 
   }();
   if (!attr) return CRN_EINVAL;
   hipLaunchKernelGGL(convt_par_dgrad_kernel, dim3((unsigned)tiles), dim3(kT), kLdsFwd, (hipStream_t)stream, g);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_convt_s2k7_wgrad_bf3(const float* x, int64_t x_sB, int B, int D, int H, int W, const crnInTransform* tr,
+                                        const float* dy, int64_t dy_sB, int64_t dy_sC, int Cout, float* dw, int Npad,
+                                        int zero_first, crnStream stream) {
+  CRN_ENTRY(stream);
+  if (!x || !dy || !dw || B < 1 || Cout < 1 || Cout > 16 || Npad < 8 * Cout) return CRN_EINVAL;
+  if (D % WTD || H % TH || W % TW) return CRN_EINVAL;
+  if (crn_deterministic()) return CRN_EINVAL;                 // (split sums with atomics: the caller takes the generic engine)
+  if ((int64_t)16 * D * H * W >= ((int64_t)1 << 29) || (int64_t)Cout * dy_sC >= ((int64_t)1 << 29)) return CRN_EINVAL;
+  if ((((uintptr_t)x) & 15) || (x_sB & 3) || (((uintptr_t)dy) & 15) || (dy_sB & 3) || (dy_sC & 3)) return CRN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (zero_first) CRN_HIP(hipMemsetAsync(dw, 0, (size_t)16 * 64 * Npad * sizeof(float), st));
+  CtWgGeom g{};
+  g.x = x; g.x_sB = x_sB; g.B = B; g.D = D; g.H = H; g.W = W;
+  if (tr && tr->scale) { g.scale = tr->scale; g.shift = tr->shift; g.pre_relu = tr->pre_relu; g.post_relu = tr->post_relu; }
+  g.dy = dy; g.dy_sB = dy_sB; g.dy_sC = dy_sC; g.Cout = Cout; g.dw = dw; g.Npad = Npad;
+  g.tilesD = D / WTD; g.tilesH = H / TH; g.tilesW = W / TW;
+  const int64_t ntiles = (int64_t)B * g.tilesD * g.tilesH * g.tilesW;
+  if (ntiles > 0x7fffffff) return CRN_EINVAL;
+  g.ntiles = (int)ntiles;
+  static const int kSplits = getenv("CRN_CT_WG_SPLITS") ? std::max(1, atoi(getenv("CRN_CT_WG_SPLITS"))) : 64;   // 4 pairs x 64 = one round of 256 CUs
+  int splits = (int)std::min<int64_t>(kSplits, ntiles);
+  g.tiles_per_split = crn_cdiv(ntiles, splits);
+  splits = crn_cdiv(ntiles, g.tiles_per_split);
+  static const bool attr = [] {
+    return hipFuncSetAttribute((const void*)convt_par_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsWg) == hipSuccess;
+  }();
+  if (!attr) return CRN_EINVAL;
+  hipLaunchKernelGGL(convt_par_wgrad_kernel, dim3(4, (unsigned)splits), dim3(kT), kLdsWg, st, g);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+// Two classes (h7): the resident-weights kernels (see convt_res_kernel).  wimg: conv_geometry.convt_res_fwd_table / _dgrad_table.
+extern "C" int crn_convt_s2k7_c2_fwd_bf3(const float* x, int64_t x_sB, int B, int D, int H, int W, const crnInTransform* tr,
+                                         const void* wimg, const float* bias, float* y, int64_t y_sB, int64_t y_sC, int Cout,
+                                         crnStream stream) {
+  CRN_ENTRY(stream);
+  if (!x || !wimg || !y || B < 1 || Cout != 2) return CRN_EINVAL;
+  if (D % TD || H % TH || W % TW) return CRN_EINVAL;
+  if ((int64_t)16 * D * H * W >= ((int64_t)1 << 29)) return CRN_EINVAL;
+  if ((((uintptr_t)x) & 15) || (x_sB & 3) || (((uintptr_t)y) & 15) || (y_sB & 3) || (y_sC & 3)) return CRN_EINVAL;
+  CtGeom g{};
+  g.x = x; g.x_sB = x_sB; g.B = B; g.D = D; g.H = H; g.W = W;
+  if (tr && tr->scale) { g.scale = tr->scale; g.shift = tr->shift; g.pre_relu = tr->pre_relu; g.post_relu = tr->post_relu; }
+  g.wimg = wimg; g.bias = bias; g.y = y; g.y_sB = y_sB; g.y_sC = y_sC; g.Cout = Cout;
+  g.tilesD = D / TD; g.tilesH = H / TH; g.tilesW = W / TW;
+  const int64_t tiles = (int64_t)B * g.tilesD * g.tilesH * g.tilesW;
+  if (tiles > 0x7fffffff) return CRN_EINVAL;
+  static const int kWgs = getenv("CRN_CT_RES_WGS") ? std::max(1, atoi(getenv("CRN_CT_RES_WGS"))) : 256;
+  const int per = crn_cdiv(tiles, std::min<int64_t>(tiles, kWgs)), wgs = crn_cdiv(tiles, per);
+  static const bool attr = [] {
+    return hipFuncSetAttribute((const void*)convt_res_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsRes) == hipSuccess;
+  }();
+  if (!attr) return CRN_EINVAL;
+  hipLaunchKernelGGL(convt_res_kernel<false>, dim3((unsigned)wgs), dim3(kT), kLdsRes, (hipStream_t)stream, g, (int)tiles, per);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
+extern "C" int crn_convt_s2k7_c2_dgrad_bf3(const float* dy, int64_t dy_sB, int64_t dy_sC, int Cout, int B, int D, int H, int W,
+                                           const void* wimg, float* dx, int64_t dx_sB, int accumulate, crnStream stream) {
+  CRN_ENTRY(stream);
+  if (!dy || !wimg || !dx || B < 1 || Cout < 1 || Cout > 2) return CRN_EINVAL;
+  if (D % TD || H % TH || W % TW) return CRN_EINVAL;
+  if ((int64_t)Cout * dy_sC >= ((int64_t)1 << 29)) return CRN_EINVAL;
+  if ((((uintptr_t)dy) & 15) || (dy_sB & 3) || (dy_sC & 3) || (((uintptr_t)dx) & 15) || (dx_sB & 3)) return CRN_EINVAL;
+  CtGeom g{};
+  g.x = dx; g.x_sB = dx_sB; g.B = B; g.D = D; g.H = H; g.W = W;
+  g.wimg = wimg; g.y = const_cast<float*>(dy); g.y_sB = dy_sB; g.y_sC = dy_sC; g.Cout = Cout; g.accumulate = accumulate ? 1 : 0;
+  g.tilesD = D / TD; g.tilesH = H / TH; g.tilesW = W / TW;
+  const int64_t tiles = (int64_t)B * g.tilesD * g.tilesH * g.tilesW;
+  if (tiles > 0x7fffffff) return CRN_EINVAL;
+  static const int kWgs = getenv("CRN_CT_RES_WGS") ? std::max(1, atoi(getenv("CRN_CT_RES_WGS"))) : 256;
+  const int per = crn_cdiv(tiles, std::min<int64_t>(tiles, kWgs)), wgs = crn_cdiv(tiles, per);
+  static const bool attr = [] {
+    return hipFuncSetAttribute((const void*)convt_res_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsRes) == hipSuccess;
+  }();
+  if (!attr) return CRN_EINVAL;
+  hipLaunchKernelGGL(convt_res_kernel<true>, dim3((unsigned)wgs), dim3(kT), kLdsRes, (hipStream_t)stream, g, (int)tiles, per);
   CRN_CHECK_LAUNCH();
   return CRN_OK;
 }

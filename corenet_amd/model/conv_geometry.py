@@ -418,3 +418,46 @@ def convt_par_dgrad_table(wshape, wofs: int = 0):
           return [(wofs + ((c * N + nh * 8 + j) * ks + kd) * ks * ks + kh * ks + kw) if nh * 8 + j < N else -1 for j in range(8)]
         steps.append((3 + rh, entry))
   return _ct_table(steps)
+
+
+def convt_res_fwd_table(wshape, wofs: int = 0):
+  """Two classes: the resident-weights forward kernel (convt_res_kernel<false>).  Image = its LDS layout: hi[chunk][zd][zh][tap zw][16
+  columns] then lo[...]; column = ((rd * 2 + rh) * 2 + rw) * 2 + n; entry = 8 input channels of the chunk; tap k = 5 - 2 z + r."""
+  Cc, N, ks = wshape[0], wshape[1], wshape[2]
+  assert Cc == 16 and ks == 7 and N == 2
+  tab = []
+  for c in range(2):
+    for zd in range(4):
+      for zh in range(4):
+        for kk in range(4):
+          for col in range(16):
+            rd, rh, rw, n = col >> 3, (col >> 2) & 1, (col >> 1) & 1, col & 1
+            kd, kh, kw = 5 - 2 * zd + rd, 5 - 2 * zh + rh, 5 - 2 * kk + rw
+            e = ((c * 4 + zd) * 4 + zh) * 64 + kk * 16 + col
+            if min(kd, kh, kw) < 0:
+              src = [-1] * 8
+            else:
+              src = [wofs + (((c * 8 + j) * N + n) * ks + kd) * ks * ks + kh * ks + kw for j in range(8)]
+            tab.append(src + [e, 2048 + e])
+  return np.asarray(tab, np.int32), 2 * 2048 * 16
+
+
+def convt_res_dgrad_table(wshape, wofs: int = 0):
+  """... and its data gradient (convt_res_kernel<true>): chunk = rd, the 8 channels of an entry are (rh, rw, n) of dy, column = input
+  channel c; tap k = 2 z - 1 + r."""
+  Cc, N, ks = wshape[0], wshape[1], wshape[2]
+  assert Cc == 16 and ks == 7 and N <= 2
+  tab = []
+  for rd in range(2):
+    for zd in range(4):
+      for zh in range(4):
+        for kk in range(4):
+          for c in range(16):
+            e = ((rd * 4 + zd) * 4 + zh) * 64 + kk * 16 + c
+            src = []
+            for j in range(8):
+              rh, rw, n = j >> 2, (j >> 1) & 1, j & 1
+              kd, kh, kw = 2 * zd - 1 + rd, 2 * zh - 1 + rh, 2 * kk - 1 + rw
+              src.append(-1 if min(kd, kh, kw) < 0 or n >= N else wofs + ((c * N + n) * ks + kd) * ks * ks + kh * ks + kw)
+            tab.append(src + [e, 2048 + e])
+  return np.asarray(tab, np.int32), 2 * 2048 * 16

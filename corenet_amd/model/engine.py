@@ -195,6 +195,7 @@ class Conv:
   wop_kind: str = ""                 # slab images for the decoder's bf16x3 engine ("slab"); None: not used
   ct_f: Optional[t.Tensor] = None    # step-ordered weight images of the parity-walk kernels (csrc/convt_par.hip; decoder stage_6.t1
   ct_d: Optional[t.Tensor] = None    # with more than 8 classes): forward / data gradient
+  ct_kind: str = ""                  # "par": the parity walk (> 8 classes, also the weight gradient); "res": resident weights (2 classes)
 
 
 _ORPHANS = []      # (backend, graphs, capture stream) of engines dropped by the garbage collector: Engine.orphan_graph_resources
@@ -473,12 +474,18 @@ class Engine:
         or name not in self.convs or not hasattr(self.be, "convt_par_fwd")):
       return
     shape = tuple(self.store.off[name + "weight"][1])
-    if shape[0] != 16 or shape[1] > 16 or shape[1] < int(os.environ.get("CRN_CT_PAR_MIN", "9")) or tuple(shape[2:]) != (7, 7, 7):
+    if shape[0] != 16 or shape[1] > 16 or tuple(shape[2:]) != (7, 7, 7) or tuple(self.resolution) != (128, 128, 128):
       return
-    if tuple(self.resolution) != (128, 128, 128):
+    if shape[1] == 2 and os.environ.get("CRN_CT_RES", "1") != "0":
+      # two classes (h7): 8 parities x 2 classes are ONE 16-column block and the layer's weights stay resident in LDS
+      kind_, tabs = "res", (G.convt_res_fwd_table, G.convt_res_dgrad_table)
+    elif shape[1] >= int(os.environ.get("CRN_CT_PAR_MIN", "9")):
+      kind_, tabs = "par", (G.convt_par_fwd_table, G.convt_par_dgrad_table)
+    else:
       return
+    self.convs[name].ct_kind = kind_
     wofs = self.store.offset(name + "weight")
-    for kind, fn, field in (("dec", G.convt_par_fwd_table, "ct_f"), ("bwd", G.convt_par_dgrad_table, "ct_d")):
+    for kind, fn, field in (("dec", tabs[0], "ct_f"), ("bwd", tabs[1], "ct_d")):
       tab, nbytes = fn(shape, wofs)
       img = t.zeros(nbytes, dtype=t.uint8, device=self.device)
       setattr(self.convs[name], field, img)
@@ -919,6 +926,8 @@ class Plan:
         and (cv.name.startswith("encoder.stage") and not cv.name.startswith("encoder.stage1")
              or cv.name.startswith("decoder.rt_skip"))):
       math = "bf16x3_2d"          # both operands straight from HBM, K = positions (csrc/conv_e2d.hip)
+    if cv.ct_kind == "par" and math == "bf16x3":
+      math = "ct_par"             # the logits layer with > 8 classes: parity-walk kernel (csrc/convt_par.hip; generic engine in deterministic mode)
     if self.side is None or self.trace is not None:
       self._timed("wgrad " + cv.name, lambda: self.be.conv_wgrad(
           x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes), math=math))
@@ -1157,12 +1166,12 @@ class Plan:
         # the logits layer with > 8 classes: parity-walk kernel (csrc/convt_par.hip)
         if self.trace is not None and self.conv_positions is not None:
           self.conv_positions[ct.name] = S
-        self._timed("fwd   " + ct.name, lambda: be.convt_par_fwd(
+        self._probe(f"conv3d_stage{k}_t1_fwd", lambda: self._timed("fwd   " + ct.name, lambda: be.convt_par_fwd(
             d["w"], Transform(b2_.scale, b2_.shift, pre_relu=True), ct.ct_f, ct.bias, out, d["cout"],
-            host_table=eng.ct_tables["dec"][2]))
+            host_table=eng.ct_tables["dec"][2], resident=ct.ct_kind == "res")))
       else:
         ov = self.s2d(out, d["cout"], (2, 2, 2))
-        self._conv(ct, self.vw(d["w"]), Transform(b2_.scale, b2_.shift, pre_relu=True), ov)
+        self._probe(f"conv3d_stage{k}_t1_fwd", lambda: self._conv(ct, self.vw(d["w"]), Transform(b2_.scale, b2_.shift, pre_relu=True), ov))
       if k < 6 and not skip_async:
         self._skip_fwd(k)
     if training:
@@ -1325,7 +1334,7 @@ class Plan:
       # is its second pass alone (_dgrad_bn_bwd)
       if ct.ct_d is not None and self._math(ct, "dgrad") == "bf16x3":
         self._timed("dgrad " + ct.name, lambda: be.convt_par_dgrad(g_out, d["cout"], ct.ct_d, d["gv2"], False,
-                                                                     host_table=eng.ct_tables["bwd"][2]))
+                                                                     host_table=eng.ct_tables["bwd"][2], resident=ct.ct_kind == "res"))
         ct_done = False
       else:
         ct_done = self._dgrad_bn_bwd(ct, gv, d["gv2"], d["w"], d["cmid"], S, b2_, d["gw"], cc)

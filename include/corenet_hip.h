@@ -476,6 +476,21 @@ int crn_convt_s2k7_fwd_bf3(const float* x, int64_t x_sB, int B, int D, int H, in
                            const void* wimg, const float* bias, float* y, int64_t y_sB, int64_t y_sC, int Cout, crnStream s);
 int crn_convt_s2k7_dgrad_bf3(const float* dy, int64_t dy_sB, int64_t dy_sC, int Cout, int B, int D, int H, int W,
                              const void* wimg, float* dx, int64_t dx_sB, int accumulate, crnStream s);
+/* The same two operations for exactly 2 classes (h7), where 8 parities x 2 classes are one 16-column block and the layer's
+ * weights (64 KB as bf16 hi / lo) stay resident in LDS: one persistent workgroup per CU walks its tiles (convt_res_kernel).
+ * Images: conv_geometry.convt_res_fwd_table / convt_res_dgrad_table.                                                     */
+int crn_convt_s2k7_c2_fwd_bf3(const float* x, int64_t x_sB, int B, int D, int H, int W, const crnInTransform* tr,
+                              const void* wimg, const float* bias, float* y, int64_t y_sB, int64_t y_sC, int Cout, crnStream s);
+int crn_convt_s2k7_c2_dgrad_bf3(const float* dy, int64_t dy_sB, int64_t dy_sC, int Cout, int B, int D, int H, int W,
+                                const void* wimg, float* dx, int64_t dx_sB, int accumulate, crnStream s);
+/* wgrad of the same layer (autograd of reconstruction_decoder.py:89-95): dw += sum over (b, q) of T(x)[b, c, q + z - 1] *
+ * dy[b, n, 2 q + r] into the layer's PACKED gradient [16][64 window taps][Npad] (parity-major columns: the layout crn_conv_wgrad
+ * writes for the window-correlation form, conv_geometry.convt_fwd), partial sums over position slices added with atomics;
+ * zero_first clears dw.  D % 2 == H % 8 == W % 16 == 0.  Returns CRN_EINVAL in deterministic mode (crn_set_deterministic):
+ * the caller then takes crn_conv_wgrad_bf3_boxes, whose unsplit form has a fixed order.                                  */
+int crn_convt_s2k7_wgrad_bf3(const float* x, int64_t x_sB, int B, int D, int H, int W, const crnInTransform* tr,
+                             const float* dy, int64_t dy_sB, int64_t dy_sC, int Cout, float* dw, int Npad, int zero_first,
+                             crnStream s);
 
 /* ---------------- ground-truth side -------------------------------------------
  * fill_inside_voxels_gpu (cc/fill_voxels_gpu.cu:136-171, module.cc:18-29):

@@ -137,7 +137,7 @@ class EmuBackend:
     w[tab[:, :8][m]] = v[m]
     return w.view(16, cout, 7, 7, 7)
 
-  def convt_par_fwd(self, x, tr, wimg, bias, y, cout, host_table=None):
+  def convt_par_fwd(self, x, tr, wimg, bias, y, cout, host_table=None, resident=False):
     w = self._ct_weights(wimg, host_table, cout)
     xt = x.float()
     if tr is not None:
@@ -147,7 +147,7 @@ class EmuBackend:
     b = bias[:cout].float() if bias is not None else None
     y[:, :cout] = t.nn.functional.conv_transpose3d(xt, w, b, stride=2, padding=3, output_padding=1).to(y.dtype)
 
-  def convt_par_dgrad(self, dy, cout, wimg, dx, accumulate=False, host_table=None):
+  def convt_par_dgrad(self, dy, cout, wimg, dx, accumulate=False, host_table=None, resident=False):
     w = self._ct_weights(wimg, host_table, cout)
     g = t.nn.functional.conv3d(dy[:, :cout].float(), w, stride=2, padding=3)          # the adjoint of the transposed conv
     if accumulate: dx += g.to(dx.dtype)

@@ -295,15 +295,100 @@ def test_convt_parity_walk_fwd_dgrad(be, cout, dims, B):
   assert float((dxg.cpu() - xr.grad).abs().max() / xr.grad.abs().max()) <= 2e-5          # ... and autograd of torch's own op
   if _SELF:
     return
+  # weight gradient (crn_convt_s2k7_wgrad_bf3 through conv_wgrad(math="ct_par")): the real entries of the layer's packed gradient
+  # against the contract of the window-correlation form, un-packed against autograd of torch's own op, and accumulating
+  from corenet_amd import views as V
+  fwd = G.convt_fwd(wshape, 3)
+  dyc = dy[:, :cout].contiguous(); dyg = dyc.to(DEV); xg = x.to(DEV)
+  yv = lambda tt: V.space_to_depth_view(V.view_of(tt), (2, 2, 2), parity_major=True)
+  dw = t.zeros(fwd.index.size); dwg = t.full((fwd.index.size,), 7.0, device=DEV)
+  EMU.conv_wgrad(V.view_of(x), trc, yv(dyc), dw, fwd.npad, fwd.window, fwd.pad_lo, True)
+  be.conv_wgrad(V.view_of(xg), trg, yv(dyg), dwg, fwd.npad, fwd.window, fwd.pad_lo, True, boxes=(fwd.n_boxes, fwd.c_boxes), math="ct_par")
+  real = t.as_tensor(fwd.index) >= 0
+  got = t.where(real, dwg.cpu(), t.zeros(())); want = t.where(real, dw, t.zeros(()))
+  e = float((got - want).abs().max() / want.abs().max())
+  print(f"parity walk cout {cout} {dims} wgrad: max-abs-err/max = {e:.2e}")
+  assert e <= 2e-5, ("wgrad", e)
+  assert float(t.where(real, t.zeros(()), dwg.cpu()).abs().max()) == 0.0             # structural zeros of the packed layout stay zero
+  wref = w.clone().requires_grad_(True)
+  t.nn.functional.conv_transpose3d(x.relu() * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1), wref, None, stride=2, padding=3,
+                                   output_padding=1).backward(dyc)
+  gw = t.zeros(w.numel())
+  EMU.scatter(dwg.cpu(), t.as_tensor(fwd.index), gw)
+  e = float((gw.view(wshape) - wref.grad).abs().max() / wref.grad.abs().max())
+  print(f"parity walk cout {cout} {dims} wgrad vs torch autograd: max-abs-err/max = {e:.2e}")
+  assert e <= 5e-5, ("wgrad-vs-autograd", e)
+  dwg2 = dwg.clone()
+  be.conv_wgrad(V.view_of(xg), trg, yv(dyg), dwg2, fwd.npad, fwd.window, fwd.pad_lo, False, boxes=(fwd.n_boxes, fwd.c_boxes), math="ct_par")
+  assert float((t.where(real, dwg2.cpu(), t.zeros(())) - 2 * want).abs().max() / want.abs().max()) <= 4e-5
   if dims == (64, 64, 64):
-    for nm, fn in (("fwd", lambda: be.convt_par_fwd(x.to(DEV), trg, imgs["fwd"][1], bias.to(DEV), yg, cout)),
-                   ("dgrad", lambda: be.convt_par_dgrad(dy.to(DEV), cout, imgs["dgrad"][1], dxg, False))):
+    dyfull = dy.to(DEV); biasg = bias.to(DEV)
+    for nm, fn in (("fwd", lambda: be.convt_par_fwd(xg, trg, imgs["fwd"][1], biasg, yg, cout)),
+                   ("dgrad", lambda: be.convt_par_dgrad(dyfull, cout, imgs["dgrad"][1], dxg, False)),
+                   ("wgrad", lambda: be.conv_wgrad(V.view_of(xg), trg, yv(dyg), dwg2, fwd.npad, fwd.window, fwd.pad_lo, False,
+                                                   boxes=(fwd.n_boxes, fwd.c_boxes), math="ct_par"))):
       xs = [fn() for _ in range(2)]
       a, b_ = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
       t.cuda.synchronize(); a.record()
       for _ in range(5): fn()
       b_.record(); t.cuda.synchronize()
-      print(f"parity walk cout {cout} B {B} {nm}: {a.elapsed_time(b_) / 5 * 1e3:.0f} us (incl. upload)")
+      print(f"parity walk cout {cout} B {B} {nm}: {a.elapsed_time(b_) / 5 * 1e3:.0f} us")
+
+
+@pytest.mark.parametrize("dims,B", [((64, 64, 64), 2), ((8, 16, 32), 3), ((4, 8, 16), 1), ((12, 24, 16), 2)])
+def test_convt_resident_weights_two_classes(be, dims, B):
+  """The two-class (h7) kernels of decoder stage_6.t1 (convt_res_kernel, csrc/convt_par.hip: weights resident in LDS, one persistent
+  workgroup per CU): forward with transform + bias into a channel slice, data gradient plain and accumulating, against torch's
+  conv_transpose3d / its adjoint (2e-5 of the range) and autograd; tiles at every border, workgroups that walk several tiles and
+  fewer tiles than CUs."""
+  from corenet_amd.backend import Transform
+  from corenet_amd.model import conv_geometry as G
+  g = t.Generator().manual_seed(dims[0] + B)
+  D, H, W = dims
+  wshape = (16, 2, 7, 7, 7)
+  w = t.randn(wshape, generator=g) / np.sqrt(16 * 343 / 8)
+  x = t.randn(B, 16, D, H, W, generator=g)
+  scale, shift = t.rand(16, generator=g) + 0.5, t.randn(16, generator=g) * 0.3
+  bias = t.randn(2, generator=g)
+  imgs = {}
+  for kind, fn in (("fwd", G.convt_res_fwd_table), ("dgrad", G.convt_res_dgrad_table)):
+    tab, nbytes = fn(wshape, 0)
+    ic, ig = t.zeros(nbytes, dtype=t.uint8), t.zeros(nbytes, dtype=t.uint8, device=DEV)
+    EMU.bf3_gather_image(w.reshape(-1), t.as_tensor(tab), ic)
+    be.bf3_gather_image(w.reshape(-1).to(DEV), t.as_tensor(tab).to(DEV), ig)
+    assert t.equal(ig.cpu(), ic), (kind, "image")
+    imgs[kind] = (ic, ig, tab)
+  y = t.full((B, 5, 2 * D, 2 * H, 2 * W), 0.25); yg = y.to(DEV)
+  trg = Transform(scale.to(DEV), shift.to(DEV), pre_relu=True)
+  ref = t.nn.functional.conv_transpose3d(x.relu() * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1), w, bias, stride=2,
+                                         padding=3, output_padding=1)
+  be.convt_par_fwd(x.to(DEV), trg, imgs["fwd"][1], bias.to(DEV), yg, 2, host_table=imgs["fwd"][2], resident=True)
+  e = float((yg[:, :2].cpu() - ref).abs().max() / ref.abs().max())
+  print(f"resident weights {dims} B {B} fwd: max-abs-err/max = {e:.2e}")
+  assert e <= 2e-5, ("fwd", e)
+  assert bool((yg[:, 2:] == 0.25).all())
+  dy = t.randn(B, 5, 2 * D, 2 * H, 2 * W, generator=g)
+  xr = x.clone().requires_grad_(True)
+  t.nn.functional.conv_transpose3d(xr, w, None, stride=2, padding=3, output_padding=1).backward(dy[:, :2])
+  dx0 = t.randn(B, 16, D, H, W, generator=g)
+  for accumulate in (False, True):
+    dxg = dx0.clone().to(DEV)
+    be.convt_par_dgrad(dy.to(DEV), 2, imgs["dgrad"][1], dxg, accumulate, host_table=imgs["dgrad"][2], resident=True)
+    want = xr.grad + (dx0 if accumulate else 0)
+    e = float((dxg.cpu() - want).abs().max() / want.abs().max())
+    print(f"resident weights {dims} B {B} dgrad accumulate={accumulate}: max-abs-err/max = {e:.2e}")
+    assert e <= 2e-5, ("dgrad", accumulate, e)
+  if _SELF or dims != (64, 64, 64):
+    return
+  xg, dyg, bg = x.to(DEV), dy.to(DEV), bias.to(DEV)
+  for nm, fn in (("fwd", lambda: be.convt_par_fwd(xg, trg, imgs["fwd"][1], bg, yg, 2, resident=True)),
+                 ("dgrad", lambda: be.convt_par_dgrad(dyg, 2, imgs["dgrad"][1], dxg, False, resident=True))):
+    fn(); fn()
+    a, b_ = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+    t.cuda.synchronize(); a.record()
+    for _ in range(5): fn()
+    b_.record(); t.cuda.synchronize()
+    print(f"resident weights B {B} {nm}: {a.elapsed_time(b_) / 5 * 1e3:.0f} us")
 
 
 @pytest.mark.parametrize("name,kind,wshape,pad,dims,B", BF3_CASES, ids=[c[0] for c in BF3_CASES])

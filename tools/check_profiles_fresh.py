@@ -2,10 +2,10 @@
 """Fails (exit 1) when a tracked profile of the current round is OLDER than the last commit that touched the kernels
 (corenet_amd/csrc/): round 4 shipped a profile that contradicted the code it was supposed to document.  Run after
 tools/refresh_profiles.sh and the commit of its output; hardware probes that do not depend on the library's kernels are exempt.
-usage: check_profiles_fresh.py [round prefix, default r05]"""
+usage: check_profiles_fresh.py [round prefix, default r06]"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-prefix = sys.argv[1] if len(sys.argv) > 1 else "r05"
+prefix = sys.argv[1] if len(sys.argv) > 1 else "r06"
 EXEMPT = ("lds_atomic_probe", "grid_barrier_probe",           # properties of the part, not of csrc/
           "defer_wgrad_experiment", "wgrad_handover",         # host-side schedule experiments (corenet_amd/model/engine.py), dated in the file
           "ray_sweep")                                        # the development sweep of the scatter (variants that no longer exist, dated in the file);

@@ -6,11 +6,12 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=${1:-$R/gpurun_out/pmc_traffic.json}
 MATH=${2:-bf16x3}
+EXTRA=${3:-}          # extra bench.py arguments, e.g. "--classes 14" (profiles/r06_pmc_traffic_c14.json)
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pt_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pt_$c -o a -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-side --no-m9-side --math $MATH > /tmp/pt_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pt_$c -o a -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-fp32-side --no-m9-side --math $MATH $EXTRA > /tmp/pt_$c.log 2>&1
 done
-python - "$OUT" "$MATH" <<'PY'
+python - "$OUT" "$MATH $EXTRA" <<'PY'
 import csv, glob, json, sys
 def collect(c):
   acc, seq = {}, {}
@@ -29,7 +30,7 @@ out = {"command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, 
        "kernels": {}}
 for k in sorted(F, key=lambda k: -F[k] - W.get(k, 0)):
   name, grid = k
-  if not any(s in name for s in ("conv_fwd_kernel", "conv_wgrad_kernel", "conv_bf3", "ray_sample", "ray_scatter", "fill_fused", "pointwise")): continue
+  if not any(s in name for s in ("conv_fwd_kernel", "conv_wgrad_kernel", "conv_bf3", "convt_", "ray_sample", "ray_scatter", "fill_fused", "pointwise")): continue
   f_kb = 2.0 * F[k]; w_kb = W.get(k, 0.0)
   out["kernels"][f"{name} grid {grid}"] = {"launches": nF[k], "FETCH_SIZE_KB_x2": round(f_kb, 1), "WRITE_SIZE_KB": round(w_kb, 1),
                                            "hbm_bytes": int((f_kb + w_kb) * 1024)}
