@@ -237,7 +237,7 @@ def super_resolution_leg(state, batch_cpu, dev, math, reps=5):
     e1.record(); t.cuda.synchronize()
   eight_s = e0.elapsed_time(e1) / reps * 1e-3
   with t.no_grad():                                                              # the oracle's 8 passes on sample 0
-    t.set_num_threads(host_threads())
+    t.set_num_threads(max(1, min(host_threads(), 16)))           # (oneDNN oversubscribes on many-core hosts: see cpu_baseline)
     want = t.empty(2, 256, 256, 256)
     for n in range(8):
       iz, iy, ix = n // 4, (n // 2) % 2, n % 2
@@ -269,6 +269,14 @@ def cpu_baseline_fill(shells_cpu, seconds_budget=5.0):
 
 
 GRAPH = os.environ.get("CRN_GRAPH", "0") == "1"      # replay the captured HIP graph of the step (off: measured slower)
+
+
+_T0 = time.time()
+
+
+def progress(msg):
+  """Timestamped progress on stderr (stdout carries the one JSON line only)."""
+  print("bench.py [%6.1f s] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
 
 
 def main():
@@ -343,7 +351,9 @@ def main():
     pl.probes = None
     return float(tt), pr, loss
 
+  progress("model built; timing the headline step")
   dt, probes, loss = timed(model, plan)
+  progress("headline: %.3f ms per step" % (dt / args.steps * 1e3))
   replicas = None
   if world > 1:
     # data parallelism keeps the replicas identical (pipeline.py:199: DDP averages the gradients, every rank takes the same
@@ -370,6 +380,7 @@ def main():
                               "bound": "mfma", "achieved": CONV6_FLOP * B / c32 / 1e12, "peak": PEAK_F32_MFMA / 1e12,
                               "unit": "TFLOP/s", "frac": CONV6_FLOP * B / c32 / PEAK_F32_MFMA, "avg_launch_ms": c32 * 1e3}}
     del m32
+    progress("fp32 leg done")
   m9_side = None
   if world == 1 and C == 2 and not args.no_m9_side:
     # the m7 / m9 head (BASELINE configs: 14 classes incl. void, xent_times_iou_agnostic): the same step, same batch
@@ -406,6 +417,7 @@ def main():
                             "avg_launch_ms": t1s * 1e3,
                             "note": "achieved counts the layer's real 2*M*K*N (16 x 343 taps x 14 classes per coarse voxel)"}}
     del m14, pl14
+    progress("m7/m9 leg done")
   if rank != 0:
     return
   conv_s, ray_s = probes["conv3d_stage6_c1_fwd"], probes["ray_sample_fwd_64"]
@@ -563,12 +575,16 @@ def main():
                        buckets_mb=[round((hi - lo) * 4 / 1e6, 1) for _, lo, hi in model.engine.grad_buckets],
                        exposed_ms_per_bucket=[round(v, 4) for v in sync.exposed_ms_per_bucket()],
                        exposed_exchange_ms=probes.get("grad_exchange_wait", 0.0) * 1e3, replicas=replicas)
+  progress("kernel legs done")
   if not args.no_cpu_baseline and world == 1:
     out["cpu_baseline"] = cpu_baseline(state0, batch_cpu, loss_name)
+    progress("cpu baseline done")
     del model, plan
     out["parity"] = parity_check(state0, batch_cpu, C, dev, args.math)
+    progress("parity check done")
     if C == 2 and not args.no_sr_side:
       out["super_resolution_x2"] = super_resolution_leg(state0, batch_cpu, dev, args.math)
+      progress("super-resolution leg done")
     out["cpu_baseline_fill_voxels"] = cpu_baseline_fill(shells.cpu())
   print(json.dumps(out))
 
