@@ -79,7 +79,8 @@ _SIGS = {
     "crn_convt_s2k7_dgrad_bf3": [vp, i64, i64, i32, i32, i32, i32, i32, vp, vp, i64, i32, vp],
     "crn_convt_s2k7_c2_fwd_bf3": [vp, i64, i32, i32, i32, i32, C.POINTER(CrnInTransform), vp, vp, vp, i64, i64, i32, vp],
     "crn_convt_s2k7_c2_dgrad_bf3": [vp, i64, i64, i32, i32, i32, i32, i32, vp, vp, i64, i32, vp],
-    "crn_convt_s2k7_wgrad_bf3": [vp, i64, i32, i32, i32, i32, C.POINTER(CrnInTransform), vp, i64, i64, i32, vp, i32, i32, vp],
+    "crn_convt_s2k7_wgrad_bf3": [vp, i64, i32, i32, i32, i32, C.POINTER(CrnInTransform), vp, i64, i64, i32, vp, i32, i32, vp, vp],
+    "crn_convt_s2k7_ximage": [vp, i64, i32, i32, i32, i32, C.POINTER(CrnInTransform), vp, sz, vp],
     "crn_splitk_defer": [i32],
     "crn_splitk_reserve": [i64, vp],
     "crn_splitk_release": [vp],
@@ -151,6 +152,7 @@ _SIZE_FNS = {
     "crn_batch_renorm_workspace_bytes": [i32],
     "crn_loss_workspace_bytes": [i32, i32],
     "crn_fill_voxels_workspace_bytes": [i32, i32, i32, i32],
+    "crn_convt_s2k7_ximage_bytes": [i32, i32, i32, i32],
     "crn_stem_conv_parts": [i32, i32, i32],
 }
 _PTR_FNS = {

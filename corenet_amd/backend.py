@@ -8,6 +8,7 @@ an executable specification of each kernel's contract (test-only).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import torch as t
@@ -71,6 +72,7 @@ class HipBackend:
   def __init__(self):
     self.lib = _lib.lib()
     self._ws = {}
+    self._deterministic = False
 
   # -- workspaces -----------------------------------------------------------
   def workspace(self, key: str, nbytes: int, device) -> t.Tensor:
@@ -146,6 +148,7 @@ class HipBackend:
   def set_deterministic(self, on: bool = True):
     """Order-independent sums everywhere (crn_set_deterministic): two runs from the same state are bit-identical."""
     self.lib.crn_set_deterministic(int(on))
+    self._deterministic = bool(on)
 
   def splitk_reserve(self, stream: t.cuda.Stream, floats: int = 0):
     """Give `stream` its split-K scratch ahead of a HIP-graph capture (crn_splitk_reserve)."""
@@ -192,8 +195,22 @@ class HipBackend:
     self.lib.crn_conv2d_bf3(C.byref(_cview(x)), _ctr(tr), ptr(wop), npad, ptr(bias), bias_sB, C.byref(_cview(y)),
                             window[1], window[2], pad_lo[1], pad_lo[2], int(accumulate), _lib.stream())
 
+  def convt_ximage(self, x: t.Tensor, tr: Optional[Transform], img: Optional[t.Tensor] = None) -> Optional[t.Tensor]:
+    """Operand image of T(x) for the parity-walk weight gradient (crn_convt_s2k7_ximage): x [B,16,D,H,W] dense inside a sample.
+    Returns the image (`img` when it is large enough, else a fresh buffer the caller should keep) or None when the path is off
+    (CRN_CT_XIMG=0, deterministic mode)."""
+    if os.environ.get("CRN_CT_XIMG", "1") == "0" or self._deterministic:
+      return None
+    B, cin, D, H, W = x.shape
+    assert cin == 16 and x[0].is_contiguous()
+    nb = self.lib.crn_convt_s2k7_ximage_bytes(B, D, H, W)
+    if img is None or img.numel() < nb:
+      img = t.empty(nb, dtype=t.uint8, device=x.device)
+    self.lib.crn_convt_s2k7_ximage(ptr(x), x.stride(0), B, D, H, W, _ctr(tr), ptr(img), nb, _lib.stream())
+    return img
+
   def conv_wgrad(self, x: View, tr: Optional[Transform], dy: View, dw: t.Tensor, npad: int,
-                 window, pad_lo, zero_first: bool = True, boxes=None, math: str = "fp32"):
+                 window, pad_lo, zero_first: bool = True, boxes=None, math: str = "fp32", ximg: Optional[t.Tensor] = None):
     if math == "bf16x3_1x1":       # 1x1 layers: both operands straight from HBM (csrc/conv_e2d.hip)
       self.lib.crn_conv_wgrad_1x1_bf3(C.byref(_cview(x)), _ctr(tr), C.byref(_cview(dy)), ptr(dw), npad, int(zero_first),
                                       _lib.stream())
@@ -204,9 +221,16 @@ class HipBackend:
       return
     if math == "ct_par":           # decoder stage_6.t1 with > 8 classes: the parity-walk weight gradient (csrc/convt_par.hip); x: the plain view
       xs, ds = x.storage, dy.storage     # of the layer's input, dy: the space-to-depth view of the output gradient tensor
-      rc = self.lib._crn_convt_s2k7_wgrad_bf3(xs.data_ptr() + 4 * (x.offset - xs.storage_offset()), x.sB, x.B, x.D, x.H, x.W, _ctr(tr),
+      xp = xs.data_ptr() + 4 * (x.offset - xs.storage_offset())
+      img = ximg                   # (the caller made it earlier, e.g. under the forward pass on its side stream)
+      if img is None and os.environ.get("CRN_CT_XIMG", "1") != "0" and not self._deterministic:
+        # T(x) transformed and split once (crn_convt_s2k7_ximage) instead of in every workgroup of the four parity pairs
+        nb = self.lib.crn_convt_s2k7_ximage_bytes(x.B, x.D, x.H, x.W)
+        img = self.workspace("ct_ximg", nb, xs.device)
+        self.lib.crn_convt_s2k7_ximage(xp, x.sB, x.B, x.D, x.H, x.W, _ctr(tr), ptr(img), nb, _lib.stream())
+      rc = self.lib._crn_convt_s2k7_wgrad_bf3(xp, x.sB, x.B, x.D, x.H, x.W, _ctr(tr),
                                               ds.data_ptr(), ds.stride(0), ds.stride(1), dy.C // 8, ptr(dw), npad, int(zero_first),
-                                              _lib.stream())
+                                              ptr(img), _lib.stream())
       if rc == 0:
         return
       if rc != -1:                 # CRN_EINVAL: deterministic mode or a shape it does not cover -> the generic split-bf16 engine

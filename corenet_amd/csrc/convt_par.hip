@@ -383,8 +383,8 @@ __global__ __launch_bounds__(kT) void convt_par_dgrad_kernel(CtGeom g) {
 // dW[c, n, k] = sum over (b, q) of T(x)[b, c, q + z - 1] * dy[b, n, 2 q + r],  k = 5 - 2 z + r: per output parity r a GEMM
 // D_z[c][n] = X_z^T . dY_r with K = positions, like conv_bf3_wgrad_kernel (conv_bf3.hip) -- 32 positions per MFMA, both
 // operands read out of position-major LDS images with the transposing ds_read_b64_tr_b16 -- but cut the way the layer is:
-// a workgroup owns ONE (rd, rh) pair (blockIdx.x), both rw (2 x 16 columns), ALL 16 input channels (the MFMA's 16 rows = 2
-// chunks x 8 channels of one tap instead of 2 taps x 8 channels) and a slice of the 2 x 8 x 16 position tiles (blockIdx.y).
+// a workgroup owns ONE (rd, rh) pair (a range of blockIdx.x: the pairs get workgroups in proportion to their cost), both rw (2 x 16 columns), ALL 16 input channels (the MFMA's 16 rows = 2
+// chunks x 8 channels of one tap instead of 2 taps x 8 channels) and a slice of the 2 x 8 x 16 position tiles.
 // So dy is read once in total (each pair's workgroups load only their own fine rows, 16-byte loads that serve both rw), the
 // taps are exactly the (3 + rd)(3 + rh) 4 of the pair's box, dealt round-robin to the 8 waves, and nothing is multiplied for
 // columns of another parity (the generic kernel's 16-column blocks straddle parities at 14 classes: 956 us at B = 4).
@@ -400,12 +400,14 @@ struct CtWgGeom {
   const float* x; long long x_sB; int B, D, H, W;
   const float* scale; const float* shift; int pre_relu, post_relu;
   const float* dy; long long dy_sB, dy_sC; int Cout;
+  const float* ximg; long long ximg_sB;                      // operand image of T(x) (convt_ximage_kernel): floats per sample, or nullptr
   float* dw; int Npad;
-  int tilesD, tilesH, tilesW, ntiles, tiles_per_split;
+  int tilesD, tilesH, tilesW, ntiles;
+  int wg_end[4], tiles_per_wg[4];                            // workgroups [wg_end[p - 1], wg_end[p]) walk pair p, tiles_per_wg[p] tiles each
 };
 
-template <int TPW>
-__device__ __forceinline__ void convt_par_wgrad_body(const CtWgGeom& g) {
+template <int TPW, bool XIMG>
+__device__ __forceinline__ void convt_par_wgrad_body(const CtWgGeom& g, int pp, int slot) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* tscale = reinterpret_cast<float*>(smem);
   float* tshift = tscale + 16;
@@ -415,9 +417,9 @@ __device__ __forceinline__ void convt_par_wgrad_body(const CtWgGeom& g) {
   char* Ylo = Yhi + (size_t)kWgPos * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, kk = lane >> 4;
-  const int pp = blockIdx.x, rd = pp >> 1, rh = pp & 1, dz = 3 + rd, dh = 3 + rh;
+  const int rd = pp >> 1, rh = pp & 1, dz = 3 + rd, dh = 3 + rh;
   const int ntaps = dz * dh * 4;
-  const int tbeg = min((int)blockIdx.y * g.tiles_per_split, g.ntiles), tend = min(tbeg + g.tiles_per_split, g.ntiles);
+  const int tbeg = min(slot * g.tiles_per_wg[pp], g.ntiles), tend = min(tbeg + g.tiles_per_wg[pp], g.ntiles);
 
   if (tid < 16) {
     tscale[tid] = g.scale ? g.scale[tid] : 1.f;
@@ -429,14 +431,19 @@ __device__ __forceinline__ void convt_par_wgrad_body(const CtWgGeom& g) {
   // A (input patch): column quad q = (chunk q >> 1, channel half q & 1) of the 16 input channels
   const int abase = (((k1 >> 4) * PW + (k1 & 15)) << 4) + ((q & 1) << 3) + (q >> 1) * (WNP * 16);
   // TPW = taps per wave = ceil(ntaps / 8): 36 / 48 / 48 / 64 taps -> 5 / 6 / 6 / 8 (compile time: the tap loop is straight-line
-  // code and software-pipelined).  Wave w multiplies taps w + 8 ti; with 36 taps waves 4-7 have no fifth one: they multiply the
-  // clamped last tap once more and drop the result (an eighth of that pair's MFMAs, no branch in the loop)
+  // code and software-pipelined).  With 36 taps four waves have no fifth one: they multiply the clamped last tap (zw = 3: one
+  // triple) once more and drop the result
+  // Round ti deals taps 8 ti .. 8 ti + 7 to the waves ROTATED by ti (wave w takes 8 ti + ((w + ti) & 7)): the window column zw = tap & 3
+  // then walks through a wave's taps instead of being the wave's own, and the taps with zw = 3 -- which have no weight for rw = 0
+  // (k = 5 - 2 z + r < 0) and whose rw = 0 triple is therefore skipped, an eighth of all MFMAs -- are spread evenly over the waves
   int toffL[TPW];
+  bool skip0[TPW];
 #pragma unroll
   for (int ti = 0; ti < TPW; ++ti) {
-    const int tp = min(wave + 8 * ti, ntaps - 1);
+    const int tp = min(8 * ti + ((wave + ti) & 7), ntaps - 1);
     const int zw = tp & 3, zr = tp >> 2, zh = zr % dh, zd = zr / dh;
     toffL[ti] = ((zd * PH + zh) * PW + zw) << 4;
+    skip0[ti] = zw == 3;
   }
   const int ybase = k1 * 64 + (q << 3);
   constexpr int xlo = 2 * WNP * 16, ylo = kWgPos * 64;
@@ -471,8 +478,21 @@ __device__ __forceinline__ void convt_par_wgrad_body(const CtWgGeom& g) {
     xin = tid < kXUnits && (unsigned)gd < (unsigned)g.D && (unsigned)gh < (unsigned)g.H && (unsigned)gw < (unsigned)g.W;
     const unsigned sp = ((unsigned)gd * (unsigned)g.H + (unsigned)gh) * (unsigned)g.W + (unsigned)gw;
     const unsigned sC = (unsigned)g.D * (unsigned)g.H * (unsigned)g.W;
+    if constexpr (XIMG) {
+      // the input arrives transformed and split (convt_ximage_kernel): [region = chunk * 2 + (hi, lo)][position] entries of 8 bf16;
+      // register r * 4 + e = region r, position e of the unit's four -- the commit is a plain copy
+      const crn_rsrc irs = make_rsrc(g.ximg + (long long)b * g.ximg_sB);
 #pragma unroll
-    for (int c = 0; c < 16; ++c) crn_bload4(pv[c], xrs, xin ? ((unsigned)c * sC + sp) * 4u : 0x80000000u);
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int pl = 4 * xquad + e - 3;
+          crn_bload4(pv[r * 4 + e], irs, (xin && pl >= 0 && pl < PW) ? ((unsigned)r * sC + sp + (unsigned)e) * 16u : 0x80000000u);
+        }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) crn_bload4(pv[c], xrs, xin ? ((unsigned)c * sC + sp) * 4u : 0x80000000u);
+    }
     const unsigned od = 2 * (d0 + ddp) + rd, oh = 2 * (h0 + dhp) + rh, ow = 2 * (w0 + dwp);
     const unsigned dsp = (od * (unsigned)OH + oh) * (unsigned)OW + ow;
 #pragma unroll
@@ -482,6 +502,20 @@ __device__ __forceinline__ void convt_par_wgrad_body(const CtWgGeom& g) {
     }
   };
   auto stage_commit = [&]() {
+    if constexpr (XIMG) {
+      if (tid < kXUnits) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int pl = 4 * xquad + e - 3;
+          if (pl < 0 || pl >= PW) continue;
+#pragma unroll
+          for (int ch = 0; ch < 2; ++ch) {
+            *reinterpret_cast<f32x4*>(Xhi + ((size_t)ch * WNP + xrow * PW + pl) * 16) = pv[(ch * 2 + 0) * 4 + e];
+            *reinterpret_cast<f32x4*>(Xlo + ((size_t)ch * WNP + xrow * PW + pl) * 16) = pv[(ch * 2 + 1) * 4 + e];
+          }
+        }
+      }
+    } else
     if (tid < kXUnits) {
 #pragma unroll
       for (int ch = 0; ch < 2; ++ch) {
@@ -562,7 +596,7 @@ __device__ __forceinline__ void convt_par_wgrad_body(const CtWgGeom& g) {
         if (ti + 1 < TPW) ldA(kbx, ti + 1, qa ^ 1);
         else { const int kn = min(kb + 1, 7); ldB(kn, qb ^ 1); ldA(kbx_of(kn), 0, qa ^ 1); }
         __builtin_amdgcn_sched_barrier(0);
-        mfma3(acc[ti][0], ah[qa], al[qa], bh[qb][0], bl[qb][0]);
+        if (!skip0[ti]) mfma3(acc[ti][0], ah[qa], al[qa], bh[qb][0], bl[qb][0]);
         mfma3(acc[ti][1], ah[qa], al[qa], bh[qb][1], bl[qb][1]);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -580,8 +614,8 @@ __device__ __forceinline__ void convt_par_wgrad_body(const CtWgGeom& g) {
   if (i16 < g.Cout) {
 #pragma unroll
     for (int ti = 0; ti < TPW; ++ti) {
-      const int tp = wave + 8 * ti;
-      if (tp >= ntaps) continue;                               // (the clamped duplicate of waves 4-7 at 36 taps)
+      const int tp = 8 * ti + ((wave + ti) & 7);
+      if (tp >= ntaps) continue;                               // (the clamped duplicates of the last round at 36 taps)
       const int zw = tp & 3, zr = tp >> 2, zh = zr % dh, zd = zr / dh;
 #pragma unroll
       for (int ns = 0; ns < 2; ++ns) {
@@ -599,10 +633,63 @@ __device__ __forceinline__ void convt_par_wgrad_body(const CtWgGeom& g) {
 
 __global__ __launch_bounds__(kT) void convt_par_wgrad_kernel(CtWgGeom g) {
   crn_kernarg_touch(g);
-  switch (blockIdx.x) {                                      // the (rd, rh) pair: 36 / 48 / 48 / 64 taps
-    case 0: convt_par_wgrad_body<5>(g); break;
-    case 3: convt_par_wgrad_body<8>(g); break;
-    default: convt_par_wgrad_body<6>(g); break;
+  // the (rd, rh) pair of this workgroup: 36 / 48 / 48 / 64 taps.  The pairs get workgroups in proportion to what a tile costs them
+  // (host side): with the same number of tiles per workgroup for every pair the launch lasted as long as pair 3's 64 taps
+  const int wg = blockIdx.x;
+  const int pp = wg < g.wg_end[0] ? 0 : wg < g.wg_end[1] ? 1 : wg < g.wg_end[2] ? 2 : 3;
+  const int slot = wg - (pp ? g.wg_end[pp - 1] : 0);
+  if (g.ximg) {
+    switch (pp) {
+      case 0: convt_par_wgrad_body<5, true>(g, 0, slot); break;
+      case 3: convt_par_wgrad_body<8, true>(g, 3, slot); break;
+      default: convt_par_wgrad_body<6, true>(g, pp, slot); break;
+    }
+    return;
+  }
+  switch (pp) {
+    case 0: convt_par_wgrad_body<5, false>(g, 0, slot); break;
+    case 3: convt_par_wgrad_body<8, false>(g, 3, slot); break;
+    default: convt_par_wgrad_body<6, false>(g, pp, slot); break;
+  }
+}
+
+// ------------------------------------------------------------------ operand image of the layer's input ----------
+// The weight-gradient workgroups of the four (rd, rh) pairs all stage the same patches of T(x) = BatchRenorm + ReLU of the layer's
+// input, each with a 4.3x halo: transformed and split into bf16 hi / lo in every one of them, the conversion was ~400 VALU
+// instructions per staging unit and tile -- about as long as a tile's MFMAs.  One pass over x does it once: img[b][region = chunk * 2
+// + (hi, lo)][position] = entry of 8 bf16 (the 8 channels of the chunk), the same transform expression for expression and the same
+// split as the fused staging (bit-identical operands).  67 MB read, 67 MB written at B = 4.
+__global__ __launch_bounds__(256) void convt_ximage_kernel(const float* x, long long x_sB, int S4, const float* scale, const float* shift,
+                                                           int pre_relu, int post_relu, float* img, long long img_sB) {
+  const int q = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y, b = blockIdx.z;
+  if (q >= S4) return;
+  const long long S = (long long)S4 * 4;
+  const float* xp = x + (long long)b * x_sB + (long long)(ch * 8) * S + (long long)q * 4;
+  f32x4 v[8];
+#pragma unroll
+  for (int cl = 0; cl < 8; ++cl) v[cl] = *reinterpret_cast<const f32x4*>(xp + (long long)cl * S);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int cl = 0; cl < 8; ++cl) { sc[cl] = scale ? scale[ch * 8 + cl] : 1.f; sh[cl] = scale ? shift[ch * 8 + cl] : 0.f; }
+  float* hi = img + (long long)b * img_sB + ((long long)(ch * 2) * S + (long long)q * 4) * 4;      // (entries of 4 floats)
+  float* lo = hi + S * 4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float a[8];
+#pragma unroll
+    for (int cl = 0; cl < 8; ++cl) {
+      float t = v[cl][e];
+      if (scale) {
+        if (pre_relu) t = fmaxf(t, 0.f);
+        t = t * sc[cl] + sh[cl];
+        if (post_relu) t = fmaxf(t, 0.f);
+      }
+      a[cl] = t;
+    }
+    bf16x8 h, l;
+    split8(a, h, l);
+    *reinterpret_cast<bf16x8*>(hi + e * 4) = h;
+    *reinterpret_cast<bf16x8*>(lo + e * 4) = l;
   }
 }
 
@@ -890,11 +977,32 @@ extern "C" int crn_convt_s2k7_dgrad_bf3(const float* dy, int64_t dy_sB, int64_t 
   return CRN_OK;
 }
 
+extern "C" size_t crn_convt_s2k7_ximage_bytes(int B, int D, int H, int W) {
+  return (size_t)B * 4 * D * H * W * 16;
+}
+
+extern "C" int crn_convt_s2k7_ximage(const float* x, int64_t x_sB, int B, int D, int H, int W, const crnInTransform* tr,
+                                     void* img, size_t img_bytes, crnStream stream) {
+  CRN_ENTRY(stream);
+  if (!x || !img || B < 1 || D < 1 || H < 1 || W < 1 || (W & 3)) return CRN_EINVAL;
+  if (img_bytes < crn_convt_s2k7_ximage_bytes(B, D, H, W)) return CRN_ENOMEM;
+  if ((int64_t)16 * D * H * W >= ((int64_t)1 << 29)) return CRN_EINVAL;          // 32-bit byte offsets inside a sample of the image
+  if ((((uintptr_t)x) & 15) || (x_sB & 3) || (((uintptr_t)img) & 15)) return CRN_EINVAL;
+  const int S4 = D * H * W / 4;
+  const bool has = tr && tr->scale;
+  hipLaunchKernelGGL(convt_ximage_kernel, dim3((unsigned)crn_cdiv(S4, 256), 2, (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                     x, (long long)x_sB, S4, has ? tr->scale : nullptr, has ? tr->shift : nullptr, has ? tr->pre_relu : 0,
+                     has ? tr->post_relu : 0, reinterpret_cast<float*>(img), (long long)16 * D * H * W);
+  CRN_CHECK_LAUNCH();
+  return CRN_OK;
+}
+
 extern "C" int crn_convt_s2k7_wgrad_bf3(const float* x, int64_t x_sB, int B, int D, int H, int W, const crnInTransform* tr,
                                         const float* dy, int64_t dy_sB, int64_t dy_sC, int Cout, float* dw, int Npad,
-                                        int zero_first, crnStream stream) {
+                                        int zero_first, const void* ximg, crnStream stream) {
   CRN_ENTRY(stream);
   if (!x || !dy || !dw || B < 1 || Cout < 1 || Cout > 16 || Npad < 8 * Cout) return CRN_EINVAL;
+  if (ximg && (((uintptr_t)ximg) & 15)) return CRN_EINVAL;
   if (D % WTD || H % TH || W % TW) return CRN_EINVAL;
   if (crn_deterministic()) return CRN_EINVAL;                 // (split sums with atomics: the caller takes the generic engine)
   if ((int64_t)16 * D * H * W >= ((int64_t)1 << 29) || (int64_t)Cout * dy_sC >= ((int64_t)1 << 29)) return CRN_EINVAL;
@@ -905,19 +1013,35 @@ extern "C" int crn_convt_s2k7_wgrad_bf3(const float* x, int64_t x_sB, int B, int
   g.x = x; g.x_sB = x_sB; g.B = B; g.D = D; g.H = H; g.W = W;
   if (tr && tr->scale) { g.scale = tr->scale; g.shift = tr->shift; g.pre_relu = tr->pre_relu; g.post_relu = tr->post_relu; }
   g.dy = dy; g.dy_sB = dy_sB; g.dy_sC = dy_sC; g.Cout = Cout; g.dw = dw; g.Npad = Npad;
+  g.ximg = reinterpret_cast<const float*>(ximg); g.ximg_sB = (long long)16 * D * H * W;      // (floats per sample: 4 regions x 4 floats per entry)
   g.tilesD = D / WTD; g.tilesH = H / TH; g.tilesW = W / TW;
   const int64_t ntiles = (int64_t)B * g.tilesD * g.tilesH * g.tilesW;
   if (ntiles > 0x7fffffff) return CRN_EINVAL;
   g.ntiles = (int)ntiles;
-  static const int kSplits = getenv("CRN_CT_WG_SPLITS") ? std::max(1, atoi(getenv("CRN_CT_WG_SPLITS"))) : 64;   // 4 pairs x 64 = one round of 256 CUs
-  int splits = (int)std::min<int64_t>(kSplits, ntiles);
-  g.tiles_per_split = crn_cdiv(ntiles, splits);
-  splits = crn_cdiv(ntiles, g.tiles_per_split);
+  // One round of 256 workgroups (one per CU), dealt to the four (rd, rh) pairs in proportion to the cost of a tile: its multiplies
+  // (taps per wave x 8 waves: 40 / 48 / 48 / 64) plus the staging of the tile, which is the same for every pair (kStage, in taps:
+  // CRN_CT_WG_STAGE; 0 = by multiplies alone, CRN_CT_WG_EVEN=1 = the same number of tiles for every pair)
+  static const int kBlocks = getenv("CRN_CT_WG_BLOCKS") ? std::max(4, atoi(getenv("CRN_CT_WG_BLOCKS"))) : 256;
+  static const int kStage = getenv("CRN_CT_WG_STAGE") ? std::max(0, atoi(getenv("CRN_CT_WG_STAGE"))) : 24;
+  static const bool kEven = getenv("CRN_CT_WG_EVEN") != nullptr && atoi(getenv("CRN_CT_WG_EVEN")) != 0;
+  const int taps[4] = {40, 48, 48, 64};
+  int cost[4], total = 0;
+  for (int p = 0; p < 4; ++p) { cost[p] = kEven ? 1 : taps[p] + kStage; total += cost[p]; }
+  const int blocks = (int)std::min<int64_t>(kBlocks, 4 * ntiles);
+  int wgs = 0;
+  for (int p = 0; p < 4; ++p) {
+    int n = std::max(1, (int)((int64_t)blocks * cost[p] / total));
+    n = (int)std::min<int64_t>(n, ntiles);
+    g.tiles_per_wg[p] = crn_cdiv(ntiles, n);
+    n = crn_cdiv(ntiles, g.tiles_per_wg[p]);
+    wgs += n;
+    g.wg_end[p] = wgs;
+  }
   static const bool attr = [] {
     return hipFuncSetAttribute((const void*)convt_par_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsWg) == hipSuccess;
   }();
   if (!attr) return CRN_EINVAL;
-  hipLaunchKernelGGL(convt_par_wgrad_kernel, dim3(4, (unsigned)splits), dim3(kT), kLdsWg, st, g);
+  hipLaunchKernelGGL(convt_par_wgrad_kernel, dim3((unsigned)wgs), dim3(kT), kLdsWg, st, g);
   CRN_CHECK_LAUNCH();
   return CRN_OK;
 }

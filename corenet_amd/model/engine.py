@@ -766,6 +766,8 @@ class Plan:
     use_side = self.side is not None
     self._side_ev, self._side_i = [], 0
     self._side_done = t.cuda.Event() if use_side else None
+    self._ximg_ev = t.cuda.Event() if use_side else None     # hand-over of the logits layer's operand image (forward_decoder)
+    self._ct_ximg = self._ct_ximg_buf = None
     # Every hand-over to the side stream costs the data-gradient chain an event record (a marker packet between two dependent
     # launches: ~3.5 us).  The encoder's weight gradients are therefore handed over one bottleneck at a time (3-4 convolutions behind
     # ONE event) and a gradient bucket's un-pack rides on the hand-over in front of it: 7.58 -> 7.44 ms per step
@@ -930,12 +932,12 @@ class Plan:
       math = "ct_par"             # the logits layer with > 8 classes: parity-walk kernel (csrc/convt_par.hip; generic engine in deterministic mode)
     if self.side is None or self.trace is not None:
       self._timed("wgrad " + cv.name, lambda: self.be.conv_wgrad(
-          x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes), math=math))
+          x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes), math=math, **self._ximg_kw(math)))
       return
     if self.wg_batch and (cv.name.startswith("encoder.") or self.wg_batch_dec):
       # the encoder's small weight gradients are handed to the side stream one bottleneck at a time (_flush_wgrads): ONE event on
       # the data-gradient chain per block instead of one per convolution
-      self._wg_pending.append((cv, x, tr, dy, math))
+      self._wg_pending.append((cv, x, tr, dy, math, self._ximg_kw(math)))
       return
     if self._handed_over:
       # the side stream already waits for an event recorded after dy became final (the skip path's hand-over, just before this
@@ -943,7 +945,8 @@ class Plan:
       self._handed_over = False
       self._side_i = max(self._side_i, 1)
       with t.cuda.stream(self.side), _lib.pinned_stream(self.side), _lib.roctx_range("wgrad " + cv.name):
-        self.be.conv_wgrad(x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes), math=math)
+        self.be.conv_wgrad(x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes), math=math,
+                           **self._ximg_kw(math))
       return
     if self._side_i == len(self._side_ev):
       self._side_ev.append(t.cuda.Event())
@@ -951,7 +954,15 @@ class Plan:
     ev.record()                                   # dy (and the zeroed slab) are ready on the main stream
     with t.cuda.stream(self.side), _lib.pinned_stream(self.side), _lib.roctx_range("wgrad " + cv.name):
       self.side.wait_event(ev)
-      self.be.conv_wgrad(x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes), math=math)
+      self.be.conv_wgrad(x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes), math=math,
+                         **self._ximg_kw(math))
+
+  def _ximg_kw(self, math: str) -> dict:
+    """The operand image the forward pass left for the parity-walk weight gradient (forward_decoder), consumed once."""
+    if math != "ct_par" or self._ct_ximg is None:
+      return {}
+    img, self._ct_ximg = self._ct_ximg, None
+    return {"ximg": img}
 
   def _flush_wgrads(self, then=None):
     """Launches the weight gradients collected since the last flush on the side stream, behind ONE event of the main stream;
@@ -964,10 +975,10 @@ class Plan:
     ev.record()
     with t.cuda.stream(self.side), _lib.pinned_stream(self.side):
       self.side.wait_event(ev)
-      for cv, x, tr, dy, math in self._wg_pending:
+      for cv, x, tr, dy, math, kw in self._wg_pending:
         g = cv.fwd
         with _lib.roctx_range("wgrad " + cv.name):
-          self.be.conv_wgrad(x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes), math=math)
+          self.be.conv_wgrad(x, tr, dy, cv.gwf, g.npad, g.window, g.pad_lo, False, boxes=(g.n_boxes, g.c_boxes), math=math, **kw)
       if then is not None:
         then()
     self._wg_pending = []
@@ -1162,6 +1173,16 @@ class Plan:
         self._stats(b2_, d["w"], S, d["cmid"] * S, True, training)
       out = self.dec[k + 1]["u"] if k < 6 else self.logits
       ct = cv[p + "t1."]
+      self._ct_ximg = None
+      if (training and ct.ct_kind == "par" and self.side is not None and self.trace is None and hasattr(be, "convt_ximage")
+          and self._math(ct, "wgrad") == "bf16x3"):
+        # the parity-walk weight gradient of the logits layer reads T(w) as an operand image (crn_convt_s2k7_ximage): made here on the
+        # side stream, which is idle under the decoder's forward pass -- the norm's scale / shift are final, backward finds it ready
+        self._ximg_ev.record()
+        with t.cuda.stream(self.side), _lib.pinned_stream(self.side):
+          self.side.wait_event(self._ximg_ev)
+          self._ct_ximg_buf = be.convt_ximage(d["w"], Transform(b2_.scale, b2_.shift, pre_relu=True), self._ct_ximg_buf)   # (this plan's own buffer)
+          self._ct_ximg = self._ct_ximg_buf
       if ct.ct_f is not None and self._math(ct, "fwd") == "bf16x3":
         # the logits layer with > 8 classes: parity-walk kernel (csrc/convt_par.hip)
         if self.trace is not None and self.conv_positions is not None:

@@ -487,10 +487,18 @@ int crn_convt_s2k7_c2_dgrad_bf3(const float* dy, int64_t dy_sB, int64_t dy_sC, i
  * dy[b, n, 2 q + r] into the layer's PACKED gradient [16][64 window taps][Npad] (parity-major columns: the layout crn_conv_wgrad
  * writes for the window-correlation form, conv_geometry.convt_fwd), partial sums over position slices added with atomics;
  * zero_first clears dw.  D % 2 == H % 8 == W % 16 == 0.  Returns CRN_EINVAL in deterministic mode (crn_set_deterministic):
- * the caller then takes crn_conv_wgrad_bf3_boxes, whose unsplit form has a fixed order.                                  */
+ * the caller then takes crn_conv_wgrad_bf3_boxes, whose unsplit form has a fixed order.
+ * ximg (may be NULL): the operand image of T(x) left by crn_convt_s2k7_ximage for the same x and tr -- the workgroups then copy
+ * their patches from it instead of transforming and splitting x themselves (same operands bit for bit, same result).     */
 int crn_convt_s2k7_wgrad_bf3(const float* x, int64_t x_sB, int B, int D, int H, int W, const crnInTransform* tr,
                              const float* dy, int64_t dy_sB, int64_t dy_sC, int Cout, float* dw, int Npad, int zero_first,
-                             crnStream s);
+                             const void* ximg, crnStream s);
+/* Operand image of that layer's input for the weight gradient: img[b][chunk * 2 + (hi, lo)][D * H * W] entries of 8 bf16 = the
+ * split-bf16 halves of T(x)[b, chunk * 8 .. + 7, position] (T = the BatchRenorm + ReLU in front of the layer,
+ * reconstruction_decoder.py:56-60, 89-95).  One pass: x read once, crn_convt_s2k7_ximage_bytes(B, D, H, W) written.     */
+size_t crn_convt_s2k7_ximage_bytes(int B, int D, int H, int W);
+int crn_convt_s2k7_ximage(const float* x, int64_t x_sB, int B, int D, int H, int W, const crnInTransform* tr,
+                          void* img, size_t img_bytes, crnStream s);
 
 /* ---------------- ground-truth side -------------------------------------------
  * fill_inside_voxels_gpu (cc/fill_voxels_gpu.cu:136-171, module.cc:18-29):

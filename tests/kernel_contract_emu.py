@@ -162,7 +162,7 @@ class EmuBackend:
     self.conv_fwd(x, tr, w, npad, bias, bias_sB, y, window, pad_lo, 1, accumulate)
 
   @t.enable_grad()        # uses autograd as a calculator; may be called from inside an autograd Function
-  def conv_wgrad(self, x, tr, dy, dw, npad, window, pad_lo, zero_first=True, boxes=None, math="fp32"):
+  def conv_wgrad(self, x, tr, dy, dw, npad, window, pad_lo, zero_first=True, boxes=None, math="fp32", ximg=None):
     xl = _transform(logical(x), tr)
     xp = _padded(xl, window, pad_lo, (dy.D, dy.H, dy.W))
     dyl = logical(dy)

@@ -310,6 +310,24 @@ def test_convt_parity_walk_fwd_dgrad(be, cout, dims, B):
   print(f"parity walk cout {cout} {dims} wgrad: max-abs-err/max = {e:.2e}")
   assert e <= 2e-5, ("wgrad", e)
   assert float(t.where(real, t.zeros(()), dwg.cpu()).abs().max()) == 0.0             # structural zeros of the packed layout stay zero
+  # the two ways the workgroups get T(x): the operand image made ahead by the caller (crn_convt_s2k7_ximage, what the engine does
+  # under the forward pass) and the fused transform + split of the fp32 input (CRN_CT_XIMG=0) -- same contract
+  img = be.convt_ximage(xg, trg)
+  assert img is not None
+  for label, kw, env in (("image made ahead", {"ximg": img}, None), ("fused staging", {}, "0")):
+    old_env = os.environ.get("CRN_CT_XIMG")
+    if env is not None:
+      os.environ["CRN_CT_XIMG"] = env
+    try:
+      dwg3 = t.full((fwd.index.size,), 3.0, device=DEV)
+      be.conv_wgrad(V.view_of(xg), trg, yv(dyg), dwg3, fwd.npad, fwd.window, fwd.pad_lo, True, boxes=(fwd.n_boxes, fwd.c_boxes), math="ct_par", **kw)
+    finally:
+      if env is not None:
+        if old_env is None: os.environ.pop("CRN_CT_XIMG")
+        else: os.environ["CRN_CT_XIMG"] = old_env
+    e3 = float((t.where(real, dwg3.cpu(), t.zeros(())) - want).abs().max() / want.abs().max())
+    print(f"parity walk cout {cout} {dims} wgrad ({label}): max-abs-err/max = {e3:.2e}")
+    assert e3 <= 2e-5, ("wgrad", label, e3)
   wref = w.clone().requires_grad_(True)
   t.nn.functional.conv_transpose3d(x.relu() * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1), wref, None, stride=2, padding=3,
                                    output_padding=1).backward(dyc)
