@@ -1346,7 +1346,14 @@ class Plan:
       self._wgrad(ct, self.vw(d["w"]), tr2, gv)
       self._handed_over = False
       if k == 6:   # gradient of the logits comes from the loss kernel; below it is a bn_bwd output
-        self._bias_grad(ct, g_out, So, ctot * So)
+        if (self.side is not None and self.trace is None and not self.wg_batch_dec and os.environ.get("CRN_BIAS_GRAD_SIDE", "1") != "0"):
+          # one pass over the loss gradient (470 MB at 14 classes) whose result is only read by the bucket's un-pack: it follows the
+          # layer's weight gradient on the side stream (ordered behind the same hand-over event) instead of sitting in front of the
+          # data-gradient chain
+          with t.cuda.stream(self.side), _lib.pinned_stream(self.side):
+            self._bias_grad(ct, g_out, So, ctot * So)
+        else:
+          self._bias_grad(ct, g_out, So, ctot * So)
       cc = cv[p + "c1."]
       # every conv bias gradient below is sum(dx) of the norm that consumes the conv output: fused
       # into bn_bwd (dsum) instead of a second pass over dx.
