@@ -54,7 +54,9 @@ ENC_STAGES = (("stage2", "abc", (64, 64, 256), 1), ("stage3", "abcd", (128, 128,
 # the first (lowest-offset) parameter of the bucket, the last bucket runs down to offset 0.  pipeline.py:199
 # gets the same effect from DDP's reverse-order 25 MB buckets.
 GRAD_BUCKET_LABELS = ("decoder.stage_3.", "decoder.stage_0.", "encoder.stage5.c.", "encoder.stage5.b.",
-                      "encoder.stage5.a.", "encoder.stage4.a.", "")
+                      "encoder.stage5.a.", "encoder.stage4.a.", "encoder.stage2.a.", "")
+# (the last bucket is the stem alone: what follows the step's last weight gradient -- un-pack, exchange, Adam -- is the exposed tail of
+# the step, so encoder stages 2-3 are handed over when their last block is done, under the stem's own backward)
 # Layers (and directions) that run on the split-bf16 MFMA engine when Engine(decoder_math="bf16x3"): the
 # Conv3d k5 / ConvTranspose3d k7 of decoder stages 3-6 (reconstruction_decoder.py:64-95): forward, data gradient
 # and weight gradient.  Decoder stages 0-2 and the stem stay on the fp32 MFMA engine, the encoder's 3x3 layers go to

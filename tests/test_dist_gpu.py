@@ -49,7 +49,7 @@ def test_two_ranks_one_gpu_overlapped_train_steps(tmp_path):
   mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
   a, b = t.load(tmp_path / "g0.pt"), t.load(tmp_path / "g1.pt")
   assert t.equal(a["g"], b["g"]) and t.equal(a["p"], b["p"])          # same summed gradients, same parameters
-  assert sum(a["pushed"]) == a["n"] and len(a["pushed"]) == 7
+  assert sum(a["pushed"]) == a["n"] and len(a["pushed"]) == 8
   assert t.equal(a["buf"], b["buf"])                                   # ... and the same running statistics (rank 0's)
   assert a["losses"][0] != b["losses"][0]                              # different samples per rank
   assert a["losses"][-1] < a["losses"][0] and b["losses"][-1] < b["losses"][0]
@@ -81,9 +81,9 @@ def test_bench_two_rank_launch_path_dry_run():
     assert k in d, k
   assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
   assert abs(d["value"] - 8 * 128 ** 3 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
-  assert d["rccl"]["ranks"] == 2 and d["rccl"]["backend"] == "gloo" and len(d["rccl"]["buckets_mb"]) == 7
+  assert d["rccl"]["ranks"] == 2 and d["rccl"]["backend"] == "gloo" and len(d["rccl"]["buckets_mb"]) == 8
   assert d["rccl"]["transport"] == "torch.distributed/gloo" and d["rccl"]["buffers_on_first_bucket"] is True
-  assert len(d["rccl"]["exposed_ms_per_bucket"]) == 7 and all(v >= 0 for v in d["rccl"]["exposed_ms_per_bucket"])
+  assert len(d["rccl"]["exposed_ms_per_bucket"]) == 8 and all(v >= 0 for v in d["rccl"]["exposed_ms_per_bucket"])
   assert "NCCL_ALGO" in d["rccl"] and d["rccl"]["exposed_exchange_ms"] >= 0
   # the replicas hold the same parameters and buffers after the timed steps (MIN == MAX of their checksums over the
   # communicator), and the line names the communicator's own size

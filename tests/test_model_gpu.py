@@ -534,7 +534,7 @@ def test_native_rccl_from_the_library_single_rank():
     t.cuda.synchronize()
   finally:
     be.set_deterministic(False)
-  assert len(sync.pushed) == 7 and float(la) == float(lb)
+  assert len(sync.pushed) == len(ma.engine.grad_buckets) == 8 and float(la) == float(lb)
   assert t.equal(ma.engine.store.params, mb.engine.store.params) and t.equal(ma.engine.store.buffers, mb.engine.store.buffers)
   sync.native.close()
 
