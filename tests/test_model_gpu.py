@@ -63,6 +63,15 @@ def test_forward_eval_golden():
   assert abs(float(losses.iou_fgbg(grid.cuda(), logits)) - float(z["loss"])) < 1e-5
 
 
+def TRAIN_LOGIT_TOL(B):
+  """Train-mode logits against the reference fixtures.  north_star's tolerance is 1e-3 relative.  The B = 1 fixtures sit at ~4.5e-4
+  of it: BatchRenorm over ONE sample at num_batches_tracked = 0 divides by the standard deviation of a single map, which amplifies
+  any difference in summation order ~400x (the oracle in fp32 vs fp64 moves by as much; DESIGN section 4, "Conditioning"), so they
+  keep the north_star bar.  With B >= 2 the statistics are conditioned like in training and the library measures <= 1e-4: bar 2e-4
+  (VERDICT round 5, item 7)."""
+  return 1e-3 if B == 1 else 2e-4
+
+
 def test_bf16x3_mode_against_goldens_and_fp32_mode():
   """Engine(decoder_math="bf16x3"): decoder stages 4-6 on the split-bf16 MFMA engine.  It must hold the same
   bars as the fp32 mode -- eval logits 1e-4 against the reference fixture, train logits 1e-3 (north_star), loss,
@@ -86,7 +95,7 @@ def test_bf16x3_mode_against_goldens_and_fp32_mode():
     logits = m(image.cuda(), v2s.cuda(), off.cuda())
     e = relerr(logits[:, :, ::16, ::16, ::16], z["logits_sub"])
     print(f"bf16x3 {tag} logits vs reference fixture: {e:.2e}")
-    assert e < 1e-3
+    assert e < TRAIN_LOGIT_TOL(B), (tag, e)
     loss = getattr(losses, lossname)(grid.cuda(), logits)
     assert abs(float(loss) - float(z["loss"])) < 2e-4 * max(1.0, abs(float(z["loss"])))
     loss.backward()
@@ -339,7 +348,9 @@ def test_train_forward_backward_golden(tag, nc, nbt, B, lossname):
   m = _model(nc, sd).train()
   image, v2s, off, grid = O.synthetic_batch(B, 0, nc)
   logits = m(image.cuda(), v2s.cuda(), off.cuda())
-  assert relerr(logits[:, :, ::16, ::16, ::16], z["logits_sub"]) < 1e-3          # north_star tolerance
+  e = relerr(logits[:, :, ::16, ::16, ::16], z["logits_sub"])
+  print(f"fp32 {tag} logits vs reference fixture: {e:.2e}")
+  assert e < TRAIN_LOGIT_TOL(B), (tag, e)
   loss = getattr(losses, lossname)(grid.cuda(), logits)
   assert abs(float(loss) - float(z["loss"])) < 2e-4 * max(1.0, abs(float(z["loss"])))
   loss.backward()
