@@ -39,6 +39,7 @@ timeout 200 python tools/run_noise.py 2 0 2>/dev/null | grep -v amdgpu > $O/r06_
 timeout 200 python tools/run_noise.py 4 30000 2>/dev/null | grep -v amdgpu >> $O/r06_run_to_run_spread.txt
 timeout 200 python tools/cpu_enqueue.py bf16x3 2>/dev/null | grep graph= > $O/r06_graph_vs_eager.txt
 DEBUG_HIP_FORCE_GRAPH_QUEUES=1 timeout 200 python tools/cpu_enqueue.py bf16x3 2>/dev/null | grep graph= | sed 's/^/DEBUG_HIP_FORCE_GRAPH_QUEUES=1: /' >> $O/r06_graph_vs_eager.txt
+{ timeout 200 python tools/host_ahead.py 2 6 2>/dev/null | grep live; timeout 200 python tools/host_ahead.py 14 6 2>/dev/null | grep live; } > $O/r06_host_ahead.txt
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pv -o v -- python $R/tools/bench_voxelize.py > $O/r06_voxelize.txt 2>/dev/null
 cp /tmp/pv/v_kernel_stats.csv $O/r06_voxelize_kernel_stats.csv
