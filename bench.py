@@ -93,7 +93,7 @@ def synthetic_meshes(batch, dev):
 
 
 def load_traffic(math, B, C, want):
-  """HBM bytes per launch from the PMC passes of this same command (profiles/r05_pmc_traffic*.json; FETCH_SIZE / WRITE_SIZE
+  """HBM bytes per launch from the PMC passes of this same command (profiles/r06_pmc_traffic*.json; FETCH_SIZE / WRITE_SIZE
   need their own rocprofv3 runs and cannot be read from inside the process).  Returns ({key: bytes}, file name)."""
   traffic = {}
   traffic_file = os.path.join("profiles", TRAFFIC_FILES[math])
