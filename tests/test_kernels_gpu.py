@@ -314,6 +314,13 @@ def test_convt_parity_walk_fwd_dgrad(be, cout, dims, B):
   # under the forward pass) and the fused transform + split of the fp32 input (CRN_CT_XIMG=0) -- same contract
   img = be.convt_ximage(xg, trg)
   assert img is not None
+  # ... the image itself, bit for bit: entry [b][chunk * 2 + (hi, lo)][position] = the 8 channels of the chunk of T(x) as bf16, hi = the
+  # round-to-nearest-even bf16 of the fp32 value, lo = the bf16 of what is left (the split of conv_bf3.hip)
+  tx = (x.relu() * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)).float()            # trc: pre_relu, then scale / shift
+  hi = tx.to(t.bfloat16); lo = (tx - hi.float()).to(t.bfloat16)
+  want_img = t.stack([hi[:, :8], lo[:, :8], hi[:, 8:], lo[:, 8:]], 1).reshape(B, 4, 8, -1).permute(0, 1, 3, 2).contiguous()   # [B][4][S][8]
+  got_img = img[:want_img.numel() * 2].view(t.bfloat16).view(B, 4, -1, 8).cpu()
+  assert t.equal(got_img.view(t.int16), want_img.view(t.int16)), "operand image differs from bf16 hi / lo of T(x)"
   for label, kw, env in (("image made ahead", {"ximg": img}, None), ("fused staging", {}, "0")):
     old_env = os.environ.get("CRN_CT_XIMG")
     if env is not None:
