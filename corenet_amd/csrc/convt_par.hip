@@ -393,6 +393,7 @@ __global__ __launch_bounds__(kT) void convt_par_dgrad_kernel(CtGeom g) {
 // with fire-and-forget atomics, like the generic kernel: the un-pack is unchanged.
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+constexpr int kYSwz = 1;                                      // 1: bank swizzle of the dy image (0: the plain layout, for A/B runs of the build)
 constexpr int WTD = 2, WPD = WTD + 3, WNP = WPD * PHW;       // weight-gradient tile: 2 x 8 x 16 positions = 8 K blocks of 32
 constexpr int kWgPos = WTD * TH * TW;                        // 256
 constexpr size_t kLdsWg = kLdsTab + (size_t)4 * WNP * 16 + (size_t)2 * kWgPos * 32 * 2;
@@ -447,6 +448,7 @@ __device__ __forceinline__ void convt_par_wgrad_body(const CtWgGeom& g, int pp, 
     skip0[ti] = zw == 3;
   }
   const int ybase = k1 * 64 + (q << 3);
+  const int yswz = (kk & kYSwz) * 32;
   constexpr int xlo = 2 * WNP * 16, ylo = kWgPos * 64;
 
   f32x4 acc[TPW][2];
@@ -553,7 +555,11 @@ __device__ __forceinline__ void convt_par_wgrad_body(const CtWgGeom& g, int pp, 
         for (int cl = 0; cl < 8; ++cl) v[cl] = dv[cl][e];
         bf16x8 h, l;
         split8(v, h, l);
-        const size_t o = (size_t)(dp + (e >> 1)) * 64 + (size_t)((e & 1) * 16 + doct * 8) * 2;
+        // (the two 32-byte halves of a position's row -- rw 0 / rw 1 -- swap places on positions with bit 3 set: the transposing
+        // reads of lanes kk and kk + 1, eight positions = 512 bytes apart, then fall into different banks; without it every
+        // B-fragment read was a 2-way bank conflict, SQ_LDS_BANK_CONFLICT 46 % of the kernel's LDS cycles)
+        const int pos = dp + (e >> 1);
+        const size_t o = (size_t)pos * 64 + (size_t)((((e & 1) ^ ((pos >> 3) & kYSwz)) * 16 + doct * 8) * 2);
         *reinterpret_cast<bf16x8*>(Yhi + o) = h;
         *reinterpret_cast<bf16x8*>(Ylo + o) = l;
       }
@@ -579,8 +585,9 @@ __device__ __forceinline__ void convt_par_wgrad_body(const CtWgGeom& g, int pp, 
       const char* yb = Yhi + ybase + kb * (32 * 64);
 #pragma unroll
       for (int ns = 0; ns < 2; ++ns) {
-        bh[qb][ns] = cat(trd(yb + ns * 32), trd(yb + ns * 32 + 4 * 64));
-        bl[qb][ns] = cat(trd(yb + ylo + ns * 32), trd(yb + ylo + ns * 32 + 4 * 64));
+        const int co = (ns * 32) ^ yswz;                     // (this lane's positions 8 kk + j [+ 4] have bit 3 = kk & 1)
+        bh[qb][ns] = cat(trd(yb + co), trd(yb + co + 4 * 64));
+        bl[qb][ns] = cat(trd(yb + ylo + co), trd(yb + ylo + co + 4 * 64));
       }
     };
     auto ldA = [&](int kbx, int ti, int qa) {
