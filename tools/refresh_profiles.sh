@@ -16,6 +16,8 @@ timeout 900 bash tools/pmc_traffic.sh $O/r06_pmc_traffic_c14.json bf16x3 "--clas
 timeout 300 bash tools/pmc_mfma.sh fwd s6c1 $O/r06_conv_mfma_pmc_bf16x3_fwd.txt bf16x3 > /dev/null 2>&1
 timeout 300 bash tools/pmc_mfma.sh dgrad s6c1 $O/r06_conv_mfma_pmc_bf16x3_dgrad.txt bf16x3 > /dev/null 2>&1
 timeout 300 bash tools/pmc_mfma.sh wgrad s6c1 $O/r06_conv_mfma_pmc_bf16x3_wgrad.txt bf16x3 > /dev/null 2>&1
+timeout 300 bash tools/pmc_ct14.sh $O/r06_ct14_pmc.txt 14 > /dev/null 2>&1
+timeout 300 bash tools/pmc_ct14.sh $O/r06_bf3_pmc_c2.txt 2 > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r06 -- python $R/tools/prof_step.py bf16x3 10 > /dev/null 2>&1
 cp /tmp/prof/r06_kernel_stats.csv $O/r06_step_kernel_stats.csv
