@@ -148,6 +148,27 @@ __global__ void bn_finalize_kernel(const double* ws, int nparts, int C, double c
     bn_finalize_channel_in(c, C, s1, s2, count, cin, running_mean, running_var, eps, momentum, scale, shift, saved);
 }
 
+// The same for MANY parts per channel (the partial sums a convolution's workgroups leave: 2048 for decoder stage_6.c1): one
+// workgroup per channel, every thread has its share of the loads in flight at once (a wave's 64 lanes walked 32 of them one
+// after the other: 12.7 us for 16 channels)
+__global__ __launch_bounds__(kThreads) void bn_finalize_wide_kernel(const double* ws, int nparts, int C, double count,
+                                                                    const float* gamma, const float* beta, float* running_mean,
+                                                                    float* running_var, const int64_t* nbt, float eps, float momentum,
+                                                                    float* scale, float* shift, float* saved) {
+  __shared__ double red[2 * (kThreads / 64)];
+  const int c = blockIdx.x;
+  const BnChannelIn cin = bn_channel_in(c, gamma, beta, running_mean, running_var, nbt);
+  typedef double f64x2 __attribute__((ext_vector_type(2)));
+  const f64x2* p = reinterpret_cast<const f64x2*>(ws) + (int64_t)c * nparts;
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < nparts; i += kThreads) { const f64x2 v = p[i]; s1 += v.x; s2 += v.y; }
+  double t1, t2;
+  crn_block_sum2(s1, s2, red, t1, t2);
+  if (threadIdx.x == 0)
+    bn_finalize_channel_in(c, C, t1, t2, count, cin, running_mean, running_var, eps, momentum, scale, shift, saved);
+}
+
 // Eval mode: scale/shift of EVERY BatchRenorm of the model from the running statistics in one launch
 // (batch_renorm.py:59); table rows = (gamma, beta offsets in the parameter slab; running_mean, running_var
 // offsets in the buffer slab; output offset in the scale/shift slabs).  Same arithmetic as the eval branch of
@@ -815,6 +836,11 @@ extern "C" int crn_batch_renorm_finalize(const double* ws, int nparts, int C, do
                                          float* scale, float* shift, float* saved, crnStream stream) {
   CRN_ENTRY(stream);
   if (!ws || nparts < 1 || nparts > kMaxParts || C < 1 || !(count >= 1.0)) return CRN_EINVAL;
+  static const int kWide = getenv("CRN_BN_FINALIZE_WIDE") ? atoi(getenv("CRN_BN_FINALIZE_WIDE")) : 512;      // parts per channel from which on
+  if (kWide > 0 && nparts >= kWide && (((uintptr_t)ws) & 15) == 0)
+    hipLaunchKernelGGL(bn_finalize_wide_kernel, dim3(C), dim3(kThreads), 0, (hipStream_t)stream, ws, nparts, C, count,
+                       gamma, beta, running_mean, running_var, nbt, eps, momentum, scale, shift, saved);
+  else
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(crn_cdiv(C, 4)), dim3(256), 0, (hipStream_t)stream, ws, nparts, C, count,
                      gamma, beta, running_mean, running_var, nbt, eps, momentum, 1, scale, shift, saved);
   CRN_CHECK_LAUNCH();
