@@ -276,7 +276,8 @@ _T0 = time.time()
 
 def progress(msg):
   """Timestamped progress on stderr (stdout carries the one JSON line only)."""
-  print("bench.py [%6.1f s] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
+  if os.environ.get("RANK", "0") == "0":
+    print("bench.py [%6.1f s] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
 
 
 def main():
