@@ -46,5 +46,6 @@ cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pv -o v -- python $R/tools/bench_voxelize.py > $O/r06_voxelize.txt 2>/dev/null
 cp /tmp/pv/v_kernel_stats.csv $O/r06_voxelize_kernel_stats.csv
 cd $R
+bash tools/trace_step.sh bf16x3 > /dev/null 2>&1; cp $R/gpurun_out/timeline.txt $O/r06_timeline.txt     # one step launch by launch (durations are real; gaps are stretched by the profiler)
 ls -la $O
 echo "copy gpurun_out/prof/r06_* to profiles/, commit, then: python tools/check_profiles_fresh.py"
