@@ -484,7 +484,10 @@ extern "C" int crn_copy_tiles_f32(const float* src, float* dst, const int32_t* d
   CRN_ENTRY(s);
   if (!src || !dst || !desc || !mask || ntiles < 0) return CRN_EINVAL;
   if (ntiles == 0) return CRN_OK;
-  const unsigned blocks = (unsigned)std::min<int64_t>(crn_cdiv(ntiles, 4), 16384);
+  // (grid-stride loops: the cap decides how much of the chip a pack / un-pack occupies while it runs BESIDE the step's latency-bound
+  // launches on the other stream -- CRN_COPY_TILES_BLOCKS)
+  static const int64_t kCap = getenv("CRN_COPY_TILES_BLOCKS") ? std::max(1, atoi(getenv("CRN_COPY_TILES_BLOCKS"))) : 16384;
+  const unsigned blocks = (unsigned)std::min<int64_t>(crn_cdiv(ntiles, 4), kCap);
   if (reverse)
     hipLaunchKernelGGL(copy_tiles_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)s, src, dst, desc,
                        reinterpret_cast<const unsigned long long*>(mask), explicit_idx, ntiles);
@@ -499,7 +502,8 @@ extern "C" int crn_copy_mats_f32(const float* src, float* dst, const int32_t* de
   CRN_ENTRY(s);
   if (!src || !dst || !desc || ntiles < 0) return CRN_EINVAL;
   if (ntiles == 0) return CRN_OK;
-  const unsigned blocks = (unsigned)std::min<int64_t>(ntiles, 8192);
+  static const int64_t kCap = getenv("CRN_COPY_MATS_BLOCKS") ? std::max(1, atoi(getenv("CRN_COPY_MATS_BLOCKS"))) : 8192;
+  const unsigned blocks = (unsigned)std::min<int64_t>(ntiles, kCap);
   if (reverse)
     hipLaunchKernelGGL(copy_mats_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)s, src, dst, desc, ntiles);
   else

@@ -64,6 +64,10 @@ GRAD_BUCKET_LABELS = ("decoder.stage_3.", "decoder.stage_0.", "encoder.stage5.c.
 BF16X3_LAUNCHES = frozenset(
     [(f"decoder.stage_{k}.{l}.", d) for k in (3, 4, 5, 6) for l in ("c1", "t1") for d in ("fwd", "dgrad")] +
     [(f"decoder.stage_{k}.{l}.", "wgrad") for k in (3, 4, 5, 6) for l in ("c1", "t1")])
+# MEASUREMENT ONLY: bits 1 / 2 / 4 = the forward weight packs / the data-gradient weight pack / the gradient
+# un-packs are NOT launched -- the kernels then read stale packed weights and Adam steps on stale gradients, so every result is WRONG; it
+# prices what the step would gain without these copies (master weights kept in the kernels' layout).  Never set outside a timing run.
+_TIMING_ONLY_SKIP_COPIES = int(os.environ.get("CRN_TIMING_ONLY_SKIP_COPIES", "0"))
 LOSS_KINDS = {"iou_fgbg": 0, "xent_times_iou_agnostic": 1, "iou_agnostic": 2, "xent": 3,
               "xent_times_iou_fgbg": 4}
 
@@ -584,7 +588,8 @@ class Engine:
     """flat parameter slab -> packed forward weights and biases ("enc" / "dec": one of the two pieces)."""
     tiles = {"all": self.pack_tiles, "enc": self.pack_tiles_enc, "dec": self.pack_tiles_dec,
              "enc_early": self.pack_tiles_enc_early, "enc_late": self.pack_tiles_enc_late}[part]
-    self.be.copy_tiles(self.store.params, self.packed, tiles)
+    if not _TIMING_ONLY_SKIP_COPIES & 1:
+      self.be.copy_tiles(self.store.params, self.packed, tiles)
     self._operands(*{"all": ("enc_early", "enc_late", "dec"), "enc": ("enc_early", "enc_late"), "dec": ("dec",),
                      "enc_early": ("enc_early",), "enc_late": ("enc_late",)}[part])
     if part in ("all", "dec"):
@@ -592,7 +597,8 @@ class Engine:
 
   def pack_dgrad_weights(self):
     """flat parameter slab -> packed data-gradient weights (1 launch; backward only)."""
-    self.be.copy_tiles(self.store.params, self.packed, self.pack_tiles_bwd)
+    if not _TIMING_ONLY_SKIP_COPIES & 2:
+      self.be.copy_tiles(self.store.params, self.packed, self.pack_tiles_bwd)
     self._operands("bwd")
     self.dgrad_dirty = False
 
@@ -1273,7 +1279,7 @@ class Plan:
     _, lo, hi = eng.grad_buckets[i]
     tiles = eng.bucket_unpack_tiles(i)
     def run():
-      if tiles[0].numel() or tiles[3].numel():
+      if (tiles[0].numel() or tiles[3].numel()) and not _TIMING_ONLY_SKIP_COPIES & 4:
         self.be.copy_tiles(eng.gpacked, eng.store.grads, tiles, reverse=True)
       hook(eng.store.grads[lo:hi])
     if self.side is None or self.trace is not None:
