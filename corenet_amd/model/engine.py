@@ -408,24 +408,28 @@ class Engine:
         return np.where(ix >= 0, ix.astype(np.int64) + o, -1)
       parts = [shift(fwd.index, wo), shift(G.bias_index(nref, repeat, fwd.npad, parity_major=(repeat == 8)), bo)]
       if dgrad is not None:
-        parts.append(shift(dgrad.index, wo))
+        # a data-gradient layout that IS the reference layout (the 1x1 convolutions: [Cout][Cin], no padding -- 12 M of the 30 M
+        # weights of the plain convolutions) is not packed at all: the kernels read the parameter slab (an empty part here)
+        alias = (os.environ.get("CRN_DGRAD_ALIAS", "1") != "0" and len(dgrad.index) == int(np.prod(s.off[name + "weight"][1]))
+                 and np.array_equal(dgrad.index, np.arange(len(dgrad.index))))
+        parts.append(np.zeros(0, np.int64) if alias else shift(dgrad.index, wo))
       idx_parts.append(parts)
     flat_len = sum(len(p) for parts in idx_parts for p in parts)
-    assert max(int(p.max()) for parts in idx_parts for p in parts) < 2 ** 31
+    assert max(int(p.max()) for parts in idx_parts for p in parts if len(p)) < 2 ** 31
     self.packed = t.zeros(flat_len, dtype=self.dtype, device=self.device)
     gsize = sum(len(parts[0]) for parts in idx_parts)
     self.gpacked = t.zeros(gsize, dtype=self.dtype, device=self.device)
     # 8x8-tile descriptors of the pack (reference -> packed) and un-pack (packed grad -> reference grad)
     # copies: crn_copy_tiles_f32 moves both sides in full 32-byte sectors and reads ~0.5 B of index per element
     # instead of 4 (conv_geometry.tile_index)
-    pack_parts, pack_is_bwd, unpack_parts = [], [], []
+    pack_parts, pack_is_bwd, pack_names, unpack_parts = [], [], [], []
     po, go = 0, 0
     for (name, fwd, dgrad, repeat, nref), parts in zip(reg, idx_parts):
-      pack_parts.append((po, parts[0], fwd.npad, 0)); po += len(parts[0]); pack_is_bwd.append(False)
-      pack_parts.append((po, parts[1], len(parts[1]), 0)); po += len(parts[1]); pack_is_bwd.append(False)
-      if dgrad is not None:
+      pack_parts.append((po, parts[0], fwd.npad, 0)); po += len(parts[0]); pack_is_bwd.append(False); pack_names.append(name)
+      pack_parts.append((po, parts[1], len(parts[1]), 0)); po += len(parts[1]); pack_is_bwd.append(False); pack_names.append(name)
+      if dgrad is not None and len(parts[2]):
         pack_parts.append((po, parts[2], dgrad.npad, dgrad.taps if dgrad.taps > 1 else 0)); po += len(parts[2])
-        pack_is_bwd.append(True)
+        pack_is_bwd.append(True); pack_names.append(name)
       unpack_parts.append((go, parts[0], fwd.npad, 0)); go += len(parts[0])
     dev = self._tiles_dev
     # two packs: what forward reads (forward weights + biases) and what only backward reads (data-gradient
@@ -433,7 +437,6 @@ class Engine:
     self.pack_tiles = dev([pp for pp, bwd in zip(pack_parts, pack_is_bwd) if not bwd])
     # ... and the forward pack once more in two pieces: the encoder's weights are needed at once, the decoder's
     # ~1.4 ms later, so in training the decoder piece is packed on the side stream under the encoder
-    pack_names = [name for (name, *_rest) in reg for _ in range(3 if _rest[1] is not None else 2)]
     sel = lambda pred: [pp for pp, bwd, nm in zip(pack_parts, pack_is_bwd, pack_names) if not bwd and pred(nm)]
     early = lambda nm: nm.startswith("encoder.stage1") or nm.startswith("encoder.stage2")
     self.pack_tiles_enc = dev(sel(lambda nm: nm.startswith("encoder.")))
@@ -463,7 +466,10 @@ class Engine:
       bias = self.packed[po:po + nb]; po += nb
       wd = None
       if dgrad is not None:
-        wd = self.packed[po:po + len(parts[2])]; po += len(parts[2])
+        if len(parts[2]):
+          wd = self.packed[po:po + len(parts[2])]; po += len(parts[2])
+        else:
+          wd = s.view(name + "weight").view(-1)          # (the reference layout is the data-gradient layout: see above)
       gwf = self.gpacked[go:go + nwf]; go += nwf
       self.convs[name] = Conv(name, fwd, dgrad, wf, wd, bias, gwf,
                               s.view(name + "bias", grad=True), nref)
@@ -537,7 +543,7 @@ class Engine:
       if G.operand_eligible(fwd) and name[len("encoder.stage")] in fwd_stages and not only_dgrad:
         groups["enc_early" if name.startswith("encoder.stage2") else "enc_late"].append((src_f, eo, fwd))
         slices.append((name, "wop_f", eo, G.operand_entries(fwd))); eo += G.operand_entries(fwd)
-      if dgrad is not None and G.operand_eligible(dgrad):
+      if dgrad is not None and len(parts[2]) and G.operand_eligible(dgrad):     # (not the layers whose data-gradient layout is the slab's)
         groups["bwd"].append((src_d, eo, dgrad))
         slices.append((name, "wop_d", eo, G.operand_entries(dgrad))); eo += G.operand_entries(dgrad)
     if not eo:
