@@ -198,7 +198,7 @@ def test_forward_eval_b4_matches_oracle():
 def test_bf16x3_eval_b4_matches_oracle(nc):
   """The HEADLINE mode of bench.py (decoder_math="bf16x3": split-bf16 MFMA in decoder stages 3-6 and the encoder's 3x3
   layers) at the bench batch, against the oracle and not against this library's own fp32 mode: eval-mode logits, every
-  voxel, 1e-4 relative, for the h7 (C=2) and the m7 / m9 (C=14) heads.  The fp32 mode is measured beside it."""
+  voxel, 5e-5 relative (fp32 mode beside it: 2e-5), for the h7 (C=2) and the m7 / m9 (C=14) heads."""
   sd = O.make_state(0, nc, nbt=100)
   image, v2s, off, grid = O.synthetic_batch(4, 0, nc)
   with t.no_grad():
@@ -211,7 +211,7 @@ def test_bf16x3_eval_b4_matches_oracle(nc):
       errs[math] = max(relerr(logits[b], want[b]) for b in range(4))
       del m
   print(f"B=4 C={nc} eval logits vs oracle, every voxel: bf16x3 {errs['bf16x3']:.2e}, fp32 {errs['fp32']:.2e}")
-  assert errs["bf16x3"] < 1e-4 and errs["fp32"] < 1e-4, errs
+  assert errs["bf16x3"] < 5e-5 and errs["fp32"] < 2e-5, errs        # (measured 2.1e-5 / 4.4e-6; the bars were 1e-4 until round 6)
 
 
 GRAD_NOISE_FACTOR, GRAD_ERR_FLOOR, GRAD_BAR_CAP, GRAD_OUTLIER_CAP = 8.0, 2e-3, 0.1, 0.5   # see the docstring below
